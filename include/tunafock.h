@@ -1,0 +1,169 @@
+/*
+ * tunafock.h -- C ABI of libtunafock.so: the MI355X (gfx950) two-electron-integral / Fock-build /
+ * SCF engine that stands behind TUNA's integral module and SCF functions.
+ *
+ * Every entry point is plain C: pointers and sizes only, row-major float64, no torch/NumPy types.
+ * Each one names the reference interface it replaces (h-brough/TUNA v0.12.0; "pyx" =
+ * TUNA/tuna_integrals/tuna_integral.pyx, "scf" = TUNA/tuna_scf.py, "kernel" = TUNA/tuna_kernel.py).
+ * INTEGRATION.md shows the ctypes stubs a TUNA maintainer would add.
+ *
+ * Conventions
+ *   - return value: 0 on success, negative on failure (TF_E*); tf_last_error() has the message.
+ *     No exception crosses this boundary.  There is NO CPU fallback: without a usable GPU every
+ *     compute entry point fails with TF_ENODEVICE.
+ *   - host arrays are caller-owned; device memory is owned by the context; one context per process
+ *     (one process per GPU); calls are synchronous unless they take a stream; a context is
+ *     thread-compatible, not thread-safe.
+ *   - AO order, geometry (atoms on the z axis), normalisation and the Cartesian->spherical
+ *     convention are the reference's.
+ */
+#ifndef TUNAFOCK_H
+#define TUNAFOCK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tf_ctx tf_ctx;
+
+enum {
+    TF_OK = 0,
+    TF_EINVAL = -1,    /* bad argument / call order                              */
+    TF_ENODEVICE = -2, /* no HIP device, or HIP runtime error                    */
+    TF_ENOMEM = -3,    /* host or device allocation failed (pyx:1120,1290 MemoryError) */
+    TF_ENOTCONV = -4,  /* SCF not converged in max_iter (scf:1435)               */
+    TF_ELINALG = -5,   /* rocSOLVER/rocBLAS failure                              */
+    TF_EGEOM = -6      /* molecule not on the z axis (kernel:386-388)            */
+};
+
+/* ---- life cycle -------------------------------------------------------------------------- */
+
+/* One context per process/GPU.  `device` is the HIP device ordinal; (rank, world) select this
+ * process's shard of the (ij) shell-pair rows of the ERI tensor; use
+ * rank 0 / world 1 for a single GPU.  Returns NULL on failure (see tf_last_error(NULL)). */
+tf_ctx *tf_create(int device, int rank, int world);
+void tf_destroy(tf_ctx *ctx);
+/* Message of the last failure on `ctx` (or of the last failed tf_create when ctx == NULL). */
+const char *tf_last_error(const tf_ctx *ctx);
+/* ABI version of the library (major*100 + minor). */
+int tf_version(void);
+
+/* ---- basis: replaces `Basis.__cinit__` / `Basis.normalize` (pyx:144-210) ------------------ */
+
+/* Stateless helper = Basis.normalize for ONE Cartesian AO: fills norm[nprim] and rescales
+ * coefs[nprim] in place, exactly as pyx:174-210 does. */
+int tf_normalize(int l, int m, int n, int nprim, const double *exps, double *coefs_inout, double *norm_out);
+
+/* The ordered Cartesian AO list, as `form_basis` (tuna_molecule.py:532-587) hands it to the engine:
+ * for AO i: origin[3i..3i+2], lmn[3i..3i+2], primitives prim_off[i]..prim_off[i+1]-1 of exps /
+ * coefs_raw (un-normalised contraction coefficients).  The engine normalises (a1), groups
+ * consecutive AOs into shells, and builds the shell-pair data (pyx:1050-1128). */
+int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t *lmn, const int32_t *prim_off,
+                 const double *exps, const double *coefs_raw);
+/* Parity hook for a1: per-primitive norm and normalised coefficients, same layout as exps. */
+int tf_get_norms(const tf_ctx *ctx, double *norm, double *coefs_normalised);
+/* Dimensions after tf_set_basis: Cartesian / spherical AO counts and number of shells. */
+int tf_dims(const tf_ctx *ctx, int *n_cart, int *n_sph, int *n_shell);
+/* The Cartesian->spherical matrix U [n_sph, n_cart] (kernel:540-649). */
+int tf_get_sph_matrix(const tf_ctx *ctx, double *U);
+
+/* ---- one-electron companions: replace calculate_one_electron_integrals (pyx:282-435) and
+ *      calculate_cross_basis_overlap_matrix (pyx:626-768) --------------------------------- */
+
+/* S,T,V [n,n]; D,Q [3,n,n] with n = n_sph if spherical else n_cart (transform kernel:495-502).
+ * atom_xyz [3*n_atoms] must be on the z axis; D,Q may be NULL. */
+int tf_one_electron(tf_ctx *ctx, int n_atoms, const double *atom_xyz, const double *atom_charge,
+                    const double *dipole_origin, int spherical, double *S, double *T, double *V, double *D,
+                    double *Q);
+/* Overlap between the context's basis (rows) and a second AO list (columns), Cartesian, [n1,n2]. */
+int tf_cross_overlap(tf_ctx *ctx, int n_ao2, const double *origin2, const int32_t *lmn2, const int32_t *prim_off2,
+                     const double *exps2, const double *coefs_raw2, double *S_cross);
+
+/* ---- two-electron integrals: replace calculate_electron_repulsion_integrals (pyx:1267-1355)
+ *      + transform_to_spherical_harmonics (kernel:454-529) -------------------------------- */
+
+/* Build this rank's rows of the (ij|kl) tensor on the device.  spherical = 0 is CARTHARM
+ * (kernel:481).  The tensor stays resident in HBM: rows (i >= j) x full (k,l). */
+int tf_build_eri(tf_ctx *ctx, int spherical);
+/* Bytes of HBM holding the stored rows, number of stored rows, row length (leading dimension). */
+int tf_eri_storage(const tf_ctx *ctx, int64_t *bytes, int64_t *n_rows, int32_t *n, int32_t *ld);
+/* Dense N^4 tensor with all 8 images, as the reference leaves it in `ERI_AO` (caller-allocated,
+ * every element written).  Rows owned by other ranks are filled with zeros when world > 1. */
+int tf_copy_eri(tf_ctx *ctx, double *host_out);
+/* Values at n_idx index quadruples idx[4*q..4*q+3] = (i,j,k,l) (parity/debug at sizes where the
+ * dense copy does not fit the host). */
+int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values);
+/* One contracted Cartesian integral between four AOs given explicitly
+ * (calculate_electron_repulsion_integral, pyx:1376-1414).  Arrays describe 4 AOs like tf_set_basis. */
+int tf_eri_element(tf_ctx *ctx, const double *origin, const int32_t *lmn, const int32_t *prim_off,
+                   const double *exps, const double *coefs_raw, double *value);
+
+/* ---- Fock build: replaces calculate_coulomb_matrix (scf:55-72) and
+ *      calculate_exchange_matrix (scf:27-44) --------------------------------------------- */
+
+/* J_ij = sum_kl (ij|kl) P_kl ;  K_ij = sum_kl (il|kj) P_kl  for n_dens densities, host buffers
+ * [n_dens,N,N].  With world > 1 the result is this rank's PARTIAL J and K (sum over ranks =
+ * full matrices); the caller all-reduces (RCCL) -- see tuna_amd/distributed.py. */
+int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K);
+/* Same with device pointers, asynchronous on `stream` (a hipStream_t, may be NULL for the
+ * default stream).  Inputs already in HBM; nothing is synchronised or copied. */
+int tf_fock_jk_device(tf_ctx *ctx, int n_dens, const double *dP, double *dJ, double *dK, void *stream);
+
+/* ---- SCF: replaces run_self_consistent_field_cycle (scf:1292-1435) for RHF ---------------- */
+
+typedef struct {
+    int32_t max_iter;           /* MAXITER, calc:158 (100)                         */
+    int32_t use_diis;           /* DIIS / NODIIS, calc:198,100                     */
+    int32_t max_diis;           /* DIIS n (6)                                      */
+    int32_t damping;            /* 0 = NODAMP, 1 = dynamic (default), 2 = static   */
+    double damping_factor;      /* DAMP x (static)                                 */
+    double max_damping;         /* MAXDAMP (0.7), calc:159                         */
+    double conv_delta_E;        /* thresholds of util:109-116                      */
+    double conv_max_DP;
+    double conv_rms_DP;
+    double conv_commutator;
+    double hfx;                 /* HFX_prop, calc:207 (1.0)                        */
+    int32_t n_atom_ao[2];       /* AOs on atom A / B (partition_ranges) for the Mulliken damping */
+    int32_t n_atoms;
+} tf_scf_opts;
+
+typedef struct {
+    double energy;              /* E_total = E_elec + V_NN                         */
+    double components[7];       /* kinetic, nuc-el, coulomb, exchange, correlation, field, field-gradient (scf:402) */
+    int32_t n_iter;
+    int32_t converged;
+    double *P;                  /* [N,N] caller-allocated, may be NULL             */
+    double *C;                  /* [N,N] molecular orbitals                        */
+    double *eps;                /* [N]                                             */
+    double *F;                  /* [N,N]                                           */
+    double *table;              /* [max_iter,7]: step, E_total, dE, rms(DP), max(DP), commutator, damping (scf:105) */
+    double fock_seconds;        /* accumulated device time inside the J/K kernels  */
+    double eig_seconds;         /* accumulated time in the eigensolver             */
+    double wall_seconds;
+} tf_scf_result;
+
+/* Runs the RHF cycle of scf:1072-1154 / 1292-1435 with the tensor built by tf_build_eri.
+ * S,T,V,Fext (field terms, may be NULL = 0), X = S^-1/2 (kernel:756-816; NULL => computed here),
+ * P0 guess density with guess energy E0, n_occ doubly occupied orbitals. */
+int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const double *T, const double *V,
+               const double *Fext, const double *X, const double *P0, double E0, int n_occ, double V_NN,
+               tf_scf_result *out);
+
+/* X = S^-1/2, S^-1 and the smallest overlap eigenvalue (kernel:756-816), host buffers [N,N]. */
+int tf_orthogonaliser(tf_ctx *ctx, int n, const double *S, double *X, double *S_inv, double *smallest_eig);
+
+/* ---- instrumentation ------------------------------------------------------------------- */
+
+/* Device-side seconds of the last tf_build_eri broken down by stage:
+ * [0] total, [1] primitive/contracted Cartesian kernel, [2] ket transform, [3] bra transform+store. */
+int tf_eri_timings(const tf_ctx *ctx, double *seconds4);
+/* Work counters of the last tf_build_eri: [0] shell quartets, [1] primitive shell quartets,
+ * [2] Cartesian component quartets. */
+int tf_eri_counts(const tf_ctx *ctx, int64_t *counts3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUNAFOCK_H */
