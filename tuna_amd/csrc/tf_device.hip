@@ -1,0 +1,602 @@
+// tf_device.hip -- context, device memory, launch logic and the C ABI of libtunafock.so (include/tunafock.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/tunafock.h"
+#include "tf_internal.h"
+#include "tf_kernels.hip.h"
+#include "tf_oneel.hip.h"
+#include "tf_scf.hip.h"
+
+using namespace tfk;
+
+static std::string g_create_error;
+static const bool g_dbg = getenv("TF_DEBUG") != nullptr;
+#define DBG(...) do { if (g_dbg) { fprintf(stderr, "[tf] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
+
+struct tf_ctx {
+    int device = 0, rank = 0, world = 1;
+    mutable std::string err;
+    tf::Basis bs;
+    bool have_basis = false, have_eri = false;
+    // device copy of the basis
+    DBasis db{};
+    std::vector<void *> basis_allocs;
+    int *d_csr_ptr = nullptr, *d_csr_idx = nullptr;
+    double *d_csr_val = nullptr;
+    int csr_rows = 0;
+    // stored tensor
+    int spherical = 1, N = 0, ld = 0;
+    long long n_rows = 0;
+    double *d_eri = nullptr;
+    int2 *d_row_ij = nullptr;
+    int *d_rowmap = nullptr;
+    std::vector<int> my_pairs;          // bra shell pairs owned by this rank
+    // J/K scratch
+    double *d_Jrow = nullptr, *d_Kp = nullptr, *d_Ppad = nullptr, *d_J = nullptr, *d_K = nullptr, *d_P = nullptr;
+    // instrumentation
+    double eri_seconds[4] = {0, 0, 0, 0};
+    long long eri_counts[3] = {0, 0, 0};
+    tfscf::Workspace scf;
+};
+
+#define TF_FAIL(ctx, code, ...)                                  \
+    do {                                                         \
+        char _b[512];                                            \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                   \
+        (ctx)->err = _b;                                         \
+        return (code);                                           \
+    } while (0)
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            TF_FAIL(ctx, (_e == hipErrorOutOfMemory ? TF_ENOMEM : TF_ENODEVICE), "%s failed: %s (%s:%d)", #call, \
+                    hipGetErrorString(_e), __FILE__, __LINE__);                                    \
+    } while (0)
+
+template <class T>
+static int upload(tf_ctx *ctx, const std::vector<T> &h, T **d, bool track = true)
+{
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIPCHK(ctx, hipMalloc((void **)d, bytes));
+    if (track) ctx->basis_allocs.push_back(*d);
+    if (!h.empty()) HIPCHK(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return TF_OK;
+}
+
+static void free_eri(tf_ctx *ctx)
+{
+    for (void *p : {(void *)ctx->d_eri, (void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
+                    (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P})
+        if (p) (void)hipFree(p);
+    ctx->d_eri = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
+    ctx->d_Ppad = nullptr; ctx->d_J = nullptr; ctx->d_K = nullptr; ctx->d_P = nullptr;
+    ctx->have_eri = false;
+}
+
+static void free_basis(tf_ctx *ctx)
+{
+    for (void *p : ctx->basis_allocs) (void)hipFree(p);
+    ctx->basis_allocs.clear();
+    for (void *p : {(void *)ctx->d_csr_ptr, (void *)ctx->d_csr_idx, (void *)ctx->d_csr_val})
+        if (p) (void)hipFree(p);
+    ctx->d_csr_ptr = ctx->d_csr_idx = nullptr; ctx->d_csr_val = nullptr;
+    ctx->have_basis = false;
+}
+
+extern "C" {
+
+int tf_version(void) { return 100; }
+
+tf_ctx *tf_create(int device, int rank, int world)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device available (") + hipGetErrorString(e) + "); libtunafock has no CPU fallback";
+        return nullptr;
+    }
+    if (device < 0 || device >= n || world < 1 || rank < 0 || rank >= world) {
+        g_create_error = "tf_create: bad device ordinal or rank/world";
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        g_create_error = "hipSetDevice failed";
+        return nullptr;
+    }
+    tf_ctx *ctx = new tf_ctx();
+    ctx->device = device; ctx->rank = rank; ctx->world = world;
+    return ctx;
+}
+
+void tf_destroy(tf_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    free_eri(ctx);
+    free_basis(ctx);
+    tfscf::release(ctx->scf);
+    delete ctx;
+}
+
+const char *tf_last_error(const tf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int tf_normalize(int l, int m, int n, int nprim, const double *exps, double *coefs_inout, double *norm_out)
+{
+    if (l < 0 || m < 0 || n < 0 || nprim <= 0 || !exps || !coefs_inout || !norm_out) return TF_EINVAL;
+    tf::normalize_ao(l, m, n, nprim, exps, coefs_inout, norm_out);
+    return TF_OK;
+}
+
+int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t *lmn, const int32_t *prim_off,
+                 const double *exps, const double *coefs_raw)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!origin || !lmn || !prim_off || !exps || !coefs_raw) TF_FAIL(ctx, TF_EINVAL, "tf_set_basis: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    free_eri(ctx);
+    free_basis(ctx);
+    std::string msg = tf::build_basis(ctx->bs, n_ao_cart, origin, lmn, prim_off, exps, coefs_raw);
+    if (!msg.empty()) TF_FAIL(ctx, msg.find("aligned") != std::string::npos ? TF_EGEOM : TF_EINVAL, "%s", msg.c_str());
+    const tf::Basis &bs = ctx->bs;
+    std::vector<DShell> hs(bs.shells.size());
+    for (size_t i = 0; i < hs.size(); ++i) hs[i] = {bs.shells[i].L, bs.shells[i].ncomp, bs.shells[i].comp_off, bs.shells[i].cart_off};
+    std::vector<DPair> hp(bs.pairs.size());
+    for (size_t i = 0; i < hp.size(); ++i) {
+        const tf::Pair &p = bs.pairs[i];
+        hp[i] = {p.A, p.B, p.La, p.Lb, p.npp, p.pp_off, p.nE, 0, p.e_off};
+    }
+    std::vector<double> boys;
+    tf::boys_table(boys);
+    DShell *d_sh; DPair *d_pr; int8_t *d_lx, *d_ly, *d_lz; double *d_sc, *d_p, *d_Pz, *d_K, *d_E, *d_boys;
+    int rc;
+    if ((rc = upload(ctx, hs, &d_sh)) || (rc = upload(ctx, hp, &d_pr)) || (rc = upload(ctx, bs.c_lx, &d_lx)) ||
+        (rc = upload(ctx, bs.c_ly, &d_ly)) || (rc = upload(ctx, bs.c_lz, &d_lz)) || (rc = upload(ctx, bs.c_scale, &d_sc)) ||
+        (rc = upload(ctx, bs.pp_p, &d_p)) || (rc = upload(ctx, bs.pp_Pz, &d_Pz)) || (rc = upload(ctx, bs.pp_K, &d_K)) ||
+        (rc = upload(ctx, bs.epool, &d_E)) || (rc = upload(ctx, boys, &d_boys)))
+        return rc;
+    ctx->db = DBasis{d_sh, d_pr, d_lx, d_ly, d_lz, d_sc, d_p, d_Pz, d_K, d_E, d_boys};
+    ctx->have_basis = true;
+    return TF_OK;
+}
+
+int tf_get_norms(const tf_ctx *ctx, double *norm, double *coefs_normalised)
+{
+    if (!ctx || !ctx->have_basis) return TF_EINVAL;
+    if (norm) std::copy(ctx->bs.ao_norm.begin(), ctx->bs.ao_norm.end(), norm);
+    if (coefs_normalised) std::copy(ctx->bs.ao_coef.begin(), ctx->bs.ao_coef.end(), coefs_normalised);
+    return TF_OK;
+}
+
+int tf_dims(const tf_ctx *ctx, int *n_cart, int *n_sph, int *n_shell)
+{
+    if (!ctx || !ctx->have_basis) return TF_EINVAL;
+    if (n_cart) *n_cart = ctx->bs.n_cart;
+    if (n_sph) *n_sph = ctx->bs.n_sph;
+    if (n_shell) *n_shell = (int)ctx->bs.shells.size();
+    return TF_OK;
+}
+
+int tf_get_sph_matrix(const tf_ctx *ctx, double *U)
+{
+    if (!ctx || !ctx->have_basis || !U) return TF_EINVAL;
+    std::vector<double> u;
+    tf::dense_sph_matrix(ctx->bs, u);
+    std::copy(u.begin(), u.end(), U);
+    return TF_OK;
+}
+
+// AO-level CSR of U (or identity for Cartesian output) on the device
+static int upload_csr(tf_ctx *ctx, int spherical)
+{
+    const tf::Basis &bs = ctx->bs;
+    std::vector<int> ptr{0}, idx;
+    std::vector<double> val;
+    if (spherical) {
+        std::vector<double> blk;
+        for (const auto &sh : bs.shells) {
+            tf::sph_block(sh.L, blk);
+            for (int r = 0; r < sh.nsph; ++r) {
+                for (int c = 0; c < sh.ncomp; ++c) {
+                    const double v = blk[(size_t)r * sh.ncomp + c];
+                    if (v != 0.0) { idx.push_back(sh.cart_off + c); val.push_back(v); }
+                }
+                ptr.push_back((int)idx.size());
+            }
+        }
+    } else {
+        for (int i = 0; i < bs.n_cart; ++i) { idx.push_back(i); val.push_back(1.0); ptr.push_back(i + 1); }
+    }
+    for (void *p : {(void *)ctx->d_csr_ptr, (void *)ctx->d_csr_idx, (void *)ctx->d_csr_val})
+        if (p) (void)hipFree(p);
+    int rc;
+    if ((rc = upload(ctx, ptr, &ctx->d_csr_ptr, false)) || (rc = upload(ctx, idx, &ctx->d_csr_idx, false)) ||
+        (rc = upload(ctx, val, &ctx->d_csr_val, false)))
+        return rc;
+    ctx->csr_rows = (int)ptr.size() - 1;
+    return TF_OK;
+}
+
+static double seconds_between(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms * 1e-3;
+}
+
+int tf_build_eri(tf_ctx *ctx, int spherical)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_basis) TF_FAIL(ctx, TF_EINVAL, "tf_build_eri: call tf_set_basis first");
+    const tf::Basis &bs = ctx->bs;
+    if (spherical && !bs.all_full)
+        TF_FAIL(ctx, TF_EINVAL, "spherical output needs complete shells in canonical Cartesian order (use CARTHARM / spherical=0)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    free_eri(ctx);
+    DBG("build_eri start");
+    int rc = upload_csr(ctx, spherical);
+    if (rc) return rc;
+    DBG("csr uploaded");
+    const int Nc = bs.n_cart, N = spherical ? bs.n_sph : bs.n_cart, ld = (N + 1) & ~1;
+    ctx->spherical = spherical; ctx->N = N; ctx->ld = ld;
+    const int npairs = (int)bs.pairs.size();
+
+    // ---- which bra shell pairs (= row blocks) belong to this rank: longest-processing-time on row counts
+    auto out_dim = [&](const tf::Shell &s) { return spherical ? s.nsph : s.ncomp; };
+    auto out_off = [&](const tf::Shell &s) { return spherical ? s.sph_off : s.cart_off; };
+    std::vector<long long> pair_rows(npairs);
+    for (int p = 0; p < npairs; ++p) {
+        const tf::Shell &a = bs.shells[bs.pairs[p].A], &b = bs.shells[bs.pairs[p].B];
+        pair_rows[p] = (bs.pairs[p].A == bs.pairs[p].B) ? (long long)out_dim(a) * (out_dim(a) + 1) / 2
+                                                        : (long long)out_dim(a) * out_dim(b);
+    }
+    std::vector<int> order(npairs);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return pair_rows[x] > pair_rows[y]; });
+    std::vector<long long> load(ctx->world, 0);
+    std::vector<char> mine(npairs, 0);
+    for (int p : order) {
+        int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[r] += pair_rows[p];
+        if (r == ctx->rank) mine[p] = 1;
+    }
+    ctx->my_pairs.clear();
+    for (int p = 0; p < npairs; ++p)
+        if (mine[p]) ctx->my_pairs.push_back(p);
+
+    // ---- row tables
+    std::vector<int2> row_ij;
+    std::vector<int> rowmap((size_t)N * (N + 1) / 2, -1);
+    std::vector<long long> pair_first_row(npairs, -1);
+    for (int p : ctx->my_pairs) {
+        const tf::Shell &a = bs.shells[bs.pairs[p].A], &b = bs.shells[bs.pairs[p].B];
+        pair_first_row[p] = (long long)row_ij.size();
+        for (int x = 0; x < out_dim(a); ++x)
+            for (int y = 0; y < out_dim(b); ++y) {
+                const int i = out_off(a) + x, j = out_off(b) + y;
+                if (i < j) continue;
+                rowmap[(size_t)i * (i + 1) / 2 + j] = (int)row_ij.size();
+                row_ij.push_back(make_int2(i, j));
+            }
+    }
+    ctx->n_rows = (long long)row_ij.size();
+    const long long row_len = (long long)N * ld;
+    if (ctx->n_rows > 0x7fffffffLL) TF_FAIL(ctx, TF_EINVAL, "too many tensor rows for this build");
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_eri, std::max<size_t>(1, (size_t)ctx->n_rows * row_len * sizeof(double))));
+    if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
+
+    DBG("rows=%lld N=%d ld=%d", ctx->n_rows, N, ld);
+    // ---- slabs of bra pairs: Cartesian block -> ket transform -> bra transform -> tensor rows
+    size_t slab_bytes = (size_t)1 << 30;
+    if (const char *e = getenv("TF_SLAB_MB")) slab_bytes = (size_t)std::max(1, atoi(e)) << 20;
+    const size_t cart_row_bytes = (size_t)Nc * Nc * sizeof(double);
+    long long max_rows_c = std::max<long long>(1, (long long)(slab_bytes / cart_row_bytes));
+    long long biggest = 1;
+    for (int p : ctx->my_pairs)
+        biggest = std::max<long long>(biggest, (long long)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp);
+    max_rows_c = std::max(max_rows_c, biggest);
+    double *d_C = nullptr, *d_T1 = nullptr, *d_T2 = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_C, (size_t)max_rows_c * Nc * Nc * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&d_T1, (size_t)max_rows_c * Nc * N * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&d_T2, (size_t)max_rows_c * N * ld * sizeof(double)));
+    hipEvent_t ev[5];
+    for (auto &e : ev) HIPCHK(ctx, hipEventCreate(&e));
+    double t_stage[4] = {0, 0, 0, 0};
+    long long n_quart = 0, n_primq = 0, n_compq = 0;
+    long long tot_pp = 0, tot_comp = 0;
+    for (int p = 0; p < npairs; ++p) {
+        tot_pp += bs.pairs[p].npp;
+        tot_comp += (long long)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
+    }
+    auto t_wall0 = std::chrono::steady_clock::now();
+    size_t cursor = 0;
+    int *d_bra = nullptr; long long *d_braoff = nullptr; OutRow *d_out = nullptr;
+    while (cursor < ctx->my_pairs.size()) {
+        std::vector<int> bra; std::vector<long long> braoff; std::vector<OutRow> outs;
+        long long rows_c = 0;
+        while (cursor < ctx->my_pairs.size()) {
+            const int p = ctx->my_pairs[cursor];
+            const tf::Shell &a = bs.shells[bs.pairs[p].A], &b = bs.shells[bs.pairs[p].B];
+            const long long nr = (long long)a.ncomp * b.ncomp;
+            if (!bra.empty() && (rows_c + nr > max_rows_c || bra.size() >= 65535)) break;
+            bra.push_back(p); braoff.push_back(rows_c);
+            long long r = pair_first_row[p];
+            for (int x = 0; x < out_dim(a); ++x)
+                for (int y = 0; y < out_dim(b); ++y) {
+                    const int i = out_off(a) + x, j = out_off(b) + y;
+                    if (i < j) continue;
+                    outs.push_back(OutRow{i, j, a.cart_off, b.cart_off, b.ncomp, 0, rows_c, r++});
+                }
+            rows_c += nr;
+            n_quart += npairs;
+            n_primq += (long long)bs.pairs[p].npp * tot_pp;
+            n_compq += nr * tot_comp;
+            ++cursor;
+        }
+        if (d_bra) { (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out); d_bra = nullptr; }
+        if ((rc = upload(ctx, bra, &d_bra, false)) || (rc = upload(ctx, braoff, &d_braoff, false)) ||
+            (rc = upload(ctx, outs, &d_out, false)))
+            return rc;
+        DBG("slab: %zu bra pairs, %lld cart rows, %zu out rows", bra.size(), rows_c, outs.size());
+        HIPCHK(ctx, hipEventRecord(ev[0], 0));
+        hipLaunchKernelGGL(eri_cart_kernel, dim3(npairs, (unsigned)bra.size()), dim3(TF_ERI_THREADS), 0, 0, ctx->db, d_bra,
+                           d_braoff, Nc, d_C);
+        HIPCHK(ctx, hipEventRecord(ev[1], 0));
+        {
+            const long long tot1 = rows_c * Nc * (long long)N;
+            const unsigned g1 = (unsigned)std::min<long long>((tot1 + 255) / 256, 1 << 20);
+            hipLaunchKernelGGL(xform_last_axis, dim3(g1), dim3(256), 0, 0, d_C, d_T1, rows_c * Nc, Nc, N, ctx->d_csr_ptr,
+                               ctx->d_csr_idx, ctx->d_csr_val);
+            const long long tot2 = rows_c * (long long)N * ld;
+            const unsigned g2 = (unsigned)std::min<long long>((tot2 + 255) / 256, 1 << 20);
+            hipLaunchKernelGGL(xform_mid_axis, dim3(g2), dim3(256), 0, 0, d_T1, d_T2, rows_c, Nc, N, ld, ctx->d_csr_ptr,
+                               ctx->d_csr_idx, ctx->d_csr_val);
+        }
+        HIPCHK(ctx, hipEventRecord(ev[2], 0));
+        if (!outs.empty()) {
+            const unsigned gx = (unsigned)std::min<long long>((row_len + 255) / 256, 4096);
+            for (size_t o0 = 0; o0 < outs.size(); o0 += 65535) {
+                const unsigned ny = (unsigned)std::min<size_t>(65535, outs.size() - o0);
+                hipLaunchKernelGGL(xform_bra_store, dim3(gx, ny), dim3(256), 0, 0, d_T2, ctx->d_eri, d_out + o0, row_len,
+                                   ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val);
+            }
+        }
+        HIPCHK(ctx, hipEventRecord(ev[3], 0));
+        DBG("slab launched");
+        HIPCHK(ctx, hipEventSynchronize(ev[3]));
+        DBG("slab done");
+        HIPCHK(ctx, hipGetLastError());
+        t_stage[1] += seconds_between(ev[0], ev[1]);
+        t_stage[2] += seconds_between(ev[1], ev[2]);
+        t_stage[3] += seconds_between(ev[2], ev[3]);
+    }
+    if (d_bra) { (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out); }
+    HIPCHK(ctx, hipDeviceSynchronize());
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    (void)hipFree(d_C); (void)hipFree(d_T1); (void)hipFree(d_T2);
+    t_stage[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall0).count();
+    std::copy(t_stage, t_stage + 4, ctx->eri_seconds);
+    ctx->eri_counts[0] = n_quart; ctx->eri_counts[1] = n_primq; ctx->eri_counts[2] = n_compq;
+
+    // ---- J/K scratch
+    const size_t nn = (size_t)N * N;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Kp, std::max<size_t>(1, (size_t)ctx->n_rows) * 2 * ld * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Ppad, (size_t)N * ld * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_J, nn * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_K, nn * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_P, nn * sizeof(double)));
+    ctx->have_eri = true;
+    return TF_OK;
+}
+
+int tf_eri_storage(const tf_ctx *ctx, int64_t *bytes, int64_t *n_rows, int32_t *n, int32_t *ld)
+{
+    if (!ctx || !ctx->have_eri) return TF_EINVAL;
+    if (bytes) *bytes = (int64_t)ctx->n_rows * ctx->N * ctx->ld * (int64_t)sizeof(double);
+    if (n_rows) *n_rows = ctx->n_rows;
+    if (n) *n = ctx->N;
+    if (ld) *ld = ctx->ld;
+    return TF_OK;
+}
+
+int tf_eri_timings(const tf_ctx *ctx, double *s4)
+{
+    if (!ctx || !s4) return TF_EINVAL;
+    std::copy(ctx->eri_seconds, ctx->eri_seconds + 4, s4);
+    return TF_OK;
+}
+
+int tf_eri_counts(const tf_ctx *ctx, int64_t *c3)
+{
+    if (!ctx || !c3) return TF_EINVAL;
+    for (int i = 0; i < 3; ++i) c3[i] = ctx->eri_counts[i];
+    return TF_OK;
+}
+
+int tf_copy_eri(tf_ctx *ctx, double *host_out)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri || !host_out) TF_FAIL(ctx, TF_EINVAL, "tf_copy_eri: no tensor built / null output");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t total = (size_t)ctx->N * ctx->N * ctx->N * ctx->N;
+    double *d_dense = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_dense, total * sizeof(double)));
+    const unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(expand_dense_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N, ctx->ld, d_dense);
+    hipError_t e = hipMemcpy(host_out, d_dense, total * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_dense);
+    HIPCHK(ctx, e);
+    return TF_OK;
+}
+
+int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri || !idx || !values || n_idx < 0) TF_FAIL(ctx, TF_EINVAL, "tf_sample_eri: bad arguments");
+    for (int64_t q = 0; q < 4 * n_idx; ++q)
+        if (idx[q] < 0 || idx[q] >= ctx->N) TF_FAIL(ctx, TF_EINVAL, "tf_sample_eri: index out of range");
+    if (n_idx == 0) return TF_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int *d_idx = nullptr; double *d_val = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_idx, (size_t)n_idx * 4 * sizeof(int)));
+    HIPCHK(ctx, hipMalloc((void **)&d_val, (size_t)n_idx * sizeof(double)));
+    HIPCHK(ctx, hipMemcpy(d_idx, idx, (size_t)n_idx * 4 * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N,
+                       ctx->ld, (long long)n_idx, d_idx, d_val);
+    hipError_t e = hipMemcpy(values, d_val, (size_t)n_idx * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_idx); (void)hipFree(d_val);
+    HIPCHK(ctx, e);
+    return TF_OK;
+}
+
+// ---- J/K ------------------------------------------------------------------------------------------
+
+static int launch_jk(tf_ctx *ctx, const double *dP, double *dJ, double *dK, hipStream_t st)
+{
+    const int N = ctx->N, ld = ctx->ld;
+    const double *Ppad = dP;
+    if (ld != N) {
+        hipLaunchKernelGGL(pad_matrix_kernel, dim3((N * ld + 255) / 256), dim3(256), 0, st, dP, ctx->d_Ppad, N, ld);
+        Ppad = ctx->d_Ppad;
+    }
+    if (ctx->n_rows > 0) {
+        const size_t smem = (size_t)(2 * N + 4 * TF_JK_THREADS) * sizeof(double);
+        const int npair = ld / 2;
+        const dim3 grid((unsigned)ctx->n_rows), block(TF_JK_THREADS);
+        if (npair <= TF_JK_THREADS)
+            hipLaunchKernelGGL(jk_rows_kernel<1>, grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, N, ld, Ppad, ctx->d_Jrow, ctx->d_Kp);
+        else if (npair <= 2 * TF_JK_THREADS)
+            hipLaunchKernelGGL(jk_rows_kernel<2>, grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, N, ld, Ppad, ctx->d_Jrow, ctx->d_Kp);
+        else if (npair <= 4 * TF_JK_THREADS)
+            hipLaunchKernelGGL(jk_rows_kernel<4>, grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, N, ld, Ppad, ctx->d_Jrow, ctx->d_Kp);
+        else
+            TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the J/K kernel's row length limit (2048)", N);
+    }
+    hipLaunchKernelGGL(jk_reduce_kernel, dim3((N + 127) / 128, N), dim3(128), 0, st, ctx->d_Jrow, ctx->d_Kp, ctx->d_rowmap, N, ld,
+                       dJ, dK);
+    return TF_OK;
+}
+
+int tf_fock_jk_device(tf_ctx *ctx, int n_dens, const double *dP, double *dJ, double *dK, void *stream)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: call tf_build_eri first");
+    if (n_dens < 1 || !dP || !dJ || !dK) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: bad arguments");
+    const size_t nn = (size_t)ctx->N * ctx->N;
+    for (int d = 0; d < n_dens; ++d) {
+        int rc = launch_jk(ctx, dP + d * nn, dJ + d * nn, dK + d * nn, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return TF_OK;
+}
+
+int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: call tf_build_eri first");
+    if (n_dens < 1 || !P || !J || !K) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)ctx->N * ctx->N;
+    for (int d = 0; d < n_dens; ++d) {
+        HIPCHK(ctx, hipMemcpy(ctx->d_P, P + d * nn, nn * sizeof(double), hipMemcpyHostToDevice));
+        int rc = launch_jk(ctx, ctx->d_P, ctx->d_J, ctx->d_K, 0);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpy(J + d * nn, ctx->d_J, nn * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(K + d * nn, ctx->d_K, nn * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return TF_OK;
+}
+
+// ---- one-electron integrals -------------------------------------------------------------------------
+
+int tf_one_electron(tf_ctx *ctx, int n_atoms, const double *atom_xyz, const double *atom_charge, const double *dipole_origin,
+                    int spherical, double *S, double *T, double *V, double *D, double *Q)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_basis) TF_FAIL(ctx, TF_EINVAL, "tf_one_electron: call tf_set_basis first");
+    if (n_atoms < 1 || n_atoms > 2 || !atom_xyz || !atom_charge || !dipole_origin || !S || !T || !V)
+        TF_FAIL(ctx, TF_EINVAL, "tf_one_electron: bad arguments");
+    for (int a = 0; a < n_atoms; ++a)
+        if (atom_xyz[3 * a] != 0.0 || atom_xyz[3 * a + 1] != 0.0)
+            TF_FAIL(ctx, TF_EGEOM, "Molecule is incorrectly aligned! Unable to calculate molecular integrals.");
+    if (spherical && !ctx->bs.all_full) TF_FAIL(ctx, TF_EINVAL, "spherical output needs complete shells");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string msg = tfone::one_electron(ctx->bs, n_atoms, atom_xyz, atom_charge, dipole_origin, spherical, S, T, V, D, Q);
+    if (!msg.empty()) TF_FAIL(ctx, TF_ENODEVICE, "%s", msg.c_str());
+    return TF_OK;
+}
+
+int tf_cross_overlap(tf_ctx *ctx, int n2, const double *origin2, const int32_t *lmn2, const int32_t *prim_off2,
+                     const double *exps2, const double *coefs_raw2, double *S_cross)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_basis) TF_FAIL(ctx, TF_EINVAL, "tf_cross_overlap: call tf_set_basis first");
+    if (n2 < 1 || !origin2 || !lmn2 || !prim_off2 || !exps2 || !coefs_raw2 || !S_cross)
+        TF_FAIL(ctx, TF_EINVAL, "tf_cross_overlap: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    tf::Basis other;
+    std::string msg = tf::build_basis(other, n2, origin2, lmn2, prim_off2, exps2, coefs_raw2);
+    if (!msg.empty()) TF_FAIL(ctx, TF_EINVAL, "%s", msg.c_str());
+    msg = tfone::cross_overlap(ctx->bs, other, S_cross);
+    if (!msg.empty()) TF_FAIL(ctx, TF_ENODEVICE, "%s", msg.c_str());
+    return TF_OK;
+}
+
+int tf_eri_element(tf_ctx *ctx, const double *origin, const int32_t *lmn, const int32_t *prim_off, const double *exps,
+                   const double *coefs_raw, double *value)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!origin || !lmn || !prim_off || !exps || !coefs_raw || !value) TF_FAIL(ctx, TF_EINVAL, "tf_eri_element: null argument");
+    // A throw-away 4-AO context; (b0 b1|b2 b3) is element [0,1,2,3] of its Cartesian tensor.
+    tf_ctx *tmp = tf_create(ctx->device, 0, 1);
+    if (!tmp) TF_FAIL(ctx, TF_ENODEVICE, "%s", g_create_error.c_str());
+    int rc = tf_set_basis(tmp, 4, origin, lmn, prim_off, exps, coefs_raw);
+    if (!rc) rc = tf_build_eri(tmp, 0);
+    const int32_t idx[4] = {0, 1, 2, 3};
+    if (!rc) rc = tf_sample_eri(tmp, 1, idx, value);
+    if (rc) ctx->err = tmp->err;
+    tf_destroy(tmp);
+    return rc;
+}
+
+// ---- SCF --------------------------------------------------------------------------------------------
+
+int tf_orthogonaliser(tf_ctx *ctx, int n, const double *S, double *X, double *S_inv, double *smallest_eig)
+{
+    if (!ctx) return TF_EINVAL;
+    if (n < 1 || !S || !X) TF_FAIL(ctx, TF_EINVAL, "tf_orthogonaliser: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string msg;
+    int rc = tfscf::orthogonaliser(ctx->scf, n, S, X, S_inv, smallest_eig, msg);
+    if (rc) ctx->err = msg;
+    return rc;
+}
+
+int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const double *T, const double *V, const double *Fext,
+               const double *X, const double *P0, double E0, int n_occ, double V_NN, tf_scf_result *out)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_scf_rhf: call tf_build_eri first");
+    if (!opts || !S || !T || !V || !P0 || !out || n_occ < 1 || n_occ > ctx->N) TF_FAIL(ctx, TF_EINVAL, "tf_scf_rhf: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string msg;
+    auto jk = [&](const double *dP, double *dJ, double *dK, hipStream_t st) { return launch_jk(ctx, dP, dJ, dK, st); };
+    int rc = tfscf::run_rhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0, E0, n_occ, V_NN, jk, ctx->world, *out, msg);
+    if (rc) ctx->err = msg;
+    return rc;
+}
+
+}  // extern "C"

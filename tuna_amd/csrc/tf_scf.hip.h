@@ -1,0 +1,450 @@
+// tf_scf.hip.h -- the restricted SCF cycle, resident on the GPU: J/K from the stored tensor (tf_kernels),
+// rocBLAS for the O(N^3) products, rocSOLVER dsyevd for the symmetric eigenproblem; only scalars and the
+// tiny DIIS system touch the host.
+// Reference: run_restricted_SCF_cycle scf:1072-1154, run_self_consistent_field_cycle scf:1292-1435,
+// calculate_DIIS_error scf:879-949, apply_DIIS scf:960-1061, apply_damping scf:763-868,
+// diagonalise_Fock_matrix scf:222-250, construct_density_matrix scf:183-211,
+// calculate_restricted_electronic_energy scf:344-404, calculate_orthogonalisation_matrix kernel:756-816.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/tunafock.h"
+
+namespace tfscf {
+
+struct Workspace {
+    rocblas_handle blas = nullptr;
+    int n = 0;
+    double *pool = nullptr;      // all N x N device matrices live in one allocation
+    size_t pool_doubles = 0;
+    double *d_scal = nullptr;    // small device scalar array
+    rocblas_int *d_info = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+inline void release(Workspace &w)
+{
+    if (w.pool) (void)hipFree(w.pool);
+    if (w.d_scal) (void)hipFree(w.d_scal);
+    if (w.d_info) (void)hipFree(w.d_info);
+    if (w.blas) (void)rocblas_destroy_handle(w.blas);
+    if (w.ev0) (void)hipEventDestroy(w.ev0);
+    if (w.ev1) (void)hipEventDestroy(w.ev1);
+    w = Workspace();
+}
+
+#define TFS_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (call);                                                                         \
+        if (_e != hipSuccess) { msg = std::string(#call) + " failed: " + hipGetErrorString(_e); return TF_ENODEVICE; } \
+    } while (0)
+#define TFS_BLAS(call)                                                                                  \
+    do {                                                                                                \
+        rocblas_status _s = (call);                                                                     \
+        if (_s != rocblas_status_success) { msg = std::string(#call) + " failed (rocBLAS/rocSOLVER status " + std::to_string((int)_s) + ")"; return TF_ELINALG; } \
+    } while (0)
+
+inline int ensure(Workspace &w, int n, int n_mats, std::string &msg)
+{
+    if (!w.blas) {
+        TFS_BLAS(rocblas_create_handle(&w.blas));
+        TFS_HIP(hipMalloc((void **)&w.d_scal, 64 * sizeof(double)));
+        TFS_HIP(hipMalloc((void **)&w.d_info, sizeof(rocblas_int)));
+        TFS_HIP(hipEventCreate(&w.ev0));
+        TFS_HIP(hipEventCreate(&w.ev1));
+    }
+    const size_t need = (size_t)n_mats * n * n + 4 * (size_t)n;
+    if (need > w.pool_doubles) {
+        if (w.pool) (void)hipFree(w.pool);
+        w.pool = nullptr; w.pool_doubles = 0;
+        TFS_HIP(hipMalloc((void **)&w.pool, need * sizeof(double)));
+        w.pool_doubles = need;
+    }
+    w.n = n;
+    return TF_OK;
+}
+
+// ---- small element-wise kernels -------------------------------------------------------------------
+
+__global__ void k_symmetrise(const double *__restrict__ in, double *__restrict__ out, int n)   // tuna_util.py:762
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e / n, j = e - i * n;
+    out[e] = (1.0 / 2.0) * (in[e] + in[(size_t)j * n + i]);
+}
+
+// F = H + J - 1/2 * hfx * K   (scf:525), then symmetrised by k_symmetrise
+__global__ void k_fock(const double *__restrict__ H, const double *__restrict__ J, const double *__restrict__ K, double hfx,
+                       double *__restrict__ F, int nn)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nn) F[e] = H[e] + J[e] - (1.0 / 2.0) * K[e] * hfx;
+}
+
+__global__ void k_axpby(double a, const double *__restrict__ x, double b, const double *__restrict__ y, double *__restrict__ out, int nn)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nn) out[e] = a * x[e] + b * y[e];
+}
+
+__global__ void k_scale_cols(const double *__restrict__ V, const double *__restrict__ s, int mode, double *__restrict__ out, int n)
+{
+    // out[i][k] = V[i][k] * f(s[k]);  mode 0: s^-1/2, mode 1: 1/s     (row-major V, eigenvector k in column k)
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * n) return;
+    const int k = e % n;
+    out[e] = V[e] * (mode == 0 ? 1.0 / sqrt(s[k]) : 1.0 / s[k]);
+}
+
+struct Ptr8 { const double *p[8]; double c[8]; };
+__global__ void k_lincomb(Ptr8 a, int m, double *__restrict__ out, int nn)     // F_DIIS = sum_k c_k F_k (scf:1025)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nn) return;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s += a.c[k] * a.p[k][e];
+    out[e] = s;
+}
+
+// res[0] = max |a-b|, res[1] = sum (a-b)^2       (scf:285-286), single block
+__global__ void k_delta_norms(const double *__restrict__ a, const double *__restrict__ b, int nn, double *__restrict__ res)
+{
+    __shared__ double smax[256], ssum[256];
+    double mx = 0.0, sm = 0.0;
+    for (int e = threadIdx.x; e < nn; e += 256) {
+        const double d = a[e] - b[e];
+        mx = fmax(mx, fabs(d));
+        sm += d * d;
+    }
+    smax[threadIdx.x] = mx; ssum[threadIdx.x] = sm;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]); ssum[threadIdx.x] += ssum[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { res[0] = smax[0]; res[1] = ssum[0]; }
+}
+
+// Mulliken gross atomic populations: res[a] = sum_{i in atom a} (P S)_ii   (scf:789-818), single block
+__global__ void k_mulliken(const double *__restrict__ P, const double *__restrict__ S, int n, int nA, double *__restrict__ res)
+{
+    __shared__ double s0[256], s1[256];
+    double a0 = 0.0, a1 = 0.0;
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        const double v = P[e] * S[(size_t)j * n + i];
+        if (i < nA) a0 += v; else a1 += v;
+    }
+    s0[threadIdx.x] = a0; s1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { s0[threadIdx.x] += s0[threadIdx.x + s]; s1[threadIdx.x] += s1[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { res[0] = s0[0]; res[1] = s1[0]; }
+}
+
+// row-major C = alpha * op(A) * op(B) + beta * C, all n x n (k = inner dimension, default n)
+inline rocblas_status gemm_rm(rocblas_handle h, bool tA, bool tB, int n, double alpha, const double *A, const double *B, double beta,
+                              double *C)
+{
+    return rocblas_dgemm(h, tB ? rocblas_operation_transpose : rocblas_operation_none,
+                         tA ? rocblas_operation_transpose : rocblas_operation_none, n, n, n, &alpha, B, n, A, n, &beta, C, n);
+}
+
+// Symmetric eigenproblem: W (in: symmetric matrix, out: row k = eigenvector k in row-major terms), vals ascending.
+inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, std::string &msg)
+{
+    TFS_BLAS(rocsolver_dsyevd(w.blas, rocblas_evect_original, rocblas_fill_upper, n, W, n, vals, work_e, w.d_info));
+    return TF_OK;
+}
+
+// dense solve A x = b for the (m <= 9) DIIS system; false if A is exactly singular (np.linalg.solve -> LinAlgError)
+inline bool small_solve(int m, std::vector<double> A, std::vector<double> b, std::vector<double> &x)
+{
+    for (int c = 0; c < m; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < m; ++r)
+            if (std::fabs(A[r * m + c]) > std::fabs(A[piv * m + c])) piv = r;
+        if (A[piv * m + c] == 0.0 || !std::isfinite(A[piv * m + c])) return false;
+        if (piv != c) {
+            for (int k = 0; k < m; ++k) std::swap(A[c * m + k], A[piv * m + k]);
+            std::swap(b[c], b[piv]);
+        }
+        for (int r = c + 1; r < m; ++r) {
+            const double f = A[r * m + c] / A[c * m + c];
+            if (f == 0.0) continue;
+            for (int k = c; k < m; ++k) A[r * m + k] -= f * A[c * m + k];
+            b[r] -= f * b[c];
+        }
+    }
+    x.assign(m, 0.0);
+    for (int r = m - 1; r >= 0; --r) {
+        double s = b[r];
+        for (int k = r + 1; k < m; ++k) s -= A[r * m + k] * x[k];
+        x[r] = s / A[r * m + r];
+    }
+    return true;
+}
+
+// X = S^-1/2, S^-1, smallest eigenvalue (kernel:756-816).  The reference forms V sqrt(s) V^T and inverts it with
+// LAPACK; here the inverse is applied in the eigenbasis, X = V s^-1/2 V^T, which is the same matrix.
+inline int orthogonaliser_device(Workspace &w, int n, const double *dS, double *dX, double *dSinv, double *smallest, double *scratch,
+                                 std::string &msg)
+{
+    const int nn = n * n, g = (nn + 255) / 256;
+    double *W = scratch, *Vs = scratch + nn, *vals = scratch + 2 * (size_t)nn, *e = vals + n;
+    hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, dS, W, n);
+    int rc = eigh(w, n, W, vals, e, msg);
+    if (rc) return rc;
+    std::vector<double> hv(n);
+    TFS_HIP(hipMemcpy(hv.data(), vals, n * sizeof(double), hipMemcpyDeviceToHost));
+    double mn = hv[0];
+    for (double v : hv) mn = std::min(mn, v);
+    if (smallest) *smallest = mn;
+    if (mn < 0) { msg = "A negative overlap matrix eigenvalue was found!"; return TF_ELINALG; }
+    // W holds V^T in row-major terms (row k = eigenvector k).  X = V f(s) V^T = (W^T diag) W
+    // scale rows of W: Vs[k][i] = W[k][i] * f(s_k)  == scale "columns" of W^T
+    for (int mode = 0; mode < 2; ++mode) {
+        double *out = mode == 0 ? dX : dSinv;
+        if (!out) continue;
+        // Vs = diag(f(s)) W  -> use k_scale_cols on the transposed view: element e=(k,i) scaled by s[k]: need row scaling
+        // row scaling = column scaling of the transpose; do it with a gemm-free kernel on W^T:
+        // form Wt = W^T, scale columns, then X = Wt_scaled * W
+        double one = 1.0, zero = 0.0;
+        TFS_BLAS(rocblas_dgeam(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, &one, W, n, &zero, W, n, Vs, n));
+        hipLaunchKernelGGL(k_scale_cols, dim3(g), dim3(256), 0, 0, Vs, vals, mode, Vs, n);
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, Vs, W, 0.0, out));
+    }
+    return TF_OK;
+}
+
+inline int orthogonaliser(Workspace &w, int n, const double *S, double *X, double *S_inv, double *smallest, std::string &msg)
+{
+    int rc = ensure(w, n, 6, msg);
+    if (rc) return rc;
+    const size_t nn = (size_t)n * n;
+    double *dS = w.pool, *dX = dS + nn, *dSi = dX + nn, *scr = dSi + nn;
+    TFS_HIP(hipMemcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
+    rc = orthogonaliser_device(w, n, dS, dX, S_inv ? dSi : nullptr, smallest, scr, msg);
+    if (rc) return rc;
+    TFS_HIP(hipMemcpy(X, dX, nn * sizeof(double), hipMemcpyDeviceToHost));
+    if (S_inv) TFS_HIP(hipMemcpy(S_inv, dSi, nn * sizeof(double), hipMemcpyDeviceToHost));
+    return TF_OK;
+}
+
+using JKFn = std::function<int(const double *, double *, double *, hipStream_t)>;
+
+inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, const double *T, const double *V, const double *Fext,
+                   const double *X, const double *P0, double E0, int n_occ, double V_NN, const JKFn &jk, int world,
+                   tf_scf_result &out, std::string &msg)
+{
+    if (world != 1) { msg = "tf_scf_rhf runs on one GPU; use tuna_amd.scf (torch.distributed all-reduce) for sharded tensors"; return TF_EINVAL; }
+    const int max_diis = std::max(1, std::min(8, (int)o.max_diis));
+    const int n_mats = 20 + 2 * max_diis;
+    int rc = ensure(w, n, n_mats, msg);
+    if (rc) return rc;
+    const size_t nn = (size_t)n * n;
+    const int g = (int)((nn + 255) / 256);
+    auto t_wall = std::chrono::steady_clock::now();
+    double *base = w.pool;
+    auto mat = [&](int k) { return base + (size_t)k * nn; };
+    double *dS = mat(0), *dH = mat(1), *dX = mat(2), *dP = mat(3), *dPold = mat(4), *dPbd = mat(5), *dPvold = mat(6), *dPoldbd = mat(7);
+    double *dF = mat(8), *dJ = mat(9), *dK = mat(10), *dT = mat(11), *dV = mat(12), *dFx = mat(13), *t1 = mat(14), *t2 = mat(15);
+    double *dC = mat(16), *dW = mat(17), *dPn = mat(18), *scr = mat(19);
+    double *hist = mat(20);
+    double *vals = base + (size_t)n_mats * nn, *ework = vals + n;
+    auto histF = [&](int k) { return hist + (size_t)(2 * k) * nn; };
+    auto histE = [&](int k) { return hist + (size_t)(2 * k + 1) * nn; };
+
+    TFS_HIP(hipMemcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(hipMemcpy(dT, T, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(hipMemcpy(dV, V, nn * sizeof(double), hipMemcpyHostToDevice));
+    if (Fext) TFS_HIP(hipMemcpy(dFx, Fext, nn * sizeof(double), hipMemcpyHostToDevice));
+    else TFS_HIP(hipMemset(dFx, 0, nn * sizeof(double)));
+    TFS_HIP(hipMemcpy(dP, P0, nn * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dT, 1.0, dV, dH, (int)nn);      // H = T + V (+ field)
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dH, 1.0, dFx, dH, (int)nn);
+    if (X) TFS_HIP(hipMemcpy(dX, X, nn * sizeof(double), hipMemcpyHostToDevice));
+    else {
+        double sm = 0;
+        rc = orthogonaliser_device(w, n, dS, dX, nullptr, &sm, scr - 0 /*uses scr..*/, msg);
+        if (rc) return rc;
+    }
+    TFS_HIP(hipMemset(dPold, 0, nn * sizeof(double)));
+    TFS_HIP(hipMemset(dPbd, 0, nn * sizeof(double)));
+    TFS_HIP(hipMemset(dPvold, 0, nn * sizeof(double)));
+    TFS_HIP(hipMemset(dPoldbd, 0, nn * sizeof(double)));
+
+    TFS_BLAS(rocblas_set_pointer_mode(w.blas, rocblas_pointer_mode_host));
+    auto dot = [&](const double *a, const double *b, double *res) { return rocblas_ddot(w.blas, (int)nn, a, 1, b, 1, res); };
+
+    // diagonalise F (AO) -> eps, C ; P = 2 C_occ C_occ^T symmetrised      (scf:222-250, 183-211)
+    auto diag_density = [&](const double *Fao, double *Pout) -> int {
+        TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, Fao, 0.0, t1));     // X^T F
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));     // (X^T F) X
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+        auto te = std::chrono::steady_clock::now();
+        int r = eigh(w, n, dW, vals, ework, msg);
+        if (r) return r;
+        TFS_HIP(hipDeviceSynchronize());
+        out.eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - te).count();
+        TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));      // C = X V   (dW rows = eigenvectors)
+        const double two = 2.0, zero = 0.0;
+        // col-major view of dC is C^T: P = sum_{k<nocc} C[:,k] C[:,k]^T = M[:nocc,:]^T M[:nocc,:]
+        TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, n_occ, &two, dC, n, dC, n, &zero, t1, n));
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, Pout, n);
+        return TF_OK;
+    };
+
+    std::vector<double> B((size_t)max_diis * max_diis, 0.0);
+    int n_hist = 0;
+    double E = E0, E_old = E0, commutator = 1.0;
+    double comps[7] = {0, 0, 0, 0, 0, 0, 0};
+    out.fock_seconds = 0; out.eig_seconds = 0; out.n_iter = 0; out.converged = 0;
+    const int nA = (o.n_atoms >= 2) ? o.n_atom_ao[0] : n;
+
+    for (int step = 1; step <= o.max_iter; ++step) {
+        E_old = E;
+        // P_very_old = P_old ; P_old_before_damping = P_before_damping ; P_old = P    (scf:1114-1117)
+        std::swap(dPvold, dPold);            // dPvold <- old P_old ; dPold free to be overwritten
+        std::swap(dPoldbd, dPbd);            // dPoldbd <- P_before_damping
+        TFS_HIP(hipMemcpyAsync(dPold, dP, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        // Fock matrix (scf:497-531)
+        TFS_HIP(hipEventRecord(w.ev0, 0));
+        rc = jk(dP, dJ, dK, 0);
+        if (rc) { msg = "J/K launch failed"; return rc; }
+        TFS_HIP(hipEventRecord(w.ev1, 0));
+        hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, 0, dH, dJ, dK, o.hfx, t1, (int)nn);
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, dF, n);
+        // DIIS error e = X^T (F P S - S P F) X   (scf:906-920)
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dF, dP, 0.0, t1));        // F P
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dS, 0.0, t2));        // F P S
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dS, dP, 0.0, t1));        // S P
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, -1.0, t1, dF, 1.0, t2));       // F P S - S P F
+        TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, t2, 0.0, t1));         // X^T e
+        // push into the history (trim to max_diis, scf:943-946)
+        if (n_hist == max_diis) {
+            double *f0 = histF(0), *e0 = histE(0);
+            (void)f0; (void)e0;
+            // rotate: slot k <- slot k+1 by pointer arithmetic is not possible in one pool; copy down
+            for (int k = 0; k + 1 < n_hist; ++k) {
+                TFS_HIP(hipMemcpyAsync(histF(k), histF(k + 1), nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+                TFS_HIP(hipMemcpyAsync(histE(k), histE(k + 1), nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            }
+            for (int r = 0; r + 1 < n_hist; ++r)
+                for (int c = 0; c + 1 < n_hist; ++c) B[r * max_diis + c] = B[(r + 1) * max_diis + c + 1];
+            --n_hist;
+        }
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, histE(n_hist)));   // (X^T e) X
+        TFS_HIP(hipMemcpyAsync(histF(n_hist), dF, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        ++n_hist;
+        double ee = 0.0;
+        for (int k = 0; k < n_hist; ++k) {
+            double d = 0.0;
+            TFS_BLAS(dot(histE(n_hist - 1), histE(k), &d));
+            // the reference stores the error twice (alpha and beta copies, scf:934), hence the factor 2
+            B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = 2.0 * d;
+            if (k == n_hist - 1) ee = d;
+        }
+        commutator = std::sqrt(ee / (double)nn);                                       // scf:918
+        {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, w.ev0, w.ev1);
+            out.fock_seconds += ms * 1e-3;
+        }
+        // diagonalise, new density, energy with the NEW P and the OLD J,K   (scf:1133-1141)
+        rc = diag_density(dF, dPn);
+        if (rc) return rc;
+        double eT, eV, eF, eJ, eK;
+        TFS_BLAS(dot(dPn, dT, &eT));
+        TFS_BLAS(dot(dPn, dV, &eV));
+        TFS_BLAS(dot(dPn, dFx, &eF));
+        TFS_BLAS(dot(dPn, dJ, &eJ));
+        TFS_BLAS(dot(dPn, dK, &eK));
+        comps[0] = eT; comps[1] = eV; comps[2] = (1.0 / 2.0) * eJ; comps[3] = -(1.0 / 4.0) * eK * o.hfx; comps[4] = 0.0;
+        comps[5] = eF; comps[6] = 0.0;
+        E = comps[0] + comps[1] + comps[2] + comps[3] + comps[4] + comps[5] + comps[6];
+        if (out.eps) TFS_HIP(hipMemcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (out.C) TFS_HIP(hipMemcpy(out.C, dC, nn * sizeof(double), hipMemcpyDeviceToHost));
+        // DIIS extrapolation (scf:991-1059)
+        double *Pcur = dPn;
+        if (step > 2 && o.use_diis && commutator < 0.3) {
+            const int m = n_hist + 1;
+            std::vector<double> A((size_t)m * m, 0.0), rhs(m, 0.0), x;
+            for (int r = 0; r < n_hist; ++r) {
+                for (int c = 0; c < n_hist; ++c) A[r * m + c] = B[r * max_diis + c];
+                A[r * m + n_hist] = -1.0; A[n_hist * m + r] = -1.0;
+            }
+            rhs[n_hist] = -1.0;
+            if (small_solve(m, A, rhs, x)) {
+                Ptr8 a;
+                for (int k = 0; k < 8; ++k) { a.p[k] = histF(0); a.c[k] = 0.0; }
+                for (int k = 0; k < n_hist; ++k) { a.p[k] = histF(k); a.c[k] = x[k]; }
+                hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, 0, a, n_hist, scr, (int)nn);
+                rc = diag_density(scr, dPn);     // overwrites dC/vals: results were copied out above
+                if (rc) return rc;
+            } else {
+                n_hist = 0;                        // "Resetting DIIS", scf:1042-1048
+            }
+        }
+        // P_before_damping = P ; damping (scf:763-868)
+        TFS_HIP(hipMemcpyAsync(dPbd, Pcur, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        double damp = 0.0;
+        if (o.damping == 2) damp = o.damping_factor;
+        else if (o.damping == 1 && commutator > 0.01 && step > 1) {
+            double pop[4][2];
+            const double *dens[4] = {dPbd, dPold, dPoldbd, dPvold};   // A_n_out, A_n1_in, A_n1_out, A_n2_in
+            for (int q = 0; q < 4; ++q) {
+                hipLaunchKernelGGL(k_mulliken, dim3(1), dim3(256), 0, 0, dens[q], dS, n, nA, w.d_scal + 2 * q);
+            }
+            TFS_HIP(hipMemcpy(&pop[0][0], w.d_scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
+            if (o.n_atoms < 2) { for (int q = 0; q < 4; ++q) pop[q][1] = 0.0; }
+            double den[2], alpha[2] = {0.0, 0.0};
+            for (int a = 0; a < 2; ++a) den[a] = pop[0][a] - pop[2][a] - pop[1][a] + pop[3][a];
+            if (den[0] != 0.0 && den[1] != 0.0)
+                for (int a = 0; a < 2; ++a) alpha[a] = (pop[0][a] - pop[2][a]) / den[a];
+            if (o.n_atoms >= 2) {
+                const double r0 = o.n_atom_ao[0], r1 = o.n_atom_ao[1];
+                damp = (alpha[0] * r0 + alpha[1] * r1) / (r0 + r1);
+            } else damp = alpha[0] * o.n_atom_ao[0];
+            damp = std::max(damp, 0.0);
+            damp = (damp < std::min(o.max_damping, 1.0)) ? damp : o.max_damping;
+        }
+        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, damp, dPold, 1.0 - damp, dPbd, dP, (int)nn);
+        // changes and convergence (scf:261-333)
+        hipLaunchKernelGGL(k_delta_norms, dim3(1), dim3(256), 0, 0, dP, dPold, (int)nn, w.d_scal + 16);
+        double res[2];
+        TFS_HIP(hipMemcpy(res, w.d_scal + 16, 2 * sizeof(double), hipMemcpyDeviceToHost));
+        const double dE = E - E_old, maxDP = res[0], rmsDP = std::sqrt(res[1] / (double)nn);
+        out.n_iter = step;
+        if (out.table) {
+            double *row = out.table + (size_t)(step - 1) * 7;
+            row[0] = step; row[1] = E + V_NN; row[2] = dE; row[3] = rmsDP; row[4] = maxDP; row[5] = commutator; row[6] = damp;
+        }
+        if (std::fabs(dE) < o.conv_delta_E && std::fabs(maxDP) < o.conv_max_DP && std::fabs(rmsDP) < o.conv_rms_DP &&
+            std::fabs(commutator) < o.conv_commutator) {
+            out.converged = 1;
+            break;
+        }
+    }
+    out.energy = E + V_NN;
+    std::memcpy(out.components, comps, sizeof(comps));
+    if (out.P) TFS_HIP(hipMemcpy(out.P, dP, nn * sizeof(double), hipMemcpyDeviceToHost));
+    if (out.F) TFS_HIP(hipMemcpy(out.F, dF, nn * sizeof(double), hipMemcpyDeviceToHost));
+    out.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall).count();
+    if (!out.converged) { msg = "Self-consistent field not converged in " + std::to_string(o.max_iter) + " iterations! Increase maximum iterations or give up."; return TF_ENOTCONV; }
+    return TF_OK;
+}
+
+}  // namespace tfscf

@@ -1,0 +1,188 @@
+"""Engine -- one context of libtunafock per process/GPU: basis set-up, device-resident ERI tensor,
+Fock builds and the native RHF cycle.  Thin: every numerical step happens in the HIP library."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ScfOpts, ScfResult, TunaError, f64, i32, ptr
+from .molecule import AOList
+
+# SCF convergence thresholds (tuna_util.py:109-116)
+SCF_CONVERGENCE = {
+    "loose": {"delta_E": 0.000001, "max_DP": 0.00001, "RMS_DP": 0.000001, "commutator": 0.0001, "name": "loose"},
+    "medium": {"delta_E": 0.0000001, "max_DP": 0.000001, "RMS_DP": 0.0000001, "commutator": 0.00001, "name": "medium"},
+    "tight": {"delta_E": 0.000000001, "max_DP": 0.00000001, "RMS_DP": 0.000000001, "commutator": 0.0000001, "name": "tight"},
+    "extreme": {"delta_E": 0.00000000001, "max_DP": 0.0000000001, "RMS_DP": 0.00000000001, "commutator": 0.000000001,
+                "name": "extreme"},
+}
+
+
+class Engine:
+    def __init__(self, device: int = 0, rank: int = 0, world: int = 1):
+        self._L = _lib.lib()
+        self._ctx = self._L.tf_create(int(device), int(rank), int(world))
+        if not self._ctx:
+            raise TunaError(self._L.tf_last_error(None).decode(), -2)
+        self.device, self.rank, self.world = device, rank, world
+        self.aos: AOList | None = None
+        self.n_cart = self.n_sph = self.n_shell = 0
+        self.N = 0
+        self.spherical = True
+
+    # ---- plumbing --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.tf_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise TunaError(self._L.tf_last_error(self._ctx).decode(), rc)
+
+    # ---- basis -----------------------------------------------------------------------------
+    def set_basis(self, aos: AOList):
+        self.aos = aos
+        self._keep = (f64(aos.origin), i32(aos.lmn), i32(aos.prim_off), f64(aos.exps), f64(aos.coefs))
+        o, l, p, e, c = self._keep
+        self._check(self._L.tf_set_basis(self._ctx, aos.n, ptr(o), ptr(l), ptr(p), ptr(e), ptr(c)))
+        a, b, s = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.tf_dims(self._ctx, a, b, s))
+        self.n_cart, self.n_sph, self.n_shell = a.value, b.value, s.value
+        return self
+
+    def norms(self):
+        norm = np.zeros_like(self.aos.exps)
+        coef = np.zeros_like(self.aos.exps)
+        self._check(self._L.tf_get_norms(self._ctx, ptr(norm), ptr(coef)))
+        return norm, coef
+
+    def sph_matrix(self) -> np.ndarray:
+        U = np.zeros((self.n_sph, self.n_cart))
+        self._check(self._L.tf_get_sph_matrix(self._ctx, ptr(U)))
+        return U
+
+    # ---- one-electron ------------------------------------------------------------------------
+    def one_electron(self, atom_xyz, atom_charge, dipole_origin, spherical: bool = True):
+        n = self.n_sph if spherical else self.n_cart
+        xyz, chg, org = f64(np.asarray(atom_xyz).reshape(-1, 3)), f64(atom_charge), f64(dipole_origin)
+        S, T, V = np.zeros((n, n)), np.zeros((n, n)), np.zeros((n, n))
+        D, Q = np.zeros((3, n, n)), np.zeros((3, n, n))
+        self._check(self._L.tf_one_electron(self._ctx, len(chg), ptr(xyz), ptr(chg), ptr(org), int(spherical),
+                                            ptr(S), ptr(T), ptr(V), ptr(D), ptr(Q)))
+        return S, T, V, D, Q
+
+    def cross_overlap(self, other: AOList) -> np.ndarray:
+        S = np.zeros((self.n_cart, other.n))
+        o, l, p, e, c = f64(other.origin), i32(other.lmn), i32(other.prim_off), f64(other.exps), f64(other.coefs)
+        self._check(self._L.tf_cross_overlap(self._ctx, other.n, ptr(o), ptr(l), ptr(p), ptr(e), ptr(c), ptr(S)))
+        return S
+
+    # ---- two-electron ------------------------------------------------------------------------
+    def build_eri(self, spherical: bool = True):
+        self._check(self._L.tf_build_eri(self._ctx, int(spherical)))
+        self.spherical = spherical
+        self.N = self.n_sph if spherical else self.n_cart
+        return self
+
+    def eri_storage(self) -> dict:
+        b, r = C.c_int64(), C.c_int64()
+        n, ld = C.c_int32(), C.c_int32()
+        self._check(self._L.tf_eri_storage(self._ctx, b, r, n, ld))
+        return {"bytes": b.value, "rows": r.value, "N": n.value, "ld": ld.value}
+
+    def eri_timings(self) -> dict:
+        t = np.zeros(4)
+        self._check(self._L.tf_eri_timings(self._ctx, ptr(t)))
+        c = np.zeros(3, dtype=np.int64)
+        self._check(self._L.tf_eri_counts(self._ctx, ptr(c)))
+        return {"total_s": t[0], "cart_kernel_s": t[1], "ket_transform_s": t[2], "bra_transform_s": t[3],
+                "shell_quartets": int(c[0]), "primitive_shell_quartets": int(c[1]), "component_quartets": int(c[2])}
+
+    def copy_eri(self, out: np.ndarray | None = None) -> np.ndarray:
+        N = self.N
+        if out is None:
+            out = np.empty((N, N, N, N))
+        assert out.flags.c_contiguous and out.dtype == np.float64 and out.size == N ** 4
+        self._check(self._L.tf_copy_eri(self._ctx, ptr(out)))
+        return out
+
+    def sample_eri(self, idx) -> np.ndarray:
+        idx = i32(idx).reshape(-1, 4)
+        out = np.zeros(len(idx))
+        self._check(self._L.tf_sample_eri(self._ctx, len(idx), ptr(idx), ptr(out)))
+        return out
+
+    def eri_element(self, aos4: AOList) -> float:
+        v = C.c_double()
+        o, l, p, e, c = f64(aos4.origin), i32(aos4.lmn), i32(aos4.prim_off), f64(aos4.exps), f64(aos4.coefs)
+        self._check(self._L.tf_eri_element(self._ctx, ptr(o), ptr(l), ptr(p), ptr(e), ptr(c), C.byref(v)))
+        return v.value
+
+    # ---- Fock build --------------------------------------------------------------------------
+    def fock_jk(self, P: np.ndarray):
+        """J, K for one [N,N] or several [n,N,N] densities (host buffers).  Partial sums when world > 1."""
+        P = f64(P)
+        nd = 1 if P.ndim == 2 else P.shape[0]
+        J, K = np.zeros_like(P), np.zeros_like(P)
+        self._check(self._L.tf_fock_jk(self._ctx, nd, ptr(P), ptr(J), ptr(K)))
+        return J, K
+
+    def fock_jk_device(self, dP: int, dJ: int, dK: int, n_dens: int = 1, stream: int = 0):
+        """Device-pointer variant (integers from tensor.data_ptr()); asynchronous on `stream`."""
+        self._check(self._L.tf_fock_jk_device(self._ctx, n_dens, C.c_void_p(dP), C.c_void_p(dJ), C.c_void_p(dK),
+                                              C.c_void_p(stream)))
+
+    # ---- SCF -----------------------------------------------------------------------------------
+    def orthogonaliser(self, S: np.ndarray):
+        S = f64(S)
+        n = S.shape[0]
+        X, Si = np.zeros((n, n)), np.zeros((n, n))
+        sm = C.c_double()
+        self._check(self._L.tf_orthogonaliser(self._ctx, n, ptr(S), ptr(X), ptr(Si), C.byref(sm)))
+        return X, sm.value, Si
+
+    def scf_rhf(self, S, T, V, P0, E0, n_occ, V_NN, *, X=None, Fext=None, conv="medium", max_iter=100, diis=True,
+                max_diis=6, damping="dynamic", damping_factor=0.0, max_damping=0.7, hfx=1.0, n_atom_ao=None):
+        N = self.N
+        conv_d = SCF_CONVERGENCE[conv] if isinstance(conv, str) else conv
+        o = ScfOpts()
+        o.max_iter, o.use_diis, o.max_diis = max_iter, int(diis), max_diis
+        o.damping = {"none": 0, False: 0, None: 0, "dynamic": 1, True: 1, "static": 2}[damping]
+        o.damping_factor, o.max_damping = damping_factor, max_damping
+        o.conv_delta_E, o.conv_max_DP = conv_d["delta_E"], conv_d["max_DP"]
+        o.conv_rms_DP, o.conv_commutator = conv_d["RMS_DP"], conv_d["commutator"]
+        o.hfx = hfx
+        n_atom_ao = list(n_atom_ao) if n_atom_ao is not None else [N]
+        o.n_atoms = len(n_atom_ao)
+        o.n_atom_ao[0] = n_atom_ao[0]
+        o.n_atom_ao[1] = n_atom_ao[1] if len(n_atom_ao) > 1 else 0
+        r = ScfResult()
+        P, Cm, F, eps = np.zeros((N, N)), np.zeros((N, N)), np.zeros((N, N)), np.zeros(N)
+        table = np.zeros((max_iter, 7))
+        r.P, r.C, r.F, r.eps, r.table = (a.ctypes.data for a in (P, Cm, F, eps, table))
+        arrs = [f64(S), f64(T), f64(V), None if Fext is None else f64(Fext), None if X is None else f64(X), f64(P0)]
+        rc = self._L.tf_scf_rhf(self._ctx, C.byref(o), *[ptr(a) for a in arrs], float(E0), int(n_occ), float(V_NN),
+                                C.byref(r))
+        res = {"energy": r.energy, "components": np.array(r.components[:]), "n_iter": r.n_iter, "converged": bool(r.converged),
+               "P": P, "C": Cm, "F": F, "epsilons": eps, "table": table[:r.n_iter].copy(), "fock_seconds": r.fock_seconds,
+               "eig_seconds": r.eig_seconds, "wall_seconds": r.wall_seconds}
+        if rc != 0:
+            err = TunaError(self._L.tf_last_error(self._ctx).decode(), rc)
+            err.partial = res
+            raise err
+        return res
