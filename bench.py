@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- Fock builds/s (+ SCF wall time) of the MI355X engine, with roofline and CPU baseline.
+
+    python bench.py --gpus N --steps K --warmup W [--workload synth-400|n2-cc-pvtz|ar2-cc-pvqz|synth-<N>]
+
+A "step" is ONE Fock build: J and K (scf:70, scf:42 of the reference) for one density matrix from the ERI tensor
+resident in HBM, then -- for N > 1 ranks -- one RCCL all-reduce of the stacked [J;K] (each rank holds a shard of
+the (ij) shell-pair rows of the tensor).  Inputs (tensor and density) are resident in HBM before the timed region.
+One JSON line on rank 0; see DESIGN.md section "Measurement" for every field.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+ANCHOR_N2_CCPVTZ = -108.9834703056   # SURVEY.md section 6.2 (reference engine + reference tuna_scf.py, golden/c2)
+
+
+def build_workload(name: str):
+    from tuna_amd import molecule as mol
+    name = name.lower()
+    if name.startswith("synth-"):
+        n = int(name.split("-")[1])
+        counts = mol.synthetic_counts(n)
+        atoms = mol.make_atoms(["AR", "AR"], 7.1)
+        shells = mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)})
+        desc = (f"synthetic even-tempered uncontracted Ar2-like diatomic, {counts[0]}s{counts[1]}p{counts[2]}d{counts[3]}f per atom, "
+                f"R = 7.1 a0 (SURVEY.md section 8d)")
+        nocc = 18
+    elif name == "n2-cc-pvtz":
+        atoms = mol.make_atoms(["N", "N"], mol.angstrom_to_bohr(1.0977))
+        shells = mol.build_shells(atoms, "cc-pVTZ")
+        desc, nocc = "N2 RHF/cc-pVTZ, R = 1.0977 A (BASELINE.json configs[1])", 7
+    elif name == "ar2-cc-pvqz":
+        atoms = mol.make_atoms(["AR", "AR"], mol.angstrom_to_bohr(3.76))
+        shells = mol.build_shells(atoms, "cc-pVQZ")
+        desc, nocc = "Ar2 RHF/cc-pVQZ, R = 3.76 A (BASELINE.json configs[2])", 18
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return atoms, shells, mol.expand_cartesian_aos(shells), nocc, desc
+
+
+def cpu_baseline_fock(N_workload: int, budget_s: float = 12.0):
+    """The reference's CPU Fock build -- np.einsum("ijkl,kl->ij") + np.einsum("ilkj,kl->ij"), optimize=True
+    (scf:70, scf:42, restated in oracle/scf_oracle.py) -- timed on a BOUNDED dense sample tensor and scaled by N^4."""
+    from oracle import scf_oracle as so
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    Ns = min(N_workload, 96)
+    rng = np.random.default_rng(0)
+    T = rng.standard_normal((Ns, Ns, Ns, Ns))
+    A = rng.standard_normal((Ns, Ns))
+    P = A + A.T
+    so.coulomb(P, T); so.exchange(P, T)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        so.coulomb(P, T)
+        so.exchange(P, T)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 200:
+            break
+    per_build = (time.perf_counter() - t0) / n
+    scaled = per_build * (N_workload / Ns) ** 4
+    return {"value": 1.0 / scaled, "unit": "Fock builds/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} J+K builds with the reference einsum strings on a dense random {Ns}^4 f64 tensor "
+                      f"({per_build * 1e3:.1f} ms each), scaled by (N/{Ns})^4 to N = {N_workload}",
+            "seconds_per_build_at_workload_size": scaled}
+
+
+def cpu_baseline_eri(aos, limit_s: float = 20.0):
+    """ERI build on the host for the SCF leg: the compiled reference engine when oracle/_ref is present, else the C port."""
+    from oracle import oracle as orc
+    if aos.n > 80:
+        return None
+    kind = "reference" if orc.ref_engine() is not None else "port"
+    t0 = time.perf_counter()
+    (orc.ref_eri if kind == "reference" else orc.eri)(aos, os.cpu_count())
+    return {"seconds": time.perf_counter() - t0, "kind": kind, "cores": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("TUNA_BENCH_WORKLOAD", "synth-400"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scf", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: tuna_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from tuna_amd.engine import Engine
+    atoms, shells, aos, nocc, desc = build_workload(args.workload)
+    eng = Engine(local_rank, rank, world)
+    eng.set_basis(aos)
+    t0 = time.perf_counter()
+    eng.build_eri(True)
+    torch.cuda.synchronize()
+    eri_wall = time.perf_counter() - t0
+    N = eng.N
+    st = eng.eri_storage()
+    eri_t = eng.eri_timings()
+
+    # density: P = A + A^T, A ~ N(0,1) (default_rng(0)), scaled to tr(PS) = n_elec
+    xyz, chg = [a.origin for a in atoms], [float(a.charge) for a in atoms]
+    S, T, V, _, _ = eng.one_electron(xyz, chg, [0, 0, 0.5 * atoms[-1].origin[2]])
+    A = np.random.default_rng(0).standard_normal((N, N))
+    P = A + A.T
+    P *= 2 * nocc / np.trace(P @ S)
+    dP = torch.from_numpy(P).to(dev)
+    dJK = torch.zeros((2, N, N), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, stream)
+        if world > 1:
+            dist.all_reduce(dJK)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.jk_profile(True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_s, kern_n = eng.jk_profile_read()
+    eng.jk_profile(False)
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    k_max = torch.tensor([kern_s / max(kern_n, 1)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    kernel_avg_s = float(k_max.item())
+
+    # sanity of the timed result: J symmetric, tr-type identity <P|J> > 0
+    Jh = dJK[0].cpu().numpy()
+    ok = bool(np.isfinite(Jh).all() and np.abs(Jh - Jh.T).max() < 1e-8 * max(1.0, np.abs(Jh).max()))
+
+    if rank == 0:
+        alg_bytes = 8.0 * N ** 4 / world                    # 8 N^4 bytes per build, per GPU 8 N^4 / G
+        stored_bytes = float(st["bytes"])
+        achieved = alg_bytes / kernel_avg_s / 1e9
+        out = {
+            "metric": "Fock builds/sec (J+K from the HBM-resident ERI tensor, one density) + SCF wall time",
+            "value": args.steps / elapsed, "unit": "Fock builds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "n_ao_spherical": N, "n_ao_cartesian": eng.n_cart,
+                       "n_shells": eng.n_shell, "n_densities": 1,
+                       "storage": "rows (i>=j) x full (k,l) of the spherical tensor, f64, sharded by (ij) shell pair over ranks",
+                       "stored_bytes_per_gpu": stored_bytes, "parallelism": f"ij-row shards x{world} + RCCL all-reduce of [J;K]" if world > 1 else "1 GPU",
+                       "result_ok": ok},
+            "roofline": {"bound": "hbm", "kernel": "tfk::jk_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_avg_ms": 1e3 * kernel_avg_s,
+                         "stored_bytes_per_launch": stored_bytes, "achieved_on_stored_bytes": stored_bytes / kernel_avg_s / 1e9,
+                         "frac_on_stored_bytes": stored_bytes / kernel_avg_s / 1e9 / HBM_PEAK_GBS,
+                         "note": "achieved prices the 8*N^4 algorithmic bytes of SURVEY 8d; the kernel physically reads the (i>=j) half "
+                                 "(stored_bytes), so frac can exceed what the physical stream alone would give"},
+            "eri_build": {"wall_s": eri_wall, "device_s": {k: float(v) for k, v in eri_t.items() if k.endswith("_s")},
+                          "shell_quartets": eri_t["shell_quartets"], "primitive_shell_quartets": eri_t["primitive_shell_quartets"],
+                          "component_quartets": eri_t["component_quartets"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_fock(N)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_scf:
+            out["scf"] = scf_leg(eng, args)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def scf_leg(eng, args):
+    """SCF wall time on BASELINE.json configs[1] (N2 RHF/cc-pVTZ): ERI build + native RHF (EXTREME thresholds, core guess,
+    DIIS 6, no damping) on the GPU, energy checked against the reference anchor; CPU ERI build beside it."""
+    from oracle import scf_oracle as so
+    from tuna_amd import molecule as mol
+    atoms, shells, aos, nocc, desc = build_workload("n2-cc-pvtz")
+    t0 = time.perf_counter()
+    eng.set_basis(aos).build_eri(True)
+    t_eri = time.perf_counter() - t0
+    xyz, chg = [a.origin for a in atoms], [float(a.charge) for a in atoms]
+    t1 = time.perf_counter()
+    S, T, V, _, _ = eng.one_electron(xyz, chg, [0, 0, 0.5 * atoms[1].origin[2]])
+    X, _, _ = eng.orthogonaliser(S)
+    P0, E0 = so.core_guess(T, V, X, nocc)
+    r = eng.scf_rhf(S, T, V, P0, E0, nocc, mol.nuclear_repulsion(atoms), X=X, conv="extreme", damping="none", n_atom_ao=[30, 30])
+    t_scf = time.perf_counter() - t1
+    # Fock builds/s on this config too (device-resident P)
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dP = torch.from_numpy(r["P"]).to(dev)
+    dJK = torch.zeros((2, eng.N, eng.N), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, stream)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(200):
+        eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, stream)
+    torch.cuda.synchronize()
+    fps = 200 / (time.perf_counter() - t2)
+    out = {"workload": desc, "energy_Eh": r["energy"], "abs_error_vs_reference_anchor_Eh": abs(r["energy"] - ANCHOR_N2_CCPVTZ),
+           "iterations": r["n_iter"], "eri_build_wall_s": t_eri, "scf_wall_s": t_scf, "total_wall_s": t_eri + t_scf,
+           "fock_kernel_s": r["fock_seconds"], "eigensolver_s": r["eig_seconds"], "fock_builds_per_s": fps,
+           "cpu_reference_fock_builds_per_s_8core_container": 23.4}
+    if not args.no_cpu_baseline:
+        out["cpu_eri_build"] = cpu_baseline_eri(aos)
+    return out
+
+
+if __name__ == "__main__":
+    main()

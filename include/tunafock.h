@@ -50,6 +50,10 @@ const char *tf_last_error(const tf_ctx *ctx);
 /* ABI version of the library (major*100 + minor). */
 int tf_version(void);
 
+/* Stateless, host only: the row-block -> rank plan tf_build_eri uses (longest-processing-time on
+ * weight[b] = rows of block b).  Replaces the `schedule="dynamic"` load balancing of pyx:1314.  owner[n_blocks]. */
+int tf_shard_plan(int n_blocks, const int64_t *weight, int world, int32_t *owner);
+
 /* ---- basis: replaces `Basis.__cinit__` / `Basis.normalize` (pyx:144-210) ------------------ */
 
 /* Stateless helper = Basis.normalize for ONE Cartesian AO: fills norm[nprim] and rescales
@@ -162,6 +166,12 @@ int tf_eri_timings(const tf_ctx *ctx, double *seconds4);
 /* Work counters of the last tf_build_eri: [0] shell quartets, [1] primitive shell quartets,
  * [2] Cartesian component quartets. */
 int tf_eri_counts(const tf_ctx *ctx, int64_t *counts3);
+
+/* HIP-event timing of the dominant kernel of the Fock build (the row pass over the stored tensor), recorded on
+ * the stream each build is launched on.  enable: start (and reset) / stop collecting; read: synchronises the
+ * recorded events, returns their summed duration and the number of launches, and resets. */
+int tf_jk_profile(tf_ctx *ctx, int enable);
+int tf_jk_profile_read(tf_ctx *ctx, double *seconds_total, int64_t *launches);
 
 #ifdef __cplusplus
 }

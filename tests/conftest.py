@@ -1,0 +1,81 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = np.load(os.path.join(GOLD, name + ".npz"))
+        return cache[name]
+    return load
+
+
+@pytest.fixture(scope="session")
+def small(golden):
+    """tests/golden/small_systems.npz split by system tag."""
+    z = golden("small_systems")
+    out = {}
+    for key in z.files:
+        tag, name = key.split("__", 1)
+        out.setdefault(tag, {})[name] = z[key]
+    return out
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One libtunafock context on cuda:0 -- fails loudly (no fallback) if the HIP library or the GPU is missing."""
+    from tuna_amd.engine import Engine
+    eng = Engine(0)
+    yield eng
+    eng.close()
+
+
+from tuna_amd import molecule as mol  # noqa: E402
+
+R_H2 = mol.angstrom_to_bohr(0.74)
+R_N2 = mol.angstrom_to_bohr(1.0977)
+R_CO = mol.angstrom_to_bohr(1.128)
+R_AR2 = mol.angstrom_to_bohr(3.76)
+HIGH_L_BASIS = {7: [("S", [(1.3, 1.0)]), ("P", [(0.9, 1.0)]), ("D", [(1.1, 1.0)]), ("F", [(0.8, 1.0)]), ("G", [(1.0, 1.0)]),
+                    ("H", [(0.7, 1.0)])],
+                8: [("S", [(2.0, 0.6), (0.5, 0.5)]), ("D", [(0.9, 0.7), (0.4, 0.4)]), ("H", [(1.2, 1.0)])]}
+SYSTEMS = {
+    "h2_sto3g_1p4": (["H", "H"], 1.4, "STO-3G", 1),
+    "h2_sto3g": (["H", "H"], R_H2, "STO-3G", 1),
+    "n2_sto3g": (["N", "N"], R_N2, "STO-3G", 7),
+    "he_631g": (["HE"], None, "6-31G", 1),
+    "n2_ccpvdz": (["N", "N"], R_N2, "cc-pVDZ", 7),
+    "c2_n2_ccpvtz": (["N", "N"], R_N2, "cc-pVTZ", 7),
+    "c4_co_def2tzvp": (["C", "O"], R_CO, "def2-TZVP", 7),
+    "c3_ar2_ccpvqz": (["AR", "AR"], R_AR2, "cc-pVQZ", 18),
+    "high_l": (["N", "O"], 2.1, HIGH_L_BASIS, 7),
+}
+
+
+def make_system(tag):
+    sym, R, basis, nocc = SYSTEMS[tag]
+    atoms = mol.make_atoms(sym, R)
+    shells = mol.build_shells(atoms, basis)
+    return atoms, shells, mol.expand_cartesian_aos(shells), nocc
+
+
+def atom_arrays(atoms):
+    xyz = [a.origin for a in atoms]
+    chg = [float(a.charge) for a in atoms]
+    org = [0.0, 0.0, 0.5 * atoms[-1].origin[2] if len(atoms) == 2 else 0.0]
+    return xyz, chg, org

@@ -1,0 +1,197 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle, the reference's golden vectors
+and size-independent properties.  Tolerances: integrals 1e-12 absolute (north star asks 1e-8 Eh on energies),
+J/K 1e-10 absolute on O(10) values, energies 1e-9 Eh."""
+import numpy as np
+import pytest
+
+from conftest import R_N2, atom_arrays, make_system
+from oracle import oracle as orc
+from oracle import scf_oracle as so
+from tuna_amd import molecule as mol
+
+pytestmark = pytest.mark.gpu
+
+TOL_INT = 1e-12
+
+
+@pytest.mark.parametrize("tag", ["h2_sto3g_1p4", "h2_sto3g", "n2_sto3g", "he_631g"])
+def test_small_systems_against_reference_golden(engine, small, tag):
+    atoms, shells, aos, _ = make_system(tag)
+    g = small[tag]
+    engine.set_basis(aos)
+    norm, coefs = engine.norms()
+    np.testing.assert_allclose(norm, g["norm"], rtol=1e-15)
+    np.testing.assert_allclose(coefs, g["coefs"], rtol=1e-15)
+    np.testing.assert_allclose(engine.sph_matrix(), g["U"], atol=3e-16)
+    engine.build_eri(spherical=False)
+    E = engine.copy_eri()
+    assert np.abs(E - g["ERI"]).max() < TOL_INT
+    xyz, chg, org = atom_arrays(atoms)
+    for got, name in zip(engine.one_electron(xyz, chg, org, spherical=False), "STVDQ"):
+        assert np.abs(got - g[name]).max() < TOL_INT, name
+
+
+@pytest.mark.parametrize("tag", ["n2_ccpvdz", "c2_n2_ccpvtz", "c4_co_def2tzvp", "high_l"])
+def test_full_tensor_against_oracle(engine, golden, tag):
+    """Every element of the Cartesian and the spherical tensor vs the C oracle; samples vs the reference golden."""
+    atoms, shells, aos, _ = make_system(tag)
+    g = golden(tag)
+    engine.set_basis(aos)
+    Eo = orc.eri(aos)
+    engine.build_eri(spherical=False)
+    Ec = engine.copy_eri()
+    assert np.abs(Ec - Eo).max() < TOL_INT
+    # exact zeros where the x- or y-parity is odd (pyx:1324-1327)
+    lx = aos.lmn[:, 0]; ly = aos.lmn[:, 1]
+    odd = ((lx[:, None, None, None] + lx[None, :, None, None] + lx[None, None, :, None] + lx[None, None, None, :]) % 2 == 1) | \
+          ((ly[:, None, None, None] + ly[None, :, None, None] + ly[None, None, :, None] + ly[None, None, None, :]) % 2 == 1)
+    assert np.all(Ec[odd] == 0.0)
+    idx = g["eri_idx"]
+    assert np.abs(engine.sample_eri(idx) - g["eri_val"]).max() < TOL_INT
+    del Ec
+    U = engine.sph_matrix()
+    np.testing.assert_allclose(U, g["U"], atol=3e-16)
+    engine.build_eri(spherical=True)
+    Es = engine.copy_eri()
+    Eos = so.eri_to_spherical(U, Eo)
+    assert np.abs(Es - Eos).max() < TOL_INT
+    assert np.abs(engine.sample_eri(g["eri_sph_idx"]) - g["eri_sph_val"]).max() < TOL_INT
+    assert abs(np.sqrt(np.sum(Es * Es)) - g["eri_sph_fro"]) < 1e-10 * g["eri_sph_fro"]
+    # the dense copy carries all eight images
+    for perm in [(1, 0, 2, 3), (0, 1, 3, 2), (2, 3, 0, 1), (3, 2, 1, 0)]:
+        assert np.abs(Es - Es.transpose(perm)).max() < 1e-13
+    # one-electron matrices, spherical
+    xyz, chg, org = atom_arrays(atoms)
+    for got, name in zip(engine.one_electron(xyz, chg, org, spherical=True), "STV"):
+        assert np.abs(got - so.to_spherical(g["U"], g[name])).max() < TOL_INT, name
+    # J/K vs the reference einsums
+    if "P_rand" in g.files:
+        J, K = engine.fock_jk(g["P_rand"])
+        assert np.abs(J - g["J_rand"]).max() < 1e-10
+        assert np.abs(K - g["K_rand"]).max() < 1e-10
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((engine.N, engine.N))
+    P = A + A.T
+    J, K = engine.fock_jk(P)
+    assert np.abs(J - so.coulomb(P, Eos)).max() < 1e-10 and np.abs(K - so.exchange(P, Eos)).max() < 1e-10
+
+
+def test_c3_ar2_ccpvqz_samples_and_jk(engine, golden):
+    """C3 (148 Cartesian / 118 spherical AOs, 13-primitive s contractions, g shells): samples of the reference tensor."""
+    atoms, shells, aos, _ = make_system("c3_ar2_ccpvqz")
+    g = golden("c3_ar2_ccpvqz")
+    engine.set_basis(aos)
+    engine.build_eri(spherical=False)
+    assert np.abs(engine.sample_eri(g["eri_idx"]) - g["eri_val"]).max() < TOL_INT
+    engine.build_eri(spherical=True)
+    assert np.abs(engine.sample_eri(g["eri_sph_idx"]) - g["eri_sph_val"]).max() < TOL_INT
+    J, K = engine.fock_jk(g["P_rand"])
+    assert np.abs(J - g["J_rand"]).max() < 1e-9
+    assert np.abs(K - g["K_rand"]).max() < 1e-9
+    xyz, chg, org = atom_arrays(atoms)
+    for got, name in zip(engine.one_electron(xyz, chg, org, spherical=False), "STVDQ"):
+        assert np.abs(got - g[name]).max() < 1e-11, name
+
+
+def test_odd_dimension_padding_and_multi_density(engine):
+    """N odd -> padded leading dimension; several densities in one call."""
+    basis = {1: [("S", [(1.1, 1.0)]), ("P", [(0.8, 1.0)])], 2: [("S", [(2.0, 0.5), (0.6, 0.6)]), ("D", [(1.0, 1.0)]), ("S", [(0.3, 1.0)])]}
+    atoms = mol.make_atoms(["H", "HE"], 1.7)
+    aos = mol.expand_cartesian_aos(mol.build_shells(atoms, basis))
+    engine.set_basis(aos).build_eri(True)
+    assert engine.N % 2 == 1 and engine.eri_storage()["ld"] == engine.N + 1
+    Es = so.eri_to_spherical(engine.sph_matrix(), orc.eri(aos))
+    assert np.abs(engine.copy_eri() - Es).max() < TOL_INT
+    rng = np.random.default_rng(5)
+    P = rng.standard_normal((3, engine.N, engine.N))
+    J, K = engine.fock_jk(P)
+    for d in range(3):   # non-symmetric densities too: the einsum definitions are what is implemented
+        assert np.abs(J[d] - so.coulomb(P[d], Es)).max() < 1e-11
+        assert np.abs(K[d] - so.exchange(P[d], Es)).max() < 1e-11
+
+
+def test_decontracted_ao_order_falls_back_to_single_component_shells(engine):
+    """The reference's DECONTRACT emits, per Cartesian component, one AO per primitive (tuna_molecule.py:564-570);
+    such a list has no contiguous shells, is handled AO by AO, and is Cartesian-only."""
+    atoms = mol.make_atoms(["N", "N"], R_N2)
+    tbl = mol.atomic_basis("6-31G*", 7)
+    origin, lmn, nprim, exps, coefs = [], [], [], [], []
+    for at in atoms:
+        for letter, prims in tbl:
+            L = mol.SHELL_LETTERS.find(letter)
+            for comp in mol.cartesian_components(L):
+                for e, _ in prims:
+                    origin.append(at.origin); lmn.append(comp); nprim.append(1); exps.append([e]); coefs.append([1.0])
+    off = np.zeros(len(nprim) + 1, dtype=np.int32); off[1:] = np.cumsum(nprim)
+    aos = mol.AOList(np.array(origin, dtype=float), np.array(lmn, dtype=np.int32), np.array(nprim, dtype=np.int32), off,
+                     np.concatenate(exps), np.concatenate(coefs))
+    engine.set_basis(aos).build_eri(spherical=False)
+    assert np.abs(engine.copy_eri() - orc.eri(aos)).max() < TOL_INT
+    from tuna_amd._lib import TunaError
+    with pytest.raises(TunaError):
+        engine.build_eri(spherical=True)
+
+
+def test_single_integral_and_cross_overlap(engine):
+    atoms, shells, aos, _ = make_system("n2_ccpvdz")
+    rng = np.random.default_rng(11)
+    Eo = None
+    for _ in range(4):
+        q = rng.integers(0, aos.n, 4)
+        sub = mol.AOList(aos.origin[q], aos.lmn[q], aos.nprim[q], np.concatenate([[0], np.cumsum(aos.nprim[q])]).astype(np.int32),
+                         np.concatenate([aos.exps[aos.prim_off[i]:aos.prim_off[i + 1]] for i in q]),
+                         np.concatenate([aos.coefs[aos.prim_off[i]:aos.prim_off[i + 1]] for i in q]))
+        if Eo is None:
+            Eo = orc.eri(aos)
+        assert abs(engine.eri_element(sub) - Eo[q[0], q[1], q[2], q[3]]) < TOL_INT
+    _, _, aos2, _ = make_system("n2_sto3g")
+    engine.set_basis(aos)
+    assert np.abs(engine.cross_overlap(aos2) - orc.cross_overlap(aos, aos2)).max() < TOL_INT
+
+
+def test_error_behaviour(engine):
+    from tuna_amd._lib import TunaError
+    atoms, shells, aos, _ = make_system("h2_sto3g")
+    bad = mol.AOList(aos.origin.copy(), aos.lmn, aos.nprim, aos.prim_off, aos.exps, aos.coefs)
+    bad.origin[1, 0] = 0.3          # off the z axis (kernel:386-388)
+    with pytest.raises(TunaError) as e:
+        engine.set_basis(bad)
+    assert "aligned" in str(e.value) and e.value.code == -6
+    engine.set_basis(aos)
+    with pytest.raises(TunaError):
+        engine.fock_jk(np.eye(2))   # no tensor built yet
+
+
+@pytest.mark.parametrize("n_sph", [120, 200])
+def test_synthetic_series_properties(engine, n_sph):
+    """Synthetic even-tempered Ar2-like diatomic: properties that hold at any size."""
+    counts = mol.synthetic_counts(n_sph)
+    atoms = mol.make_atoms(["AR", "AR"], 7.1)
+    aos = mol.expand_cartesian_aos(mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)}))
+    engine.set_basis(aos).build_eri(True)
+    N = engine.N
+    assert N == n_sph
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, N, size=(4000, 4)).astype(np.int32)
+    v = engine.sample_eri(idx)
+    for perm in [(1, 0, 2, 3), (0, 1, 3, 2), (2, 3, 0, 1), (3, 2, 0, 1)]:     # 8-fold symmetry
+        assert np.abs(v - engine.sample_eri(idx[:, perm])).max() < 1e-12
+    diag = engine.sample_eri(np.stack([idx[:, 0], idx[:, 1], idx[:, 0], idx[:, 1]], axis=1))
+    assert diag.min() > -1e-13                                              # (ij|ij) >= 0
+    assert np.all(np.abs(v) <= np.sqrt(np.abs(diag) * np.abs(engine.sample_eri(np.stack([idx[:, 2], idx[:, 3], idx[:, 2], idx[:, 3]], axis=1)))) + 1e-10)  # Schwarz
+    A = rng.standard_normal((N, N)); B = rng.standard_normal((N, N))
+    P1, P2 = A + A.T, B + B.T
+    J1, K1 = engine.fock_jk(P1)
+    J2, K2 = engine.fock_jk(P2)
+    J3, K3 = engine.fock_jk(2.0 * P1 - 0.5 * P2)
+    scale = np.abs(J1).max()
+    assert np.abs(J3 - (2.0 * J1 - 0.5 * J2)).max() < 1e-11 * scale          # linearity
+    assert np.abs(K3 - (2.0 * K1 - 0.5 * K2)).max() < 1e-11 * scale
+    assert np.abs(J1 - J1.T).max() < 1e-11 * scale and np.abs(K1 - K1.T).max() < 1e-11 * scale
+    assert abs(np.sum(P2 * J1) - np.sum(P1 * J2)) < 1e-9 * abs(np.sum(P2 * J1))   # <P2|J[P1]> = <P1|J[P2]>
+    assert abs(np.sum(P2 * K1) - np.sum(P1 * K2)) < 1e-9 * abs(np.sum(P2 * K1))
+    # a sample of rows of J and K against a direct contraction of sampled tensor rows
+    i, j = 7, 3
+    rows = np.array([[i, j, k, l] for k in range(N) for l in range(N)], dtype=np.int32)
+    M = engine.sample_eri(rows).reshape(N, N)
+    assert abs(J1[i, j] - np.sum(M * P1)) < 1e-10 * scale

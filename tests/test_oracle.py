@@ -1,0 +1,139 @@
+"""CPU: the oracle (C restatement + NumPy SCF) against the golden vectors the REAL reference produced."""
+import numpy as np
+import pytest
+
+from conftest import SYSTEMS, atom_arrays, make_system
+from oracle import oracle as orc
+from oracle import scf_oracle as so
+
+
+def test_boys_against_hyp1f1_samples(golden):
+    g = golden("boys")
+    # SciPy's hyp1f1 (the routine the reference calls, pyx:1505) is itself only good to ~2e-11 relative for
+    # T > 50 and high order, where F_m(T) < 1e-15 in absolute terms (checked against mpmath); below T = 50 it
+    # and the oracle's series agree to a few ulp.  Absolute agreement is < 1e-15 everywhere.
+    worst_rel_small_T = worst_rel = worst_abs = 0.0
+    for mi, m in enumerate(g["m"]):
+        for ti, T in enumerate(g["T"]):
+            ref = g["F"][mi, ti]
+            got = orc.boys(int(m), float(T))
+            rel = abs(got - ref) / abs(ref)
+            worst_rel = max(worst_rel, rel)
+            worst_abs = max(worst_abs, abs(got - ref))
+            if T < 50:
+                worst_rel_small_T = max(worst_rel_small_T, rel)
+    assert worst_rel_small_T < 1e-14 and worst_rel < 1e-10 and worst_abs < 2e-15
+
+
+@pytest.mark.parametrize("tag", ["h2_sto3g_1p4", "h2_sto3g", "n2_sto3g", "he_631g"])
+def test_small_systems_full_tensors(small, tag):
+    atoms, shells, aos, _ = make_system(tag)
+    g = small[tag]
+    np.testing.assert_array_equal(aos.lmn, g["lmn"])
+    norm, coefs = orc.normalize(aos)
+    np.testing.assert_allclose(norm, g["norm"], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(coefs, g["coefs"], rtol=1e-15, atol=0)
+    E = orc.eri(aos)
+    assert np.abs(E - g["ERI"]).max() < 2e-15
+    xyz, chg, org = atom_arrays(atoms)
+    for got, name in zip(orc.one_electron(aos, xyz, chg, org), "STVDQ"):
+        assert np.abs(got - g[name]).max() < 2e-14, name
+
+
+def test_szabo_ostlund_known_answers(small):
+    """H2/STO-3G at R = 1.4 a0 (Szabo & Ostlund section 3.5.2)."""
+    _, _, aos, _ = make_system("h2_sto3g_1p4")
+    E = orc.eri(aos)
+    assert abs(E[0, 0, 0, 0] - 0.7746059442) < 1e-9
+    assert abs(E[0, 0, 1, 1] - 0.5696759265) < 1e-9
+    assert abs(E[1, 0, 0, 0] - 0.4441076589) < 1e-9
+    assert abs(E[1, 0, 1, 0] - 0.2970285412) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["n2_ccpvdz", "c2_n2_ccpvtz", "c4_co_def2tzvp", "high_l"])
+def test_eri_samples_and_one_electron(golden, tag):
+    atoms, shells, aos, _ = make_system(tag)
+    g = golden(tag)
+    np.testing.assert_array_equal(aos.lmn, g["lmn"])
+    E = orc.eri(aos)
+    idx = g["eri_idx"]
+    assert np.abs(E[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] - g["eri_val"]).max() < 1e-13
+    assert abs(np.sqrt(np.sum(E * E)) - g["eri_fro"]) < 1e-10 * g["eri_fro"]
+    xyz, chg, org = atom_arrays(atoms)
+    for got, name in zip(orc.one_electron(aos, xyz, chg, org), "STVDQ"):
+        assert np.abs(got - g[name]).max() < 1e-12, name
+    Es = so.eri_to_spherical(g["U"], E)
+    ids = g["eri_sph_idx"]
+    assert np.abs(Es[ids[:, 0], ids[:, 1], ids[:, 2], ids[:, 3]] - g["eri_sph_val"]).max() < 1e-13
+    if "P_rand" in g.files:
+        assert np.abs(so.coulomb(g["P_rand"], Es) - g["J_rand"]).max() < 1e-11
+        assert np.abs(so.exchange(g["P_rand"], Es) - g["K_rand"]).max() < 1e-11
+
+
+@pytest.mark.parametrize("tag", ["h2_sto3g", "n2_sto3g", "he_631g", "h2_sto3g_1p4"])
+@pytest.mark.parametrize("damping", [True, False])
+def test_scf_restatement_replays_reference_trajectory(small, tag, damping):
+    """NumPy RHF restatement vs the table printed by the reference's own tuna_scf.py (same integrals, same guess)."""
+    g = small[tag]
+    atoms, shells, aos, nocc = make_system(tag)
+    U = g["U"]
+    S, T, V = (so.to_spherical(U, g[k]) for k in "STV")
+    Es = so.eri_to_spherical(U, g["ERI"])
+    X, _, _ = so.orthogonaliser(S)
+    np.testing.assert_allclose(X, g["X"], atol=1e-13)
+    P0, E0 = so.core_guess(T, V, X, nocc)
+    assert abs(E0 - g["E0"]) < 1e-11
+    ranges = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
+    r = so.run_rhf(S, T, V, Es, X, P0, E0, nocc, float(g["V_NN"]), ranges, conv="extreme", damping=damping)
+    sfx = "" if damping else "_nodamp"
+    assert abs(r["energy"] - float(g["scf_energy" + sfx])) < 1e-11
+    ref_table = g["scf_table" + sfx]
+    if not damping or len(atoms) == 1 or tag.startswith("h2"):
+        assert r["table"].shape == ref_table.shape
+        np.testing.assert_allclose(r["table"][:, 1], ref_table[:, 1], atol=1e-10)   # E_total per iteration
+        np.testing.assert_allclose(r["table"][:, 5], ref_table[:, 5], atol=1e-9)    # commutator
+    np.testing.assert_allclose(r["epsilons"], g["scf_eps" + sfx], atol=1e-8)
+
+
+def test_scf_restatement_c2_anchor(golden):
+    """C2 = N2/cc-pVTZ: converged energy of the restatement (oracle integrals) vs the reference run and the SURVEY anchor."""
+    g = golden("c2_n2_ccpvtz")
+    atoms, shells, aos, nocc = make_system("c2_n2_ccpvtz")
+    U = g["U"]
+    Es = so.eri_to_spherical(U, orc.eri(aos))
+    S, T, V = (so.to_spherical(U, g[k]) for k in "STV")
+    X, _, _ = so.orthogonaliser(S)
+    P0, E0 = so.core_guess(T, V, X, nocc)
+    r = so.run_rhf(S, T, V, Es, X, P0, E0, nocc, float(g["V_NN"]), [30, 30], conv="extreme", damping=False)
+    assert abs(r["energy"] - float(g["scf_energy_nodamp"])) < 1e-10
+    assert abs(r["energy"] - (-108.9834703056)) < 5e-10          # SURVEY.md section 6.2 anchor
+    ref = g["scf_table_nodamp"]
+    assert len(r["table"]) == len(ref)
+    np.testing.assert_allclose(r["table"][:, 1], ref[:, 1], atol=1e-9)
+
+
+def test_golden_anchor_energies(golden):
+    """The four converged RHF anchors of SURVEY.md section 6.2 are what the reference code produced here."""
+    assert abs(float(golden("c2_n2_ccpvtz")["scf_energy"]) - (-108.9834703056)) < 5e-10
+    assert abs(float(golden("c4_co_def2tzvp")["scf_energy"]) - (-112.7855372010)) < 5e-10
+    assert abs(float(golden("c3_ar2_ccpvqz")["scf_energy"]) - (-1053.6331483153)) < 5e-10
+    z = golden("small_systems")
+    assert abs(float(z["h2_sto3g__scf_energy"]) - (-1.1167593075)) < 5e-10
+
+
+def test_oracle_matches_compiled_reference_on_random_basis():
+    """Direct check against the compiled, unmodified reference engine (oracle/_ref) when it is present."""
+    if orc.ref_engine() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(7)
+    from tuna_amd import molecule as mol
+    basis = {6: [("S", [(float(rng.uniform(0.3, 8)), 0.4), (float(rng.uniform(0.1, 0.3)), 0.7)]),
+                 ("P", [(float(rng.uniform(0.2, 3)), 1.0)]), ("F", [(float(rng.uniform(0.3, 2)), 1.0)])],
+             9: [("S", [(float(rng.uniform(0.3, 5)), 1.0)]), ("D", [(float(rng.uniform(0.2, 2)), 0.5), (0.31, 0.6)]),
+                 ("G", [(0.9, 1.0)])]}
+    atoms = mol.make_atoms(["C", "F"], 2.3)
+    aos = mol.expand_cartesian_aos(mol.build_shells(atoms, basis))
+    assert np.abs(orc.eri(aos) - orc.ref_eri(aos)).max() < 1e-14
+    xyz, chg = [a.origin for a in atoms], [float(a.charge) for a in atoms]
+    for a, b in zip(orc.one_electron(aos, xyz, chg, [0, 0, 1.0]), orc.ref_one_electron(aos, xyz, chg, [0, 0, 1.0])):
+        assert np.abs(a - b).max() < 1e-13

@@ -36,7 +36,8 @@ class ScfResult(C.Structure):
 EXPORTS = ["tf_create", "tf_destroy", "tf_last_error", "tf_version", "tf_normalize", "tf_set_basis", "tf_get_norms",
            "tf_dims", "tf_get_sph_matrix", "tf_one_electron", "tf_cross_overlap", "tf_build_eri", "tf_eri_storage",
            "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf",
-           "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts"]
+           "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts", "tf_shard_plan", "tf_jk_profile",
+           "tf_jk_profile_read"]
 
 _lib = None
 
@@ -83,6 +84,9 @@ def lib():
     L.tf_orthogonaliser.restype = ci; L.tf_orthogonaliser.argtypes = [vp, ci, vp, vp, vp, dp]
     L.tf_eri_timings.restype = ci; L.tf_eri_timings.argtypes = [vp, vp]
     L.tf_eri_counts.restype = ci; L.tf_eri_counts.argtypes = [vp, vp]
+    L.tf_shard_plan.restype = ci; L.tf_shard_plan.argtypes = [ci, vp, ci, vp]
+    L.tf_jk_profile.restype = ci; L.tf_jk_profile.argtypes = [vp, ci]
+    L.tf_jk_profile_read.restype = ci; L.tf_jk_profile_read.argtypes = [vp, dp, lp]
     _lib = L
     return L
 

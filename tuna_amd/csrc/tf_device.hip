@@ -44,6 +44,9 @@ struct tf_ctx {
     // J/K scratch
     double *d_Jrow = nullptr, *d_Kp = nullptr, *d_Ppad = nullptr, *d_J = nullptr, *d_K = nullptr, *d_P = nullptr;
     // instrumentation
+    bool prof_jk = false;
+    std::vector<hipEvent_t> prof_ev;     // pairs (before, after) around the row kernel, on the launch stream
+    size_t prof_used = 0;
     double eri_seconds[4] = {0, 0, 0, 0};
     long long eri_counts[3] = {0, 0, 0};
     tfscf::Workspace scf;
@@ -95,9 +98,36 @@ static void free_basis(tf_ctx *ctx)
     ctx->have_basis = false;
 }
 
+// Longest-processing-time assignment of row blocks (bra shell pairs) to ranks: heaviest block first, always to
+// the least loaded rank.  Deterministic, so every rank computes the same plan without communication.
+static void shard_plan(const std::vector<long long> &weight, int world, std::vector<int> &owner)
+{
+    const int n = (int)weight.size();
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight[x] > weight[y]; });
+    std::vector<long long> load(world, 0);
+    owner.assign(n, 0);
+    for (int p : order) {
+        const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[r] += weight[p];
+        owner[p] = r;
+    }
+}
+
 extern "C" {
 
 int tf_version(void) { return 100; }
+
+int tf_shard_plan(int n_blocks, const int64_t *weight, int world, int32_t *owner)
+{
+    if (n_blocks < 0 || world < 1 || !weight || !owner) return TF_EINVAL;
+    std::vector<long long> w(weight, weight + n_blocks);
+    std::vector<int> o;
+    shard_plan(w, world, o);
+    std::copy(o.begin(), o.end(), owner);
+    return TF_OK;
+}
 
 tf_ctx *tf_create(int device, int rank, int world)
 {
@@ -127,6 +157,7 @@ void tf_destroy(tf_ctx *ctx)
     free_eri(ctx);
     free_basis(ctx);
     tfscf::release(ctx->scf);
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -261,19 +292,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         pair_rows[p] = (bs.pairs[p].A == bs.pairs[p].B) ? (long long)out_dim(a) * (out_dim(a) + 1) / 2
                                                         : (long long)out_dim(a) * out_dim(b);
     }
-    std::vector<int> order(npairs);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return pair_rows[x] > pair_rows[y]; });
-    std::vector<long long> load(ctx->world, 0);
-    std::vector<char> mine(npairs, 0);
-    for (int p : order) {
-        int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        load[r] += pair_rows[p];
-        if (r == ctx->rank) mine[p] = 1;
-    }
+    std::vector<int> owner;
+    shard_plan(pair_rows, ctx->world, owner);
     ctx->my_pairs.clear();
     for (int p = 0; p < npairs; ++p)
-        if (mine[p]) ctx->my_pairs.push_back(p);
+        if (owner[p] == ctx->rank) ctx->my_pairs.push_back(p);
 
     // ---- row tables
     std::vector<int2> row_ij;
@@ -475,6 +498,18 @@ static int launch_jk(tf_ctx *ctx, const double *dP, double *dJ, double *dK, hipS
         const size_t smem = (size_t)(2 * N + 4 * TF_JK_THREADS) * sizeof(double);
         const int npair = ld / 2;
         const dim3 grid((unsigned)ctx->n_rows), block(TF_JK_THREADS);
+        hipEvent_t ev_after = nullptr;
+        if (ctx->prof_jk) {
+            if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { ctx->prof_ev.push_back(a); ctx->prof_ev.push_back(b); }
+            }
+            if (ctx->prof_used + 2 <= ctx->prof_ev.size()) {
+                (void)hipEventRecord(ctx->prof_ev[ctx->prof_used], st);
+                ev_after = ctx->prof_ev[ctx->prof_used + 1];
+                ctx->prof_used += 2;
+            }
+        }
         if (npair <= TF_JK_THREADS)
             hipLaunchKernelGGL(jk_rows_kernel<1>, grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, N, ld, Ppad, ctx->d_Jrow, ctx->d_Kp);
         else if (npair <= 2 * TF_JK_THREADS)
@@ -483,6 +518,7 @@ static int launch_jk(tf_ctx *ctx, const double *dP, double *dJ, double *dK, hipS
             hipLaunchKernelGGL(jk_rows_kernel<4>, grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, N, ld, Ppad, ctx->d_Jrow, ctx->d_Kp);
         else
             TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the J/K kernel's row length limit (2048)", N);
+        if (ev_after) (void)hipEventRecord(ev_after, st);
     }
     hipLaunchKernelGGL(jk_reduce_kernel, dim3((N + 127) / 128, N), dim3(128), 0, st, ctx->d_Jrow, ctx->d_Kp, ctx->d_rowmap, N, ld,
                        dJ, dK);
@@ -517,6 +553,30 @@ int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K)
         HIPCHK(ctx, hipMemcpy(K + d * nn, ctx->d_K, nn * sizeof(double), hipMemcpyDeviceToHost));
     }
     HIPCHK(ctx, hipGetLastError());
+    return TF_OK;
+}
+
+int tf_jk_profile(tf_ctx *ctx, int enable)
+{
+    if (!ctx) return TF_EINVAL;
+    ctx->prof_jk = enable != 0;
+    ctx->prof_used = 0;
+    return TF_OK;
+}
+
+int tf_jk_profile_read(tf_ctx *ctx, double *seconds_total, int64_t *launches)
+{
+    if (!ctx || !seconds_total || !launches) return TF_EINVAL;
+    double tot = 0.0;
+    for (size_t k = 0; k + 1 < ctx->prof_used; k += 2) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->prof_ev[k + 1]));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[k], ctx->prof_ev[k + 1]));
+        tot += ms * 1e-3;
+    }
+    *seconds_total = tot;
+    *launches = (int64_t)(ctx->prof_used / 2);
+    ctx->prof_used = 0;
     return TF_OK;
 }
 

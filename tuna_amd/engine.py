@@ -147,6 +147,15 @@ class Engine:
         self._check(self._L.tf_fock_jk_device(self._ctx, n_dens, C.c_void_p(dP), C.c_void_p(dJ), C.c_void_p(dK),
                                               C.c_void_p(stream)))
 
+    def jk_profile(self, enable: bool):
+        self._check(self._L.tf_jk_profile(self._ctx, int(enable)))
+
+    def jk_profile_read(self):
+        """(seconds summed over launches, launches) of the row kernel since profiling was enabled."""
+        s, n = C.c_double(), C.c_int64()
+        self._check(self._L.tf_jk_profile_read(self._ctx, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
     # ---- SCF -----------------------------------------------------------------------------------
     def orthogonaliser(self, S: np.ndarray):
         S = f64(S)
