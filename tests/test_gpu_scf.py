@@ -38,6 +38,9 @@ def test_native_rhf_matches_reference_without_damping(engine, golden, small, tag
     # the stopping iteration may differ by one when a criterion sits at its threshold to within rounding (1e-11 / 1e-12)
     assert abs(r["n_iter"] - len(ref_table)) <= 1
     n = min(r["n_iter"], len(ref_table))
+    if tag == "he_631g":
+        n = 3   # N = 2: the DIIS error vectors span one dimension, the Pulay system is singular to rounding and the
+                # extrapolated iterates (step >= 3) are noise-driven in the reference too; only pre-DIIS steps compare
     np.testing.assert_allclose(r["table"][:n, 1], ref_table[:n, 1], atol=2e-9)        # E_total, every iteration
     np.testing.assert_allclose(r["table"][:n, 5], ref_table[:n, 5], atol=1e-8)        # commutator
     np.testing.assert_allclose(r["epsilons"], g["scf_eps_nodamp"], atol=1e-7)
@@ -48,21 +51,19 @@ def test_native_rhf_matches_reference_without_damping(engine, golden, small, tag
     assert np.abs(r["F"] @ r["P"] @ S - S @ r["P"] @ r["F"]).max() < 1e-7
 
 
-@pytest.mark.parametrize("tag", ["h2_sto3g", "he_631g", "c4_co_def2tzvp", "c2_n2_ccpvtz"])
+@pytest.mark.parametrize("tag", ["h2_sto3g", "n2_sto3g", "n2_ccpvdz", "c4_co_def2tzvp", "c2_n2_ccpvtz", "c3_ar2_ccpvqz"])
 def test_native_rhf_default_dynamic_damping(engine, golden, small, tag):
-    """Default keywords (DIIS 6 + dynamic damping).  For heteronuclear CO the damping factors are well defined and the
-    trajectory matches the reference; for homonuclear molecules they are rounding noise, so
-    only the converged energy is compared."""
+    """Default keywords (DIIS 6 + dynamic Zerner-Hehenberger damping): iteration count, per-iteration energies and damping
+    factors of the reference run, including its always-zero "P_old_before_damping" (scf:1154 vs scf:1373)."""
     g = small[tag] if tag in small else golden(tag)
     atoms, S, T, V, X, P0, E0, nocc, ranges = _prepare(engine, tag)
     r = engine.scf_rhf(S, T, V, P0, E0, nocc, mol.nuclear_repulsion(atoms), X=X, conv="extreme", damping="dynamic", n_atom_ao=ranges)
     assert abs(r["energy"] - float(g["scf_energy"])) < 1e-9
-    if tag in ("c4_co_def2tzvp", "he_631g", "h2_sto3g"):
-        ref = g["scf_table"]
-        assert abs(r["n_iter"] - len(ref)) <= 1
-        n = min(r["n_iter"], len(ref))
-        np.testing.assert_allclose(r["table"][:n, 6], ref[:n, 6], atol=1e-6)           # damping factors
-        np.testing.assert_allclose(r["table"][:n, 1], ref[:n, 1], atol=1e-8)
+    ref = g["scf_table"]
+    assert abs(r["n_iter"] - len(ref)) <= 1
+    n = min(r["n_iter"], len(ref))
+    np.testing.assert_allclose(r["table"][:n, 6], ref[:n, 6], atol=1e-6)               # damping factors
+    np.testing.assert_allclose(r["table"][:n, 1], ref[:n, 1], atol=1e-8)
 
 
 def test_oracle_loop_driven_by_hip_fock_builds(engine, golden):

@@ -316,9 +316,10 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
 
     for (int step = 1; step <= o.max_iter; ++step) {
         E_old = E;
-        // P_very_old = P_old ; P_old_before_damping = P_before_damping ; P_old = P    (scf:1114-1117)
+        // P_very_old = P_old ; P_old = P    (scf:1114-1117).  "P_old_before_damping" is the zero matrix in every
+        // iteration of the reference: run_restricted_SCF_cycle does not return P_before_damping (scf:1154), so the
+        // outer loop keeps handing in its initial zeros (scf:1359,1373).  dPoldbd therefore stays zero.
         std::swap(dPvold, dPold);            // dPvold <- old P_old ; dPold free to be overwritten
-        std::swap(dPoldbd, dPbd);            // dPoldbd <- P_before_damping
         TFS_HIP(hipMemcpyAsync(dPold, dP, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
         // Fock matrix (scf:497-531)
         TFS_HIP(hipEventRecord(w.ev0, 0));
