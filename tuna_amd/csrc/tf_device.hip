@@ -495,9 +495,11 @@ static int launch_jk(tf_ctx *ctx, const double *dP, double *dJ, double *dK, hipS
         Ppad = ctx->d_Ppad;
     }
     if (ctx->n_rows > 0) {
-        const size_t smem = (size_t)(2 * N + 4 * TF_JK_THREADS) * sizeof(double);
         const int npair = ld / 2;
-        const dim3 grid((unsigned)ctx->n_rows), block(TF_JK_THREADS);
+        // rows per workgroup: share each P tile among JB rows, but keep >= ~2 workgroups per CU in flight
+        const int JB = (ctx->n_rows >= 4 * 2048) ? 4 : (ctx->n_rows >= 2 * 2048 ? 2 : 1);
+        const size_t smem = (size_t)(2 * JB * N + 4 * TF_JK_THREADS) * sizeof(double);
+        const dim3 grid((unsigned)((ctx->n_rows + JB - 1) / JB)), block(TF_JK_THREADS);
         hipEvent_t ev_after = nullptr;
         if (ctx->prof_jk) {
             if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
@@ -510,17 +512,21 @@ static int launch_jk(tf_ctx *ctx, const double *dP, double *dJ, double *dK, hipS
                 ctx->prof_used += 2;
             }
         }
-        if (npair <= TF_JK_THREADS)
-            hipLaunchKernelGGL(jk_rows_kernel<1>, grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, N, ld, Ppad, ctx->d_Jrow, ctx->d_Kp);
-        else if (npair <= 2 * TF_JK_THREADS)
-            hipLaunchKernelGGL(jk_rows_kernel<2>, grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, N, ld, Ppad, ctx->d_Jrow, ctx->d_Kp);
-        else if (npair <= 4 * TF_JK_THREADS)
-            hipLaunchKernelGGL(jk_rows_kernel<4>, grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, N, ld, Ppad, ctx->d_Jrow, ctx->d_Kp);
-        else
+#define TF_JK_LAUNCH(NLC, JBV)                                                                                              \
+        hipLaunchKernelGGL((jk_rows_kernel<NLC, JBV>), grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, ctx->n_rows, N, ld, Ppad, \
+                           ctx->d_Jrow, ctx->d_Kp)
+        if (npair <= TF_JK_THREADS) {
+            if (JB == 4) TF_JK_LAUNCH(1, 4); else if (JB == 2) TF_JK_LAUNCH(1, 2); else TF_JK_LAUNCH(1, 1);
+        } else if (npair <= 2 * TF_JK_THREADS) {
+            if (JB == 4) TF_JK_LAUNCH(2, 4); else if (JB == 2) TF_JK_LAUNCH(2, 2); else TF_JK_LAUNCH(2, 1);
+        } else if (npair <= 4 * TF_JK_THREADS) {
+            if (JB >= 2) TF_JK_LAUNCH(4, 2); else TF_JK_LAUNCH(4, 1);
+        } else
             TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the J/K kernel's row length limit (2048)", N);
+#undef TF_JK_LAUNCH
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
-    hipLaunchKernelGGL(jk_reduce_kernel, dim3((N + 127) / 128, N), dim3(128), 0, st, ctx->d_Jrow, ctx->d_Kp, ctx->d_rowmap, N, ld,
+    hipLaunchKernelGGL(jk_reduce_kernel, dim3(N), dim3(256), 0, st, ctx->d_Jrow, ctx->d_Kp, ctx->d_rowmap, N, ld,
                        dJ, dK);
     return TF_OK;
 }

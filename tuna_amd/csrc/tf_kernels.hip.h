@@ -83,12 +83,66 @@ __device__ __forceinline__ void build_R_column(double *R, int stride, int col, i
     }
 }
 
+// Boys values F_0..F_L(T), already multiplied by (-2 alpha)^n, into row 0 of column `col` (leader part of the
+// cooperative table build below; same arithmetic as build_R_column).
+__device__ __forceinline__ void build_R_row0(double *R, int stride, int col, int L, double alpha, double PQ,
+                                             const double *__restrict__ boys)
+{
+    const double T = alpha * PQ * PQ;
+    double *F = R + col;
+    if (T == 0.0) {
+        for (int m = 0; m <= L; ++m) F[m * stride] = 1.0 / (2.0 * m + 1.0);
+    } else if (T < TF_BOYS_TMAX) {
+        const int i = (int)(T * (1.0 / TF_BOYS_STEP) + 0.5);
+        const double d = (double)i * TF_BOYS_STEP - T;
+        const double *row = boys + (size_t)i * TF_BOYS_NORD + L;
+        double f = row[8];
+        f = row[7] + f * d * (1.0 / 8.0);
+        f = row[6] + f * d * (1.0 / 7.0);
+        f = row[5] + f * d * (1.0 / 6.0);
+        f = row[4] + f * d * (1.0 / 5.0);
+        f = row[3] + f * d * (1.0 / 4.0);
+        f = row[2] + f * d * (1.0 / 3.0);
+        f = row[1] + f * d * (1.0 / 2.0);
+        f = row[0] + f * d;
+        const double e = exp(-T), two_T = 2.0 * T;
+        F[L * stride] = f;
+        for (int m = L; m > 0; --m) {
+            f = (two_T * f + e) / (2.0 * m - 1.0);
+            F[(m - 1) * stride] = f;
+        }
+    } else {
+        const double e = exp(-T), inv2T = 1.0 / (2.0 * T);
+        double f = 0.5 * sqrt(3.141592653589793238462643383279 / T);
+        F[0] = f;
+        for (int m = 0; m < L; ++m) {
+            f = ((2.0 * m + 1.0) * f - e) * inv2T;
+            F[(m + 1) * stride] = f;
+        }
+    }
+    double pw = 1.0;
+    const double fac = -2.0 * alpha;
+    for (int n = 0; n <= L; ++n) { F[n * stride] *= pw; pw *= fac; }
+}
+
+// One Cartesian component quartet of a shell quartet, decoded once per thread.
+struct CompQuartet {
+    int lx12, ly12, lz12, lx34, ly34, lz34;
+    int ixab, iyab, izab, ixcd, iycd, izcd;
+    int ca, cb, cc, cd;
+    bool nonzero;
+    double cscale;
+};
+
 // ------------------------------------------------------------------------------------------------
 // K1: contracted Cartesian integrals of one shell quartet (AB|CD) per workgroup.
 //   grid.x = ket shell pair (all pairs C >= D), grid.y = bra shell pair of the current slab.
-//   Primitive quartets are processed in batches: phase 1 -- one thread per primitive quartet builds
-//   its Boys/R table into LDS; phase 2 -- threads own Cartesian component quartets and contract the
-//   Hermite expansion tables (global, L1/L2 resident) with the R tables (LDS).
+//   Primitive quartets are processed in batches of PB (as many Boys/R tables as fit the LDS budget):
+//   phase 1 builds the tables -- cooperatively (L+1 lanes per table, one barrier per row) when the batch is
+//   small, one thread per table when there are many; phase 2 -- threads own Cartesian component quartets and
+//   contract the Hermite expansion tables (global, L1/L2 resident) with the R tables (LDS).
+//   When all primitive quartets fit one batch (every uncontracted shell quartet) the tables are built once
+//   and reused by every component chunk.
 //   Output: rows (ca,cb) of the Cartesian slab C[row][Nc][Nc], positions [k][l] and [l][k].
 // Reference: primitive_pair_eri pyx:1142-1221, contraction pyx:1235-1253, driver pyx:1314-1342.
 // ------------------------------------------------------------------------------------------------
@@ -98,6 +152,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_cart_kernel(DBasis B, cons
 {
     __shared__ double sR[TF_RT_DOUBLES];
     __shared__ double sPref[TF_ERI_THREADS];
+    __shared__ double sPQ[TF_ERI_THREADS];
     __shared__ double sRed[TF_ERI_THREADS];
 
     const int tid = threadIdx.x;
@@ -117,7 +172,110 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_cart_kernel(DBasis B, cons
     const double *__restrict__ Ecd0 = B.epool + cd.e_off;
     const long long row0 = bra_rowoff[blockIdx.y];
     const size_t NcNc = (size_t)Nc * Nc;
+    const bool one_batch = npq <= PB;
 
+    // ---- phase 1: Boys + R tables of primitive quartets [b0, b0+nb) into LDS columns 0..nb-1 (all threads call) ----
+    auto phase1 = [&](int b0, int nb) {
+        const int L1 = L + 1;
+        if (nb * L1 <= TF_ERI_THREADS) {
+            const int q = tid / L1, n = tid - q * L1;
+            const bool mine = q < nb;
+            if (mine && n == 0) {
+                const int pq = b0 + q;
+                const int pab = pq / cd.npp, pcd = pq - pab * cd.npp;
+                const double p = B.pp_p[ab.pp_off + pab], qq = B.pp_p[cd.pp_off + pcd];
+                const double s = p + qq, alpha = p * qq / s;
+                const double PQ = B.pp_Pz[ab.pp_off + pab] - B.pp_Pz[cd.pp_off + pcd];
+                build_R_row0(sR, stride, q, L, alpha, PQ, B.boys);
+                sPQ[q] = PQ;
+                sPref[q] = B.pp_K[ab.pp_off + pab] * B.pp_K[cd.pp_off + pcd] * (34.986836655249725 / (p * qq * sqrt(s)));
+            }
+            for (int v = 1; v <= L; ++v) {
+                __syncthreads();
+                if (mine && n <= L - v) {
+                    const int r0 = tri_index(v, 0, L), r1 = tri_index(v - 1, 0, L);
+                    double val = sPQ[q] * sR[(r1 + n + 1) * stride + q];
+                    if (v > 1) val += (double)(v - 1) * sR[(tri_index(v - 2, 0, L) + n + 1) * stride + q];
+                    sR[(r0 + n) * stride + q] = val;
+                }
+            }
+        } else if (tid < nb) {
+            const int pq = b0 + tid;
+            const int pab = pq / cd.npp, pcd = pq - pab * cd.npp;
+            const double p = B.pp_p[ab.pp_off + pab], qq = B.pp_p[cd.pp_off + pcd];
+            const double s = p + qq, alpha = p * qq / s;
+            const double PQ = B.pp_Pz[ab.pp_off + pab] - B.pp_Pz[cd.pp_off + pcd];
+            build_R_column(sR, stride, tid, L, alpha, PQ, B.boys);
+            // 2 pi^(5/2) / (p q sqrt(p+q)) * coefficient product, pyx:1219-1221
+            sPref[tid] = B.pp_K[ab.pp_off + pab] * B.pp_K[cd.pp_off + pcd] * (34.986836655249725 / (p * qq * sqrt(s)));
+        }
+    };
+
+    // ---- decode the component quartet `c` of this shell quartet ----
+    auto decode = [&](int c, CompQuartet &Q) {
+        Q.cd = c % sd.ncomp; c /= sd.ncomp;
+        Q.cc = c % sc.ncomp; c /= sc.ncomp;
+        Q.cb = c % sb.ncomp; Q.ca = c / sb.ncomp;
+        const int ia = sa.comp_off + Q.ca, ib = sb.comp_off + Q.cb, ic = sc.comp_off + Q.cc, id = sd.comp_off + Q.cd;
+        const int ax = B.c_lx[ia], ay = B.c_ly[ia], az = B.c_lz[ia];
+        const int bx = B.c_lx[ib], by = B.c_ly[ib], bz = B.c_lz[ib];
+        const int cx = B.c_lx[ic], cy = B.c_ly[ic], cz = B.c_lz[ic];
+        const int dx = B.c_lx[id], dy = B.c_ly[id], dz = B.c_lz[id];
+        Q.lx12 = ax + bx; Q.ly12 = ay + by; Q.lz12 = az + bz;
+        Q.lx34 = cx + dx; Q.ly34 = cy + dy; Q.lz34 = cz + dz;
+        Q.ixab = (ax * (ab.Lb + 1) + bx) * Lab1; Q.iyab = (ay * (ab.Lb + 1) + by) * Lab1; Q.izab = (az * (ab.Lb + 1) + bz) * Lab1;
+        Q.ixcd = (cx * (cd.Lb + 1) + dx) * Lcd1; Q.iycd = (cy * (cd.Lb + 1) + dy) * Lcd1; Q.izcd = (cz * (cd.Lb + 1) + dz) * Lcd1;
+        Q.nonzero = !(((Q.lx12 + Q.lx34) & 1) || ((Q.ly12 + Q.ly34) & 1));      // x/y parity, pyx:1324-1327
+        Q.cscale = B.c_scale[ia] * B.c_scale[ib] * B.c_scale[ic] * B.c_scale[id];
+        if ((Q.lx34 + Q.ly34) & 1) Q.cscale = -Q.cscale;                          // (-1)^(tau+nu) is fixed by parity
+    };
+
+    // ---- phase 2: my component against primitive quartets g, g+NG, ... of the batch in LDS ----
+    auto phase2 = [&](const CompQuartet &Q, int b0, int nb, int g, int NG) -> double {
+        double acc = 0.0;
+        for (int qq = g; qq < nb; qq += NG) {
+            const int pq = b0 + qq;
+            const int pab = pq / cd.npp, pcd = pq - pab * cd.npp;
+            const double *__restrict__ Exy12 = Eab0 + (size_t)pab * 2 * nEab;
+            const double *__restrict__ Ez12 = Exy12 + nEab;
+            const double *__restrict__ Exy34 = Ecd0 + (size_t)pcd * 2 * nEcd;
+            const double *__restrict__ Ez34 = Exy34 + nEcd;
+            const double *__restrict__ Rq = sR + qq;
+            double sum = 0.0;
+            for (int t = Q.lx12 & 1; t <= Q.lx12; t += 2) {
+                const double ex12 = Exy12[Q.ixab + t];
+                for (int tau = Q.lx34 & 1; tau <= Q.lx34; tau += 2) {
+                    const double xf = ex12 * Exy34[Q.ixcd + tau] * c_dfact[(t + tau) >> 1];
+                    for (int u = Q.ly12 & 1; u <= Q.ly12; u += 2) {
+                        const double ey12 = Exy12[Q.iyab + u];
+                        for (int nu = Q.ly34 & 1; nu <= Q.ly34; nu += 2) {
+                            const double xyf = xf * ey12 * Exy34[Q.iycd + nu] * c_dfact[(u + nu) >> 1];
+                            const int nxy = ((t + tau) >> 1) + ((u + nu) >> 1);
+                            double zs = 0.0;
+                            for (int v = 0; v <= Q.lz12; ++v) {
+                                const double ez12 = Ez12[Q.izab + v];
+                                double zphi = 0.0;
+                                for (int phi = 0; phi <= Q.lz34; ++phi) {
+                                    const double r = Rq[(tri_index(v + phi, nxy, L)) * stride];
+                                    const double e34 = Ez34[Q.izcd + phi];
+                                    zphi += (phi & 1) ? -(e34 * r) : (e34 * r);
+                                }
+                                zs += ez12 * zphi;
+                            }
+                            sum += xyf * zs;
+                        }
+                    }
+                }
+            }
+            acc += sPref[qq] * sum;
+        }
+        return acc;
+    };
+
+    if (one_batch) {
+        phase1(0, npq);
+        __syncthreads();
+    }
     for (int chunk0 = 0; chunk0 < ncomp; chunk0 += TF_ERI_THREADS) {
         const int nchunk = min(TF_ERI_THREADS, ncomp - chunk0);
         // thread -> (group g, component c0): groups split the primitive quartets of a batch
@@ -126,83 +284,19 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_cart_kernel(DBasis B, cons
         const int NG = TF_ERI_THREADS / ncp;
         const int g = tid / ncp, c0 = tid - g * ncp;
         const bool active = c0 < nchunk;
-        // decode my component quartet
-        int lx12 = 0, ly12 = 0, lz12 = 0, lx34 = 0, ly34 = 0, lz34 = 0;
-        int ixab = 0, iyab = 0, izab = 0, ixcd = 0, iycd = 0, izcd = 0;
-        int ca = 0, cb = 0, cc = 0, cdd = 0;
-        bool nonzero = false;
-        double cscale = 0.0;
-        if (active) {
-            int c = chunk0 + c0;
-            cdd = c % sd.ncomp; c /= sd.ncomp;
-            cc = c % sc.ncomp; c /= sc.ncomp;
-            cb = c % sb.ncomp; ca = c / sb.ncomp;
-            const int ia = sa.comp_off + ca, ib = sb.comp_off + cb, ic = sc.comp_off + cc, id = sd.comp_off + cdd;
-            const int ax = B.c_lx[ia], ay = B.c_ly[ia], az = B.c_lz[ia];
-            const int bx = B.c_lx[ib], by = B.c_ly[ib], bz = B.c_lz[ib];
-            const int cx = B.c_lx[ic], cy = B.c_ly[ic], cz = B.c_lz[ic];
-            const int dx = B.c_lx[id], dy = B.c_ly[id], dz = B.c_lz[id];
-            lx12 = ax + bx; ly12 = ay + by; lz12 = az + bz;
-            lx34 = cx + dx; ly34 = cy + dy; lz34 = cz + dz;
-            ixab = (ax * (ab.Lb + 1) + bx) * Lab1; iyab = (ay * (ab.Lb + 1) + by) * Lab1; izab = (az * (ab.Lb + 1) + bz) * Lab1;
-            ixcd = (cx * (cd.Lb + 1) + dx) * Lcd1; iycd = (cy * (cd.Lb + 1) + dy) * Lcd1; izcd = (cz * (cd.Lb + 1) + dz) * Lcd1;
-            nonzero = !(((lx12 + lx34) & 1) || ((ly12 + ly34) & 1));      // x/y parity, pyx:1324-1327
-            cscale = B.c_scale[ia] * B.c_scale[ib] * B.c_scale[ic] * B.c_scale[id];
-            if ((lx34 + ly34) & 1) cscale = -cscale;                       // (-1)^(tau+nu) is fixed by parity
-        }
+        CompQuartet Q;
+        Q.nonzero = false; Q.cscale = 0.0; Q.ca = Q.cb = Q.cc = Q.cd = 0;
+        if (active) decode(chunk0 + c0, Q);
         double acc = 0.0;
-        for (int b0 = 0; b0 < npq; b0 += PB) {
-            const int nb = min(PB, npq - b0);
-            __syncthreads();
-            if (tid < nb) {
-                const int pq = b0 + tid;
-                const int pab = pq / cd.npp, pcd = pq - pab * cd.npp;
-                const double p = B.pp_p[ab.pp_off + pab], q = B.pp_p[cd.pp_off + pcd];
-                const double s = p + q;
-                const double alpha = p * q / s;
-                const double PQ = B.pp_Pz[ab.pp_off + pab] - B.pp_Pz[cd.pp_off + pcd];
-                build_R_column(sR, stride, tid, L, alpha, PQ, B.boys);
-                // 2 pi^(5/2) / (p q sqrt(p+q)) * coefficient product, pyx:1219-1221
-                sPref[tid] = B.pp_K[ab.pp_off + pab] * B.pp_K[cd.pp_off + pcd] * (34.986836655249725 / (p * q * sqrt(s)));
-            }
-            __syncthreads();
-            if (active && nonzero) {
-                for (int qq = g; qq < nb; qq += NG) {
-                    const int pq = b0 + qq;
-                    const int pab = pq / cd.npp, pcd = pq - pab * cd.npp;
-                    const double *__restrict__ Exy12 = Eab0 + (size_t)pab * 2 * nEab;
-                    const double *__restrict__ Ez12 = Exy12 + nEab;
-                    const double *__restrict__ Exy34 = Ecd0 + (size_t)pcd * 2 * nEcd;
-                    const double *__restrict__ Ez34 = Exy34 + nEcd;
-                    const double *__restrict__ Rq = sR + qq;
-                    double sum = 0.0;
-                    for (int t = lx12 & 1; t <= lx12; t += 2) {
-                        const double ex12 = Exy12[ixab + t];
-                        for (int tau = lx34 & 1; tau <= lx34; tau += 2) {
-                            const double xf = ex12 * Exy34[ixcd + tau] * c_dfact[(t + tau) >> 1];
-                            for (int u = ly12 & 1; u <= ly12; u += 2) {
-                                const double ey12 = Exy12[iyab + u];
-                                for (int nu = ly34 & 1; nu <= ly34; nu += 2) {
-                                    const double xyf = xf * ey12 * Exy34[iycd + nu] * c_dfact[(u + nu) >> 1];
-                                    const int nxy = ((t + tau) >> 1) + ((u + nu) >> 1);
-                                    double zs = 0.0;
-                                    for (int v = 0; v <= lz12; ++v) {
-                                        const double ez12 = Ez12[izab + v];
-                                        double zphi = 0.0;
-                                        for (int phi = 0; phi <= lz34; ++phi) {
-                                            const double r = Rq[(tri_index(v + phi, nxy, L)) * stride];
-                                            const double e34 = Ez34[izcd + phi];
-                                            zphi += (phi & 1) ? -(e34 * r) : (e34 * r);
-                                        }
-                                        zs += ez12 * zphi;
-                                    }
-                                    sum += xyf * zs;
-                                }
-                            }
-                        }
-                    }
-                    acc += sPref[qq] * sum;
-                }
+        if (one_batch) {
+            if (active && Q.nonzero) acc = phase2(Q, 0, npq, g, NG);
+        } else {
+            for (int b0 = 0; b0 < npq; b0 += PB) {
+                const int nb = min(PB, npq - b0);
+                __syncthreads();
+                phase1(b0, nb);
+                __syncthreads();
+                if (active && Q.nonzero) acc += phase2(Q, b0, nb, g, NG);
             }
         }
         // combine the groups (fixed order -> bitwise reproducible)
@@ -217,9 +311,9 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_cart_kernel(DBasis B, cons
             }
         }
         if (g == 0 && active) {
-            const double val = acc * cscale;
-            const size_t row = (size_t)(row0 + (long long)ca * sb.ncomp + cb);
-            const int k = sc.cart_off + cc, l = sd.cart_off + cdd;
+            const double val = acc * Q.cscale;
+            const size_t row = (size_t)(row0 + (long long)Q.ca * sb.ncomp + Q.cb);
+            const int k = sc.cart_off + Q.cc, l = sd.cart_off + Q.cd;
             Cslab[row * NcNc + (size_t)k * Nc + l] = val;
             if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
         }
@@ -300,28 +394,47 @@ __global__ void xform_bra_store(const double *__restrict__ in, double *__restric
 // Fock build from the stored tensor (reference: scf:70 "ijkl,kl->ij" and scf:42 "ilkj,kl->ij").
 // Stored rows are (i >= j) x full [k][l] (leading dimension ld).  One pass over a row M = (ij|..) gives
 //     J_ij = J_ji = <M, P>,   K_i. += M^T P[:,j],   K_j. += M^T P[:,i]   (second one only when i != j)
-// so every stored byte is read exactly once per build.  Per-row partial K vectors go to a scratch
-// buffer and are summed in a fixed order by jk_reduce_kernel (no atomics: results are reproducible).
+// so every stored byte is read exactly once per build.  A workgroup streams JB consecutive rows together so
+// that each P[k][l] it pulls from L2 serves JB rows; M is read with non-temporal 16-byte loads (touched once,
+// must not evict P from L2).  Per-row partial K vectors go to a scratch buffer and are summed in a fixed order
+// by jk_reduce_kernel (no atomics: results are bitwise reproducible).
 // ------------------------------------------------------------------------------------------------
 #define TF_JK_THREADS 256
 
-template <int NLC>
+__device__ __forceinline__ double2 load_stream(const double2 *p)
+{
+    double2 v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    return v;
+}
+
+template <int NLC, int JB>
 __global__ __launch_bounds__(TF_JK_THREADS) void jk_rows_kernel(const double *__restrict__ eri,
-                                                                const int2 *__restrict__ row_ij, int N, int ld,
-                                                                const double *__restrict__ P /*[N][ld]*/,
+                                                                const int2 *__restrict__ row_ij, long long n_rows, int N,
+                                                                int ld, const double *__restrict__ P /*[N][ld]*/,
                                                                 double *__restrict__ Jrow, double *__restrict__ Kp)
 {
     extern __shared__ double smem[];
-    double *sPj = smem;            // P[:, j]
-    double *sPi = smem + N;        // P[:, i]
-    double *sRed = smem + 2 * N;   // reduction scratch: 2 * NLC * 2 * TF_JK_THREADS doubles + TF_JK_THREADS
+    double *sPj = smem;                 // [JB][N]  P[:, j_b]
+    double *sPi = smem + JB * N;        // [JB][N]  P[:, i_b]
+    double *sRed = smem + 2 * JB * N;   // reduction scratch: 4 * TF_JK_THREADS doubles
 
-    const long long row = blockIdx.x;
-    const int2 ij = row_ij[row];
+    const long long row0 = (long long)blockIdx.x * JB;
     const int tid = threadIdx.x;
+    int2 ij[JB];
+    bool valid[JB];
+#pragma unroll
+    for (int b = 0; b < JB; ++b) {
+        valid[b] = row0 + b < n_rows;
+        ij[b] = valid[b] ? row_ij[row0 + b] : make_int2(0, 0);
+    }
     for (int k = tid; k < N; k += TF_JK_THREADS) {
-        sPj[k] = P[(size_t)k * ld + ij.y];
-        sPi[k] = P[(size_t)k * ld + ij.x];
+#pragma unroll
+        for (int b = 0; b < JB; ++b) {
+            sPj[b * N + k] = P[(size_t)k * ld + ij[b].y];
+            sPi[b * N + k] = P[(size_t)k * ld + ij[b].x];
+        }
     }
     __syncthreads();
 
@@ -330,83 +443,115 @@ __global__ __launch_bounds__(TF_JK_THREADS) void jk_rows_kernel(const double *__
     const int TK = TF_JK_THREADS / TL;
     const int tk = tid / TL, tl = tid - tk * TL;
     const bool active = tk < TK;
-    const double *__restrict__ M = eri + (size_t)row * N * ld;
+    const size_t row_len = (size_t)N * ld;
+    const double *__restrict__ M0 = eri + (size_t)row0 * row_len;
 
-    double accJ = 0.0;
-    double2 k1[NLC], k2[NLC];
+    double accJ[JB];
+    double2 k1[JB][NLC], k2[JB][NLC];
 #pragma unroll
-    for (int c = 0; c < NLC; ++c) { k1[c] = make_double2(0.0, 0.0); k2[c] = make_double2(0.0, 0.0); }
+    for (int b = 0; b < JB; ++b) {
+        accJ[b] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NLC; ++c) { k1[b][c] = make_double2(0.0, 0.0); k2[b][c] = make_double2(0.0, 0.0); }
+    }
 
     if (active) {
+#pragma unroll 2
         for (int k = tk; k < N; k += TK) {
-            const double pj = sPj[k], pi = sPi[k];
-            const double2 *__restrict__ Mk = reinterpret_cast<const double2 *>(M + (size_t)k * ld);
             const double2 *__restrict__ Pk = reinterpret_cast<const double2 *>(P + (size_t)k * ld);
 #pragma unroll
             for (int c = 0; c < NLC; ++c) {
                 const int lp = tl + c * TF_JK_THREADS;
                 if (NLC == 1 || lp < npair) {
-                    const double2 m = Mk[lp];
                     const double2 p = Pk[lp];
-                    accJ += m.x * p.x + m.y * p.y;
-                    k1[c].x += m.x * pj; k1[c].y += m.y * pj;
-                    k2[c].x += m.x * pi; k2[c].y += m.y * pi;
+                    double2 m[JB];
+#pragma unroll
+                    for (int b = 0; b < JB; ++b)
+                        m[b] = valid[b] ? load_stream(reinterpret_cast<const double2 *>(M0 + b * row_len + (size_t)k * ld) + lp)
+                                        : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int b = 0; b < JB; ++b) {
+                        const double pj = sPj[b * N + k], pi = sPi[b * N + k];
+                        accJ[b] += m[b].x * p.x + m[b].y * p.y;
+                        k1[b][c].x += m[b].x * pj; k1[b][c].y += m[b].y * pj;
+                        k2[b][c].x += m[b].x * pi; k2[b][c].y += m[b].y * pi;
+                    }
                 }
             }
         }
     }
-    // J: block reduction
-    double *sJ = sRed;
-    sJ[tid] = accJ;
-    __syncthreads();
-    for (int s = TF_JK_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s) sJ[tid] += sJ[tid + s];
+    // J: block reduction per row (fixed tree)
+#pragma unroll
+    for (int b = 0; b < JB; ++b) {
         __syncthreads();
+        sRed[tid] = accJ[b];
+        __syncthreads();
+        for (int s = TF_JK_THREADS / 2; s > 0; s >>= 1) {
+            if (tid < s) sRed[tid] += sRed[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0 && valid[b]) Jrow[row0 + b] = sRed[0];
     }
-    if (tid == 0) Jrow[row] = sJ[0];
-    __syncthreads();
     // K partials: sum over tk for each column pair
     double2 *sK = reinterpret_cast<double2 *>(sRed);
-    double *Kp1 = Kp + (size_t)row * 2 * ld, *Kp2 = Kp1 + ld;
 #pragma unroll
-    for (int c = 0; c < NLC; ++c) {
-        if (active) { sK[tid] = k1[c]; sK[TF_JK_THREADS + tid] = k2[c]; }
-        __syncthreads();
-        const int lp = tl + c * TF_JK_THREADS;
-        if (tk == 0 && lp < npair) {
-            double2 a = make_double2(0.0, 0.0), b = make_double2(0.0, 0.0);
-            for (int q = 0; q < TK; ++q) {
-                const double2 u = sK[q * TL + tl], w = sK[TF_JK_THREADS + q * TL + tl];
-                a.x += u.x; a.y += u.y; b.x += w.x; b.y += w.y;
+    for (int b = 0; b < JB; ++b) {
+        double *Kp1 = Kp + (size_t)(row0 + b) * 2 * ld, *Kp2 = Kp1 + ld;
+#pragma unroll
+        for (int c = 0; c < NLC; ++c) {
+            const int lp = tl + c * TF_JK_THREADS;
+            if (TK == 1) {                                     // one thread per column pair: nothing to combine
+                if (valid[b] && lp < npair) {
+                    reinterpret_cast<double2 *>(Kp1)[lp] = k1[b][c];
+                    reinterpret_cast<double2 *>(Kp2)[lp] = k2[b][c];
+                }
+                continue;
             }
-            reinterpret_cast<double2 *>(Kp1)[lp] = a;
-            reinterpret_cast<double2 *>(Kp2)[lp] = b;
+            __syncthreads();
+            if (active) { sK[tid] = k1[b][c]; sK[TF_JK_THREADS + tid] = k2[b][c]; }
+            __syncthreads();
+            if (tk == 0 && lp < npair && valid[b]) {
+                double2 u = make_double2(0.0, 0.0), w = make_double2(0.0, 0.0);
+                for (int q = 0; q < TK; ++q) {
+                    const double2 x = sK[q * TL + tl], y = sK[TF_JK_THREADS + q * TL + tl];
+                    u.x += x.x; u.y += x.y; w.x += y.x; w.y += y.y;
+                }
+                reinterpret_cast<double2 *>(Kp1)[lp] = u;
+                reinterpret_cast<double2 *>(Kp2)[lp] = w;
+            }
         }
-        __syncthreads();
     }
 }
 
-// J[i][j], K[i][l] from the per-row partials.  rowmap[i(i+1)/2+j] = local row or -1 (row owned by another rank).
-__global__ void jk_reduce_kernel(const double *__restrict__ Jrow, const double *__restrict__ Kp,
-                                 const int *__restrict__ rowmap, int N, int ld, double *__restrict__ J,
-                                 double *__restrict__ K)
+// J[i][:], K[i][:] from the per-row partials; one workgroup per i, 4 groups of 64 lanes split the j sum.
+// rowmap[i(i+1)/2+j] = local row or -1 (row owned by another rank).
+__global__ __launch_bounds__(256) void jk_reduce_kernel(const double *__restrict__ Jrow, const double *__restrict__ Kp,
+                                                        const int *__restrict__ rowmap, int N, int ld, double *__restrict__ J,
+                                                        double *__restrict__ K)
 {
-    const int i = blockIdx.y;
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= N) return;
-    double s = 0.0;
-    for (int j = 0; j <= i; ++j) {
-        const int r = rowmap[i * (i + 1) / 2 + j];
-        if (r >= 0) s += Kp[(size_t)r * 2 * ld + l];
+    __shared__ double sPart[256];
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x & 63, jg = threadIdx.x >> 6;
+    for (int l0 = 0; l0 < N; l0 += 64) {
+        const int l = l0 + lane;
+        double s = 0.0;
+        if (l < N) {
+            for (int j = jg; j < N; j += 4) {
+                const int hi = max(i, j), lo = min(i, j);
+                const int r = rowmap[hi * (hi + 1) / 2 + lo];
+                if (r >= 0) s += Kp[(size_t)r * 2 * ld + (j <= i ? 0 : ld) + l];
+            }
+        }
+        sPart[threadIdx.x] = s;
+        __syncthreads();
+        if (jg == 0 && l < N) {
+            K[(size_t)i * N + l] = ((sPart[lane] + sPart[64 + lane]) + sPart[128 + lane]) + sPart[192 + lane];
+            const int hi = max(i, l), lo = min(i, l);
+            const int r = rowmap[hi * (hi + 1) / 2 + lo];
+            J[(size_t)i * N + l] = (r >= 0) ? Jrow[r] : 0.0;
+        }
+        __syncthreads();
     }
-    for (int j = i + 1; j < N; ++j) {
-        const int r = rowmap[j * (j + 1) / 2 + i];
-        if (r >= 0) s += Kp[(size_t)r * 2 * ld + ld + l];
-    }
-    K[(size_t)i * N + l] = s;
-    const int hi = max(i, l), lo = min(i, l);
-    const int r = rowmap[hi * (hi + 1) / 2 + lo];
-    J[(size_t)i * N + l] = (r >= 0) ? Jrow[r] : 0.0;
 }
 
 // dense P [N][N] -> padded [N][ld]
