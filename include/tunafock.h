@@ -158,6 +158,10 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
 /* X = S^-1/2, S^-1 and the smallest overlap eigenvalue (kernel:756-816), host buffers [N,N]. */
 int tf_orthogonaliser(tf_ctx *ctx, int n, const double *S, double *X, double *S_inv, double *smallest_eig);
 
+/* eps[N], C[N,N] = eigenpairs of the Fock matrix in the orthogonalised basis, C = X C' (diagonalise_Fock_matrix,
+ * scf:222-250): rocBLAS dgemm + rocSOLVER dsyevd; host buffers. */
+int tf_diagonalise(tf_ctx *ctx, int n, const double *F, const double *X, double *eps, double *C);
+
 /* ---- instrumentation ------------------------------------------------------------------- */
 
 /* Device-side seconds of the last tf_build_eri broken down by stage:

@@ -1,0 +1,89 @@
+"""CPU, gloo, world_size 2: the N > 1 path -- shard plan (from the C library), partial J/K per rank over its rows of
+the tensor, ONE all-reduce of the stacked [J;K] -- reproduces the full reference einsums."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import make_system
+from oracle import oracle as orc
+from oracle import scf_oracle as so
+from tuna_amd import distributed as tdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _partial_jk(Es, P, owner, rank):
+    """What one rank's row pass produces (same algebra as jk_rows_kernel/jk_reduce_kernel) for the rows it owns."""
+    N = P.shape[0]
+    J = np.zeros((N, N)); K = np.zeros((N, N))
+    for i in range(N):
+        for j in range(i + 1):
+            if owner[i, j] != rank:
+                continue
+            M = Es[i, j]
+            J[i, j] = J[j, i] = np.sum(M * P)
+            K[i, :] += M.T @ P[:, j]
+            if i != j:
+                K[j, :] += M.T @ P[:, i]
+    return J, K
+
+
+def _worker(rank, world, port, tag, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert tdist.env_rank_world() == (rank, world, rank)
+        atoms, shells, aos, nocc = make_system(tag)
+        from tuna_amd import spherical
+        U = spherical.transformation_matrix([s.L for s in shells])
+        Es = so.eri_to_spherical(U, orc.eri(aos, 2))
+        N = Es.shape[0]
+        P = np.random.default_rng(0).standard_normal((N, N)); P = P + P.T
+        owner = tdist.row_owner_matrix(shells, world)
+        J, K = _partial_jk(Es, P, owner, rank)
+        jk = torch.from_numpy(np.stack([J, K]))
+        tdist.all_reduce_jk_(jk)
+        Jf, Kf = jk.numpy()
+        errJ = float(np.abs(Jf - so.coulomb(P, Es)).max()); errK = float(np.abs(Kf - so.exchange(P, Es)).max())
+        mine = int((owner == rank).sum()); total = int((owner >= 0).sum())
+        ret[rank] = (errJ, errK, mine, total)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag", ["n2_sto3g", "n2_ccpvdz"])
+def test_two_rank_sharded_fock_build(tag):
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, tag, ret), nprocs=world, join=True)
+        res = dict(ret)
+    assert set(res) == {0, 1}
+    for rank, (eJ, eK, mine, total) in res.items():
+        assert eJ < 1e-11 and eK < 1e-11
+    assert res[0][2] + res[1][2] == res[0][3]                     # every row has exactly one owner
+    assert abs(res[0][2] - res[1][2]) <= 0.1 * res[0][3] + 25      # and the plan is balanced
+
+
+def test_shard_plan_deterministic_and_consistent_with_rows():
+    _, shells, _, _ = make_system("c3_ar2_ccpvqz")
+    w = tdist.shell_pair_rows(shells)
+    N = sum(s.n_sph for s in shells)
+    assert w.sum() == N * (N + 1) // 2
+    for world in (1, 2, 4, 8):
+        o1, o2 = tdist.shard_owner(shells, world), tdist.shard_owner(shells, world)
+        assert np.array_equal(o1, o2)
+        loads = np.array([w[o1 == r].sum() for r in range(world)])
+        assert loads.max() - loads.min() <= w.max()
+        M = tdist.row_owner_matrix(shells, world)
+        assert (M[np.tril_indices(N)] >= 0).all() and (M[np.triu_indices(N, 1)] == -1).all()

@@ -1,0 +1,89 @@
+"""GPU: the Python face that mirrors the reference's module/function names (seams 1 and 2 of SURVEY.md section 8b)."""
+import numpy as np
+import pytest
+
+from conftest import atom_arrays, make_system
+from oracle import oracle as orc
+from oracle import scf_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+class _Atom:
+    def __init__(self, origin, charge):
+        self.origin, self.charge = origin, charge
+
+
+def test_integral_module_mirror(golden):
+    from tuna_amd import integral as ints
+    atoms, shells, aos, _ = make_system("n2_ccpvdz")
+    g = golden("n2_ccpvdz")
+    bfs = [ints.Basis(aos.origin[i], aos.lmn[i], int(aos.nprim[i]), aos.exps[aos.prim_off[i]:aos.prim_off[i + 1]],
+                      aos.coefs[aos.prim_off[i]:aos.prim_off[i + 1]]) for i in range(aos.n)]
+    np.testing.assert_allclose(np.concatenate([b.norm for b in bfs]), g["norm"], rtol=1e-15)
+    np.testing.assert_allclose(np.concatenate([b.coefs for b in bfs]), g["coefs"], rtol=1e-15)
+    xyz, chg, org = atom_arrays(atoms)
+    S, T, V, D, Q = ints.calculate_one_electron_integrals(aos.n, bfs, 2, [_Atom(x, c) for x, c in zip(xyz, chg)], np.array(org), 4)
+    for got, name in zip((S, T, V, D, Q), "STVDQ"):
+        assert np.abs(got - g[name]).max() < 1e-12
+    ERI = np.empty((aos.n,) * 4)                                   # caller-allocated, uninitialised (kernel:349)
+    out = ints.calculate_electron_repulsion_integrals(aos.n, ERI, bfs, 4)
+    assert out is ERI
+    idx = g["eri_idx"]
+    assert np.abs(ERI[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] - g["eri_val"]).max() < 1e-12
+    assert abs(ints.calculate_electron_repulsion_integral(bfs[3], bfs[1], bfs[17], bfs[4]) - ERI[3, 1, 17, 4]) < 1e-12
+    _, _, aos2, _ = make_system("n2_sto3g")
+    bfs2 = [ints.Basis(aos2.origin[i], aos2.lmn[i], int(aos2.nprim[i]), aos2.exps[aos2.prim_off[i]:aos2.prim_off[i + 1]],
+                       aos2.coefs[aos2.prim_off[i]:aos2.prim_off[i + 1]]) for i in range(aos2.n)]
+    Sx = ints.calculate_cross_basis_overlap_matrix(aos.n, aos2.n, bfs, bfs2, 4)
+    assert np.abs(Sx - orc.cross_overlap(aos, aos2)).max() < 1e-12
+
+
+@pytest.mark.parametrize("line,tag,key", [
+    ("SPE : H H 0.74 : HF STO-3G : EXTREME", "h2_sto3g", "scf_energy"),
+    ("SPE : N N 1.0977 : HF CC-PVTZ : EXTREME", "c2_n2_ccpvtz", "scf_energy"),
+    ("SPE : C O 1.128 : HF DEF2-TZVP : EXTREME NODAMP", "c4_co_def2tzvp", "scf_energy_nodamp"),
+    ("SPE : HE : HF 6-31G : TIGHT", "he_631g", "scf_energy"),
+])
+def test_input_line_single_points(golden, small, line, tag, key):
+    from tuna_amd.energy import run
+    g = small[tag] if tag in small else golden(tag)
+    out = run(line)
+    assert abs(out.energy - float(g[key])) < 1e-8
+    ref = g["scf_table" + ("_nodamp" if key.endswith("nodamp") else "")]
+    if "EXTREME" in line and tag != "he_631g":
+        assert abs(out.n_iterations - len(ref)) <= 1
+    assert abs(out.kinetic_energy + out.nuclear_electron_energy + out.coulomb_energy + out.exchange_energy
+               + float(g["V_NN"]) - out.energy) < 1e-9
+
+
+def test_scf_function_names_and_python_level_cycle(engine, golden):
+    """scf.* helpers by their reference names; the Python-level cycle (used for sharded tensors) against the native one."""
+    from tuna_amd import scf
+    from tuna_amd.energy import Calculation, build_molecule_and_integrals
+    from tuna_amd.engine import SCF_CONVERGENCE
+    from tuna_amd import molecule as mol
+    g = golden("n2_ccpvdz")
+    calc = Calculation(basis="cc-pVDZ", SCF_conv=SCF_CONVERGENCE["extreme"])
+    molecule, integrals, X, guess, _ = build_molecule_and_integrals(["N", "N"], mol.angstrom_to_bohr(1.0977), calc, engine)
+    P0 = guess[0]
+    J = scf.calculate_coulomb_matrix(P0, integrals.ERI_AO)
+    K = scf.calculate_exchange_matrix(P0, integrals.ERI_AO)
+    assert integrals.ERI_AO.n_builds == 1                          # one fused device pass serves both calls
+    F, J2, K2 = scf.construct_restricted_Fock_matrix(integrals, P0, 1.0, None)
+    assert np.array_equal(J, J2) and np.abs(F - F.T).max() == 0
+    eps, C = scf.diagonalise_Fock_matrix(F, X, engine)
+    eo, Co = so.diagonalise(F, X)
+    assert np.abs(eps - eo).max() < 1e-10
+    P1 = scf.construct_density_matrix(C, 7, 2)
+    assert abs(np.trace(P1 @ integrals.S) - 14) < 1e-10
+    E, comps = scf.calculate_restricted_electronic_energy(integrals, P1, J, K, calc)
+    assert abs(sum(comps) - E) < 1e-12
+    with pytest.raises(scf.TunaError):
+        scf.calculate_coulomb_matrix(P0, np.zeros((2, 2, 2, 2)))   # no CPU fallback
+    V_NN = mol.nuclear_repulsion(molecule.atoms)
+    native = scf.run_self_consistent_field_cycle(molecule, calc, integrals, V_NN, X, guess)
+    py = scf._python_level_cycle(molecule, calc, integrals, V_NN, X, guess[0], guess[3], scf._opts(calc))
+    assert abs(native.energy - float(g["scf_energy"])) < 1e-9
+    assert abs(py["energy"] - native.energy) < 1e-9 and py["n_iter"] == native.n_iterations
+    np.testing.assert_allclose(py["table"][:, 6], native.table[:, 6], atol=1e-6)

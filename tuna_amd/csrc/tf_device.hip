@@ -526,7 +526,7 @@ static int launch_jk(tf_ctx *ctx, const double *dP, double *dJ, double *dK, hipS
 #undef TF_JK_LAUNCH
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
-    hipLaunchKernelGGL(jk_reduce_kernel, dim3(N), dim3(256), 0, st, ctx->d_Jrow, ctx->d_Kp, ctx->d_rowmap, N, ld,
+    hipLaunchKernelGGL(jk_reduce_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, st, ctx->d_Jrow, ctx->d_Kp, ctx->d_rowmap, N, ld,
                        dJ, dK);
     return TF_OK;
 }
@@ -647,6 +647,17 @@ int tf_orthogonaliser(tf_ctx *ctx, int n, const double *S, double *X, double *S_
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::string msg;
     int rc = tfscf::orthogonaliser(ctx->scf, n, S, X, S_inv, smallest_eig, msg);
+    if (rc) ctx->err = msg;
+    return rc;
+}
+
+int tf_diagonalise(tf_ctx *ctx, int n, const double *F, const double *X, double *eps, double *C)
+{
+    if (!ctx) return TF_EINVAL;
+    if (n < 1 || !F || !X || !eps || !C) TF_FAIL(ctx, TF_EINVAL, "tf_diagonalise: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string msg;
+    int rc = tfscf::diagonalise(ctx->scf, n, F, X, eps, C, msg);
     if (rc) ctx->err = msg;
     return rc;
 }

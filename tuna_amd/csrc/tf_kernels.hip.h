@@ -523,8 +523,8 @@ __global__ __launch_bounds__(TF_JK_THREADS) void jk_rows_kernel(const double *__
     }
 }
 
-// J[i][:], K[i][:] from the per-row partials; one workgroup per i, 4 groups of 64 lanes split the j sum.
-// rowmap[i(i+1)/2+j] = local row or -1 (row owned by another rank).
+// J[i][l], K[i][l] from the per-row partials; workgroup = (i, 64-column chunk), 4 groups of 64 lanes split the j sum
+// (fixed combination order).  rowmap[i(i+1)/2+j] = local row or -1 (row owned by another rank).
 __global__ __launch_bounds__(256) void jk_reduce_kernel(const double *__restrict__ Jrow, const double *__restrict__ Kp,
                                                         const int *__restrict__ rowmap, int N, int ld, double *__restrict__ J,
                                                         double *__restrict__ K)
@@ -532,25 +532,23 @@ __global__ __launch_bounds__(256) void jk_reduce_kernel(const double *__restrict
     __shared__ double sPart[256];
     const int i = blockIdx.x;
     const int lane = threadIdx.x & 63, jg = threadIdx.x >> 6;
-    for (int l0 = 0; l0 < N; l0 += 64) {
-        const int l = l0 + lane;
-        double s = 0.0;
-        if (l < N) {
-            for (int j = jg; j < N; j += 4) {
-                const int hi = max(i, j), lo = min(i, j);
-                const int r = rowmap[hi * (hi + 1) / 2 + lo];
-                if (r >= 0) s += Kp[(size_t)r * 2 * ld + (j <= i ? 0 : ld) + l];
-            }
-        }
-        sPart[threadIdx.x] = s;
-        __syncthreads();
-        if (jg == 0 && l < N) {
-            K[(size_t)i * N + l] = ((sPart[lane] + sPart[64 + lane]) + sPart[128 + lane]) + sPart[192 + lane];
-            const int hi = max(i, l), lo = min(i, l);
+    const int l = blockIdx.y * 64 + lane;
+    double s = 0.0;
+    if (l < N) {
+#pragma unroll 4
+        for (int j = jg; j < N; j += 4) {
+            const int hi = max(i, j), lo = min(i, j);
             const int r = rowmap[hi * (hi + 1) / 2 + lo];
-            J[(size_t)i * N + l] = (r >= 0) ? Jrow[r] : 0.0;
+            if (r >= 0) s += Kp[(size_t)r * 2 * ld + (j <= i ? 0 : ld) + l];
         }
-        __syncthreads();
+    }
+    sPart[threadIdx.x] = s;
+    __syncthreads();
+    if (jg == 0 && l < N) {
+        K[(size_t)i * N + l] = ((sPart[lane] + sPart[64 + lane]) + sPart[128 + lane]) + sPart[192 + lane];
+        const int hi = max(i, l), lo = min(i, l);
+        const int r = rowmap[hi * (hi + 1) / 2 + lo];
+        J[(size_t)i * N + l] = (r >= 0) ? Jrow[r] : 0.0;
     }
 }
 

@@ -243,6 +243,27 @@ inline int orthogonaliser(Workspace &w, int n, const double *S, double *X, doubl
     return TF_OK;
 }
 
+// eps, C = eigh(sym(X^T F X)), C = X C'   (scf:222-250), host buffers
+inline int diagonalise(Workspace &w, int n, const double *F, const double *X, double *eps, double *C, std::string &msg)
+{
+    int rc = ensure(w, n, 6, msg);
+    if (rc) return rc;
+    const size_t nn = (size_t)n * n;
+    const int g = (int)((nn + 255) / 256);
+    double *dF = w.pool, *dX = dF + nn, *t1 = dX + nn, *t2 = t1 + nn, *dW = t2 + nn, *vals = dW + nn, *e = vals + n;
+    TFS_HIP(hipMemcpy(dF, F, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(hipMemcpy(dX, X, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, dF, 0.0, t1));
+    TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
+    hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+    rc = eigh(w, n, dW, vals, e, msg);
+    if (rc) return rc;
+    TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, t1));
+    TFS_HIP(hipMemcpy(eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
+    TFS_HIP(hipMemcpy(C, t1, nn * sizeof(double), hipMemcpyDeviceToHost));
+    return TF_OK;
+}
+
 using JKFn = std::function<int(const double *, double *, double *, hipStream_t)>;
 
 inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, const double *T, const double *V, const double *Fext,

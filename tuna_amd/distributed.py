@@ -1,0 +1,79 @@
+"""N > 1 GPUs: one process per GPU, each holding a shard of the (ij) shell-pair rows of the ERI tensor; a Fock build is
+the local J/K pass followed by ONE all-reduce of the stacked [J;K].  torch.distributed is the
+transport: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shell_pair_rows(shells, spherical: bool = True) -> np.ndarray:
+    """Row count of every bra shell pair (A >= B, A-major), the weights of the shard plan (tf_build_eri)."""
+    dim = [(s.n_sph if spherical else s.n_cart) for s in shells]
+    w = []
+    for A in range(len(shells)):
+        for B in range(A + 1):
+            w.append(dim[A] * (dim[A] + 1) // 2 if A == B else dim[A] * dim[B])
+    return np.asarray(w, dtype=np.int64)
+
+
+def shard_owner(shells, world: int, spherical: bool = True) -> np.ndarray:
+    """owner[p] = rank that generates and keeps the rows of shell pair p -- the library's own plan (tf_shard_plan)."""
+    w = shell_pair_rows(shells, spherical)
+    owner = np.zeros(len(w), dtype=np.int32)
+    rc = _lib.lib().tf_shard_plan(len(w), _lib.ptr(w), int(world), _lib.ptr(owner))
+    if rc != 0:
+        raise _lib.TunaError("tf_shard_plan failed", rc)
+    return owner
+
+
+def row_owner_matrix(shells, world: int, spherical: bool = True) -> np.ndarray:
+    """owner[i, j] (i >= j) of every AO-pair row; -1 above the diagonal."""
+    owner = shard_owner(shells, world, spherical)
+    dim = [(s.n_sph if spherical else s.n_cart) for s in shells]
+    off = np.concatenate([[0], np.cumsum(dim)])
+    N = int(off[-1])
+    out = np.full((N, N), -1, dtype=np.int32)
+    p = 0
+    for A in range(len(shells)):
+        for B in range(A + 1):
+            out[off[A]:off[A + 1], off[B]:off[B + 1]] = owner[p]
+            p += 1
+    out[np.triu_indices(N, 1)] = -1
+    return out
+
+
+def all_reduce_jk_(jk, group=None):
+    """In-place sum over ranks of a stacked [2, N, N] (or [n_dens, 2, N, N]) tensor: the single exchange step of a build."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(jk, group=group)
+    return jk
+
+
+class ShardedFock:
+    """Fock builds over a sharded tensor: engine.fock_jk_device on this rank's rows + all-reduce."""
+
+    def __init__(self, engine, device=None):
+        import torch
+        self.engine = engine
+        self.device = device if device is not None else torch.device("cuda", engine.device)
+        N = engine.N
+        self._P = torch.zeros((N, N), dtype=torch.float64, device=self.device)
+        self._JK = torch.zeros((2, N, N), dtype=torch.float64, device=self.device)
+
+    def __call__(self, P: np.ndarray):
+        import torch
+        self._P.copy_(torch.from_numpy(np.ascontiguousarray(P, dtype=np.float64)))
+        stream = torch.cuda.current_stream().cuda_stream
+        self.engine.fock_jk_device(self._P.data_ptr(), self._JK[0].data_ptr(), self._JK[1].data_ptr(), 1, stream)
+        all_reduce_jk_(self._JK)
+        out = self._JK.cpu().numpy()
+        return out[0], out[1]

@@ -1,0 +1,197 @@
+"""Energy driver: the hot-path subset of tuna_energy.calculate_energy (energy:875-964) and tuna.py's input line.
+
+    from tuna_amd.energy import run
+    out = run("SPE : N N 1.0977 : HF CC-PVTZ : EXTREME NODAMP")
+
+Input line format `TYPE : A B R : METHOD BASIS : KEYWORDS` (tuna.py:87-99).  Supported here: TYPE = SPE, METHOD = HF
+(restricted, closed shell), the basis sets shipped in tuna_amd/data, and the SCF keywords of SURVEY.md section 5
+(LOOSE/MEDIUM/TIGHT/EXTREME, MAXITER n, DIIS [n]/NODIIS, DAMP x/NODAMP/MAXDAMP x, SLOWCONV/VERYSLOWCONV, HFX x,
+CARTHARM, DECONTRACT, COREGUESS, CH n).  Everything numerical runs on the GPU through the C ABI.  The initial guess is the
+core-Hamiltonian guess (the reference's COREGUESS; its default SAD tables are data not shipped here) -- converged energies do
+not depend on it.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import molecule as mol
+from ._lib import TunaError
+from .engine import SCF_CONVERGENCE, Engine
+from .scf import DeviceERI, Integrals, construct_density_matrix, run_self_consistent_field_cycle
+
+
+@dataclass
+class Calculation:
+    """The fields of the reference's Calculation (tuna_calc.py:532-596) that the hot path reads."""
+    calculation_type: str = "SPE"
+    method: str = "HF"
+    basis: str = "STO-3G"
+    reference: str = "RHF"
+    charge: int = 0
+    SCF_conv: dict = field(default_factory=lambda: SCF_CONVERGENCE["medium"])
+    max_iter: int = 100                 # MAXITER, calc:158
+    DIIS: bool = True                   # calc:198
+    max_DIIS_matrices: int = 6
+    damping: bool = True                # calc:199
+    damping_factor: float | None = None
+    max_damping: float = 0.7            # calc:159
+    HFX_prop: float = 1.0               # calc:207
+    cartesian_harmonics: bool = False   # CARTHARM, calc:91
+    decontract: bool = False            # DECONTRACT, calc:90
+    core_guess: bool = True
+    DFT_calculation: bool = False
+
+
+@dataclass
+class Molecule:
+    atoms: list
+    shells: list
+    aos: mol.AOList
+    n_electrons: int
+    n_doubly_occ: int
+    partition_ranges: list
+    n_basis: int
+    n_cartesian_basis: int
+
+
+def parse_input(input_line: str):
+    """tuna.py:59-161 -> (calculation_type, method, basis, atomic_symbols, R_bohr | None, params)."""
+    try:
+        sections = input_line.upper().strip().split(":")
+        calculation_type = sections[0].strip()
+        geometry = [g for g in sections[1].strip().split(" ") if g.strip()]
+        method, basis = sections[2].strip().split()
+        params = sections[3].strip().split() if len(sections) == 4 else []
+    except Exception:
+        raise TunaError("Input line formatted incorrectly! Read the manual for help.")
+    symbols = geometry[:2] if len(geometry) >= 3 else geometry[:1]
+    try:
+        R = [float(x) for x in geometry[len(symbols):]]
+    except ValueError:
+        raise TunaError("Could not parse bond length!")
+    if len(symbols) == 2 and len(R) != 1:
+        raise TunaError("Two atoms requested without a bond length!")
+    if R and R[0] < 0.01:
+        raise TunaError(f"Bond length ({R[0]} angstroms) is too small! Minimum bond length is 0.01 angstroms.")
+    return calculation_type, method, basis, symbols, (mol.angstrom_to_bohr(R[0]) if R else None), params
+
+
+def interpret_keywords(params, calc: Calculation) -> Calculation:
+    """The SCF subset of tuna_calc.py:83-217, 357-521."""
+    it = iter(range(len(params)))
+    for k in it:
+        p = params[k]
+
+        def value():
+            try:
+                next(it)
+                return params[k + 1]
+            except (StopIteration, IndexError):
+                raise TunaError(f"Keyword {p} needs a value")
+        if p in ("LOOSE", "MEDIUM", "TIGHT", "EXTREME"):
+            calc.SCF_conv = SCF_CONVERGENCE[p.lower()]
+        elif p == "MAXITER":
+            calc.max_iter = int(value())
+        elif p == "NODIIS":
+            calc.DIIS = False
+        elif p == "DIIS":
+            if k + 1 < len(params) and params[k + 1].isdigit():
+                calc.max_DIIS_matrices = int(value())
+        elif p == "NODAMP":
+            calc.damping = False
+        elif p == "DAMP":
+            calc.damping, calc.damping_factor = True, float(value())
+        elif p == "SLOWCONV":
+            calc.damping, calc.damping_factor = True, 0.5
+        elif p == "VERYSLOWCONV":
+            calc.damping, calc.damping_factor = True, 0.85
+        elif p == "MAXDAMP":
+            calc.max_damping = float(value())
+        elif p == "HFX":
+            calc.HFX_prop = float(value())
+        elif p == "CARTHARM":
+            calc.cartesian_harmonics = True
+        elif p == "DECONTRACT":
+            calc.decontract = True
+        elif p in ("CH", "CHARGE"):
+            calc.charge = int(value())
+        elif p in ("COREGUESS", "T", "P", "DEBUG"):
+            pass
+        else:
+            raise TunaError(f"Keyword \"{p}\" is not supported on the GPU hot path (SCF keywords only)")
+    return calc
+
+
+def build_molecule_and_integrals(symbols, R_bohr, calc: Calculation, engine: Engine, sharded_fock_factory=None):
+    """energy:770-870 for the hot path: molecule, one- and two-electron integrals (GPU), orthogonaliser, guess."""
+    atoms = mol.make_atoms(symbols, R_bohr)
+    shells = mol.build_shells(atoms, calc.basis, calc.decontract)
+    aos = mol.expand_cartesian_aos(shells)
+    spherical = not calc.cartesian_harmonics
+    n_el = mol.electron_count(atoms, calc.charge)
+    if n_el <= 0:
+        raise TunaError("Zero electrons specified!" if n_el == 0 else "Negative number of electrons specified!")
+    if n_el % 2:
+        raise TunaError("open-shell (UHF) references are not on the GPU path in this build")
+    timings = {}
+    t0 = time.perf_counter()
+    engine.set_basis(aos)
+    xyz, chg = [a.origin for a in atoms], [float(a.charge) for a in atoms]
+    com = [0.0, 0.0, 0.5 * atoms[-1].origin[2] if len(atoms) == 2 else 0.0]
+    S, T, V, D, Q = engine.one_electron(xyz, chg, com, spherical=spherical)
+    timings["One-electron integrals"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    engine.build_eri(spherical=spherical)
+    timings["Two-electron integrals"] = time.perf_counter() - t0
+    fock = sharded_fock_factory(engine) if sharded_fock_factory is not None and engine.world > 1 else None
+    integrals = Integrals(S, T, V, D, Q, DeviceERI(engine, fock))
+    dim = (lambda s: s.n_sph) if spherical else (lambda s: s.n_cart)
+    ranges = [sum(dim(s) for s in shells if s.atom == a) for a in range(len(atoms))]
+    molecule = Molecule(atoms, shells, aos, n_el, n_el // 2, ranges, engine.N, aos.n)
+    t0 = time.perf_counter()
+    X, smallest, S_inv = engine.orthogonaliser(S)
+    timings["Fock orthogonalisation matrix"] = time.perf_counter() - t0
+    if smallest < 1e-7:                                   # STHRESH, kernel:887
+        raise TunaError("An overlap matrix eigenvalue is too small! Change the basis set or decrease the threshold with STHRESH.")
+    t0 = time.perf_counter()
+    _, C0 = engine.diagonalise(integrals.H_core, X)
+    P0 = construct_density_matrix(C0, molecule.n_doubly_occ, 2)
+    E0 = float(np.einsum("mn,mn->", integrals.H_core, P0))     # guess energy, tuna_guess.py:429
+    timings["Initial guess"] = time.perf_counter() - t0
+    return molecule, integrals, X, (P0, P0 / 2, P0 / 2, E0), timings
+
+
+def calculate_energy(symbols, R_bohr, calc: Calculation, engine: Engine | None = None, silent=True, log=print):
+    own = engine is None
+    engine = engine or Engine(0)
+    try:
+        molecule, integrals, X, guess, timings = build_molecule_and_integrals(symbols, R_bohr, calc, engine)
+        V_NN = mol.nuclear_repulsion(molecule.atoms)
+        if not silent:
+            log(f" Nuclear repulsion energy: {V_NN:.10f}\n")
+        t0 = time.perf_counter()
+        out = run_self_consistent_field_cycle(molecule, calc, integrals, V_NN, X, guess, None, silent, log)
+        timings["Self-consistent field"] = time.perf_counter() - t0
+        out.timings.update(timings)
+        if not silent:
+            log("\n Restricted Hartree-Fock energy:   " + f"{out.energy:16.10f}")       # kernel:846
+            log("\n Final single point energy: " + f"{out.energy:16.10f}")              # kernel:1305
+        out.integrals = integrals if not own else None      # the device tensor dies with an engine we own
+        return out
+    finally:
+        if own:
+            engine.close()
+
+
+def run(input_line: str, silent: bool = True, engine: Engine | None = None, log=print):
+    """tuna.py:345 `run(input_line, suppress_output)` for single-point restricted Hartree-Fock."""
+    ctype, method, basis, symbols, R, params = parse_input(input_line)
+    if ctype != "SPE":
+        raise TunaError(f"Calculation type \"{ctype}\" is not supported.")
+    if method not in ("HF", "RHF"):
+        raise TunaError(f"Electronic structure method \"{method}\" is not supported.")
+    calc = interpret_keywords(params, Calculation(ctype, "HF", basis))
+    return calculate_energy(symbols, R, calc, engine, silent, log)

@@ -165,6 +165,14 @@ class Engine:
         self._check(self._L.tf_orthogonaliser(self._ctx, n, ptr(S), ptr(X), ptr(Si), C.byref(sm)))
         return X, sm.value, Si
 
+    def diagonalise(self, F, X):
+        """(epsilons, molecular_orbitals) = eigh(sym(X^T F X)), C = X C' on the device (scf:222-250)."""
+        F, X = f64(F), f64(X)
+        n = F.shape[0]
+        eps, Cm = np.zeros(n), np.zeros((n, n))
+        self._check(self._L.tf_diagonalise(self._ctx, n, ptr(F), ptr(X), ptr(eps), ptr(Cm)))
+        return eps, Cm
+
     def scf_rhf(self, S, T, V, P0, E0, n_occ, V_NN, *, X=None, Fext=None, conv="medium", max_iter=100, diis=True,
                 max_diis=6, damping="dynamic", damping_factor=0.0, max_damping=0.7, hfx=1.0, n_atom_ao=None):
         N = self.N

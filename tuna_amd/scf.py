@@ -1,0 +1,302 @@
+"""Drop-in face of the reference's SCF functions (seam 2): the names, argument order and return
+values of TUNA/tuna_scf.py ("scf"), with the work done by libtunafock through the C ABI.
+
+* `integrals.ERI_AO` is a `DeviceERI` handle -- the tensor lives in HBM (rows i>=j, sharded over ranks), not in host RAM.
+* `calculate_coulomb_matrix` / `calculate_exchange_matrix` (scf:55-72, 27-44) are one fused device pass (cached per
+  density, so the reference's two calls cost one build); with several ranks the partial [J;K] is all-reduced (RCCL).
+* `run_self_consistent_field_cycle` (scf:1292-1435) runs the whole RHF cycle natively (`tf_scf_rhf`: HIP J/K + rocBLAS +
+  rocSOLVER) on one GPU; with a sharded tensor it runs the same iteration order in Python with device Fock builds.
+* The small helpers keep the reference's NumPy form where they are O(N^2) bookkeeping (`symmetrise`, `calculate_SCF_changes`,
+  `check_convergence`, energies as traces); `diagonalise_Fock_matrix` goes through rocSOLVER (`tf_orthogonaliser` family).
+There is no CPU fallback for the tensor contractions: a NumPy ERI array is rejected.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ._lib import TunaError
+from .engine import SCF_CONVERGENCE, Engine
+
+
+def symmetrise(matrix):                                   # tuna_util.py:748-764
+    return (1 / 2) * (matrix + matrix.T)
+
+
+class DeviceERI:
+    """Handle of the HBM-resident (ij|kl) tensor built by `Engine.build_eri` -- what `integrals.ERI_AO` holds here."""
+
+    def __init__(self, engine: Engine, sharded_fock=None):
+        self.engine = engine
+        self.shape = (engine.N,) * 4
+        self._fock = sharded_fock           # tuna_amd.distributed.ShardedFock when world > 1
+        self._key = None
+        self._jk = None
+        self.n_builds = 0
+
+    def jk(self, P):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        key = (P.shape, P.tobytes())
+        if key != self._key:
+            self._jk = self._fock(P) if self._fock is not None else self.engine.fock_jk(P)
+            self._key = key
+            self.n_builds += 1
+        return self._jk
+
+    def dense(self):
+        """The reference's dense float64[N,N,N,N] (for post-SCF consumers); moderate N only."""
+        return self.engine.copy_eri()
+
+
+def _device(ERI_AO) -> DeviceERI:
+    if not isinstance(ERI_AO, DeviceERI):
+        raise TunaError("tuna_amd contracts the ERI tensor on the GPU only: pass the DeviceERI handle (integrals.ERI_AO), "
+                        "not a NumPy array -- there is no CPU fallback")
+    return ERI_AO
+
+
+def calculate_exchange_matrix(P, ERI_AO):                 # scf:27-44   K = einsum("ilkj,kl->ij")
+    return _device(ERI_AO).jk(P)[1]
+
+
+def calculate_coulomb_matrix(P, ERI_AO):                  # scf:55-72   J = einsum("ijkl,kl->ij")
+    return _device(ERI_AO).jk(P)[0]
+
+
+def construct_density_matrix(molecular_orbitals, n_occ, n_electrons_per_orbital):   # scf:183-211
+    occupied_mos = molecular_orbitals[:, :n_occ]
+    return symmetrise(n_electrons_per_orbital * occupied_mos @ occupied_mos.T)
+
+
+def diagonalise_Fock_matrix(F, X, engine: Engine | None = None):                     # scf:222-250
+    """eigh(sym(X^T F X)) through rocSOLVER (native RHF uses the same routine); returns (epsilons, molecular_orbitals)."""
+    from .integral import default_engine
+    eng = engine or default_engine()
+    return eng.diagonalise(F, X)
+
+
+def calculate_SCF_changes(E, E_old, P, P_old):                                        # scf:261-288
+    delta_P = P - P_old
+    return E - E_old, np.max(np.abs(delta_P)), np.mean(delta_P ** 2) ** (1 / 2)
+
+
+def check_convergence(SCF_conv, step, delta_E, max_DP, RMS_DP, commutator, calculation=None, silent=False):   # scf:299-333
+    return bool(abs(delta_E) < SCF_conv["delta_E"] and abs(max_DP) < SCF_conv["max_DP"] and abs(RMS_DP) < SCF_conv["RMS_DP"]
+                and abs(commutator) < SCF_conv["commutator"])
+
+
+def calculate_restricted_electronic_energy(integrals, P, J, K, calculation, density=None, weights=None, e_X=None, e_C=None):
+    """scf:344-404 (Hartree-Fock part; the grid terms belong to the DFT row, out of scope here)."""
+    kinetic_energy = np.einsum("ij,ij->", P, integrals.T, optimize=True)
+    nuclear_electron_energy = np.einsum("ij,ij->", P, integrals.V_NE, optimize=True)
+    electric_field_energy = np.einsum("ij,ij->", P, integrals.F, optimize=True)
+    electric_field_gradient_energy = np.einsum("ij,ij->", P, integrals.G, optimize=True)
+    coulomb_energy = (1 / 2) * np.einsum("ij,ij->", P, J, optimize=True)
+    exchange_energy = -(1 / 4) * np.einsum("ij,ij->", P, K, optimize=True) * calculation.HFX_prop
+    correlation_energy = 0
+    electronic_energy = (kinetic_energy + nuclear_electron_energy + coulomb_energy + exchange_energy + correlation_energy
+                         + electric_field_energy + electric_field_gradient_energy)
+    return electronic_energy, (kinetic_energy, nuclear_electron_energy, coulomb_energy, exchange_energy, correlation_energy,
+                               electric_field_energy, electric_field_gradient_energy)
+
+
+def construct_restricted_Fock_matrix(integrals, P, HFX_prop, V_XC=None):             # scf:497-531
+    V_XC = V_XC if V_XC is not None else 0
+    J = calculate_coulomb_matrix(P, integrals.ERI_AO)
+    K = calculate_exchange_matrix(P, integrals.ERI_AO)
+    F = integrals.T + integrals.V_NE + integrals.F + integrals.G + J - (1 / 2) * K * HFX_prop + V_XC
+    return symmetrise(F), J, K
+
+
+def format_output_line(E_total, delta_E, max_DP, RMS_DP, damping_factor, step, commutator):   # scf:83-107
+    damping = f"{damping_factor:.3f}" if damping_factor != 0 else " ---"
+    return f"  {step:3.0f}  {E_total:16.10f}  {delta_E:16.10f} {RMS_DP:16.10f} {max_DP:16.10f} {commutator:16.10f}     {damping}"
+
+
+SCF_TABLE_HEADER = "  Step          E                 DE             RMS(DP)          MAX(DP)           Error       Damping"   # scf:1328
+
+
+@dataclass
+class Integrals:                                           # tuna_util.py:153-194
+    S: np.ndarray
+    T: np.ndarray
+    V_NE: np.ndarray
+    D: np.ndarray
+    Q: np.ndarray
+    ERI_AO: DeviceERI
+    F: np.ndarray | None = None
+    G: np.ndarray | None = None
+
+    def __post_init__(self):
+        if self.F is None:
+            self.F = np.zeros_like(self.S)
+        if self.G is None:
+            self.G = np.zeros_like(self.S)
+
+    @property
+    def H_core(self):
+        return self.T + self.V_NE + self.F
+
+    @property
+    def one_electron_integrals(self):
+        return self.S, self.T, self.V_NE, self.D
+
+    @property
+    def n_basis(self):
+        return self.S.shape[0]
+
+
+@dataclass
+class Output:                                              # tuna_util.py:205-288 (fields filled by the RHF path)
+    energy: float
+    kinetic_energy: float
+    nuclear_electron_energy: float
+    coulomb_energy: float
+    exchange_energy: float
+    correlation_energy: float
+    electric_field_energy: float
+    electric_field_gradient_energy: float
+    P: np.ndarray
+    P_alpha: np.ndarray
+    P_beta: np.ndarray
+    S: np.ndarray
+    X: np.ndarray
+    molecular_orbitals: np.ndarray
+    molecular_orbitals_alpha: np.ndarray
+    molecular_orbitals_beta: np.ndarray
+    epsilons: np.ndarray
+    epsilons_alpha: np.ndarray
+    epsilons_beta: np.ndarray
+    density: None
+    alpha_density: None
+    beta_density: None
+    F_alpha: np.ndarray
+    F_beta: np.ndarray
+    T: np.ndarray
+    V_NE: np.ndarray
+    integrals: Integrals
+    dispersion_energy: float = 0
+    n_iterations: int = 0
+    table: np.ndarray = field(default_factory=lambda: np.zeros((0, 7)))
+    timings: dict = field(default_factory=dict)
+
+
+def _opts(calculation):
+    damping = "none"
+    factor = 0.0
+    if getattr(calculation, "damping", True):
+        if getattr(calculation, "damping_factor", None) is not None:
+            damping, factor = "static", float(calculation.damping_factor)
+        else:
+            damping = "dynamic"
+    return dict(conv=calculation.SCF_conv, max_iter=calculation.max_iter, diis=bool(calculation.DIIS),
+                max_diis=calculation.max_DIIS_matrices, damping=damping, damping_factor=factor,
+                max_damping=calculation.max_damping, hfx=calculation.HFX_prop)
+
+
+def run_self_consistent_field_cycle(molecule, calculation, integrals: Integrals, V_NN, X, guess_objects, grid_container=None,
+                                    silent=True, log=print) -> Output:
+    """scf:1292-1435 for the restricted reference.  `molecule` needs n_doubly_occ and partition_ranges; `calculation` the
+    fields of `tuna_amd.energy.Calculation` (same names as the reference's Calculation)."""
+    if getattr(calculation, "reference", "RHF") != "RHF":
+        raise TunaError("only the restricted (RHF) cycle is on the GPU path in this build")
+    P, _, _, E = guess_objects
+    eri = _device(integrals.ERI_AO)
+    eng = eri.engine
+    o = _opts(calculation)
+    if not silent:
+        log(" Beginning self-consistent field cycle...\n")
+        log(f" Using \"{o['conv']['name']}\" SCF convergence criteria.")
+        log(SCF_TABLE_HEADER)
+    Fext = integrals.F + integrals.G
+    if eng.world == 1:
+        try:
+            r = eng.scf_rhf(integrals.S, integrals.T, integrals.V_NE, P, E, molecule.n_doubly_occ, V_NN, X=X,
+                            Fext=Fext if np.any(Fext) else None, n_atom_ao=molecule.partition_ranges, **o)
+        except TunaError as e:
+            if not silent and getattr(e, "partial", None) is not None:
+                for row in e.partial["table"]:
+                    log(format_output_line(row[1], row[2], row[4], row[3], row[6], row[0], row[5]))
+            raise
+    else:
+        r = _python_level_cycle(molecule, calculation, integrals, V_NN, X, P, E, o)
+    if not silent:
+        for row in r["table"]:
+            log(format_output_line(row[1], row[2], row[4], row[3], row[6], row[0], row[5]))
+        log(f"\n Self-consistent field converged in {r['n_iter']} cycles!\n")
+    c = r["components"]
+    Pf, Cm, eps, F = r["P"], r["C"], r["epsilons"], r["F"]
+    return Output(r["energy"], c[0], c[1], c[2], c[3], c[4], c[5], c[6], Pf, Pf / 2, Pf / 2, integrals.S, X, Cm, Cm, Cm, eps, eps, eps,
+                  None, None, None, F / 2, F / 2, integrals.T, integrals.V_NE, integrals, 0, r["n_iter"], r["table"],
+                  {k: r[k] for k in ("fock_seconds", "eig_seconds", "wall_seconds") if k in r})
+
+
+def _python_level_cycle(molecule, calculation, integrals, V_NN, X, P, E, o):
+    """The iteration order of scf:1072-1154 with device Fock builds (sharded tensor + all-reduce) and rocSOLVER
+    diagonalisations; used when the tensor is spread over several ranks.  Every rank runs it redundantly."""
+    import time
+    S, T, V = integrals.S, integrals.T, integrals.V_NE
+    Fext = integrals.F + integrals.G
+    eng = integrals.ERI_AO.engine
+    thr = o["conv"]
+    n_occ = molecule.n_doubly_occ
+    ranges = list(molecule.partition_ranges)
+    P_old = np.zeros_like(P)
+    P_zero = np.zeros_like(P)                      # "P_old_before_damping" is always zero in the reference (scf:1154/1373)
+    Fock_vector, err_vector, table = [], [], []
+    t0 = time.perf_counter()
+
+    def pops(D):
+        d = np.einsum("ij,ji->i", D, S)
+        return np.array([d[:ranges[0]].sum(), d[ranges[0]:].sum() if len(ranges) > 1 else 0.0])
+
+    for step in range(1, o["max_iter"] + 1):
+        E_old, P_very_old, P_old = E, P_old, P
+        J, K = integrals.ERI_AO.jk(P)
+        F = symmetrise(T + V + Fext + J - (1 / 2) * K * o["hfx"])
+        e = X.T @ (F @ P @ S - S @ P @ F) @ X
+        commutator = np.mean(e * e) ** (1 / 2)
+        err_vector.append(np.concatenate((e.flatten(), e.flatten())))
+        Fock_vector.append(F)
+        if len(Fock_vector) > o["max_diis"]:
+            del Fock_vector[0], err_vector[0]
+        eps, C = eng.diagonalise(F, X)
+        P = construct_density_matrix(C, n_occ, 2)
+        comps = (np.sum(P * T), np.sum(P * V), (1 / 2) * np.sum(P * J), -(1 / 4) * np.sum(P * K) * o["hfx"], 0.0, np.sum(P * Fext), 0.0)
+        E = sum(comps)
+        if step > 2 and o["diis"] and commutator < 0.3:
+            n = len(err_vector)
+            errs = np.array(err_vector)
+            B = np.empty((n + 1, n + 1))
+            B[:n, :n] = errs @ errs.T
+            B[:n, -1] = -1
+            B[-1, :n] = -1
+            B[-1, -1] = 0
+            rhs = np.zeros(n + 1)
+            rhs[-1] = -1
+            try:
+                coeffs = np.linalg.solve(B, rhs)[:n]
+                _, C_d = eng.diagonalise(np.tensordot(coeffs, np.array(Fock_vector), axes=(0, 0)), X)
+                P = symmetrise(construct_density_matrix(C_d, n_occ, 2))
+            except np.linalg.LinAlgError:
+                Fock_vector.clear()
+                err_vector.clear()
+        P_before = P
+        factor = 0.0
+        if o["damping"] == "static":
+            factor = o["damping_factor"]
+        elif o["damping"] == "dynamic" and commutator > 0.01 and step > 1:
+            A_out, A1_in, A1_out, A2_in = pops(P_before), pops(P_old), pops(P_zero), pops(P_very_old)
+            den = A_out - A1_out - A1_in + A2_in
+            alpha = (A_out - A1_out) / den if den.all() != 0 else [0, 0]
+            factor = ((alpha[0] * ranges[0] + alpha[1] * ranges[1]) / (ranges[0] + ranges[1])) if len(ranges) == 2 else alpha[0] * ranges[0]
+            factor = max(factor, 0)
+            factor = factor if factor < min(o["max_damping"], 1) else o["max_damping"]
+        P = factor * P_old + (1 - factor) * P_before
+        dE, maxDP, rmsDP = calculate_SCF_changes(E, E_old, P, P_old)
+        table.append([step, E + V_NN, dE, rmsDP, maxDP, commutator, float(factor)])
+        if check_convergence(thr, step, dE, maxDP, rmsDP, commutator):
+            return dict(energy=E + V_NN, components=np.array(comps, dtype=float), P=P, C=C, epsilons=eps, F=F, table=np.array(table),
+                        n_iter=step, converged=True, wall_seconds=time.perf_counter() - t0)
+    raise TunaError(f"Self-consistent field not converged in {o['max_iter']} iterations! Increase maximum iterations or give up.", -4)
