@@ -171,6 +171,10 @@ int tf_eri_timings(const tf_ctx *ctx, double *seconds4);
  * [2] Cartesian component quartets. */
 int tf_eri_counts(const tf_ctx *ctx, int64_t *counts3);
 
+/* Seconds per symmetric eigensolve (random n x n matrix) of the solver variants considered for a12
+ * (0 = rocsolver dsyevd, 1 = dsyev, 2 = dsyevj); instrumentation only. */
+int tf_eigh_probe(tf_ctx *ctx, int n, int variant, int reps, double *seconds);
+
 /* HIP-event timing of the dominant kernel of the Fock build (the row pass over the stored tensor), recorded on
  * the stream each build is launched on.  enable: start (and reset) / stop collecting; read: synchronises the
  * recorded events, returns their summed duration and the number of launches, and resets. */

@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
+#include <map>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -14,6 +16,7 @@
 #include "../../include/tunafock.h"
 #include "tf_internal.h"
 #include "tf_kernels.hip.h"
+#include "tf_eri.hip.h"
 #include "tf_oneel.hip.h"
 #include "tf_scf.hip.h"
 
@@ -21,7 +24,8 @@ using namespace tfk;
 
 static std::string g_create_error;
 static const bool g_dbg = getenv("TF_DEBUG") != nullptr;
-#define DBG(...) do { if (g_dbg) { fprintf(stderr, "[tf] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define DBG(...) do { if (g_dbg) { fprintf(stderr, "[tf %.6f] ", now_s()); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
 
 struct tf_ctx {
     int device = 0, rank = 0, world = 1;
@@ -41,6 +45,8 @@ struct tf_ctx {
     int2 *d_row_ij = nullptr;
     int *d_rowmap = nullptr;
     std::vector<int> my_pairs;          // bra shell pairs owned by this rank
+    std::vector<int> pair_class;        // class id of every shell pair
+    std::vector<std::vector<int>> class_pairs;   // pairs of each class, ascending
     // J/K scratch
     double *d_Jrow = nullptr, *d_Kp = nullptr, *d_Ppad = nullptr, *d_J = nullptr, *d_K = nullptr, *d_P = nullptr;
     // instrumentation
@@ -50,7 +56,24 @@ struct tf_ctx {
     double eri_seconds[4] = {0, 0, 0, 0};
     long long eri_counts[3] = {0, 0, 0};
     tfscf::Workspace scf;
+    // persistent helpers of tf_build_eri (creating streams / freeing GiB-sized buffers costs tens of ms per call)
+    static const int NSTREAM_MAX = 8;
+    hipStream_t streams[NSTREAM_MAX] = {};
+    hipEvent_t sev[NSTREAM_MAX] = {};
+    bool have_streams = false;
+    double *scr[3] = {nullptr, nullptr, nullptr};
+    size_t scr_bytes[3] = {0, 0, 0};
 };
+
+static int ensure_scratch(tf_ctx *ctx, int k, size_t bytes)
+{
+    if (bytes <= ctx->scr_bytes[k]) return TF_OK;
+    if (ctx->scr[k]) { (void)hipFree(ctx->scr[k]); ctx->scr[k] = nullptr; ctx->scr_bytes[k] = 0; }
+    hipError_t e = hipMalloc((void **)&ctx->scr[k], bytes);
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc of ERI scratch failed: ") + hipGetErrorString(e); return TF_ENOMEM; }
+    ctx->scr_bytes[k] = bytes;
+    return TF_OK;
+}
 
 #define TF_FAIL(ctx, code, ...)                                  \
     do {                                                         \
@@ -158,6 +181,10 @@ void tf_destroy(tf_ctx *ctx)
     free_basis(ctx);
     tfscf::release(ctx->scf);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    if (ctx->have_streams)
+        for (int k = 0; k < tf_ctx::NSTREAM_MAX; ++k) { (void)hipStreamDestroy(ctx->streams[k]); (void)hipEventDestroy(ctx->sev[k]); }
+    for (int k = 0; k < 3; ++k)
+        if (ctx->scr[k]) (void)hipFree(ctx->scr[k]);
     delete ctx;
 }
 
@@ -186,7 +213,22 @@ int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t
     std::vector<DPair> hp(bs.pairs.size());
     for (size_t i = 0; i < hp.size(); ++i) {
         const tf::Pair &p = bs.pairs[i];
-        hp[i] = {p.A, p.B, p.La, p.Lb, p.npp, p.pp_off, p.nE, 0, p.e_off};
+        const tf::Shell &sa = bs.shells[p.A], &sb = bs.shells[p.B];
+        hp[i] = {p.A, p.B, p.La, p.Lb, p.npp, p.pp_off, p.nE, 0, p.e_off, sa.ncomp, sb.ncomp, sa.comp_off, sb.comp_off, sa.cart_off, sb.cart_off};
+    }
+    // shell-pair classes: every pair of a class has the same angular momenta, component counts and contraction depth
+    ctx->pair_class.assign(hp.size(), 0);
+    ctx->class_pairs.clear();
+    {
+        std::map<std::array<int, 5>, int> ids;
+        for (size_t i = 0; i < hp.size(); ++i) {
+            const std::array<int, 5> key{hp[i].La, hp[i].Lb, getenv("TF_ERI_EXACT_CLASS") ? hp[i].npp : (hp[i].npp == 1 ? 1 : 0), hp[i].nca, hp[i].ncb};
+            auto it = ids.find(key);
+            if (it == ids.end()) { it = ids.emplace(key, (int)ids.size()).first; ctx->class_pairs.emplace_back(); }
+            hp[i].cls = it->second;
+            ctx->pair_class[i] = it->second;
+            ctx->class_pairs[it->second].push_back((int)i);
+        }
     }
     std::vector<double> boys;
     tf::boys_table(boys);
@@ -319,7 +361,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_eri, std::max<size_t>(1, (size_t)ctx->n_rows * row_len * sizeof(double))));
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
 
-    DBG("rows=%lld N=%d ld=%d", ctx->n_rows, N, ld);
+    DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
     // ---- slabs of bra pairs: Cartesian block -> ket transform -> bra transform -> tensor rows
     size_t slab_bytes = (size_t)1 << 30;
     if (const char *e = getenv("TF_SLAB_MB")) slab_bytes = (size_t)std::max(1, atoi(e)) << 20;
@@ -329,12 +371,16 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     for (int p : ctx->my_pairs)
         biggest = std::max<long long>(biggest, (long long)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp);
     max_rows_c = std::max(max_rows_c, biggest);
-    double *d_C = nullptr, *d_T1 = nullptr, *d_T2 = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_C, (size_t)max_rows_c * Nc * Nc * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&d_T1, (size_t)max_rows_c * Nc * N * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&d_T2, (size_t)max_rows_c * N * ld * sizeof(double)));
-    hipEvent_t ev[5];
-    for (auto &e : ev) HIPCHK(ctx, hipEventCreate(&e));
+    {
+        long long need = 0;                                      // never more than this rank's rows need
+        for (int p : ctx->my_pairs) need += (long long)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
+        max_rows_c = std::max<long long>(biggest, std::min(max_rows_c, need));
+    }
+    if ((rc = ensure_scratch(ctx, 0, (size_t)max_rows_c * Nc * Nc * sizeof(double))) ||
+        (rc = ensure_scratch(ctx, 1, (size_t)max_rows_c * Nc * N * sizeof(double))) ||
+        (rc = ensure_scratch(ctx, 2, (size_t)max_rows_c * N * ld * sizeof(double))))
+        return rc;
+    double *d_C = ctx->scr[0], *d_T1 = ctx->scr[1], *d_T2 = ctx->scr[2];
     double t_stage[4] = {0, 0, 0, 0};
     long long n_quart = 0, n_primq = 0, n_compq = 0;
     long long tot_pp = 0, tot_comp = 0;
@@ -342,17 +388,145 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         tot_pp += bs.pairs[p].npp;
         tot_comp += (long long)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
     }
+    DBG("slab buffers allocated");
     auto t_wall0 = std::chrono::steady_clock::now();
-    size_t cursor = 0;
+    // class-sorted ket lists on the device (one contiguous range per class)
+    const int ncls = (int)ctx->class_pairs.size();
+    std::vector<int> ket_sorted, ket_off(ncls + 1, 0), cls_maxnpp(ncls, 1);
+    for (int c = 0; c < ncls; ++c) {
+        ket_sorted.insert(ket_sorted.end(), ctx->class_pairs[c].begin(), ctx->class_pairs[c].end());
+        ket_off[c + 1] = (int)ket_sorted.size();
+        for (int p : ctx->class_pairs[c]) cls_maxnpp[c] = std::max(cls_maxnpp[c], bs.pairs[p].npp);
+    }
+    int *d_kets = nullptr, *d_kets_all = nullptr;
+    if ((rc = upload(ctx, ket_sorted, &d_kets, false))) return rc;
+    {
+        std::vector<int> all(npairs);
+        std::iota(all.begin(), all.end(), 0);
+        if ((rc = upload(ctx, all, &d_kets_all, false))) return rc;
+    }
+    // my bra pairs ordered by class: a slab is a run of that list, launches go per (bra class run, ket class)
+    std::vector<int> mine_sorted;
+    for (int c = 0; c < ncls; ++c)
+        for (int p : ctx->class_pairs[c])
+            if (owner[p] == ctx->rank) mine_sorted.push_back(p);
+    // streams so that the many small class launches of a slab overlap
+    const int NSTREAM_MAX = tf_ctx::NSTREAM_MAX;
+    const int NSTREAM = getenv("TF_ERI_NSTREAM") ? std::max(1, std::min(NSTREAM_MAX, atoi(getenv("TF_ERI_NSTREAM")))) : NSTREAM_MAX;
+    if (!ctx->have_streams) {
+        for (int k = 0; k < NSTREAM_MAX; ++k) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[k], hipStreamNonBlocking));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->sev[k], hipEventDisableTiming));
+        }
+        ctx->have_streams = true;
+    }
+    hipStream_t *streams = ctx->streams;
+    hipEvent_t *sev = ctx->sev;
+    int launch_count = 0;
+    DBG("streams created");
+
+    auto class_launch = [&](int bcls, int kcls, int max_npp_bra, unsigned n_bra, const int *d_bra, const long long *d_braoff) {
+        const tf::Pair &pb = bs.pairs[ctx->class_pairs[bcls][0]], &pk = bs.pairs[ctx->class_pairs[kcls][0]];
+        const tf::Shell &sa = bs.shells[pb.A], &sb = bs.shells[pb.B], &sc = bs.shells[pk.A], &sd = bs.shells[pk.B];
+        QClass q{};
+        q.La = pb.La; q.Lb = pb.Lb; q.Lc = pk.La; q.Ld = pk.Lb;
+        q.L = q.La + q.Lb + q.Lc + q.Ld;
+        q.tsize = (q.L + 1) * (q.L + 2) / 2;
+        q.nca = sa.ncomp; q.ncb = sb.ncomp; q.ncc = sc.ncomp; q.ncd = sd.ncomp;
+        q.ncomp = q.nca * q.ncb * q.ncc * q.ncd;
+        q.npp_ab = max_npp_bra; q.npp_cd = cls_maxnpp[kcls]; q.npq = q.npp_ab * q.npp_cd;      // class maxima (LDS sizing)
+        q.nEab = pb.nE; q.nEcd = pk.nE;
+        q.n_ket = ket_off[kcls + 1] - ket_off[kcls];
+        const int *d_ket = d_kets + ket_off[kcls];
+        hipStream_t st = streams[launch_count++ % NSTREAM];
+        if (q.npq == 1 && q.ncomp <= 128) {
+            // several uncontracted shell quartets per workgroup
+            int ncp = 1;
+            while (ncp < q.ncomp) ncp <<= 1;
+            q.ncp = ncp;
+            q.G = std::max(1, std::min(TF_ERI_THREADS / ncp, TF_ERI_THREADS / (q.L + 1)));
+            q.PB = q.G; q.stride = q.G | 1;
+            const int kc = q.ncc + q.ncd;
+            int o = 0;
+            q.offR = o; o += q.stride * q.tsize;
+            q.offPref = o; o += q.G;
+            q.offPQ = o; o += q.G;
+            q.offRed = o;
+            q.offEab = o; o += 2 * q.nEab;
+            q.offEcd = o; o += q.G * 2 * q.nEcd;
+            q.offScale = o; o += 42 + kc * q.G;
+            q.offLmn = o; o += (42 + kc * q.G + q.G + 1) / 2;
+            q.lds_doubles = o;
+            const dim3 grid((q.n_ket + q.G - 1) / q.G, n_bra);
+            hipLaunchKernelGGL(eri_multi_kernel, grid, dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q, d_bra, d_braoff,
+                               d_ket, Nc, d_C);
+        } else {
+            const int RB = 3584, EB = 3072;                     // LDS doubles for R tables / staged E tables
+            int PB = RB / q.tsize - 1;
+            PB = std::max(1, std::min(std::min(PB, TF_ERI_THREADS), q.npq));
+            q.PB = PB; q.stride = PB | 1; q.G = 1; q.ncp = 0;
+            const int needE = q.npp_ab * 2 * q.nEab + q.npp_cd * 2 * q.nEcd;
+            const bool stage = needE <= EB;
+            int o = 0;
+            q.offR = o; o += q.stride * q.tsize;
+            q.offPref = o; o += TF_ERI_THREADS;
+            q.offPQ = o; o += TF_ERI_THREADS;
+            q.offRed = o; o += TF_ERI_THREADS;
+            q.offEab = o; o += stage ? q.npp_ab * 2 * q.nEab : 0;
+            q.offEcd = o; o += stage ? q.npp_cd * 2 * q.nEcd : 0;
+            q.offScale = o; o += 84;
+            q.offLmn = o; o += 42;
+            q.lds_doubles = o;
+            const dim3 grid(q.n_ket, n_bra);
+            if (stage)
+                hipLaunchKernelGGL((eri_class_kernel<true, false>), grid, dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q,
+                                   d_bra, d_braoff, d_ket, Nc, d_C);
+            else
+                hipLaunchKernelGGL((eri_class_kernel<false, false>), grid, dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q,
+                                   d_bra, d_braoff, d_ket, Nc, d_C);
+        }
+    };
+
+    // Small problems: one launch per slab mixing every class (LDS carved by launch-wide capacities).
+    auto generic_launch = [&](unsigned n_bra, const int *d_bra, const long long *d_braoff) {
+        QClass q{};
+        const int RB = 3584, EBa = 1536, EBc = 1536;
+        int o = 0;
+        q.offR = o; o += RB;
+        q.offPref = o; o += TF_ERI_THREADS;
+        q.offPQ = o; o += TF_ERI_THREADS;
+        q.offRed = o; o += TF_ERI_THREADS;
+        q.offEab = o; o += EBa;
+        q.offEcd = o; o += EBc;
+        q.offScale = o; o += 84;
+        q.offLmn = o; o += 42;
+        q.lds_doubles = o;
+        q.G = 1; q.n_ket = npairs;
+        hipLaunchKernelGGL((eri_class_kernel<true, true>), dim3(npairs, n_bra), dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), streams[0],
+                           ctx->db, q, d_bra, d_braoff, d_kets_all, Nc, d_C);
+    };
+    bool per_class = (long long)mine_sorted.size() * npairs >= 2000000LL;
+    if (const char *m = getenv("TF_ERI_MODE")) per_class = (m[0] == 'c');
+
+    // device index buffers sized for the largest possible slab, reused by every slab
+    size_t max_out = 0;
+    for (int p : mine_sorted) max_out = std::max<size_t>(max_out, (size_t)pair_rows[p]);
+    const size_t cap_bra = std::min<size_t>(mine_sorted.size(), 65535) + 1;
+    const size_t cap_out = (size_t)std::min<long long>(ctx->n_rows, max_rows_c * 2 + (long long)max_out) + 1;
     int *d_bra = nullptr; long long *d_braoff = nullptr; OutRow *d_out = nullptr;
-    while (cursor < ctx->my_pairs.size()) {
+    HIPCHK(ctx, hipMalloc((void **)&d_bra, cap_bra * sizeof(int)));
+    HIPCHK(ctx, hipMalloc((void **)&d_braoff, cap_bra * sizeof(long long)));
+    HIPCHK(ctx, hipMalloc((void **)&d_out, cap_out * sizeof(OutRow)));
+    std::vector<hipEvent_t> tev;                                   // 4 timing events per slab, read at the end
+    size_t cursor = 0;
+    while (cursor < mine_sorted.size()) {
         std::vector<int> bra; std::vector<long long> braoff; std::vector<OutRow> outs;
         long long rows_c = 0;
-        while (cursor < ctx->my_pairs.size()) {
-            const int p = ctx->my_pairs[cursor];
+        while (cursor < mine_sorted.size()) {
+            const int p = mine_sorted[cursor];
             const tf::Shell &a = bs.shells[bs.pairs[p].A], &b = bs.shells[bs.pairs[p].B];
             const long long nr = (long long)a.ncomp * b.ncomp;
-            if (!bra.empty() && (rows_c + nr > max_rows_c || bra.size() >= 65535)) break;
+            if (!bra.empty() && (rows_c + nr > max_rows_c || bra.size() >= 65535 || outs.size() + (size_t)pair_rows[p] >= cap_out)) break;
             bra.push_back(p); braoff.push_back(rows_c);
             long long r = pair_first_row[p];
             for (int x = 0; x < out_dim(a); ++x)
@@ -367,15 +541,33 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             n_compq += nr * tot_comp;
             ++cursor;
         }
-        if (d_bra) { (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out); d_bra = nullptr; }
-        if ((rc = upload(ctx, bra, &d_bra, false)) || (rc = upload(ctx, braoff, &d_braoff, false)) ||
-            (rc = upload(ctx, outs, &d_out, false)))
-            return rc;
+        // the previous slab's kernels (stream 0 and the class streams) read these buffers: drain before overwriting
+        HIPCHK(ctx, hipDeviceSynchronize());
+        HIPCHK(ctx, hipMemcpy(d_bra, bra.data(), bra.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(d_braoff, braoff.data(), braoff.size() * sizeof(long long), hipMemcpyHostToDevice));
+        if (!outs.empty()) HIPCHK(ctx, hipMemcpy(d_out, outs.data(), outs.size() * sizeof(OutRow), hipMemcpyHostToDevice));
         DBG("slab: %zu bra pairs, %lld cart rows, %zu out rows", bra.size(), rows_c, outs.size());
-        HIPCHK(ctx, hipEventRecord(ev[0], 0));
-        hipLaunchKernelGGL(eri_cart_kernel, dim3(npairs, (unsigned)bra.size()), dim3(TF_ERI_THREADS), 0, 0, ctx->db, d_bra,
-                           d_braoff, Nc, d_C);
-        HIPCHK(ctx, hipEventRecord(ev[1], 0));
+        hipEvent_t e4[4];
+        for (auto &e : e4) { HIPCHK(ctx, hipEventCreate(&e)); tev.push_back(e); }
+        HIPCHK(ctx, hipEventRecord(e4[0], 0));
+        for (int k = 0; k < NSTREAM; ++k) HIPCHK(ctx, hipStreamWaitEvent(streams[k], e4[0], 0));
+        // runs of equal bra class inside the slab
+        size_t r0 = 0;
+        if (!per_class) { generic_launch((unsigned)bra.size(), d_bra, d_braoff); r0 = bra.size(); }
+        while (r0 < bra.size()) {
+            const int bcls = ctx->pair_class[bra[r0]];
+            size_t r1 = r0;
+            int max_npp = 1;
+            while (r1 < bra.size() && ctx->pair_class[bra[r1]] == bcls) { max_npp = std::max(max_npp, bs.pairs[bra[r1]].npp); ++r1; }
+            for (int kcls = 0; kcls < ncls; ++kcls)
+                class_launch(bcls, kcls, max_npp, (unsigned)(r1 - r0), d_bra + r0, d_braoff + r0);
+            r0 = r1;
+        }
+        for (int k = 0; k < NSTREAM; ++k) {
+            HIPCHK(ctx, hipEventRecord(sev[k], streams[k]));
+            HIPCHK(ctx, hipStreamWaitEvent(0, sev[k], 0));
+        }
+        HIPCHK(ctx, hipEventRecord(e4[1], 0));
         {
             const long long tot1 = rows_c * Nc * (long long)N;
             const unsigned g1 = (unsigned)std::min<long long>((tot1 + 255) / 256, 1 << 20);
@@ -386,7 +578,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             hipLaunchKernelGGL(xform_mid_axis, dim3(g2), dim3(256), 0, 0, d_T1, d_T2, rows_c, Nc, N, ld, ctx->d_csr_ptr,
                                ctx->d_csr_idx, ctx->d_csr_val);
         }
-        HIPCHK(ctx, hipEventRecord(ev[2], 0));
+        HIPCHK(ctx, hipEventRecord(e4[2], 0));
         if (!outs.empty()) {
             const unsigned gx = (unsigned)std::min<long long>((row_len + 255) / 256, 4096);
             for (size_t o0 = 0; o0 < outs.size(); o0 += 65535) {
@@ -395,23 +587,25 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                                    ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val);
             }
         }
-        HIPCHK(ctx, hipEventRecord(ev[3], 0));
-        DBG("slab launched");
-        HIPCHK(ctx, hipEventSynchronize(ev[3]));
-        DBG("slab done");
-        HIPCHK(ctx, hipGetLastError());
-        t_stage[1] += seconds_between(ev[0], ev[1]);
-        t_stage[2] += seconds_between(ev[1], ev[2]);
-        t_stage[3] += seconds_between(ev[2], ev[3]);
+        HIPCHK(ctx, hipEventRecord(e4[3], 0));
     }
-    if (d_bra) { (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out); }
+    DBG("all slabs launched (%d class launches)", launch_count);
     HIPCHK(ctx, hipDeviceSynchronize());
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    (void)hipFree(d_C); (void)hipFree(d_T1); (void)hipFree(d_T2);
+    DBG("device drained");
+    HIPCHK(ctx, hipGetLastError());
+    for (size_t k = 0; k + 3 < tev.size(); k += 4) {
+        t_stage[1] += seconds_between(tev[k], tev[k + 1]);
+        t_stage[2] += seconds_between(tev[k + 1], tev[k + 2]);
+        t_stage[3] += seconds_between(tev[k + 2], tev[k + 3]);
+    }
+    for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+    (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out);
+    (void)hipFree(d_kets); (void)hipFree(d_kets_all);
     t_stage[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall0).count();
     std::copy(t_stage, t_stage + 4, ctx->eri_seconds);
     ctx->eri_counts[0] = n_quart; ctx->eri_counts[1] = n_primq; ctx->eri_counts[2] = n_compq;
 
+    DBG("scratch freed");
     // ---- J/K scratch
     const size_t nn = (size_t)N * N;
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
@@ -420,6 +614,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_J, nn * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_K, nn * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_P, nn * sizeof(double)));
+    DBG("build_eri done");
     ctx->have_eri = true;
     return TF_OK;
 }
@@ -658,6 +853,16 @@ int tf_diagonalise(tf_ctx *ctx, int n, const double *F, const double *X, double 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::string msg;
     int rc = tfscf::diagonalise(ctx->scf, n, F, X, eps, C, msg);
+    if (rc) ctx->err = msg;
+    return rc;
+}
+
+int tf_eigh_probe(tf_ctx *ctx, int n, int variant, int reps, double *seconds)
+{
+    if (!ctx || n < 1 || reps < 1 || !seconds) return TF_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string msg;
+    int rc = tfscf::eigh_probe(ctx->scf, n, variant, reps, seconds, msg);
     if (rc) ctx->err = msg;
     return rc;
 }

@@ -1,0 +1,343 @@
+// tf_eri.hip.h -- ERI generation kernels (contracted Cartesian shell-quartet blocks into the slab buffer).
+// Reference: primitive_pair_eri pyx:1142-1221, contraction pyx:1235-1253, driver pyx:1314-1342.
+//
+// Launches are made per (bra shell-pair class, ket shell-pair class): every workgroup of a launch sees the same
+// angular momenta, component counts and contraction depths (QClass), so the LDS carve-out is exact for the class
+// (high occupancy for the cheap classes), loop bounds are wave-uniform, and the Hermite expansion tables of the two
+// shell pairs are staged in LDS once per workgroup.
+//   eri_class_kernel : one shell quartet per workgroup; primitive quartets in LDS batches; lane groups split the
+//                      primitive quartets when the quartet has < 256 Cartesian components (deep contractions).
+//   eri_multi_kernel : uncontracted quartets (one primitive quartet) with <= 128 components: G = 256/ncp ket pairs
+//                      per workgroup, one lane per component, so the cheap classes (ss|ss ... ) fill the wave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tf_kernels.hip.h"
+
+namespace tfk {
+
+struct QClass {
+    int La, Lb, Lc, Ld, L, tsize;
+    int nca, ncb, ncc, ncd, ncomp;
+    int npp_ab, npp_cd, npq;   // maxima over the launch (LDS capacity); the actual depths come from the pair records
+    int nEab, nEcd;
+    int PB, stride;        // primitive quartets per LDS batch, LDS column stride of the R tables
+    int G, ncp;            // multi kernel: shell quartets per workgroup, padded components per quartet
+    int n_ket;             // ket pairs in this launch
+    // LDS carve-out, offsets in doubles
+    int offR, offPref, offPQ, offRed, offEab, offEcd, offScale, offLmn, lds_doubles;
+};
+
+// component info staged in LDS: packed (lx | ly << 8 | lz << 16) and the normalisation ratio
+__device__ __forceinline__ void stage_components(const DBasis &B, int comp_off, int ncomp, int *dstLmn, double *dstScale, int tid,
+                                                 int nthreads)
+{
+    for (int c = tid; c < ncomp; c += nthreads) {
+        const int i = comp_off + c;
+        dstLmn[c] = (int)B.c_lx[i] | ((int)B.c_ly[i] << 8) | ((int)B.c_lz[i] << 16);
+        dstScale[c] = B.c_scale[i];
+    }
+}
+
+struct CompQuartet {
+    int lx12, ly12, lz12, lx34, ly34, lz34;
+    int ixab, iyab, izab, ixcd, iycd, izcd;
+    int ca, cb, cc, cd;
+    bool nonzero;
+    double cscale;
+};
+
+__device__ __forceinline__ void decode_component(const QClass &qc, int c, const int *lmnA, const int *lmnB, const int *lmnC,
+                                                 const int *lmnD, const double *scA, const double *scB, const double *scC,
+                                                 const double *scD, CompQuartet &Q)
+{
+    Q.cd = c % qc.ncd; c /= qc.ncd;
+    Q.cc = c % qc.ncc; c /= qc.ncc;
+    Q.cb = c % qc.ncb; Q.ca = c / qc.ncb;
+    const int a = lmnA[Q.ca], b = lmnB[Q.cb], cc = lmnC[Q.cc], d = lmnD[Q.cd];
+    const int ax = a & 255, ay = (a >> 8) & 255, az = (a >> 16) & 255;
+    const int bx = b & 255, by = (b >> 8) & 255, bz = (b >> 16) & 255;
+    const int cx = cc & 255, cy = (cc >> 8) & 255, cz = (cc >> 16) & 255;
+    const int dx = d & 255, dy = (d >> 8) & 255, dz = (d >> 16) & 255;
+    const int Lab1 = qc.La + qc.Lb + 1, Lcd1 = qc.Lc + qc.Ld + 1;
+    Q.lx12 = ax + bx; Q.ly12 = ay + by; Q.lz12 = az + bz;
+    Q.lx34 = cx + dx; Q.ly34 = cy + dy; Q.lz34 = cz + dz;
+    Q.ixab = (ax * (qc.Lb + 1) + bx) * Lab1; Q.iyab = (ay * (qc.Lb + 1) + by) * Lab1; Q.izab = (az * (qc.Lb + 1) + bz) * Lab1;
+    Q.ixcd = (cx * (qc.Ld + 1) + dx) * Lcd1; Q.iycd = (cy * (qc.Ld + 1) + dy) * Lcd1; Q.izcd = (cz * (qc.Ld + 1) + dz) * Lcd1;
+    Q.nonzero = !(((Q.lx12 + Q.lx34) & 1) || ((Q.ly12 + Q.ly34) & 1));          // x/y parity, pyx:1324-1327
+    Q.cscale = scA[Q.ca] * scB[Q.cb] * scC[Q.cc] * scD[Q.cd];
+    if ((Q.lx34 + Q.ly34) & 1) Q.cscale = -Q.cscale;                              // (-1)^(tau+nu) is fixed by parity
+}
+
+// The reference's 6-deep Hermite sum (pyx:1179-1217) for one component quartet and one primitive quartet.
+// Exy/Ez: tables of the primitive pair ([x|y shared][z]); Rq: R table column (element idx at Rq[idx * stride]).
+__device__ __forceinline__ double hermite_sum(const CompQuartet &Q, const double *__restrict__ Exy12, const double *__restrict__ Ez12,
+                                              const double *__restrict__ Exy34, const double *__restrict__ Ez34,
+                                              const double *__restrict__ Rq, int stride, int L)
+{
+    double sum = 0.0;
+    for (int t = Q.lx12 & 1; t <= Q.lx12; t += 2) {
+        const double ex12 = Exy12[Q.ixab + t];
+        for (int tau = Q.lx34 & 1; tau <= Q.lx34; tau += 2) {
+            const double xf = ex12 * Exy34[Q.ixcd + tau] * c_dfact[(t + tau) >> 1];
+            for (int u = Q.ly12 & 1; u <= Q.ly12; u += 2) {
+                const double ey12 = Exy12[Q.iyab + u];
+                for (int nu = Q.ly34 & 1; nu <= Q.ly34; nu += 2) {
+                    const double xyf = xf * ey12 * Exy34[Q.iycd + nu] * c_dfact[(u + nu) >> 1];
+                    const int nxy = ((t + tau) >> 1) + ((u + nu) >> 1);
+                    double zs = 0.0;
+                    for (int v = 0; v <= Q.lz12; ++v) {
+                        const double ez12 = Ez12[Q.izab + v];
+                        double zphi = 0.0;
+                        for (int phi = 0; phi <= Q.lz34; ++phi) {
+                            const double r = Rq[(tri_index(v + phi, nxy, L)) * stride];
+                            const double e34 = Ez34[Q.izcd + phi];
+                            zphi += (phi & 1) ? -(e34 * r) : (e34 * r);
+                        }
+                        zs += ez12 * zphi;
+                    }
+                    sum += xyf * zs;
+                }
+            }
+        }
+    }
+    return sum;
+}
+
+// Cooperative Boys/R tables: entry e of the batch (column e of sR) belongs to primitive quartet (pab[e], pcd[e]) of the
+// pairs (ab[e], cd[e]).  Lanes e*(L+1)+n, n = 0..L; one barrier per table row.  All threads of the block must call.
+template <class PairOf>
+__device__ __forceinline__ void coop_tables(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
+                                            PairOf pair_of, int tid)
+{
+    const int L1 = L + 1;
+    const int e = tid / L1, n = tid - e * L1;
+    const bool mine = e < n_entries;
+    if (mine && n == 0) {
+        int ppab, ppcd;            // absolute primitive-pair indices
+        pair_of(e, ppab, ppcd);
+        const double p = B.pp_p[ppab], q = B.pp_p[ppcd];
+        const double s = p + q, alpha = p * q / s;
+        const double PQ = B.pp_Pz[ppab] - B.pp_Pz[ppcd];
+        build_R_row0(sR, stride, e, L, alpha, PQ, B.boys);
+        sPQ[e] = PQ;
+        // 2 pi^(5/2) / (p q sqrt(p+q)) * coefficient product, pyx:1219-1221
+        sPref[e] = B.pp_K[ppab] * B.pp_K[ppcd] * (34.986836655249725 / (p * q * sqrt(s)));
+    }
+    for (int v = 1; v <= L; ++v) {
+        __syncthreads();
+        if (mine && n <= L - v) {
+            const int r0 = tri_index(v, 0, L), r1 = tri_index(v - 1, 0, L);
+            double val = sPQ[e] * sR[(r1 + n + 1) * stride + e];
+            if (v > 1) val += (double)(v - 1) * sR[(tri_index(v - 2, 0, L) + n + 1) * stride + e];
+            sR[(r0 + n) * stride + e] = val;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GENERIC = true: one launch mixes every class (small problems, where per-class launches cannot fill the GPU); the
+// workgroup derives its own class record from the two pair records, LDS offsets are the launch-wide capacities in `qc_in`
+// (offEcd - offEab doubles for the bra tables, capE_cd for the ket tables, offPref - offR for the R tables).
+template <bool STAGE_E, bool GENERIC>
+__global__ __launch_bounds__(TF_ERI_THREADS) void eri_class_kernel(DBasis B, QClass qc_in, const int *__restrict__ bra_pairs,
+                                                                   const long long *__restrict__ bra_rowoff,
+                                                                   const int *__restrict__ ket_pairs, int Nc,
+                                                                   double *__restrict__ Cslab)
+{
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x;
+    const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
+    const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
+    QClass qc = qc_in;
+    bool stage_ok = true;
+    if (GENERIC) {
+        qc.La = ab.La; qc.Lb = ab.Lb; qc.Lc = cd.La; qc.Ld = cd.Lb;
+        qc.L = qc.La + qc.Lb + qc.Lc + qc.Ld;
+        qc.tsize = (qc.L + 1) * (qc.L + 2) / 2;
+        qc.nca = ab.nca; qc.ncb = ab.ncb; qc.ncc = cd.nca; qc.ncd = cd.ncb;
+        qc.ncomp = qc.nca * qc.ncb * qc.ncc * qc.ncd;
+        qc.nEab = ab.nE; qc.nEcd = cd.nE;
+        int pb = (qc_in.offPref - qc_in.offR) / qc.tsize - 1;
+        pb = max(1, min(min(pb, TF_ERI_THREADS), ab.npp * cd.npp));
+        qc.PB = pb; qc.stride = pb | 1;
+        stage_ok = (ab.npp * 2 * ab.nE <= qc_in.offEcd - qc_in.offEab) && (cd.npp * 2 * cd.nE <= qc_in.offScale - qc_in.offEcd);
+    }
+    double *sR = smem + qc.offR, *sPref = smem + qc.offPref, *sPQ = smem + qc.offPQ, *sRed = smem + qc.offRed;
+    double *sEab = smem + qc.offEab, *sEcd = smem + qc.offEcd, *sScale = smem + qc.offScale;
+    int *sLmn = reinterpret_cast<int *>(smem + qc.offLmn);
+    const int L = qc.L, stride = qc.stride, PB = qc.PB, ncomp = qc.ncomp;
+    const int npp_ab = ab.npp, npp_cd = cd.npp, npq = npp_ab * npp_cd;
+    const int nEab = qc.nEab, nEcd = qc.nEcd;
+    const long long row0 = bra_rowoff[blockIdx.y];
+    const size_t NcNc = (size_t)Nc * Nc;
+
+    // ---- stage component tables and (if they fit) the Hermite expansion tables of both shell pairs ----
+    stage_components(B, ab.compoff_a, qc.nca, sLmn, sScale, tid, TF_ERI_THREADS);
+    stage_components(B, ab.compoff_b, qc.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
+    stage_components(B, cd.compoff_a, qc.ncc, sLmn + 42, sScale + 42, tid, TF_ERI_THREADS);
+    stage_components(B, cd.compoff_b, qc.ncd, sLmn + 63, sScale + 63, tid, TF_ERI_THREADS);
+    const double *__restrict__ gEab = B.epool + ab.e_off;
+    const double *__restrict__ gEcd = B.epool + cd.e_off;
+    const bool staged = STAGE_E && stage_ok;
+    if (staged) {
+        for (int k = tid; k < npp_ab * 2 * nEab; k += TF_ERI_THREADS) sEab[k] = gEab[k];
+        for (int k = tid; k < npp_cd * 2 * nEcd; k += TF_ERI_THREADS) sEcd[k] = gEcd[k];
+    }
+    const double *Eab0 = (GENERIC ? staged : STAGE_E) ? sEab : gEab;
+    const double *Ecd0 = (GENERIC ? staged : STAGE_E) ? sEcd : gEcd;
+    __syncthreads();
+
+    auto phase1 = [&](int b0, int nb) {
+        if (nb * (L + 1) <= TF_ERI_THREADS) {
+            coop_tables(B, L, nb, stride, sR, sPref, sPQ,
+                        [&](int e, int &ppab, int &ppcd) {
+                            const int pq = b0 + e;
+                            const int pab = pq / npp_cd;
+                            ppab = ab.pp_off + pab;
+                            ppcd = cd.pp_off + (pq - pab * npp_cd);
+                        }, tid);
+        } else if (tid < nb) {
+            const int pq = b0 + tid;
+            const int pab = pq / npp_cd, pcd = pq - pab * npp_cd;
+            const double p = B.pp_p[ab.pp_off + pab], q = B.pp_p[cd.pp_off + pcd];
+            const double s = p + q, alpha = p * q / s;
+            const double PQ = B.pp_Pz[ab.pp_off + pab] - B.pp_Pz[cd.pp_off + pcd];
+            build_R_column(sR, stride, tid, L, alpha, PQ, B.boys);
+            sPref[tid] = B.pp_K[ab.pp_off + pab] * B.pp_K[cd.pp_off + pcd] * (34.986836655249725 / (p * q * sqrt(s)));
+        }
+    };
+    auto phase2 = [&](const CompQuartet &Q, int b0, int nb, int g, int NG) -> double {
+        double acc = 0.0;
+        for (int qq = g; qq < nb; qq += NG) {
+            const int pq = b0 + qq;
+            const int pab = pq / npp_cd, pcd = pq - pab * npp_cd;
+            const double *Exy12 = Eab0 + (size_t)pab * 2 * nEab;
+            const double *Exy34 = Ecd0 + (size_t)pcd * 2 * nEcd;
+            acc += sPref[qq] * hermite_sum(Q, Exy12, Exy12 + nEab, Exy34, Exy34 + nEcd, sR + qq, stride, L);
+        }
+        return acc;
+    };
+
+    const bool one_batch = npq <= PB;
+    if (one_batch) {
+        phase1(0, npq);
+        __syncthreads();
+    }
+    for (int chunk0 = 0; chunk0 < ncomp; chunk0 += TF_ERI_THREADS) {
+        const int nchunk = min(TF_ERI_THREADS, ncomp - chunk0);
+        int ncp = 1;
+        while (ncp < nchunk) ncp <<= 1;
+        const int NG = TF_ERI_THREADS / ncp;                 // lane groups split the primitive quartets of a batch
+        const int g = tid / ncp, c0 = tid - g * ncp;
+        const bool active = c0 < nchunk;
+        CompQuartet Q;
+        Q.nonzero = false; Q.cscale = 0.0; Q.ca = Q.cb = Q.cc = Q.cd = 0;
+        if (active)
+            decode_component(qc, chunk0 + c0, sLmn, sLmn + 21, sLmn + 42, sLmn + 63, sScale, sScale + 21, sScale + 42, sScale + 63, Q);
+        double acc = 0.0;
+        if (one_batch) {
+            if (active && Q.nonzero) acc = phase2(Q, 0, npq, g, NG);
+        } else {
+            for (int b0 = 0; b0 < npq; b0 += PB) {
+                const int nb = min(PB, npq - b0);
+                __syncthreads();
+                phase1(b0, nb);
+                __syncthreads();
+                if (active && Q.nonzero) acc += phase2(Q, b0, nb, g, NG);
+            }
+        }
+        if (NG > 1) {                                          // combine the groups in fixed order (reproducible)
+            __syncthreads();
+            sRed[tid] = acc;
+            __syncthreads();
+            if (g == 0 && active) {
+                double s = 0.0;
+                for (int gg = 0; gg < NG; ++gg) s += sRed[gg * ncp + c0];
+                acc = s;
+            }
+        }
+        if (g == 0 && active) {
+            const double val = acc * Q.cscale;
+            const size_t row = (size_t)(row0 + (long long)Q.ca * qc.ncb + Q.cb);
+            const int k = cd.cartoff_a + Q.cc, l = cd.cartoff_b + Q.cd;
+            Cslab[row * NcNc + (size_t)k * Nc + l] = val;
+            if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Uncontracted quartets (npq == 1) with few components: G ket pairs per workgroup, sub-quartet s = tid / ncp.
+// LDS: shared bra tables (E, components) + per sub-quartet: R table column, prefactor, ket E tables, ket components.
+__global__ __launch_bounds__(TF_ERI_THREADS) void eri_multi_kernel(DBasis B, QClass qc, const int *__restrict__ bra_pairs,
+                                                                   const long long *__restrict__ bra_rowoff,
+                                                                   const int *__restrict__ ket_pairs, int Nc,
+                                                                   double *__restrict__ Cslab)
+{
+    extern __shared__ double smem[];
+    double *sR = smem + qc.offR, *sPref = smem + qc.offPref, *sPQ = smem + qc.offPQ;
+    double *sEab = smem + qc.offEab, *sEcd = smem + qc.offEcd, *sScale = smem + qc.offScale;
+    int *sLmn = reinterpret_cast<int *>(smem + qc.offLmn);
+    const int kc = qc.ncc + qc.ncd;                           // ket component slots per sub-quartet (C then D)
+    int *sKet = sLmn + 42 + kc * qc.G;                        // pair id of each sub-quartet (or -1)
+
+    const int tid = threadIdx.x;
+    const int G = qc.G, ncp = qc.ncp, L = qc.L, stride = qc.stride;
+    const int nEab = qc.nEab, nEcd = qc.nEcd;
+    const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
+    const long long row0 = bra_rowoff[blockIdx.y];
+    const size_t NcNc = (size_t)Nc * Nc;
+    const int ket0 = blockIdx.x * G;
+    const int nsub = min(G, qc.n_ket - ket0);
+
+    // ---- staging: bra tables once, ket tables per sub-quartet ----
+    stage_components(B, ab.compoff_a, qc.nca, sLmn, sScale, tid, TF_ERI_THREADS);
+    stage_components(B, ab.compoff_b, qc.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
+    {
+        const double *__restrict__ gEab = B.epool + ab.e_off;
+        for (int k = tid; k < 2 * nEab; k += TF_ERI_THREADS) sEab[k] = gEab[k];
+    }
+    for (int s = tid; s < G; s += TF_ERI_THREADS) sKet[s] = (s < nsub) ? ket_pairs[ket0 + s] : -1;
+    __syncthreads();
+    {
+        const int per = 2 * nEcd;
+        for (int k = tid; k < nsub * per; k += TF_ERI_THREADS) {
+            const int s = k / per, o = k - s * per;
+            sEcd[k] = B.epool[B.pairs[sKet[s]].e_off + o];
+        }
+        for (int k = tid; k < nsub * kc; k += TF_ERI_THREADS) {
+            const int s = k / kc, o = k - s * kc;
+            const DPair cd = B.pairs[sKet[s]];
+            const int i = (o < qc.ncc) ? cd.compoff_a + o : cd.compoff_b + (o - qc.ncc);
+            sLmn[42 + k] = (int)B.c_lx[i] | ((int)B.c_ly[i] << 8) | ((int)B.c_lz[i] << 16);
+            sScale[42 + k] = B.c_scale[i];
+        }
+    }
+    // ---- phase 1: one R table per sub-quartet, (L+1) lanes each ----
+    coop_tables(B, L, nsub, stride, sR, sPref, sPQ,
+                [&](int e, int &ppab, int &ppcd) {
+                    ppab = ab.pp_off;
+                    ppcd = B.pairs[sKet[e]].pp_off;
+                }, tid);
+    __syncthreads();
+    // ---- phase 2: one lane per (sub-quartet, component) ----
+    const int s = tid / ncp, c0 = tid - s * ncp;
+    if (s < nsub && c0 < qc.ncomp) {
+        const int *lmnC = sLmn + 42 + kc * s;
+        const double *scC = sScale + 42 + kc * s;
+        CompQuartet Q;
+        decode_component(qc, c0, sLmn, sLmn + 21, lmnC, lmnC + qc.ncc, sScale, sScale + 21, scC, scC + qc.ncc, Q);
+        double val = 0.0;
+        if (Q.nonzero) {
+            const double *Exy34 = sEcd + (size_t)s * 2 * nEcd;
+            val = sPref[s] * hermite_sum(Q, sEab, sEab + nEab, Exy34, Exy34 + nEcd, sR + s, stride, L) * Q.cscale;
+        }
+        const DPair cd = B.pairs[sKet[s]];
+        const size_t row = (size_t)(row0 + (long long)Q.ca * qc.ncb + Q.cb);
+        const int k = cd.cartoff_a + Q.cc, l = cd.cartoff_b + Q.cd;
+        Cslab[row * NcNc + (size_t)k * Nc + l] = val;
+        if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+    }
+}
+
+}  // namespace tfk

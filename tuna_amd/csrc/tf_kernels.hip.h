@@ -7,7 +7,11 @@
 namespace tfk {
 
 struct DShell { int L, ncomp, comp_off, cart_off; };
-struct DPair { int A, B, La, Lb, npp, pp_off, nE, pad; long long e_off; };
+struct DPair {
+    int A, B, La, Lb, npp, pp_off, nE, cls;
+    long long e_off;
+    int nca, ncb, compoff_a, compoff_b, cartoff_a, cartoff_b;
+};
 
 struct DBasis {
     const DShell *shells;
@@ -123,201 +127,6 @@ __device__ __forceinline__ void build_R_row0(double *R, int stride, int col, int
     double pw = 1.0;
     const double fac = -2.0 * alpha;
     for (int n = 0; n <= L; ++n) { F[n * stride] *= pw; pw *= fac; }
-}
-
-// One Cartesian component quartet of a shell quartet, decoded once per thread.
-struct CompQuartet {
-    int lx12, ly12, lz12, lx34, ly34, lz34;
-    int ixab, iyab, izab, ixcd, iycd, izcd;
-    int ca, cb, cc, cd;
-    bool nonzero;
-    double cscale;
-};
-
-// ------------------------------------------------------------------------------------------------
-// K1: contracted Cartesian integrals of one shell quartet (AB|CD) per workgroup.
-//   grid.x = ket shell pair (all pairs C >= D), grid.y = bra shell pair of the current slab.
-//   Primitive quartets are processed in batches of PB (as many Boys/R tables as fit the LDS budget):
-//   phase 1 builds the tables -- cooperatively (L+1 lanes per table, one barrier per row) when the batch is
-//   small, one thread per table when there are many; phase 2 -- threads own Cartesian component quartets and
-//   contract the Hermite expansion tables (global, L1/L2 resident) with the R tables (LDS).
-//   When all primitive quartets fit one batch (every uncontracted shell quartet) the tables are built once
-//   and reused by every component chunk.
-//   Output: rows (ca,cb) of the Cartesian slab C[row][Nc][Nc], positions [k][l] and [l][k].
-// Reference: primitive_pair_eri pyx:1142-1221, contraction pyx:1235-1253, driver pyx:1314-1342.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TF_ERI_THREADS) void eri_cart_kernel(DBasis B, const int *__restrict__ bra_pairs,
-                                                                  const long long *__restrict__ bra_rowoff, int Nc,
-                                                                  double *__restrict__ Cslab)
-{
-    __shared__ double sR[TF_RT_DOUBLES];
-    __shared__ double sPref[TF_ERI_THREADS];
-    __shared__ double sPQ[TF_ERI_THREADS];
-    __shared__ double sRed[TF_ERI_THREADS];
-
-    const int tid = threadIdx.x;
-    const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
-    const DPair cd = B.pairs[blockIdx.x];
-    const DShell sa = B.shells[ab.A], sb = B.shells[ab.B], sc = B.shells[cd.A], sd = B.shells[cd.B];
-    const int L = ab.La + ab.Lb + cd.La + cd.Lb;
-    const int tsize = (L + 1) * (L + 2) / 2;
-    int PB = TF_RT_DOUBLES / tsize - 1;
-    if (PB > TF_ERI_THREADS) PB = TF_ERI_THREADS;
-    const int stride = PB | 1;
-    const int npq = ab.npp * cd.npp;
-    const int ncomp = sa.ncomp * sb.ncomp * sc.ncomp * sd.ncomp;
-    const int nEab = ab.nE, nEcd = cd.nE;
-    const int Lab1 = ab.La + ab.Lb + 1, Lcd1 = cd.La + cd.Lb + 1;
-    const double *__restrict__ Eab0 = B.epool + ab.e_off;
-    const double *__restrict__ Ecd0 = B.epool + cd.e_off;
-    const long long row0 = bra_rowoff[blockIdx.y];
-    const size_t NcNc = (size_t)Nc * Nc;
-    const bool one_batch = npq <= PB;
-
-    // ---- phase 1: Boys + R tables of primitive quartets [b0, b0+nb) into LDS columns 0..nb-1 (all threads call) ----
-    auto phase1 = [&](int b0, int nb) {
-        const int L1 = L + 1;
-        if (nb * L1 <= TF_ERI_THREADS) {
-            const int q = tid / L1, n = tid - q * L1;
-            const bool mine = q < nb;
-            if (mine && n == 0) {
-                const int pq = b0 + q;
-                const int pab = pq / cd.npp, pcd = pq - pab * cd.npp;
-                const double p = B.pp_p[ab.pp_off + pab], qq = B.pp_p[cd.pp_off + pcd];
-                const double s = p + qq, alpha = p * qq / s;
-                const double PQ = B.pp_Pz[ab.pp_off + pab] - B.pp_Pz[cd.pp_off + pcd];
-                build_R_row0(sR, stride, q, L, alpha, PQ, B.boys);
-                sPQ[q] = PQ;
-                sPref[q] = B.pp_K[ab.pp_off + pab] * B.pp_K[cd.pp_off + pcd] * (34.986836655249725 / (p * qq * sqrt(s)));
-            }
-            for (int v = 1; v <= L; ++v) {
-                __syncthreads();
-                if (mine && n <= L - v) {
-                    const int r0 = tri_index(v, 0, L), r1 = tri_index(v - 1, 0, L);
-                    double val = sPQ[q] * sR[(r1 + n + 1) * stride + q];
-                    if (v > 1) val += (double)(v - 1) * sR[(tri_index(v - 2, 0, L) + n + 1) * stride + q];
-                    sR[(r0 + n) * stride + q] = val;
-                }
-            }
-        } else if (tid < nb) {
-            const int pq = b0 + tid;
-            const int pab = pq / cd.npp, pcd = pq - pab * cd.npp;
-            const double p = B.pp_p[ab.pp_off + pab], qq = B.pp_p[cd.pp_off + pcd];
-            const double s = p + qq, alpha = p * qq / s;
-            const double PQ = B.pp_Pz[ab.pp_off + pab] - B.pp_Pz[cd.pp_off + pcd];
-            build_R_column(sR, stride, tid, L, alpha, PQ, B.boys);
-            // 2 pi^(5/2) / (p q sqrt(p+q)) * coefficient product, pyx:1219-1221
-            sPref[tid] = B.pp_K[ab.pp_off + pab] * B.pp_K[cd.pp_off + pcd] * (34.986836655249725 / (p * qq * sqrt(s)));
-        }
-    };
-
-    // ---- decode the component quartet `c` of this shell quartet ----
-    auto decode = [&](int c, CompQuartet &Q) {
-        Q.cd = c % sd.ncomp; c /= sd.ncomp;
-        Q.cc = c % sc.ncomp; c /= sc.ncomp;
-        Q.cb = c % sb.ncomp; Q.ca = c / sb.ncomp;
-        const int ia = sa.comp_off + Q.ca, ib = sb.comp_off + Q.cb, ic = sc.comp_off + Q.cc, id = sd.comp_off + Q.cd;
-        const int ax = B.c_lx[ia], ay = B.c_ly[ia], az = B.c_lz[ia];
-        const int bx = B.c_lx[ib], by = B.c_ly[ib], bz = B.c_lz[ib];
-        const int cx = B.c_lx[ic], cy = B.c_ly[ic], cz = B.c_lz[ic];
-        const int dx = B.c_lx[id], dy = B.c_ly[id], dz = B.c_lz[id];
-        Q.lx12 = ax + bx; Q.ly12 = ay + by; Q.lz12 = az + bz;
-        Q.lx34 = cx + dx; Q.ly34 = cy + dy; Q.lz34 = cz + dz;
-        Q.ixab = (ax * (ab.Lb + 1) + bx) * Lab1; Q.iyab = (ay * (ab.Lb + 1) + by) * Lab1; Q.izab = (az * (ab.Lb + 1) + bz) * Lab1;
-        Q.ixcd = (cx * (cd.Lb + 1) + dx) * Lcd1; Q.iycd = (cy * (cd.Lb + 1) + dy) * Lcd1; Q.izcd = (cz * (cd.Lb + 1) + dz) * Lcd1;
-        Q.nonzero = !(((Q.lx12 + Q.lx34) & 1) || ((Q.ly12 + Q.ly34) & 1));      // x/y parity, pyx:1324-1327
-        Q.cscale = B.c_scale[ia] * B.c_scale[ib] * B.c_scale[ic] * B.c_scale[id];
-        if ((Q.lx34 + Q.ly34) & 1) Q.cscale = -Q.cscale;                          // (-1)^(tau+nu) is fixed by parity
-    };
-
-    // ---- phase 2: my component against primitive quartets g, g+NG, ... of the batch in LDS ----
-    auto phase2 = [&](const CompQuartet &Q, int b0, int nb, int g, int NG) -> double {
-        double acc = 0.0;
-        for (int qq = g; qq < nb; qq += NG) {
-            const int pq = b0 + qq;
-            const int pab = pq / cd.npp, pcd = pq - pab * cd.npp;
-            const double *__restrict__ Exy12 = Eab0 + (size_t)pab * 2 * nEab;
-            const double *__restrict__ Ez12 = Exy12 + nEab;
-            const double *__restrict__ Exy34 = Ecd0 + (size_t)pcd * 2 * nEcd;
-            const double *__restrict__ Ez34 = Exy34 + nEcd;
-            const double *__restrict__ Rq = sR + qq;
-            double sum = 0.0;
-            for (int t = Q.lx12 & 1; t <= Q.lx12; t += 2) {
-                const double ex12 = Exy12[Q.ixab + t];
-                for (int tau = Q.lx34 & 1; tau <= Q.lx34; tau += 2) {
-                    const double xf = ex12 * Exy34[Q.ixcd + tau] * c_dfact[(t + tau) >> 1];
-                    for (int u = Q.ly12 & 1; u <= Q.ly12; u += 2) {
-                        const double ey12 = Exy12[Q.iyab + u];
-                        for (int nu = Q.ly34 & 1; nu <= Q.ly34; nu += 2) {
-                            const double xyf = xf * ey12 * Exy34[Q.iycd + nu] * c_dfact[(u + nu) >> 1];
-                            const int nxy = ((t + tau) >> 1) + ((u + nu) >> 1);
-                            double zs = 0.0;
-                            for (int v = 0; v <= Q.lz12; ++v) {
-                                const double ez12 = Ez12[Q.izab + v];
-                                double zphi = 0.0;
-                                for (int phi = 0; phi <= Q.lz34; ++phi) {
-                                    const double r = Rq[(tri_index(v + phi, nxy, L)) * stride];
-                                    const double e34 = Ez34[Q.izcd + phi];
-                                    zphi += (phi & 1) ? -(e34 * r) : (e34 * r);
-                                }
-                                zs += ez12 * zphi;
-                            }
-                            sum += xyf * zs;
-                        }
-                    }
-                }
-            }
-            acc += sPref[qq] * sum;
-        }
-        return acc;
-    };
-
-    if (one_batch) {
-        phase1(0, npq);
-        __syncthreads();
-    }
-    for (int chunk0 = 0; chunk0 < ncomp; chunk0 += TF_ERI_THREADS) {
-        const int nchunk = min(TF_ERI_THREADS, ncomp - chunk0);
-        // thread -> (group g, component c0): groups split the primitive quartets of a batch
-        int ncp = 1;
-        while (ncp < nchunk) ncp <<= 1;
-        const int NG = TF_ERI_THREADS / ncp;
-        const int g = tid / ncp, c0 = tid - g * ncp;
-        const bool active = c0 < nchunk;
-        CompQuartet Q;
-        Q.nonzero = false; Q.cscale = 0.0; Q.ca = Q.cb = Q.cc = Q.cd = 0;
-        if (active) decode(chunk0 + c0, Q);
-        double acc = 0.0;
-        if (one_batch) {
-            if (active && Q.nonzero) acc = phase2(Q, 0, npq, g, NG);
-        } else {
-            for (int b0 = 0; b0 < npq; b0 += PB) {
-                const int nb = min(PB, npq - b0);
-                __syncthreads();
-                phase1(b0, nb);
-                __syncthreads();
-                if (active && Q.nonzero) acc += phase2(Q, b0, nb, g, NG);
-            }
-        }
-        // combine the groups (fixed order -> bitwise reproducible)
-        if (NG > 1) {
-            __syncthreads();
-            sRed[tid] = acc;
-            __syncthreads();
-            if (g == 0 && active) {
-                double s = 0.0;
-                for (int gg = 0; gg < NG; ++gg) s += sRed[gg * ncp + c0];
-                acc = s;
-            }
-        }
-        if (g == 0 && active) {
-            const double val = acc * Q.cscale;
-            const size_t row = (size_t)(row0 + (long long)Q.ca * sb.ncomp + Q.cb);
-            const int k = sc.cart_off + Q.cc, l = sd.cart_off + Q.cd;
-            Cslab[row * NcNc + (size_t)k * Nc + l] = val;
-            if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -264,6 +264,42 @@ inline int diagonalise(Workspace &w, int n, const double *F, const double *X, do
     return TF_OK;
 }
 
+// Instrumentation: seconds per symmetric eigensolve of a random n x n matrix, variant 0 = dsyevd, 1 = dsyev, 2 = dsyevj.
+inline int eigh_probe(Workspace &w, int n, int variant, int reps, double *seconds, std::string &msg)
+{
+    int rc = ensure(w, n, 6, msg);
+    if (rc) return rc;
+    const size_t nn = (size_t)n * n;
+    std::vector<double> h(nn);
+    unsigned long long st = 88172645463325252ULL;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            double v = (double)(st % 2000001ULL) / 1e6 - 1.0;
+            h[(size_t)i * n + j] = h[(size_t)j * n + i] = v;
+        }
+    double *A0 = w.pool, *A = A0 + nn, *V = A + nn, *vals = V + nn, *e = vals + n;
+    TFS_HIP(hipMemcpy(A0, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    double tot = 0.0;
+    for (int r = 0; r < reps + 1; ++r) {
+        TFS_HIP(hipMemcpy(A, A0, nn * sizeof(double), hipMemcpyDeviceToDevice));
+        TFS_HIP(hipDeviceSynchronize());
+        auto t0 = std::chrono::steady_clock::now();
+        if (variant == 0) TFS_BLAS(rocsolver_dsyevd(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, e, w.d_info));
+        else if (variant == 1) TFS_BLAS(rocsolver_dsyev(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, e, w.d_info));
+        else {
+            double *resid = w.d_scal + 32;
+            rocblas_int *nsweeps = w.d_info;
+            TFS_BLAS(rocsolver_dsyevj(w.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, n, A, n, 1e-14, resid, 100,
+                                      nsweeps, vals, w.d_info));
+        }
+        TFS_HIP(hipDeviceSynchronize());
+        if (r > 0) tot += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    *seconds = tot / reps;
+    return TF_OK;
+}
+
 using JKFn = std::function<int(const double *, double *, double *, hipStream_t)>;
 
 inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, const double *T, const double *V, const double *Fext,
