@@ -216,16 +216,23 @@ def scf_leg(eng, args):
     from oracle import scf_oracle as so
     from tuna_amd import molecule as mol
     atoms, shells, aos, nocc, desc = build_workload("n2-cc-pvtz")
-    t0 = time.perf_counter()
-    eng.set_basis(aos).build_eri(True)
-    t_eri = time.perf_counter() - t0
     xyz, chg = [a.origin for a in atoms], [float(a.charge) for a in atoms]
-    t1 = time.perf_counter()
-    S, T, V, _, _ = eng.one_electron(xyz, chg, [0, 0, 0.5 * atoms[1].origin[2]])
-    X, _, _ = eng.orthogonaliser(S)
-    P0, E0 = so.core_guess(T, V, X, nocc)
-    r = eng.scf_rhf(S, T, V, P0, E0, nocc, mol.nuclear_repulsion(atoms), X=X, conv="extreme", damping="none", n_atom_ao=[30, 30])
-    t_scf = time.perf_counter() - t1
+    passes = []
+    for _ in range(3):          # pass 0 is cold (rocBLAS/rocSOLVER start-up, first allocations); the last one is reported as warm
+        t0 = time.perf_counter()
+        eng.set_basis(aos).build_eri(True)
+        t_eri = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        S, T, V, _, _ = eng.one_electron(xyz, chg, [0, 0, 0.5 * atoms[1].origin[2]])
+        X, _, _ = eng.orthogonaliser(S)
+        _, C0 = eng.diagonalise(T + V, X)
+        P0 = 2.0 * C0[:, :nocc] @ C0[:, :nocc].T
+        P0 = 0.5 * (P0 + P0.T)
+        E0 = float(np.sum(P0 * (T + V)))
+        r = eng.scf_rhf(S, T, V, P0, E0, nocc, mol.nuclear_repulsion(atoms), X=X, conv="extreme", damping="none", n_atom_ao=[30, 30])
+        t_scf = time.perf_counter() - t1
+        passes.append((t_eri, t_scf))
+    cold_eri, cold_scf = passes[0]
     # Fock builds/s on this config too (device-resident P)
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -242,6 +249,8 @@ def scf_leg(eng, args):
     fps = 200 / (time.perf_counter() - t2)
     out = {"workload": desc, "energy_Eh": r["energy"], "abs_error_vs_reference_anchor_Eh": abs(r["energy"] - ANCHOR_N2_CCPVTZ),
            "iterations": r["n_iter"], "eri_build_wall_s": t_eri, "scf_wall_s": t_scf, "total_wall_s": t_eri + t_scf,
+           "cold_first_call": {"eri_build_wall_s": cold_eri, "scf_wall_s": cold_scf, "total_wall_s": cold_eri + cold_scf},
+           "note": "wall times of the 3rd repetition in this process (1e integrals + orthogonaliser + core guess + EXTREME RHF in scf_wall_s)",
            "fock_kernel_s": r["fock_seconds"], "eigensolver_s": r["eig_seconds"], "fock_builds_per_s": fps,
            "cpu_reference_fock_builds_per_s_8core_container": 23.4}
     if not args.no_cpu_baseline:

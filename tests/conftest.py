@@ -79,3 +79,28 @@ def atom_arrays(atoms):
     chg = [float(a.charge) for a in atoms]
     org = [0.0, 0.0, 0.5 * atoms[-1].origin[2] if len(atoms) == 2 else 0.0]
     return xyz, chg, org
+
+UHF_SYSTEMS = {
+    "o2_triplet_sto3g": (["O", "O"], mol.angstrom_to_bohr(1.2075), "STO-3G", 9, 7),
+    "o2_triplet_ccpvdz": (["O", "O"], mol.angstrom_to_bohr(1.2075), "cc-pVDZ", 9, 7),
+    "no_doublet_631g": (["N", "O"], mol.angstrom_to_bohr(1.1508), "6-31G", 8, 7),
+    "oh_doublet_ccpvdz": (["O", "H"], mol.angstrom_to_bohr(0.9697), "cc-pVDZ", 5, 4),
+    "li_doublet_631g": (["LI"], None, "6-31G", 2, 1),
+}
+
+
+def make_uhf_system(tag):
+    sym, R, basis, na, nb = UHF_SYSTEMS[tag]
+    atoms = mol.make_atoms(sym, R)
+    shells = mol.build_shells(atoms, basis)
+    return atoms, shells, mol.expand_cartesian_aos(shells), na, nb
+
+
+@pytest.fixture(scope="session")
+def uhf_golden(golden):
+    z = golden("uhf_systems")
+    out = {}
+    for key in z.files:
+        tag, name = key.split("__", 1)
+        out.setdefault(tag, {})[name] = z[key]
+    return out

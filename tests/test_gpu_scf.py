@@ -93,3 +93,38 @@ def test_orthogonaliser(engine, golden):
     Xo, so_small, Sio = so.orthogonaliser(S)
     assert np.abs(X - Xo).max() < 1e-10 and abs(smallest - so_small) < 1e-12 and np.abs(Sinv - Sio).max() < 1e-8 * np.abs(Sio).max()
     assert abs(smallest - float(g["smallest_S"])) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["o2_triplet_sto3g", "o2_triplet_ccpvdz", "no_doublet_631g", "oh_doublet_ccpvdz", "li_doublet_631g"])
+@pytest.mark.parametrize("damping", [True, False])
+def test_unrestricted_cycle_matches_reference(engine, uhf_golden, tag, damping):
+    """UHF (scf:1165-1281): fused two-density Fock builds on the GPU, trajectories of the reference's own unrestricted run."""
+    from conftest import UHF_SYSTEMS
+    from tuna_amd.energy import Calculation, build_molecule_and_integrals
+    from tuna_amd.engine import SCF_CONVERGENCE
+    from tuna_amd import scf
+    g = uhf_golden[tag]
+    sym, R, basis, na, nb = UHF_SYSTEMS[tag]
+    calc = Calculation(basis=basis, SCF_conv=SCF_CONVERGENCE["extreme"], multiplicity=na - nb + 1, damping=damping)
+    molecule, integrals, X, guess, _ = build_molecule_and_integrals(sym, R, calc, engine)
+    assert calc.reference == "UHF" and (molecule.n_alpha, molecule.n_beta) == (na, nb)
+    assert abs(guess[3] - float(g["E0"])) < 1e-9
+    out = scf.run_self_consistent_field_cycle(molecule, calc, integrals, float(g["V_NN"]), X, guess)
+    sfx = "" if damping else "_nodamp"
+    assert abs(out.energy - float(g["scf_energy" + sfx])) < 1e-9
+    np.testing.assert_allclose(out.epsilons_alpha, g["eps_alpha" + sfx], atol=1e-7)
+    np.testing.assert_allclose(out.epsilons_beta, g["eps_beta" + sfx], atol=1e-7)
+    assert abs(np.trace(out.P_alpha @ integrals.S) - na) < 1e-9 and abs(np.trace(out.P_beta @ integrals.S) - nb) < 1e-9
+    if damping and tag.startswith("o2"):
+        return      # homonuclear UHF + dynamic damping is rounding-noise driven in the reference (see tests/test_oracle.py)
+    ref = g["scf_table" + sfx]
+    assert abs(out.n_iterations - len(ref)) <= 1
+    n = min(out.n_iterations, len(ref))
+    np.testing.assert_allclose(out.table[:n, 1], ref[:n, 1], atol=2e-8)
+    np.testing.assert_allclose(out.table[:n, 6], ref[:n, 6], atol=1e-6)
+
+
+def test_uhf_input_line(uhf_golden):
+    from tuna_amd.energy import run
+    out = run("SPE : O O 1.2075 : UHF CC-PVDZ : EXTREME NODAMP ML 3")
+    assert abs(out.energy - float(uhf_golden["o2_triplet_ccpvdz"]["scf_energy_nodamp"])) < 1e-8

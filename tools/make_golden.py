@@ -192,6 +192,61 @@ CONV = {
 }
 
 
+def run_reference_uhf(scf, ortho, atoms, shells, S, T, V, ERI, n_alpha, n_beta, conv="extreme", damping=True):
+    """The reference's UNRESTRICTED cycle (scf:1165-1281) from a core-Hamiltonian guess with n_alpha / n_beta occupations."""
+    X, smallest, S_inv = ortho(S, None, True)
+    eps0, C0 = scf.diagonalise_Fock_matrix(T + V, X)
+    Pa0 = scf.construct_density_matrix(C0, n_alpha, 1)
+    Pb0 = scf.construct_density_matrix(C0, n_beta, 1)
+    E0 = float(np.einsum("mn,mn->", T + V, Pa0 + Pb0))
+    n_sph = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
+    molecule = types.SimpleNamespace(n_doubly_occ=n_beta, partition_ranges=n_sph, atoms=atoms, n_electrons=n_alpha + n_beta,
+                                     n_alpha=n_alpha, n_beta=n_beta)
+    table = []
+    orig = scf.format_output_line
+
+    def rec(E_total, delta_E, max_DP, RMS_DP, damping_factor, step, commutator, calculation, silent=False):
+        table.append([step, E_total, delta_E, RMS_DP, max_DP, commutator, float(damping_factor)])
+    scf.format_output_line = rec
+    try:
+        V_NN = mol.nuclear_repulsion(atoms)
+        calc = Calc(CONV[conv], damping=damping)
+        calc.reference = "UHF"
+        out = scf.run_self_consistent_field_cycle(molecule, calc, Ints(S, T, V, ERI), V_NN, X,
+                                                  (Pa0 + Pb0, Pa0, Pb0, E0), (None, None, None, None), True)
+    finally:
+        scf.format_output_line = orig
+    return dict(table=np.array(table), energy=out.energy, epsilons_alpha=out.epsilons_alpha, epsilons_beta=out.epsilons_beta,
+                P_alpha=out.P_alpha, P_beta=out.P_beta, E0=E0, V_NN=V_NN,
+                components=np.array([out.kinetic_energy, out.nuclear_electron_energy, out.coulomb_energy, out.exchange_energy]))
+
+
+def make_uhf_golden(scf, blocks, ortho):
+    """Open-shell systems for the unrestricted path: O2 triplet, NO doublet, OH doublet (hetero), Li atom."""
+    out = {}
+    for tag, (sym, R, basis, na, nb) in {
+        "o2_triplet_sto3g": (["O", "O"], mol.angstrom_to_bohr(1.2075), "STO-3G", 9, 7),
+        "o2_triplet_ccpvdz": (["O", "O"], mol.angstrom_to_bohr(1.2075), "cc-pVDZ", 9, 7),
+        "no_doublet_631g": (["N", "O"], mol.angstrom_to_bohr(1.1508), "6-31G", 8, 7),
+        "oh_doublet_ccpvdz": (["O", "H"], mol.angstrom_to_bohr(0.9697), "cc-pVDZ", 5, 4),
+        "li_doublet_631g": (["LI"], None, "6-31G", 2, 1),
+    }.items():
+        atoms, shells, aos = system(sym, R, basis)
+        S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
+        U = reference_U(shells, blocks)
+        Ss, Ts_, Vs, Es = to_spherical(U, S), to_spherical(U, T), to_spherical(U, V), eri_to_spherical(U, E)
+        d = dict(n_alpha=na, n_beta=nb)
+        for damping in (True, False):
+            r = run_reference_uhf(scf, ortho, atoms, shells, Ss, Ts_, Vs, Es, na, nb, "extreme", damping)
+            sfx = "" if damping else "_nodamp"
+            d.update({f"scf_table{sfx}": r["table"], f"scf_energy{sfx}": r["energy"], f"eps_alpha{sfx}": r["epsilons_alpha"],
+                      f"eps_beta{sfx}": r["epsilons_beta"], f"components{sfx}": r["components"]})
+        d.update(E0=r["E0"], V_NN=r["V_NN"])
+        out[tag] = d
+        print("UHF", tag, aos.n, "E =", d["scf_energy"], d["scf_energy_nodamp"], "iters", len(d["scf_table"]), len(d["scf_table_nodamp"]))
+    np.savez_compressed(os.path.join(GOLD, "uhf_systems.npz"), **{f"{t}__{k}": v for t, d in out.items() for k, v in d.items()})
+
+
 def run_reference_scf(scf, ortho, atoms, shells, S, T, V, ERI, n_occ, conv="extreme", damping=True):
     """Core-Hamiltonian guess (tuna_guess.py calculate_core_guess: diagonalise H_core, fill n_occ) + reference loop."""
     X, smallest, S_inv = ortho(S, None, True)
@@ -225,6 +280,9 @@ def main():
     assert orc.ref_engine() is not None, "run oracle/build_ref.sh first"
     scf = load_reference_scf()
     blocks, ortho = load_reference_kernel_bits()
+    if "--uhf-only" in sys.argv:
+        make_uhf_golden(scf, blocks, ortho)
+        return
     np.savez(os.path.join(GOLD, "sph_blocks.npz"), **{f"L{L}": b for L, b in blocks.items()})
 
     # Boys function samples straight from the routine the reference calls (pyx:1505)
@@ -324,6 +382,7 @@ def main():
                         eri_sph_val=Es[idxs[:, 0], idxs[:, 1], idxs[:, 2], idxs[:, 3]],
                         eri_sph_fro=np.sqrt(np.sum(Es * Es)))
     print("high_l", aos.n, U.shape[0])
+    make_uhf_golden(scf, blocks, ortho)
 
 
 if __name__ == "__main__":

@@ -608,12 +608,13 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     DBG("scratch freed");
     // ---- J/K scratch
     const size_t nn = (size_t)N * N;
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Kp, std::max<size_t>(1, (size_t)ctx->n_rows) * 2 * ld * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Ppad, (size_t)N * ld * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_J, nn * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_K, nn * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_P, nn * sizeof(double)));
+    // (sized for two densities per pass)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Kp, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * 2 * ld * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Ppad, 2 * (size_t)N * ld * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_J, 2 * nn * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_K, 2 * nn * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_P, 2 * nn * sizeof(double)));
     DBG("build_eri done");
     ctx->have_eri = true;
     return TF_OK;
@@ -681,19 +682,24 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
 
 // ---- J/K ------------------------------------------------------------------------------------------
 
-static int launch_jk(tf_ctx *ctx, const double *dP, double *dJ, double *dK, hipStream_t st)
+// nd = 1 or 2 densities in one pass over the tensor.  dP/dJ/dK: nd dense [N,N] device matrices each.
+static int launch_jk(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st)
 {
     const int N = ctx->N, ld = ctx->ld;
-    const double *Ppad = dP;
+    const double *Ppad[2] = {dP[0], nd > 1 ? dP[1] : dP[0]};
     if (ld != N) {
-        hipLaunchKernelGGL(pad_matrix_kernel, dim3((N * ld + 255) / 256), dim3(256), 0, st, dP, ctx->d_Ppad, N, ld);
-        Ppad = ctx->d_Ppad;
+        for (int d = 0; d < nd; ++d) {
+            double *dst = ctx->d_Ppad + (size_t)d * N * ld;
+            hipLaunchKernelGGL(pad_matrix_kernel, dim3((N * ld + 255) / 256), dim3(256), 0, st, dP[d], dst, N, ld);
+            Ppad[d] = dst;
+        }
     }
     if (ctx->n_rows > 0) {
         const int npair = ld / 2;
         // rows per workgroup: share each P tile among JB rows, but keep >= ~2 workgroups per CU in flight
-        const int JB = (ctx->n_rows >= 4 * 2048) ? 4 : (ctx->n_rows >= 2 * 2048 ? 2 : 1);
-        const size_t smem = (size_t)(2 * JB * N + 4 * TF_JK_THREADS) * sizeof(double);
+        int JB = (ctx->n_rows >= 4 * 2048) ? 4 : (ctx->n_rows >= 2 * 2048 ? 2 : 1);
+        if (nd == 2 && JB == 4) JB = 2;                         // register budget
+        const size_t smem = (size_t)(2 * nd * JB * N + 4 * TF_JK_THREADS) * sizeof(double);
         const dim3 grid((unsigned)((ctx->n_rows + JB - 1) / JB)), block(TF_JK_THREADS);
         hipEvent_t ev_after = nullptr;
         if (ctx->prof_jk) {
@@ -707,22 +713,34 @@ static int launch_jk(tf_ctx *ctx, const double *dP, double *dJ, double *dK, hipS
                 ctx->prof_used += 2;
             }
         }
-#define TF_JK_LAUNCH(NLC, JBV)                                                                                              \
-        hipLaunchKernelGGL((jk_rows_kernel<NLC, JBV>), grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, ctx->n_rows, N, ld, Ppad, \
-                           ctx->d_Jrow, ctx->d_Kp)
-        if (npair <= TF_JK_THREADS) {
-            if (JB == 4) TF_JK_LAUNCH(1, 4); else if (JB == 2) TF_JK_LAUNCH(1, 2); else TF_JK_LAUNCH(1, 1);
-        } else if (npair <= 2 * TF_JK_THREADS) {
-            if (JB == 4) TF_JK_LAUNCH(2, 4); else if (JB == 2) TF_JK_LAUNCH(2, 2); else TF_JK_LAUNCH(2, 1);
-        } else if (npair <= 4 * TF_JK_THREADS) {
-            if (JB >= 2) TF_JK_LAUNCH(4, 2); else TF_JK_LAUNCH(4, 1);
-        } else
-            TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the J/K kernel's row length limit (2048)", N);
+#define TF_JK_LAUNCH(NLC, JBV, NDV)                                                                                         \
+        hipLaunchKernelGGL((jk_rows_kernel<NLC, JBV, NDV>), grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, ctx->n_rows, N, ld, \
+                           Ppad[0], Ppad[1], ctx->d_Jrow, ctx->d_Kp)
+        if (nd == 1) {
+            if (npair <= TF_JK_THREADS) {
+                if (JB == 4) TF_JK_LAUNCH(1, 4, 1); else if (JB == 2) TF_JK_LAUNCH(1, 2, 1); else TF_JK_LAUNCH(1, 1, 1);
+            } else if (npair <= 2 * TF_JK_THREADS) {
+                if (JB == 4) TF_JK_LAUNCH(2, 4, 1); else if (JB == 2) TF_JK_LAUNCH(2, 2, 1); else TF_JK_LAUNCH(2, 1, 1);
+            } else if (npair <= 4 * TF_JK_THREADS) {
+                if (JB >= 2) TF_JK_LAUNCH(4, 2, 1); else TF_JK_LAUNCH(4, 1, 1);
+            } else
+                TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the J/K kernel's row length limit (2048)", N);
+        } else {
+            if (npair <= TF_JK_THREADS) {
+                if (JB == 2) TF_JK_LAUNCH(1, 2, 2); else TF_JK_LAUNCH(1, 1, 2);
+            } else if (npair <= 2 * TF_JK_THREADS) {
+                if (JB == 2) TF_JK_LAUNCH(2, 2, 2); else TF_JK_LAUNCH(2, 1, 2);
+            } else if (npair <= 4 * TF_JK_THREADS) {
+                TF_JK_LAUNCH(4, 1, 2);
+            } else
+                TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the J/K kernel's row length limit (2048)", N);
+        }
 #undef TF_JK_LAUNCH
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
-    hipLaunchKernelGGL(jk_reduce_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, st, ctx->d_Jrow, ctx->d_Kp, ctx->d_rowmap, N, ld,
-                       dJ, dK);
+    for (int d = 0; d < nd; ++d)
+        hipLaunchKernelGGL(jk_reduce_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, st, ctx->d_Jrow + (size_t)d * ctx->n_rows,
+                           ctx->d_Kp + (size_t)d * ctx->n_rows * 2 * ld, ctx->d_rowmap, N, ld, dJ[d], dK[d]);
     return TF_OK;
 }
 
@@ -732,8 +750,11 @@ int tf_fock_jk_device(tf_ctx *ctx, int n_dens, const double *dP, double *dJ, dou
     if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: call tf_build_eri first");
     if (n_dens < 1 || !dP || !dJ || !dK) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: bad arguments");
     const size_t nn = (size_t)ctx->N * ctx->N;
-    for (int d = 0; d < n_dens; ++d) {
-        int rc = launch_jk(ctx, dP + d * nn, dJ + d * nn, dK + d * nn, (hipStream_t)stream);
+    for (int d = 0; d < n_dens; d += 2) {                       // densities go through the tensor two at a time
+        const int nd = std::min(2, n_dens - d);
+        const double *p[2] = {dP + d * nn, dP + (d + nd - 1) * nn};
+        double *j[2] = {dJ + d * nn, dJ + (d + nd - 1) * nn}, *k[2] = {dK + d * nn, dK + (d + nd - 1) * nn};
+        int rc = launch_jk(ctx, nd, p, j, k, (hipStream_t)stream);
         if (rc) return rc;
     }
     return TF_OK;
@@ -746,12 +767,15 @@ int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K)
     if (n_dens < 1 || !P || !J || !K) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nn = (size_t)ctx->N * ctx->N;
-    for (int d = 0; d < n_dens; ++d) {
-        HIPCHK(ctx, hipMemcpy(ctx->d_P, P + d * nn, nn * sizeof(double), hipMemcpyHostToDevice));
-        int rc = launch_jk(ctx, ctx->d_P, ctx->d_J, ctx->d_K, 0);
+    for (int d = 0; d < n_dens; d += 2) {
+        const int nd = std::min(2, n_dens - d);
+        HIPCHK(ctx, hipMemcpy(ctx->d_P, P + d * nn, nd * nn * sizeof(double), hipMemcpyHostToDevice));
+        const double *p[2] = {ctx->d_P, ctx->d_P + (nd - 1) * nn};
+        double *j[2] = {ctx->d_J, ctx->d_J + (nd - 1) * nn}, *k[2] = {ctx->d_K, ctx->d_K + (nd - 1) * nn};
+        int rc = launch_jk(ctx, nd, p, j, k, 0);
         if (rc) return rc;
-        HIPCHK(ctx, hipMemcpy(J + d * nn, ctx->d_J, nn * sizeof(double), hipMemcpyDeviceToHost));
-        HIPCHK(ctx, hipMemcpy(K + d * nn, ctx->d_K, nn * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(J + d * nn, ctx->d_J, nd * nn * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(K + d * nn, ctx->d_K, nd * nn * sizeof(double), hipMemcpyDeviceToHost));
     }
     HIPCHK(ctx, hipGetLastError());
     return TF_OK;
@@ -875,7 +899,11 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
     if (!opts || !S || !T || !V || !P0 || !out || n_occ < 1 || n_occ > ctx->N) TF_FAIL(ctx, TF_EINVAL, "tf_scf_rhf: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::string msg;
-    auto jk = [&](const double *dP, double *dJ, double *dK, hipStream_t st) { return launch_jk(ctx, dP, dJ, dK, st); };
+    auto jk = [&](const double *dP, double *dJ, double *dK, hipStream_t st) {
+        const double *p[2] = {dP, dP};
+        double *j[2] = {dJ, dJ}, *k[2] = {dK, dK};
+        return launch_jk(ctx, 1, p, j, k, st);
+    };
     int rc = tfscf::run_rhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0, E0, n_occ, V_NN, jk, ctx->world, *out, msg);
     if (rc) ctx->err = msg;
     return rc;

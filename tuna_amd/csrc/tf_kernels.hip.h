@@ -218,19 +218,22 @@ __device__ __forceinline__ double2 load_stream(const double2 *p)
     return v;
 }
 
-template <int NLC, int JB>
+// ND densities per pass (1 = RHF, 2 = UHF alpha/beta): the same bytes of M serve ND times the flops.
+template <int NLC, int JB, int ND>
 __global__ __launch_bounds__(TF_JK_THREADS) void jk_rows_kernel(const double *__restrict__ eri,
                                                                 const int2 *__restrict__ row_ij, long long n_rows, int N,
-                                                                int ld, const double *__restrict__ P /*[N][ld]*/,
-                                                                double *__restrict__ Jrow, double *__restrict__ Kp)
+                                                                int ld, const double *__restrict__ P0 /*[N][ld]*/,
+                                                                const double *__restrict__ P1, double *__restrict__ Jrow,
+                                                                double *__restrict__ Kp)
 {
     extern __shared__ double smem[];
-    double *sPj = smem;                 // [JB][N]  P[:, j_b]
-    double *sPi = smem + JB * N;        // [JB][N]  P[:, i_b]
-    double *sRed = smem + 2 * JB * N;   // reduction scratch: 4 * TF_JK_THREADS doubles
+    double *sPj = smem;                      // [ND][JB][N]  P_d[:, j_b]
+    double *sPi = smem + ND * JB * N;        // [ND][JB][N]  P_d[:, i_b]
+    double *sRed = smem + 2 * ND * JB * N;   // reduction scratch: 4 * TF_JK_THREADS doubles
 
     const long long row0 = (long long)blockIdx.x * JB;
     const int tid = threadIdx.x;
+    const double *__restrict__ Pd[2] = {P0, ND > 1 ? P1 : P0};
     int2 ij[JB];
     bool valid[JB];
 #pragma unroll
@@ -240,10 +243,12 @@ __global__ __launch_bounds__(TF_JK_THREADS) void jk_rows_kernel(const double *__
     }
     for (int k = tid; k < N; k += TF_JK_THREADS) {
 #pragma unroll
-        for (int b = 0; b < JB; ++b) {
-            sPj[b * N + k] = P[(size_t)k * ld + ij[b].y];
-            sPi[b * N + k] = P[(size_t)k * ld + ij[b].x];
-        }
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int b = 0; b < JB; ++b) {
+                sPj[(d * JB + b) * N + k] = Pd[d][(size_t)k * ld + ij[b].y];
+                sPi[(d * JB + b) * N + k] = Pd[d][(size_t)k * ld + ij[b].x];
+            }
     }
     __syncthreads();
 
@@ -255,78 +260,88 @@ __global__ __launch_bounds__(TF_JK_THREADS) void jk_rows_kernel(const double *__
     const size_t row_len = (size_t)N * ld;
     const double *__restrict__ M0 = eri + (size_t)row0 * row_len;
 
-    double accJ[JB];
-    double2 k1[JB][NLC], k2[JB][NLC];
+    double accJ[ND][JB];
+    double2 k1[ND][JB][NLC], k2[ND][JB][NLC];
 #pragma unroll
-    for (int b = 0; b < JB; ++b) {
-        accJ[b] = 0.0;
+    for (int d = 0; d < ND; ++d)
 #pragma unroll
-        for (int c = 0; c < NLC; ++c) { k1[b][c] = make_double2(0.0, 0.0); k2[b][c] = make_double2(0.0, 0.0); }
-    }
+        for (int b = 0; b < JB; ++b) {
+            accJ[d][b] = 0.0;
+#pragma unroll
+            for (int c = 0; c < NLC; ++c) { k1[d][b][c] = make_double2(0.0, 0.0); k2[d][b][c] = make_double2(0.0, 0.0); }
+        }
 
     if (active) {
 #pragma unroll 2
         for (int k = tk; k < N; k += TK) {
-            const double2 *__restrict__ Pk = reinterpret_cast<const double2 *>(P + (size_t)k * ld);
 #pragma unroll
             for (int c = 0; c < NLC; ++c) {
                 const int lp = tl + c * TF_JK_THREADS;
                 if (NLC == 1 || lp < npair) {
-                    const double2 p = Pk[lp];
+                    double2 p[ND];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) p[d] = reinterpret_cast<const double2 *>(Pd[d] + (size_t)k * ld)[lp];
                     double2 m[JB];
 #pragma unroll
                     for (int b = 0; b < JB; ++b)
                         m[b] = valid[b] ? load_stream(reinterpret_cast<const double2 *>(M0 + b * row_len + (size_t)k * ld) + lp)
                                         : make_double2(0.0, 0.0);
 #pragma unroll
-                    for (int b = 0; b < JB; ++b) {
-                        const double pj = sPj[b * N + k], pi = sPi[b * N + k];
-                        accJ[b] += m[b].x * p.x + m[b].y * p.y;
-                        k1[b][c].x += m[b].x * pj; k1[b][c].y += m[b].y * pj;
-                        k2[b][c].x += m[b].x * pi; k2[b][c].y += m[b].y * pi;
-                    }
+                    for (int d = 0; d < ND; ++d)
+#pragma unroll
+                        for (int b = 0; b < JB; ++b) {
+                            const double pj = sPj[(d * JB + b) * N + k], pi = sPi[(d * JB + b) * N + k];
+                            accJ[d][b] += m[b].x * p[d].x + m[b].y * p[d].y;
+                            k1[d][b][c].x += m[b].x * pj; k1[d][b][c].y += m[b].y * pj;
+                            k2[d][b][c].x += m[b].x * pi; k2[d][b][c].y += m[b].y * pi;
+                        }
                 }
             }
         }
     }
-    // J: block reduction per row (fixed tree)
-#pragma unroll
-    for (int b = 0; b < JB; ++b) {
-        __syncthreads();
-        sRed[tid] = accJ[b];
-        __syncthreads();
-        for (int s = TF_JK_THREADS / 2; s > 0; s >>= 1) {
-            if (tid < s) sRed[tid] += sRed[tid + s];
-            __syncthreads();
-        }
-        if (tid == 0 && valid[b]) Jrow[row0 + b] = sRed[0];
-    }
-    // K partials: sum over tk for each column pair
     double2 *sK = reinterpret_cast<double2 *>(sRed);
 #pragma unroll
-    for (int b = 0; b < JB; ++b) {
-        double *Kp1 = Kp + (size_t)(row0 + b) * 2 * ld, *Kp2 = Kp1 + ld;
+    for (int d = 0; d < ND; ++d) {
+        double *Jrow_d = Jrow + (size_t)d * n_rows;
+        double *Kp_d = Kp + (size_t)d * n_rows * 2 * ld;
+        // J: block reduction per row (fixed tree)
 #pragma unroll
-        for (int c = 0; c < NLC; ++c) {
-            const int lp = tl + c * TF_JK_THREADS;
-            if (TK == 1) {                                     // one thread per column pair: nothing to combine
-                if (valid[b] && lp < npair) {
-                    reinterpret_cast<double2 *>(Kp1)[lp] = k1[b][c];
-                    reinterpret_cast<double2 *>(Kp2)[lp] = k2[b][c];
-                }
-                continue;
+        for (int b = 0; b < JB; ++b) {
+            __syncthreads();
+            sRed[tid] = accJ[d][b];
+            __syncthreads();
+            for (int s = TF_JK_THREADS / 2; s > 0; s >>= 1) {
+                if (tid < s) sRed[tid] += sRed[tid + s];
+                __syncthreads();
             }
-            __syncthreads();
-            if (active) { sK[tid] = k1[b][c]; sK[TF_JK_THREADS + tid] = k2[b][c]; }
-            __syncthreads();
-            if (tk == 0 && lp < npair && valid[b]) {
-                double2 u = make_double2(0.0, 0.0), w = make_double2(0.0, 0.0);
-                for (int q = 0; q < TK; ++q) {
-                    const double2 x = sK[q * TL + tl], y = sK[TF_JK_THREADS + q * TL + tl];
-                    u.x += x.x; u.y += x.y; w.x += y.x; w.y += y.y;
+            if (tid == 0 && valid[b]) Jrow_d[row0 + b] = sRed[0];
+        }
+        // K partials: sum over tk for each column pair
+#pragma unroll
+        for (int b = 0; b < JB; ++b) {
+            double *Kp1 = Kp_d + (size_t)(row0 + b) * 2 * ld, *Kp2 = Kp1 + ld;
+#pragma unroll
+            for (int c = 0; c < NLC; ++c) {
+                const int lp = tl + c * TF_JK_THREADS;
+                if (TK == 1) {                                     // one thread per column pair: nothing to combine
+                    if (valid[b] && lp < npair) {
+                        reinterpret_cast<double2 *>(Kp1)[lp] = k1[d][b][c];
+                        reinterpret_cast<double2 *>(Kp2)[lp] = k2[d][b][c];
+                    }
+                    continue;
                 }
-                reinterpret_cast<double2 *>(Kp1)[lp] = u;
-                reinterpret_cast<double2 *>(Kp2)[lp] = w;
+                __syncthreads();
+                if (active) { sK[tid] = k1[d][b][c]; sK[TF_JK_THREADS + tid] = k2[d][b][c]; }
+                __syncthreads();
+                if (tk == 0 && lp < npair && valid[b]) {
+                    double2 u = make_double2(0.0, 0.0), w = make_double2(0.0, 0.0);
+                    for (int q = 0; q < TK; ++q) {
+                        const double2 x = sK[q * TL + tl], y = sK[TF_JK_THREADS + q * TL + tl];
+                        u.x += x.x; u.y += x.y; w.x += y.x; w.y += y.y;
+                    }
+                    reinterpret_cast<double2 *>(Kp1)[lp] = u;
+                    reinterpret_cast<double2 *>(Kp2)[lp] = w;
+                }
             }
         }
     }

@@ -4,7 +4,7 @@
     out = run("SPE : N N 1.0977 : HF CC-PVTZ : EXTREME NODAMP")
 
 Input line format `TYPE : A B R : METHOD BASIS : KEYWORDS` (tuna.py:87-99).  Supported here: TYPE = SPE, METHOD = HF
-(restricted, closed shell), the basis sets shipped in tuna_amd/data, and the SCF keywords of SURVEY.md section 5
+(restricted) or UHF / any multiplicity via ML (unrestricted), the basis sets shipped in tuna_amd/data, and the SCF keywords of SURVEY.md section 5
 (LOOSE/MEDIUM/TIGHT/EXTREME, MAXITER n, DIIS [n]/NODIIS, DAMP x/NODAMP/MAXDAMP x, SLOWCONV/VERYSLOWCONV, HFX x,
 CARTHARM, DECONTRACT, COREGUESS, CH n).  Everything numerical runs on the GPU through the C ABI.  The initial guess is the
 core-Hamiltonian guess (the reference's COREGUESS; its default SAD tables are data not shipped here) -- converged energies do
@@ -43,6 +43,7 @@ class Calculation:
     decontract: bool = False            # DECONTRACT, calc:90
     core_guess: bool = True
     DFT_calculation: bool = False
+    multiplicity: int = 1               # ML, calc:151
 
 
 @dataclass
@@ -52,6 +53,8 @@ class Molecule:
     aos: mol.AOList
     n_electrons: int
     n_doubly_occ: int
+    n_alpha: int
+    n_beta: int
     partition_ranges: list
     n_basis: int
     n_cartesian_basis: int
@@ -118,6 +121,8 @@ def interpret_keywords(params, calc: Calculation) -> Calculation:
             calc.decontract = True
         elif p in ("CH", "CHARGE"):
             calc.charge = int(value())
+        elif p in ("ML", "MULTIPLICITY"):
+            calc.multiplicity = int(value())
         elif p in ("COREGUESS", "T", "P", "DEBUG"):
             pass
         else:
@@ -134,8 +139,12 @@ def build_molecule_and_integrals(symbols, R_bohr, calc: Calculation, engine: Eng
     n_el = mol.electron_count(atoms, calc.charge)
     if n_el <= 0:
         raise TunaError("Zero electrons specified!" if n_el == 0 else "Negative number of electrons specified!")
-    if n_el % 2:
-        raise TunaError("open-shell (UHF) references are not on the GPU path in this build")
+    n_unpaired = calc.multiplicity - 1
+    if calc.multiplicity < 1 or (n_el - n_unpaired) % 2 or n_unpaired > n_el:
+        raise TunaError("Impossible charge and multiplicity combination!")
+    n_alpha, n_beta = (n_el + n_unpaired) // 2, (n_el - n_unpaired) // 2
+    if calc.multiplicity != 1:
+        calc.reference = "UHF"                               # tuna_molecule.py:307
     timings = {}
     t0 = time.perf_counter()
     engine.set_basis(aos)
@@ -150,7 +159,7 @@ def build_molecule_and_integrals(symbols, R_bohr, calc: Calculation, engine: Eng
     integrals = Integrals(S, T, V, D, Q, DeviceERI(engine, fock))
     dim = (lambda s: s.n_sph) if spherical else (lambda s: s.n_cart)
     ranges = [sum(dim(s) for s in shells if s.atom == a) for a in range(len(atoms))]
-    molecule = Molecule(atoms, shells, aos, n_el, n_el // 2, ranges, engine.N, aos.n)
+    molecule = Molecule(atoms, shells, aos, n_el, n_el // 2, n_alpha, n_beta, ranges, engine.N, aos.n)
     t0 = time.perf_counter()
     X, smallest, S_inv = engine.orthogonaliser(S)
     timings["Fock orthogonalisation matrix"] = time.perf_counter() - t0
@@ -158,10 +167,15 @@ def build_molecule_and_integrals(symbols, R_bohr, calc: Calculation, engine: Eng
         raise TunaError("An overlap matrix eigenvalue is too small! Change the basis set or decrease the threshold with STHRESH.")
     t0 = time.perf_counter()
     _, C0 = engine.diagonalise(integrals.H_core, X)
-    P0 = construct_density_matrix(C0, molecule.n_doubly_occ, 2)
+    if calc.reference == "UHF":
+        Pa0, Pb0 = construct_density_matrix(C0, n_alpha, 1), construct_density_matrix(C0, n_beta, 1)
+        P0 = Pa0 + Pb0
+    else:
+        P0 = construct_density_matrix(C0, molecule.n_doubly_occ, 2)
+        Pa0 = Pb0 = P0 / 2
     E0 = float(np.einsum("mn,mn->", integrals.H_core, P0))     # guess energy, tuna_guess.py:429
     timings["Initial guess"] = time.perf_counter() - t0
-    return molecule, integrals, X, (P0, P0 / 2, P0 / 2, E0), timings
+    return molecule, integrals, X, (P0, Pa0, Pb0, E0), timings
 
 
 def calculate_energy(symbols, R_bohr, calc: Calculation, engine: Engine | None = None, silent=True, log=print):
@@ -177,7 +191,8 @@ def calculate_energy(symbols, R_bohr, calc: Calculation, engine: Engine | None =
         timings["Self-consistent field"] = time.perf_counter() - t0
         out.timings.update(timings)
         if not silent:
-            log("\n Restricted Hartree-Fock energy:   " + f"{out.energy:16.10f}")       # kernel:846
+            label = "\n Unrestricted Hartree-Fock energy: " if calc.reference == "UHF" else "\n Restricted Hartree-Fock energy:   "
+            log(label + f"{out.energy:16.10f}")                                          # kernel:846-850
             log("\n Final single point energy: " + f"{out.energy:16.10f}")              # kernel:1305
         out.integrals = integrals if not own else None      # the device tensor dies with an engine we own
         return out
@@ -191,7 +206,9 @@ def run(input_line: str, silent: bool = True, engine: Engine | None = None, log=
     ctype, method, basis, symbols, R, params = parse_input(input_line)
     if ctype != "SPE":
         raise TunaError(f"Calculation type \"{ctype}\" is not supported.")
-    if method not in ("HF", "RHF"):
+    if method not in ("HF", "RHF", "UHF"):
         raise TunaError(f"Electronic structure method \"{method}\" is not supported.")
     calc = interpret_keywords(params, Calculation(ctype, "HF", basis))
+    if method == "UHF":
+        calc.reference = "UHF"
     return calculate_energy(symbols, R, calc, engine, silent, log)

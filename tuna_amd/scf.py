@@ -109,6 +109,33 @@ def construct_restricted_Fock_matrix(integrals, P, HFX_prop, V_XC=None):        
     return symmetrise(F), J, K
 
 
+def construct_unrestricted_Fock_matrices(integrals, P_alpha, P_beta, HFX_prop, V_XC_alpha=None, V_XC_beta=None):   # scf:542-589
+    """Both spin densities go through the tensor in ONE fused device pass (tf_fock_jk, n_dens = 2)."""
+    V_XC_alpha = V_XC_alpha if V_XC_alpha is not None else 0
+    V_XC_beta = V_XC_beta if V_XC_beta is not None else 0
+    J, K = _device(integrals.ERI_AO).jk(np.stack([P_alpha, P_beta]))
+    J_alpha, J_beta, K_alpha, K_beta = J[0], J[1], K[0], K[1]
+    F_alpha = integrals.T + integrals.V_NE + J_alpha + J_beta + integrals.F + integrals.G - K_alpha * HFX_prop + V_XC_alpha
+    F_beta = integrals.T + integrals.V_NE + J_alpha + J_beta + integrals.F + integrals.G - K_beta * HFX_prop + V_XC_beta
+    return symmetrise(F_alpha), symmetrise(F_beta), J_alpha, J_beta, K_alpha, K_beta
+
+
+def calculate_unrestricted_electronic_energy(integrals, P_alpha, P_beta, J_alpha, J_beta, K_alpha, K_beta, calculation):   # scf:415-486
+    P = P_alpha + P_beta
+    kinetic_energy = np.einsum("ij,ij->", P, integrals.T, optimize=True)
+    nuclear_electron_energy = np.einsum("ij,ij->", P, integrals.V_NE, optimize=True)
+    electric_field_energy = np.einsum("ij,ij->", P, integrals.F, optimize=True)
+    electric_field_gradient_energy = np.einsum("ij,ij->", P, integrals.G, optimize=True)
+    coulomb_energy = (1 / 2) * np.einsum("ij,ij->", P, J_alpha + J_beta, optimize=True)
+    exchange_energy = (-(1 / 2) * np.einsum("ij,ij->", P_alpha, K_alpha, optimize=True) * calculation.HFX_prop
+                       + -(1 / 2) * np.einsum("ij,ij->", P_beta, K_beta, optimize=True) * calculation.HFX_prop)
+    correlation_energy = 0
+    electronic_energy = (kinetic_energy + nuclear_electron_energy + coulomb_energy + exchange_energy + correlation_energy
+                         + electric_field_energy + electric_field_gradient_energy)
+    return electronic_energy, (kinetic_energy, nuclear_electron_energy, coulomb_energy, exchange_energy, correlation_energy,
+                               electric_field_energy, electric_field_gradient_energy)
+
+
 def format_output_line(E_total, delta_E, max_DP, RMS_DP, damping_factor, step, commutator):   # scf:83-107
     damping = f"{damping_factor:.3f}" if damping_factor != 0 else " ---"
     return f"  {step:3.0f}  {E_total:16.10f}  {delta_E:16.10f} {RMS_DP:16.10f} {max_DP:16.10f} {commutator:16.10f}     {damping}"
@@ -199,8 +226,8 @@ def run_self_consistent_field_cycle(molecule, calculation, integrals: Integrals,
                                     silent=True, log=print) -> Output:
     """scf:1292-1435 for the restricted reference.  `molecule` needs n_doubly_occ and partition_ranges; `calculation` the
     fields of `tuna_amd.energy.Calculation` (same names as the reference's Calculation)."""
-    if getattr(calculation, "reference", "RHF") != "RHF":
-        raise TunaError("only the restricted (RHF) cycle is on the GPU path in this build")
+    if getattr(calculation, "reference", "RHF") == "UHF":
+        return _run_unrestricted(molecule, calculation, integrals, V_NN, X, guess_objects, silent, log)
     P, _, _, E = guess_objects
     eri = _device(integrals.ERI_AO)
     eng = eri.engine
@@ -299,4 +326,94 @@ def _python_level_cycle(molecule, calculation, integrals, V_NN, X, P, E, o):
         if check_convergence(thr, step, dE, maxDP, rmsDP, commutator):
             return dict(energy=E + V_NN, components=np.array(comps, dtype=float), P=P, C=C, epsilons=eps, F=F, table=np.array(table),
                         n_iter=step, converged=True, wall_seconds=time.perf_counter() - t0)
+    raise TunaError(f"Self-consistent field not converged in {o['max_iter']} iterations! Increase maximum iterations or give up.", -4)
+
+
+def _run_unrestricted(molecule, calculation, integrals, V_NN, X, guess_objects, silent, log) -> Output:
+    """run_unrestricted_SCF_cycle (scf:1165-1281) inside the outer loop (scf:1292-1435): fused two-density device Fock
+    builds and rocSOLVER diagonalisations; O(N^2) bookkeeping on the host as in the reference.  Reference quirks kept:
+    "P_very_old" and "P_old_before_damping" of each spin are zero matrices in every iteration (scf:1281 vs scf:1394)."""
+    import time
+    _, Pa, Pb, E = guess_objects
+    S = integrals.S
+    eng = _device(integrals.ERI_AO).engine
+    o = _opts(calculation)
+    thr = o["conv"]
+    n_alpha, n_beta = molecule.n_alpha, molecule.n_beta
+    ranges = list(molecule.partition_ranges)
+    P = Pa + Pb
+    Fock_vector, err_vector, table = [], [], []
+    t0 = time.perf_counter()
+
+    def pops(D):
+        d = np.einsum("ij,ji->i", D, S)
+        return np.array([d[:ranges[0]].sum(), d[ranges[0]:].sum() if len(ranges) > 1 else 0.0])
+
+    def commutator_of(F, D):
+        e = X.T @ (F @ D @ S - S @ D @ F) @ X
+        return np.mean(e * e) ** (1 / 2), e
+
+    def damp(P_new, P_old_spin, commutator_spin, step):
+        factor = 0.0
+        if o["damping"] == "static":
+            factor = o["damping_factor"]
+        elif o["damping"] == "dynamic" and commutator_spin > 0.01 and step > 1:
+            A_out, A1_in = pops(P_new), pops(P_old_spin)
+            den = A_out - A1_in                                  # the other two populations are of zero matrices
+            alpha = A_out / den if den.all() != 0 else [0, 0]
+            factor = ((alpha[0] * ranges[0] + alpha[1] * ranges[1]) / (ranges[0] + ranges[1])) if len(ranges) == 2 else alpha[0] * ranges[0]
+            factor = max(factor, 0)
+            factor = factor if factor < min(o["max_damping"], 1) else o["max_damping"]
+        return factor * P_old_spin + (1 - factor) * P_new, factor
+
+    if not silent:
+        log(SCF_TABLE_HEADER)
+    for step in range(1, o["max_iter"] + 1):
+        E_old, P_old, Pa_old, Pb_old = E, P, Pa, Pb
+        Fa, Fb, Ja, Jb, Ka, Kb = construct_unrestricted_Fock_matrices(integrals, Pa, Pb, o["hfx"])
+        ca, ea = commutator_of(Fa, Pa)
+        cb, eb = commutator_of(Fb, Pb)
+        commutator = max(ca, cb)
+        err_vector.append(np.concatenate((ea.flatten(), eb.flatten())))
+        Fock_vector.append((Fa, Fb))
+        if len(Fock_vector) > o["max_diis"]:
+            del Fock_vector[0], err_vector[0]
+        eps_a, Ca = eng.diagonalise(Fa, X)
+        eps_b, Cb = eng.diagonalise(Fb, X)
+        Pa, Pb = construct_density_matrix(Ca, n_alpha, 1), construct_density_matrix(Cb, n_beta, 1)
+        E, comps = calculate_unrestricted_electronic_energy(integrals, Pa, Pb, Ja, Jb, Ka, Kb, calculation)
+        if step > 2 and o["diis"] and commutator < 0.3:
+            n = len(err_vector)
+            errs = np.array(err_vector)
+            B = np.empty((n + 1, n + 1))
+            B[:n, :n] = errs @ errs.T
+            B[:n, -1] = -1
+            B[-1, :n] = -1
+            B[-1, -1] = 0
+            rhs = np.zeros(n + 1)
+            rhs[-1] = -1
+            try:
+                coeffs = np.linalg.solve(B, rhs)[:n]
+                _, Ca_d = eng.diagonalise(np.tensordot(coeffs, np.array([f[0] for f in Fock_vector]), axes=(0, 0)), X)
+                _, Cb_d = eng.diagonalise(np.tensordot(coeffs, np.array([f[1] for f in Fock_vector]), axes=(0, 0)), X)
+                Pa, Pb = symmetrise(construct_density_matrix(Ca_d, n_alpha, 1)), symmetrise(construct_density_matrix(Cb_d, n_beta, 1))
+            except np.linalg.LinAlgError:
+                Fock_vector.clear()
+                err_vector.clear()
+        Pa, fa = damp(Pa, Pa_old, ca, step)
+        Pb, fb = damp(Pb, Pb_old, cb, step)
+        P = Pa + Pb
+        dE, maxDP, rmsDP = calculate_SCF_changes(E, E_old, P, P_old)
+        table.append([step, E + V_NN, dE, rmsDP, maxDP, commutator, float(max(fa, fb))])
+        if not silent:
+            log(format_output_line(E + V_NN, dE, maxDP, rmsDP, max(fa, fb), step, commutator))
+        if check_convergence(thr, step, dE, maxDP, rmsDP, commutator):
+            eps = np.concatenate((eps_a, eps_b))
+            order = np.argsort(eps)
+            C_all = np.concatenate((Ca, Cb), axis=1)[:, order]
+            if not silent:
+                log(f"\n Self-consistent field converged in {step} cycles!\n")
+            return Output(E + V_NN, comps[0], comps[1], comps[2], comps[3], comps[4], comps[5], comps[6], P, Pa, Pb, S, X, C_all, Ca, Cb,
+                          eps[order], eps_a, eps_b, None, None, None, Fa, Fb, integrals.T, integrals.V_NE, integrals, 0, step,
+                          np.array(table), {"wall_seconds": time.perf_counter() - t0})
     raise TunaError(f"Self-consistent field not converged in {o['max_iter']} iterations! Increase maximum iterations or give up.", -4)
