@@ -213,7 +213,6 @@ def main():
 def scf_leg(eng, args):
     """SCF wall time on BASELINE.json configs[1] (N2 RHF/cc-pVTZ): ERI build + native RHF (EXTREME thresholds, core guess,
     DIIS 6, no damping) on the GPU, energy checked against the reference anchor; CPU ERI build beside it."""
-    from oracle import scf_oracle as so
     from tuna_amd import molecule as mol
     atoms, shells, aos, nocc, desc = build_workload("n2-cc-pvtz")
     xyz, chg = [a.origin for a in atoms], [float(a.charge) for a in atoms]

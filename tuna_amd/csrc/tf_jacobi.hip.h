@@ -1,0 +1,163 @@
+// tf_jacobi.hip.h -- symmetric eigensolver for the small matrices of the SCF cycle (n <= 140): parallel cyclic Jacobi,
+// one workgroup, matrix (and, when it fits, the eigenvectors) resident in LDS.
+// Why: at N = 60..120 the SCF iteration is dominated by the eigensolver, not by the Fock build (J/K of N2/cc-pVTZ takes
+// 30 us, rocSOLVER dsyevd 1.2 ms because it is a chain of ~100 tiny launches); a single-launch in-LDS Jacobi removes that
+// launch latency.  Larger matrices go to rocsolver_dsyevd.  Reference role: np.linalg.eigh in diagonalise_Fock_matrix
+// (scf:244) and calculate_orthogonalisation_matrix (kernel:784).
+// Output convention (same as tfscf::eigh): eigenvalues ascending in vals; W row k = eigenvector k.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tfjac {
+
+#define TFJ_THREADS 1024
+#define TFJ_NMAX 140
+
+// round-robin tournament: pair k of round r among m (even) players
+__device__ __forceinline__ void tournament_pair(int m, int r, int k, int &p, int &q)
+{
+    int a, b;
+    if (k == 0) { a = m - 1; b = r; }
+    else { a = (r + k) % (m - 1); b = (r - k + (m - 1)) % (m - 1); }
+    p = min(a, b); q = max(a, b);
+}
+
+template <bool V_IN_LDS>
+__global__ __launch_bounds__(TFJ_THREADS) void jacobi_eigh_kernel(int n, double *__restrict__ W /* in: A, out: eigenvector rows */,
+                                                                  double *__restrict__ vals, double *__restrict__ Vg /* n*n scratch */,
+                                                                  int max_sweeps, int *__restrict__ info)
+{
+    extern __shared__ double sm[];
+    const int lda = n | 1;
+    double *sA = sm;
+    double *sV = V_IN_LDS ? sA + (size_t)n * lda : Vg;       // row p = current eigenvector estimate p
+    const int ldv = V_IN_LDS ? lda : n;
+    double *sC = sm + (V_IN_LDS ? 2 : 1) * (size_t)n * lda;
+    double *sS = sC + (TFJ_NMAX / 2 + 1);
+    double *sRed = sS + (TFJ_NMAX / 2 + 1);                  // 2 * TFJ_THREADS
+    int *sPQ = reinterpret_cast<int *>(sRed + 2 * TFJ_THREADS);   // packed p | q << 16, or -1
+    __shared__ int sDone;
+
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += TFJ_THREADS) {
+        const int i = e / n, j = e - i * n;
+        sA[i * lda + j] = 0.5 * (W[e] + W[(size_t)j * n + i]);
+        sV[i * ldv + j] = (i == j) ? 1.0 : 0.0;
+    }
+    const int m = n + (n & 1), half = m / 2;
+    int sweeps = 0;
+    __syncthreads();
+    for (; sweeps < max_sweeps; ++sweeps) {
+        // convergence: off-diagonal weight relative to the whole matrix
+        double off = 0.0, tot = 0.0;
+        for (int e = tid; e < n * n; e += TFJ_THREADS) {
+            const int i = e / n, j = e - i * n;
+            const double a = sA[i * lda + j];
+            tot += a * a;
+            if (i != j) off += a * a;
+        }
+        sRed[tid] = off; sRed[TFJ_THREADS + tid] = tot;
+        __syncthreads();
+        for (int s = TFJ_THREADS / 2; s > 0; s >>= 1) {
+            if (tid < s) { sRed[tid] += sRed[tid + s]; sRed[TFJ_THREADS + tid] += sRed[TFJ_THREADS + tid + s]; }
+            __syncthreads();
+        }
+        if (tid == 0) sDone = (sRed[0] <= 1e-31 * sRed[TFJ_THREADS]) ? 1 : 0;
+        __syncthreads();
+        if (sDone) break;
+        for (int r = 0; r < m - 1; ++r) {
+            if (tid < half) {
+                int p, q;
+                tournament_pair(m, r, tid, p, q);
+                int code = -1;
+                double c = 1.0, s = 0.0;
+                if (q < n) {
+                    const double apq = sA[p * lda + q];
+                    if (apq != 0.0) {
+                        const double tau = (sA[q * lda + q] - sA[p * lda + p]) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        s = t * c;
+                        code = p | (q << 16);
+                    }
+                }
+                sPQ[tid] = code; sC[tid] = c; sS[tid] = s;
+            }
+            __syncthreads();
+            // A <- A J   (columns p, q of every row)
+            for (int e = tid; e < half * n; e += TFJ_THREADS) {
+                const int k = e / n, i = e - k * n;
+                const int code = sPQ[k];
+                if (code < 0) continue;
+                const int p = code & 0xffff, q = code >> 16;
+                const double c = sC[k], s = sS[k];
+                const double aip = sA[i * lda + p], aiq = sA[i * lda + q];
+                sA[i * lda + p] = c * aip - s * aiq;
+                sA[i * lda + q] = s * aip + c * aiq;
+            }
+            __syncthreads();
+            // A <- J^T A  (rows p, q), V^T rows likewise
+            for (int e = tid; e < half * n; e += TFJ_THREADS) {
+                const int k = e / n, j = e - k * n;
+                const int code = sPQ[k];
+                if (code < 0) continue;
+                const int p = code & 0xffff, q = code >> 16;
+                const double c = sC[k], s = sS[k];
+                const double apj = sA[p * lda + j], aqj = sA[q * lda + j];
+                sA[p * lda + j] = (j == q) ? 0.0 : c * apj - s * aqj;
+                sA[q * lda + j] = (j == p) ? 0.0 : s * apj + c * aqj;
+                const double vp = sV[p * ldv + j], vq = sV[q * ldv + j];
+                sV[p * ldv + j] = c * vp - s * vq;
+                sV[q * ldv + j] = s * vp + c * vq;
+            }
+            __syncthreads();
+        }
+    }
+    // sort ascending (stable rank) and write out
+    for (int i = tid; i < n; i += TFJ_THREADS) {
+        const double di = sA[i * lda + i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double dj = sA[j * lda + j];
+            rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+        }
+        sPQ[i] = rank;                       // safe: the pair codes are no longer needed
+        vals[rank] = di;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += TFJ_THREADS) {
+        const int i = e / n, j = e - i * n;
+        W[(size_t)sPQ[i] * n + j] = sV[i * ldv + j];
+    }
+    if (tid == 0 && info) *info = (sweeps >= max_sweeps) ? 1 : 0;
+}
+
+inline size_t lds_bytes(int n, bool v_in_lds)
+{
+    const size_t lda = (size_t)(n | 1);
+    size_t d = (v_in_lds ? 2 : 1) * (size_t)n * lda + 2 * (TFJ_NMAX / 2 + 1) + 2 * TFJ_THREADS;
+    return d * sizeof(double) + (size_t)(TFJ_NMAX + 2) * sizeof(int);
+}
+
+// returns false if n is outside the kernel's range (caller falls back to rocSOLVER)
+inline bool launch(int n, double *W, double *vals, double *Vscratch, int *info, hipStream_t st, hipError_t *err)
+{
+    static bool attr_set = false;
+    if (n < 2 || n > TFJ_NMAX) return false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)jacobi_eigh_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        (void)hipFuncSetAttribute((const void *)jacobi_eigh_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        attr_set = true;
+    }
+    const size_t cap = 160 * 1024 - 256;
+    const bool v_in = lds_bytes(n, true) <= cap;
+    if (!v_in && lds_bytes(n, false) > cap) return false;
+    if (v_in)
+        hipLaunchKernelGGL(jacobi_eigh_kernel<true>, dim3(1), dim3(TFJ_THREADS), lds_bytes(n, true), st, n, W, vals, Vscratch, 40, info);
+    else
+        hipLaunchKernelGGL(jacobi_eigh_kernel<false>, dim3(1), dim3(TFJ_THREADS), lds_bytes(n, false), st, n, W, vals, Vscratch, 40, info);
+    *err = hipGetLastError();
+    return *err == hipSuccess;
+}
+
+}  // namespace tfjac

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/tunafock.h"
+#include "tf_jacobi.hip.h"
 
 namespace tfscf {
 
@@ -29,6 +30,8 @@ struct Workspace {
     double *d_scal = nullptr;    // small device scalar array
     rocblas_int *d_info = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *jac_scratch = nullptr;   // eigenvector scratch of the Jacobi solver when it does not fit LDS
+    size_t jac_cap = 0;
 };
 
 inline void release(Workspace &w)
@@ -39,6 +42,7 @@ inline void release(Workspace &w)
     if (w.blas) (void)rocblas_destroy_handle(w.blas);
     if (w.ev0) (void)hipEventDestroy(w.ev0);
     if (w.ev1) (void)hipEventDestroy(w.ev1);
+    if (w.jac_scratch) (void)hipFree(w.jac_scratch);
     w = Workspace();
 }
 
@@ -163,8 +167,23 @@ inline rocblas_status gemm_rm(rocblas_handle h, bool tA, bool tB, int n, double 
 }
 
 // Symmetric eigenproblem: W (in: symmetric matrix, out: row k = eigenvector k in row-major terms), vals ascending.
+// n <= 64: single-launch in-LDS Jacobi (tf_jacobi.hip.h; measured 0.06/0.23/0.96 ms at n = 10/28/60 against 0.24/0.67/1.22 ms
+// for dsyevd); larger: rocsolver_dsyevd (faster from n ~ 70 on).  TF_EIGH=rocsolver|jacobi overrides.
 inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, std::string &msg)
 {
+    static const bool force_rocsolver = getenv("TF_EIGH") && std::string(getenv("TF_EIGH")) == "rocsolver";
+    static const bool force_jacobi = getenv("TF_EIGH") && std::string(getenv("TF_EIGH")) == "jacobi";
+    if (!force_rocsolver && n >= 2 && n <= (force_jacobi ? TFJ_NMAX : 64)) {
+        if (w.jac_cap < (size_t)n * n) {
+            if (w.jac_scratch) (void)hipFree(w.jac_scratch);
+            w.jac_scratch = nullptr; w.jac_cap = 0;
+            TFS_HIP(hipMalloc((void **)&w.jac_scratch, (size_t)n * n * sizeof(double)));
+            w.jac_cap = (size_t)n * n;
+        }
+        hipError_t e = hipSuccess;
+        if (tfjac::launch(n, W, vals, w.jac_scratch, (int *)w.d_info, 0, &e)) return TF_OK;
+        if (e != hipSuccess) { msg = std::string("Jacobi eigensolver launch failed: ") + hipGetErrorString(e); return TF_ENODEVICE; }
+    }
     TFS_BLAS(rocsolver_dsyevd(w.blas, rocblas_evect_original, rocblas_fill_upper, n, W, n, vals, work_e, w.d_info));
     return TF_OK;
 }
@@ -286,6 +305,7 @@ inline int eigh_probe(Workspace &w, int n, int variant, int reps, double *second
         TFS_HIP(hipDeviceSynchronize());
         auto t0 = std::chrono::steady_clock::now();
         if (variant == 0) TFS_BLAS(rocsolver_dsyevd(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, e, w.d_info));
+        else if (variant == 3) { int rc3 = eigh(w, n, A, vals, e, msg); if (rc3) return rc3; }
         else if (variant == 1) TFS_BLAS(rocsolver_dsyev(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, e, w.d_info));
         else {
             double *resid = w.d_scal + 32;
