@@ -22,9 +22,12 @@ __device__ __forceinline__ void tournament_pair(int m, int r, int k, int &p, int
     p = min(a, b); q = max(a, b);
 }
 
+// V0 (optional, V_IN_LDS only): rows = eigenvectors of a nearby matrix (the previous SCF iteration).  The sweeps then start
+// from A0 = V0 A V0^T, which is already almost diagonal, and converge in 2-3 sweeps instead of ~8.
 template <bool V_IN_LDS>
 __global__ __launch_bounds__(TFJ_THREADS) void jacobi_eigh_kernel(int n, double *__restrict__ W /* in: A, out: eigenvector rows */,
                                                                   double *__restrict__ vals, double *__restrict__ Vg /* n*n scratch */,
+                                                                  const double *__restrict__ V0, double *__restrict__ Vkeep,
                                                                   int max_sweeps, int *__restrict__ info)
 {
     extern __shared__ double sm[];
@@ -39,14 +42,35 @@ __global__ __launch_bounds__(TFJ_THREADS) void jacobi_eigh_kernel(int n, double 
     __shared__ int sDone;
 
     const int tid = threadIdx.x;
+    const bool warm = V_IN_LDS && V0 != nullptr;
     for (int e = tid; e < n * n; e += TFJ_THREADS) {
         const int i = e / n, j = e - i * n;
         sA[i * lda + j] = 0.5 * (W[e] + W[(size_t)j * n + i]);
-        sV[i * ldv + j] = (i == j) ? 1.0 : 0.0;
+        sV[i * ldv + j] = warm ? V0[e] : ((i == j) ? 1.0 : 0.0);
     }
     const int m = n + (n & 1), half = m / 2;
     int sweeps = 0;
     __syncthreads();
+    if (warm) {
+        // third LDS matrix (after the int scratch): T = A V^T, then A0 = V T, upper triangle mirrored
+        double *sT = reinterpret_cast<double *>(reinterpret_cast<char *>(sPQ) + (((TFJ_NMAX + 2) * sizeof(int) + 15) & ~size_t(15)));
+        for (int e = tid; e < n * n; e += TFJ_THREADS) {
+            const int i = e / n, k = e - i * n;
+            double t = 0.0;
+            for (int j = 0; j < n; ++j) t += sA[i * lda + j] * sV[k * ldv + j];
+            sT[i * lda + k] = t;
+        }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += TFJ_THREADS) {
+            const int k = e / n, l = e - k * n;
+            if (l < k) continue;
+            double t = 0.0;
+            for (int i = 0; i < n; ++i) t += sV[k * ldv + i] * sT[i * lda + l];
+            sA[k * lda + l] = t;
+            sA[l * lda + k] = t;
+        }
+        __syncthreads();
+    }
     for (; sweeps < max_sweeps; ++sweeps) {
         // convergence: off-diagonal weight relative to the whole matrix
         double off = 0.0, tot = 0.0;
@@ -127,20 +151,25 @@ __global__ __launch_bounds__(TFJ_THREADS) void jacobi_eigh_kernel(int n, double 
     __syncthreads();
     for (int e = tid; e < n * n; e += TFJ_THREADS) {
         const int i = e / n, j = e - i * n;
-        W[(size_t)sPQ[i] * n + j] = sV[i * ldv + j];
+        const double v = sV[i * ldv + j];
+        W[(size_t)sPQ[i] * n + j] = v;
+        if (Vkeep) Vkeep[(size_t)sPQ[i] * n + j] = v;
     }
     if (tid == 0 && info) *info = (sweeps >= max_sweeps) ? 1 : 0;
 }
 
-inline size_t lds_bytes(int n, bool v_in_lds)
+inline size_t lds_bytes(int n, bool v_in_lds, bool warm = false)
 {
     const size_t lda = (size_t)(n | 1);
     size_t d = (v_in_lds ? 2 : 1) * (size_t)n * lda + 2 * (TFJ_NMAX / 2 + 1) + 2 * TFJ_THREADS;
-    return d * sizeof(double) + (size_t)(TFJ_NMAX + 2) * sizeof(int);
+    size_t b = d * sizeof(double) + (((size_t)(TFJ_NMAX + 2) * sizeof(int) + 15) & ~size_t(15));
+    if (warm) b += (size_t)n * lda * sizeof(double);
+    return b;
 }
 
 // returns false if n is outside the kernel's range (caller falls back to rocSOLVER)
-inline bool launch(int n, double *W, double *vals, double *Vscratch, int *info, hipStream_t st, hipError_t *err)
+inline bool launch(int n, double *W, double *vals, double *Vscratch, int *info, hipStream_t st, hipError_t *err,
+                   const double *V0 = nullptr, double *Vkeep = nullptr)
 {
     static bool attr_set = false;
     if (n < 2 || n > TFJ_NMAX) return false;
@@ -152,10 +181,13 @@ inline bool launch(int n, double *W, double *vals, double *Vscratch, int *info, 
     const size_t cap = 160 * 1024 - 256;
     const bool v_in = lds_bytes(n, true) <= cap;
     if (!v_in && lds_bytes(n, false) > cap) return false;
-    if (v_in)
-        hipLaunchKernelGGL(jacobi_eigh_kernel<true>, dim3(1), dim3(TFJ_THREADS), lds_bytes(n, true), st, n, W, vals, Vscratch, 40, info);
-    else
-        hipLaunchKernelGGL(jacobi_eigh_kernel<false>, dim3(1), dim3(TFJ_THREADS), lds_bytes(n, false), st, n, W, vals, Vscratch, 40, info);
+    if (v_in) {
+        const bool warm = V0 != nullptr && lds_bytes(n, true, true) <= cap;
+        hipLaunchKernelGGL(jacobi_eigh_kernel<true>, dim3(1), dim3(TFJ_THREADS), lds_bytes(n, true, warm), st, n, W, vals, Vscratch,
+                           warm ? V0 : nullptr, Vkeep, 40, info);
+    } else
+        hipLaunchKernelGGL(jacobi_eigh_kernel<false>, dim3(1), dim3(TFJ_THREADS), lds_bytes(n, false), st, n, W, vals, Vscratch,
+                           (const double *)nullptr, Vkeep, 40, info);
     *err = hipGetLastError();
     return *err == hipSuccess;
 }

@@ -32,6 +32,10 @@ struct Workspace {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *jac_scratch = nullptr;   // eigenvector scratch of the Jacobi solver when it does not fit LDS
     size_t jac_cap = 0;
+    double *jac_prev = nullptr;      // eigenvectors of the previous solve (warm start inside one SCF run)
+    size_t jac_prev_cap = 0;
+    int jac_prev_n = 0;              // 0 = no valid warm start
+    bool warm_ok = false;            // set by run_rhf for the duration of one SCF cycle
 };
 
 inline void release(Workspace &w)
@@ -43,6 +47,7 @@ inline void release(Workspace &w)
     if (w.ev0) (void)hipEventDestroy(w.ev0);
     if (w.ev1) (void)hipEventDestroy(w.ev1);
     if (w.jac_scratch) (void)hipFree(w.jac_scratch);
+    if (w.jac_prev) (void)hipFree(w.jac_prev);
     w = Workspace();
 }
 
@@ -180,8 +185,19 @@ inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, st
             TFS_HIP(hipMalloc((void **)&w.jac_scratch, (size_t)n * n * sizeof(double)));
             w.jac_cap = (size_t)n * n;
         }
+        if (w.jac_prev_cap < (size_t)n * n) {
+            if (w.jac_prev) (void)hipFree(w.jac_prev);
+            w.jac_prev = nullptr; w.jac_prev_cap = 0; w.jac_prev_n = 0;
+            TFS_HIP(hipMalloc((void **)&w.jac_prev, (size_t)n * n * sizeof(double)));
+            w.jac_prev_cap = (size_t)n * n;
+        }
+        static const bool no_warm = getenv("TF_EIGH_COLD") != nullptr;
+        const double *V0 = (w.warm_ok && !no_warm && w.jac_prev_n == n) ? w.jac_prev : nullptr;
         hipError_t e = hipSuccess;
-        if (tfjac::launch(n, W, vals, w.jac_scratch, (int *)w.d_info, 0, &e)) return TF_OK;
+        if (tfjac::launch(n, W, vals, w.jac_scratch, (int *)w.d_info, 0, &e, V0, w.warm_ok ? w.jac_prev : nullptr)) {
+            if (w.warm_ok) w.jac_prev_n = n;
+            return TF_OK;
+        }
         if (e != hipSuccess) { msg = std::string("Jacobi eigensolver launch failed: ") + hipGetErrorString(e); return TF_ENODEVICE; }
     }
     TFS_BLAS(rocsolver_dsyevd(w.blas, rocblas_evect_original, rocblas_fill_upper, n, W, n, vals, work_e, w.d_info));
@@ -386,6 +402,9 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
 
     std::vector<double> B((size_t)max_diis * max_diis, 0.0);
     int n_hist = 0;
+    w.warm_ok = true;                 // successive Fock matrices are close: warm-start the Jacobi solver from the last eigenvectors
+    w.jac_prev_n = 0;
+    struct WarmGuard { Workspace &w; ~WarmGuard() { w.warm_ok = false; w.jac_prev_n = 0; } } warm_guard{w};
     double E = E0, E_old = E0, commutator = 1.0;
     double comps[7] = {0, 0, 0, 0, 0, 0, 0};
     out.fock_seconds = 0; out.eig_seconds = 0; out.n_iter = 0; out.converged = 0;
