@@ -2,13 +2,13 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from tuna_amd.engine import Engine
 eng = Engine(0)
-for n in (10, 28, 60, 62, 98, 118, 140, 200):
+for n in (60, 118, 200, 400):
     row = []
-    for v in (0, 3):
+    for v in (0, 3, 4, 5):
         s = C.c_double()
         rc = eng._L.tf_eigh_probe(eng._ctx, n, v, 5, C.byref(s))
         row.append(s.value * 1e3 if rc == 0 else float("nan"))
-    print(f"n={n}: dsyevd {row[0]:.3f} ms  in-LDS Jacobi (or fallback) {row[1]:.3f} ms")
+    print(f"n={n}: dsyevd {row[0]:.3f} ms  eigh() {row[1]:.3f} ms  dsyevdx(18 lowest) {row[2]:.3f} ms  dsyevx(18 lowest) {row[3]:.3f} ms")
 import numpy as np, time
 for n in (60, 118, 400):
     A = np.random.default_rng(0).standard_normal((n, n)); A = A + A.T

@@ -45,6 +45,8 @@ struct tf_ctx {
     int2 *d_row_ij = nullptr;
     int *d_rowmap = nullptr;
     std::vector<int> my_pairs;          // bra shell pairs owned by this rank
+    std::vector<DPair> host_pairs;      // host mirror of db.pairs (output offsets are filled in by tf_build_eri)
+    DPair *d_pairs = nullptr;
     std::vector<int> pair_class;        // class id of every shell pair
     std::vector<std::vector<int>> class_pairs;   // pairs of each class, ascending
     // J/K scratch
@@ -214,7 +216,7 @@ int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t
     for (size_t i = 0; i < hp.size(); ++i) {
         const tf::Pair &p = bs.pairs[i];
         const tf::Shell &sa = bs.shells[p.A], &sb = bs.shells[p.B];
-        hp[i] = {p.A, p.B, p.La, p.Lb, p.npp, p.pp_off, p.nE, 0, p.e_off, sa.ncomp, sb.ncomp, sa.comp_off, sb.comp_off, sa.cart_off, sb.cart_off};
+        hp[i] = {p.A, p.B, p.La, p.Lb, p.npp, p.pp_off, p.nE, 0, p.e_off, sa.ncomp, sb.ncomp, sa.comp_off, sb.comp_off, sa.cart_off, sb.cart_off, 0, 0};
     }
     // shell-pair classes: every pair of a class has the same angular momenta, component counts and contraction depth
     ctx->pair_class.assign(hp.size(), 0);
@@ -234,12 +236,32 @@ int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t
     tf::boys_table(boys);
     DShell *d_sh; DPair *d_pr; int8_t *d_lx, *d_ly, *d_lz; double *d_sc, *d_p, *d_Pz, *d_K, *d_E, *d_boys;
     int rc;
+    // per-L spherical rows as CSR over the Cartesian components of one shell
+    std::vector<int> sph_base(TF_MAX_L + 2, 0), sph_ptr{0}, sph_idx;
+    std::vector<double> sph_val;
+    {
+        std::vector<double> blk;
+        for (int L = 0; L <= TF_MAX_L; ++L) {
+            sph_base[L] = (int)sph_ptr.size() - 1;
+            tf::sph_block(L, blk);
+            const int nc = (L + 1) * (L + 2) / 2;
+            for (int r = 0; r < 2 * L + 1; ++r) {
+                for (int c = 0; c < nc; ++c)
+                    if (blk[(size_t)r * nc + c] != 0.0) { sph_idx.push_back(c); sph_val.push_back(blk[(size_t)r * nc + c]); }
+                sph_ptr.push_back((int)sph_idx.size());
+            }
+        }
+    }
+    int *d_sb, *d_sp, *d_si; double *d_sv;
     if ((rc = upload(ctx, hs, &d_sh)) || (rc = upload(ctx, hp, &d_pr)) || (rc = upload(ctx, bs.c_lx, &d_lx)) ||
         (rc = upload(ctx, bs.c_ly, &d_ly)) || (rc = upload(ctx, bs.c_lz, &d_lz)) || (rc = upload(ctx, bs.c_scale, &d_sc)) ||
         (rc = upload(ctx, bs.pp_p, &d_p)) || (rc = upload(ctx, bs.pp_Pz, &d_Pz)) || (rc = upload(ctx, bs.pp_K, &d_K)) ||
-        (rc = upload(ctx, bs.epool, &d_E)) || (rc = upload(ctx, boys, &d_boys)))
+        (rc = upload(ctx, bs.epool, &d_E)) || (rc = upload(ctx, boys, &d_boys)) || (rc = upload(ctx, sph_base, &d_sb)) ||
+        (rc = upload(ctx, sph_ptr, &d_sp)) || (rc = upload(ctx, sph_idx, &d_si)) || (rc = upload(ctx, sph_val, &d_sv)))
         return rc;
-    ctx->db = DBasis{d_sh, d_pr, d_lx, d_ly, d_lz, d_sc, d_p, d_Pz, d_K, d_E, d_boys};
+    ctx->db = DBasis{d_sh, d_pr, d_lx, d_ly, d_lz, d_sc, d_p, d_Pz, d_K, d_E, d_boys, d_sb, d_sp, d_si, d_sv};
+    ctx->host_pairs = hp;
+    ctx->d_pairs = d_pr;
     ctx->have_basis = true;
     return TF_OK;
 }
@@ -328,6 +350,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // ---- which bra shell pairs (= row blocks) belong to this rank: longest-processing-time on row counts
     auto out_dim = [&](const tf::Shell &s) { return spherical ? s.nsph : s.ncomp; };
     auto out_off = [&](const tf::Shell &s) { return spherical ? s.sph_off : s.cart_off; };
+    for (int p = 0; p < npairs; ++p) {
+        ctx->host_pairs[p].outoff_a = out_off(bs.shells[bs.pairs[p].A]);
+        ctx->host_pairs[p].outoff_b = out_off(bs.shells[bs.pairs[p].B]);
+    }
+    HIPCHK(ctx, hipMemcpy(ctx->d_pairs, ctx->host_pairs.data(), (size_t)npairs * sizeof(DPair), hipMemcpyHostToDevice));
     std::vector<long long> pair_rows(npairs);
     for (int p = 0; p < npairs; ++p) {
         const tf::Shell &a = bs.shells[bs.pairs[p].A], &b = bs.shells[bs.pairs[p].B];
@@ -437,6 +464,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         q.npp_ab = max_npp_bra; q.npp_cd = cls_maxnpp[kcls]; q.npq = q.npp_ab * q.npp_cd;      // class maxima (LDS sizing)
         q.nEab = pb.nE; q.nEcd = pk.nE;
         q.n_ket = ket_off[kcls + 1] - ket_off[kcls];
+        q.fused = 1; q.spherical = spherical ? 1 : 0;
+        q.nsc = spherical ? sc.nsph : sc.ncomp; q.nsd = spherical ? sd.nsph : sd.ncomp;
+        q.Nout = N; q.ld = ld;
+        double *d_out_slab = d_T2;                               // fused kernels write the half-transformed slab directly
         const int *d_ket = d_kets + ket_off[kcls];
         hipStream_t st = streams[launch_count++ % NSTREAM];
         if (q.npq == 1 && q.ncomp <= 128) {
@@ -456,10 +487,28 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             q.offEcd = o; o += q.G * 2 * q.nEcd;
             q.offScale = o; o += 42 + kc * q.G;
             q.offLmn = o; o += (42 + kc * q.G + q.G + 1) / 2;
+            q.offBlk = o; o += q.G * q.ncomp;
             q.lds_doubles = o;
             const dim3 grid((q.n_ket + q.G - 1) / q.G, n_bra);
             hipLaunchKernelGGL(eri_multi_kernel, grid, dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q, d_bra, d_braoff,
-                               d_ket, Nc, d_C);
+                               d_ket, Nc, d_out_slab);
+        } else if (q.npq == 1 && (q.La + 1) * (q.Lb + 1) * (q.Lc + 1) * (q.Ld + 1) * 2 * (q.L / 2 + 1) <= 7000 && !getenv("TF_ERI_NOFACT")) {
+            // uncontracted, many components: per-axis factor tables in LDS
+            const int nT = (q.La + 1) * (q.Lb + 1) * (q.Lc + 1) * (q.Ld + 1), nM = q.L / 2 + 1;
+            q.PB = 1; q.stride = 1; q.G = 1; q.ncp = 0;
+            int o = 0;
+            q.offR = o; o += q.tsize;
+            q.offPref = o; o += 2;
+            q.offPQ = o; o += 2;
+            q.offEab = o; o += 2 * q.nEab;
+            q.offEcd = o; o += 2 * q.nEcd;
+            q.offScale = o; o += 84;
+            q.offLmn = o; o += 42;
+            q.offRed = o; o += 2 * nT * nM;                      // X and Z tables
+            q.offBlk = o; o += TF_BLK_DOUBLES;
+            q.lds_doubles = o;
+            hipLaunchKernelGGL(eri_fact_kernel, dim3(q.n_ket, n_bra), dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q, d_bra,
+                               d_braoff, d_ket, Nc, d_out_slab);
         } else {
             const int RB = 3584, EB = 3072;                     // LDS doubles for R tables / staged E tables
             int PB = RB / q.tsize - 1;
@@ -476,14 +525,15 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             q.offEcd = o; o += stage ? q.npp_cd * 2 * q.nEcd : 0;
             q.offScale = o; o += 84;
             q.offLmn = o; o += 42;
+            q.offBlk = o; o += TF_BLK_DOUBLES;
             q.lds_doubles = o;
             const dim3 grid(q.n_ket, n_bra);
             if (stage)
                 hipLaunchKernelGGL((eri_class_kernel<true, false>), grid, dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q,
-                                   d_bra, d_braoff, d_ket, Nc, d_C);
+                                   d_bra, d_braoff, d_ket, Nc, d_out_slab);
             else
                 hipLaunchKernelGGL((eri_class_kernel<false, false>), grid, dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q,
-                                   d_bra, d_braoff, d_ket, Nc, d_C);
+                                   d_bra, d_braoff, d_ket, Nc, d_out_slab);
         }
     };
 
@@ -501,7 +551,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         q.offScale = o; o += 84;
         q.offLmn = o; o += 42;
         q.lds_doubles = o;
-        q.G = 1; q.n_ket = npairs;
+        q.offBlk = o;                                            // unused (unfused)
+        q.G = 1; q.n_ket = npairs; q.fused = 0;
         hipLaunchKernelGGL((eri_class_kernel<true, true>), dim3(npairs, n_bra), dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), streams[0],
                            ctx->db, q, d_bra, d_braoff, d_kets_all, Nc, d_C);
     };
@@ -549,6 +600,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         DBG("slab: %zu bra pairs, %lld cart rows, %zu out rows", bra.size(), rows_c, outs.size());
         hipEvent_t e4[4];
         for (auto &e : e4) { HIPCHK(ctx, hipEventCreate(&e)); tev.push_back(e); }
+        if (per_class && ld != N) HIPCHK(ctx, hipMemsetAsync(d_T2, 0, (size_t)rows_c * N * ld * sizeof(double), 0));   // pad columns
         HIPCHK(ctx, hipEventRecord(e4[0], 0));
         for (int k = 0; k < NSTREAM; ++k) HIPCHK(ctx, hipStreamWaitEvent(streams[k], e4[0], 0));
         // runs of equal bra class inside the slab
@@ -568,7 +620,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             HIPCHK(ctx, hipStreamWaitEvent(0, sev[k], 0));
         }
         HIPCHK(ctx, hipEventRecord(e4[1], 0));
-        {
+        if (!per_class) {
             const long long tot1 = rows_c * Nc * (long long)N;
             const unsigned g1 = (unsigned)std::min<long long>((tot1 + 255) / 256, 1 << 20);
             hipLaunchKernelGGL(xform_last_axis, dim3(g1), dim3(256), 0, 0, d_C, d_T1, rows_c * Nc, Nc, N, ctx->d_csr_ptr,

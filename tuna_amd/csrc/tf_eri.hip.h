@@ -23,6 +23,7 @@ struct QClass {
     int PB, stride;        // primitive quartets per LDS batch, LDS column stride of the R tables
     int G, ncp;            // multi kernel: shell quartets per workgroup, padded components per quartet
     int n_ket;             // ket pairs in this launch
+    int fused, spherical, nsc, nsd, Nout, ld, offBlk;   // fused ket transform: output dims of shells C, D; T2 geometry; LDS block buffer
     // LDS carve-out, offsets in doubles
     int offR, offPref, offPQ, offRed, offEab, offEcd, offScale, offLmn, lds_doubles;
 };
@@ -101,6 +102,39 @@ __device__ __forceinline__ double hermite_sum(const CompQuartet &Q, const double
         }
     }
     return sum;
+}
+
+
+#define TF_BLK_DOUBLES 1024   // LDS doubles of the Cartesian (cc,cd) sub-block buffer of the fused ket transform
+
+// Fused ket transform (reference: the ket half of transform_to_spherical_harmonics, kernel:504-523): the Cartesian values of
+// `nblk` complete (cc,cd) sub-blocks sit in LDS (sBlk[b][cc][cd]); every thread produces outputs (b, sc, sd) as short CSR dot
+// products and writes them straight into the half-transformed slab T2[row(ca,cb)][k_out][l_out] (and the mirror image).
+__device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, const double *sBlk, int nblk, long long row_first,
+                                             const DPair &cd, double *__restrict__ T2, int tid, int nthreads)
+{
+    const int per = qc.nsc * qc.nsd;
+    const size_t row_len = (size_t)qc.Nout * qc.ld;
+    const int baseC = B.sphL_base[qc.Lc], baseD = B.sphL_base[qc.Ld];
+    for (int e = tid; e < nblk * per; e += nthreads) {
+        const int b = e / per, r = e - b * per;
+        const int sc = r / qc.nsd, sd = r - sc * qc.nsd;
+        const double *blk = sBlk + (size_t)b * qc.ncc * qc.ncd;
+        double s = 0.0;
+        if (qc.spherical) {
+            for (int qa = B.sphL_ptr[baseC + sc]; qa < B.sphL_ptr[baseC + sc + 1]; ++qa) {
+                const double *rowp = blk + B.sphL_idx[qa] * qc.ncd;
+                double t = 0.0;
+                for (int qb = B.sphL_ptr[baseD + sd]; qb < B.sphL_ptr[baseD + sd + 1]; ++qb) t += B.sphL_val[qb] * rowp[B.sphL_idx[qb]];
+                s += B.sphL_val[qa] * t;
+            }
+        } else
+            s = blk[sc * qc.ncd + sd];
+        const int k = cd.outoff_a + sc, l = cd.outoff_b + sd;
+        double *dst = T2 + (size_t)(row_first + b) * row_len;
+        dst[(size_t)k * qc.ld + l] = s;
+        if (cd.A != cd.B) dst[(size_t)l * qc.ld + k] = s;
+    }
 }
 
 // Cooperative Boys/R tables: entry e of the batch (column e of sR) belongs to primitive quartet (pab[e], pcd[e]) of the
@@ -223,45 +257,62 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_class_kernel(DBasis B, QCl
         phase1(0, npq);
         __syncthreads();
     }
-    for (int chunk0 = 0; chunk0 < ncomp; chunk0 += TF_ERI_THREADS) {
-        const int nchunk = min(TF_ERI_THREADS, ncomp - chunk0);
-        int ncp = 1;
-        while (ncp < nchunk) ncp <<= 1;
-        const int NG = TF_ERI_THREADS / ncp;                 // lane groups split the primitive quartets of a batch
-        const int g = tid / ncp, c0 = tid - g * ncp;
-        const bool active = c0 < nchunk;
-        CompQuartet Q;
-        Q.nonzero = false; Q.cscale = 0.0; Q.ca = Q.cb = Q.cc = Q.cd = 0;
-        if (active)
-            decode_component(qc, chunk0 + c0, sLmn, sLmn + 21, sLmn + 42, sLmn + 63, sScale, sScale + 21, sScale + 42, sScale + 63, Q);
-        double acc = 0.0;
-        if (one_batch) {
-            if (active && Q.nonzero) acc = phase2(Q, 0, npq, g, NG);
-        } else {
-            for (int b0 = 0; b0 < npq; b0 += PB) {
-                const int nb = min(PB, npq - b0);
-                __syncthreads();
-                phase1(b0, nb);
-                __syncthreads();
-                if (active && Q.nonzero) acc += phase2(Q, b0, nb, g, NG);
+    // groups of complete (cc,cd) sub-blocks (so that the fused ket transform sees whole blocks); 256-component chunks inside
+    double *sBlk = smem + qc.offBlk;
+    const int nsub = qc.ncc * qc.ncd, nab = qc.nca * qc.ncb;
+    const int GB = qc.fused ? max(1, min(nab, TF_BLK_DOUBLES / nsub)) : nab;
+    for (int blk0 = 0; blk0 < nab; blk0 += GB) {
+        const int nblk = min(GB, nab - blk0), ncg = nblk * nsub;
+        for (int chunk0 = 0; chunk0 < ncg; chunk0 += TF_ERI_THREADS) {
+            const int nchunk = min(TF_ERI_THREADS, ncg - chunk0);
+            int ncp = 1;
+            while (ncp < nchunk) ncp <<= 1;
+            const int NG = TF_ERI_THREADS / ncp;                 // lane groups split the primitive quartets of a batch
+            const int g = tid / ncp, c0 = tid - g * ncp;
+            const bool active = c0 < nchunk;
+            CompQuartet Q;
+            Q.nonzero = false; Q.cscale = 0.0; Q.ca = Q.cb = Q.cc = Q.cd = 0;
+            if (active)
+                decode_component(qc, blk0 * nsub + chunk0 + c0, sLmn, sLmn + 21, sLmn + 42, sLmn + 63, sScale, sScale + 21, sScale + 42,
+                                 sScale + 63, Q);
+            double acc = 0.0;
+            if (one_batch) {
+                if (active && Q.nonzero) acc = phase2(Q, 0, npq, g, NG);
+            } else {
+                for (int b0 = 0; b0 < npq; b0 += PB) {
+                    const int nb = min(PB, npq - b0);
+                    __syncthreads();
+                    phase1(b0, nb);
+                    __syncthreads();
+                    if (active && Q.nonzero) acc += phase2(Q, b0, nb, g, NG);
+                }
             }
-        }
-        if (NG > 1) {                                          // combine the groups in fixed order (reproducible)
-            __syncthreads();
-            sRed[tid] = acc;
-            __syncthreads();
+            if (NG > 1) {                                          // combine the groups in fixed order (reproducible)
+                __syncthreads();
+                sRed[tid] = acc;
+                __syncthreads();
+                if (g == 0 && active) {
+                    double s = 0.0;
+                    for (int gg = 0; gg < NG; ++gg) s += sRed[gg * ncp + c0];
+                    acc = s;
+                }
+            }
             if (g == 0 && active) {
-                double s = 0.0;
-                for (int gg = 0; gg < NG; ++gg) s += sRed[gg * ncp + c0];
-                acc = s;
+                const double val = acc * Q.cscale;
+                if (qc.fused)
+                    sBlk[chunk0 + c0] = val;
+                else {
+                    const size_t row = (size_t)(row0 + (long long)Q.ca * qc.ncb + Q.cb);
+                    const int k = cd.cartoff_a + Q.cc, l = cd.cartoff_b + Q.cd;
+                    Cslab[row * NcNc + (size_t)k * Nc + l] = val;
+                    if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+                }
             }
         }
-        if (g == 0 && active) {
-            const double val = acc * Q.cscale;
-            const size_t row = (size_t)(row0 + (long long)Q.ca * qc.ncb + Q.cb);
-            const int k = cd.cartoff_a + Q.cc, l = cd.cartoff_b + Q.cd;
-            Cslab[row * NcNc + (size_t)k * Nc + l] = val;
-            if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+        if (qc.fused) {
+            __syncthreads();
+            ket_epilogue(B, qc, sBlk, nblk, row0 + blk0, cd, Cslab, tid, TF_ERI_THREADS);
+            __syncthreads();
         }
     }
 }
@@ -332,11 +383,156 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_multi_kernel(DBasis B, QCl
             const double *Exy34 = sEcd + (size_t)s * 2 * nEcd;
             val = sPref[s] * hermite_sum(Q, sEab, sEab + nEab, Exy34, Exy34 + nEcd, sR + s, stride, L) * Q.cscale;
         }
-        const DPair cd = B.pairs[sKet[s]];
-        const size_t row = (size_t)(row0 + (long long)Q.ca * qc.ncb + Q.cb);
-        const int k = cd.cartoff_a + Q.cc, l = cd.cartoff_b + Q.cd;
-        Cslab[row * NcNc + (size_t)k * Nc + l] = val;
-        if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+        if (qc.fused)
+            (smem + qc.offBlk)[s * qc.ncomp + c0] = val;
+        else {
+            const DPair cd = B.pairs[sKet[s]];
+            const size_t row = (size_t)(row0 + (long long)Q.ca * qc.ncb + Q.cb);
+            const int k = cd.cartoff_a + Q.cc, l = cd.cartoff_b + Q.cd;
+            Cslab[row * NcNc + (size_t)k * Nc + l] = val;
+            if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+        }
+    }
+    if (qc.fused) {
+        __syncthreads();
+        // all (ca,cb) sub-blocks of every sub-quartet: lanes split by sub-quartet so that each sees its own ket pair
+        const int nab = qc.nca * qc.ncb, per = nab * qc.nsc * qc.nsd;
+        const int lanes = TF_ERI_THREADS / max(1, nsub);
+        const int sq = tid / max(1, lanes), lt = tid - sq * max(1, lanes);
+        if (lanes > 0 && sq < nsub) {
+            const DPair cd = B.pairs[sKet[sq]];
+            (void)per;
+            ket_epilogue(B, qc, smem + qc.offBlk + (size_t)sq * qc.ncomp, nab, row0, cd, Cslab, lt, lanes);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Factorised kernel for uncontracted shell quartets with many components (ff|ff has 10^4).  The reference's 6-deep sum
+// separates into per-axis factors that depend only on the four exponents of that axis:
+//     X[ax,bx,cx,dx][m]  = sum_{t+tau = 2m} Ex12[t] Ex34[tau] (-1)^tau (2m-1)!!          (x and y share it: same tables)
+//     Z[az,bz,cz,dz][n]  = sum_{v,phi} Ez12[v] Ez34[phi] (-1)^phi R[v+phi][n]
+//     (ab|cd) = pref * sum_{m,m'} X[x-tuple][m] X[y-tuple][m'] Z[z-tuple][m+m']
+// There are only (La+1)(Lb+1)(Lc+1)(Ld+1) tuples (256 for ffff), so the tables are built once per shell quartet in LDS and
+// every Cartesian component costs a handful of multiply-adds instead of ~150 (same terms, different association order:
+// results agree with the reference's order to rounding).
+__global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QClass qc, const int *__restrict__ bra_pairs,
+                                                                  const long long *__restrict__ bra_rowoff,
+                                                                  const int *__restrict__ ket_pairs, int Nc,
+                                                                  double *__restrict__ Cslab)
+{
+    extern __shared__ double smem[];
+    double *sR = smem + qc.offR, *sPref = smem + qc.offPref, *sPQ = smem + qc.offPQ;
+    double *sEab = smem + qc.offEab, *sEcd = smem + qc.offEcd, *sScale = smem + qc.offScale;
+    double *sX = smem + qc.offRed;                               // [nT][nM]
+    int *sLmn = reinterpret_cast<int *>(smem + qc.offLmn);
+    const int tid = threadIdx.x;
+    const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
+    const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
+    const int L = qc.L, nEab = qc.nEab, nEcd = qc.nEcd;
+    const int La1 = qc.La + 1, Lb1 = qc.Lb + 1, Lc1 = qc.Lc + 1, Ld1 = qc.Ld + 1;
+    const int nT = La1 * Lb1 * Lc1 * Ld1, nM = L / 2 + 1;
+    double *sZ = sX + nT * nM;                                   // [nT][nM]
+    const int Lab1 = qc.La + qc.Lb + 1, Lcd1 = qc.Lc + qc.Ld + 1;
+    const long long row0 = bra_rowoff[blockIdx.y];
+    const size_t NcNc = (size_t)Nc * Nc;
+
+    stage_components(B, ab.compoff_a, qc.nca, sLmn, sScale, tid, TF_ERI_THREADS);
+    stage_components(B, ab.compoff_b, qc.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
+    stage_components(B, cd.compoff_a, qc.ncc, sLmn + 42, sScale + 42, tid, TF_ERI_THREADS);
+    stage_components(B, cd.compoff_b, qc.ncd, sLmn + 63, sScale + 63, tid, TF_ERI_THREADS);
+    {
+        const double *__restrict__ gEab = B.epool + ab.e_off;
+        const double *__restrict__ gEcd = B.epool + cd.e_off;
+        for (int k = tid; k < 2 * nEab; k += TF_ERI_THREADS) sEab[k] = gEab[k];
+        for (int k = tid; k < 2 * nEcd; k += TF_ERI_THREADS) sEcd[k] = gEcd[k];
+    }
+    coop_tables(B, L, 1, 1, sR, sPref, sPQ, [&](int, int &ppab, int &ppcd) { ppab = ab.pp_off; ppcd = cd.pp_off; }, tid);
+    __syncthreads();
+    // ---- per-axis tables ----
+    for (int e = tid; e < nT * nM; e += TF_ERI_THREADS) {
+        const int T = e / nM, m = e - T * nM;
+        int r = T;
+        const int d = r % Ld1; r /= Ld1;
+        const int c = r % Lc1; r /= Lc1;
+        const int b = r % Lb1; const int a = r / Lb1;
+        const int l12 = a + b, l34 = c + d;
+        const double *E12 = sEab + (a * Lb1 + b) * Lab1, *E34 = sEcd + (c * Ld1 + d) * Lcd1;
+        // X: t + tau = 2m, with t = l12 (mod 2) and tau = l34 (mod 2) -- other parities have zero coefficients
+        double x = 0.0;
+        if (((l12 + l34) & 1) == 0 && 2 * m <= l12 + l34) {
+            for (int t = l12 & 1; t <= l12; t += 2) {
+                const int tau = 2 * m - t;
+                if (tau < 0 || tau > l34) continue;
+                const double term = E12[t] * E34[tau];
+                x += (tau & 1) ? -term : term;
+            }
+            x *= c_dfact[m];
+        }
+        sX[e] = x;
+        // Z: all v, phi; n = m
+        double z = 0.0;
+        if (m <= L - l12 - l34) {
+            const double *Ez12 = sEab + nEab + (a * Lb1 + b) * Lab1, *Ez34 = sEcd + nEcd + (c * Ld1 + d) * Lcd1;
+            for (int v = 0; v <= l12; ++v) {
+                double zphi = 0.0;
+                for (int phi = 0; phi <= l34; ++phi) {
+                    const double term = Ez34[phi] * sR[tri_index(v + phi, m, L)];
+                    zphi += (phi & 1) ? -term : term;
+                }
+                z += Ez12[v] * zphi;
+            }
+        }
+        sZ[e] = z;
+    }
+    __syncthreads();
+    // ---- components, in groups of complete (cc,cd) sub-blocks ----
+    const double pref = sPref[0];
+    const int *lmnA = sLmn, *lmnB = sLmn + 21, *lmnC = sLmn + 42, *lmnD = sLmn + 63;
+    double *sBlk = smem + qc.offBlk;
+    const int nsubc = qc.ncc * qc.ncd, nab = qc.nca * qc.ncb;
+    const int GB = qc.fused ? max(1, min(nab, TF_BLK_DOUBLES / nsubc)) : nab;
+    for (int blk0 = 0; blk0 < nab; blk0 += GB) {
+        const int nblk = min(GB, nab - blk0), ncg = nblk * nsubc;
+        for (int cl = tid; cl < ncg; cl += TF_ERI_THREADS) {
+            int c = blk0 * nsubc + cl;
+            const int id = c % qc.ncd; c /= qc.ncd;
+            const int ic = c % qc.ncc; c /= qc.ncc;
+            const int ib = c % qc.ncb; const int ia = c / qc.ncb;
+            const int a = lmnA[ia], b = lmnB[ib], cc = lmnC[ic], d = lmnD[id];
+            const int ax = a & 255, ay = (a >> 8) & 255, az = (a >> 16) & 255;
+            const int bx = b & 255, by = (b >> 8) & 255, bz = (b >> 16) & 255;
+            const int cx = cc & 255, cy = (cc >> 8) & 255, cz = (cc >> 16) & 255;
+            const int dx = d & 255, dy = (d >> 8) & 255, dz = (d >> 16) & 255;
+            const int lxs = ax + bx + cx + dx, lys = ay + by + cy + dy;
+            double val = 0.0;
+            if (!((lxs & 1) || (lys & 1))) {                          // x/y parity, pyx:1324-1327
+                const double *X = sX + (((ax * Lb1 + bx) * Lc1 + cx) * Ld1 + dx) * nM;
+                const double *Y = sX + (((ay * Lb1 + by) * Lc1 + cy) * Ld1 + dy) * nM;
+                const double *Z = sZ + (((az * Lb1 + bz) * Lc1 + cz) * Ld1 + dz) * nM;
+                double sum = 0.0;
+                for (int m = 0; m <= lxs / 2; ++m) {
+                    const double xm = X[m];
+                    double t = 0.0;
+                    for (int mp = 0; mp <= lys / 2; ++mp) t += Y[mp] * Z[m + mp];
+                    sum += xm * t;
+                }
+                val = pref * sum * (sScale[ia] * sScale[21 + ib] * sScale[42 + ic] * sScale[63 + id]);
+            }
+            if (qc.fused)
+                sBlk[cl] = val;
+            else {
+                const size_t row = (size_t)(row0 + (long long)ia * qc.ncb + ib);
+                const int k = cd.cartoff_a + ic, l = cd.cartoff_b + id;
+                Cslab[row * NcNc + (size_t)k * Nc + l] = val;
+                if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+            }
+        }
+        if (qc.fused) {
+            __syncthreads();
+            ket_epilogue(B, qc, sBlk, nblk, row0 + blk0, cd, Cslab, tid, TF_ERI_THREADS);
+            __syncthreads();
+        }
     }
 }
 

@@ -11,6 +11,7 @@ struct DPair {
     int A, B, La, Lb, npp, pp_off, nE, cls;
     long long e_off;
     int nca, ncb, compoff_a, compoff_b, cartoff_a, cartoff_b;
+    int outoff_a, outoff_b;      // first OUTPUT AO (spherical, or Cartesian for CARTHARM) of the two shells; set by tf_build_eri
 };
 
 struct DBasis {
@@ -21,6 +22,9 @@ struct DBasis {
     const double *pp_p, *pp_Pz, *pp_K;
     const double *epool;
     const double *boys;      // [NGRID][NORD]
+    // per-L Cartesian->spherical rows (CSR over the components of one shell): row base sphL_base[L], then ptr/idx/val
+    const int *sphL_base, *sphL_ptr, *sphL_idx;
+    const double *sphL_val;
 };
 
 #define TF_ERI_THREADS 256

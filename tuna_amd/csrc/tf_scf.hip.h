@@ -299,6 +299,8 @@ inline int diagonalise(Workspace &w, int n, const double *F, const double *X, do
     return TF_OK;
 }
 
+inline double *base_ifail(Workspace &w, int n) { return w.pool + 5 * (size_t)n * n; }
+
 // Instrumentation: seconds per symmetric eigensolve of a random n x n matrix, variant 0 = dsyevd, 1 = dsyev, 2 = dsyevj.
 inline int eigh_probe(Workspace &w, int n, int variant, int reps, double *seconds, std::string &msg)
 {
@@ -322,6 +324,17 @@ inline int eigh_probe(Workspace &w, int n, int variant, int reps, double *second
         auto t0 = std::chrono::steady_clock::now();
         if (variant == 0) TFS_BLAS(rocsolver_dsyevd(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, e, w.d_info));
         else if (variant == 3) { int rc3 = eigh(w, n, A, vals, e, msg); if (rc3) return rc3; }
+        else if (variant == 4 || variant == 5) {
+            // partial spectrum: lowest 18 eigenpairs (the occupied orbitals of an Ar2-like SCF)
+            rocblas_int *nev = w.d_info + 0;
+            const int k = n < 18 ? n : 18;
+            if (variant == 4)
+                TFS_BLAS(rocsolver_dsyevdx(w.blas, rocblas_evect_original, rocblas_erange_index, rocblas_fill_upper, n, A, n, 0.0, 0.0, 1, k, nev,
+                                           vals, V, n, (rocblas_int *)(w.d_scal + 40)));
+            else
+                TFS_BLAS(rocsolver_dsyevx(w.blas, rocblas_evect_original, rocblas_erange_index, rocblas_fill_upper, n, A, n, 0.0, 0.0, 1, k, 0.0, nev,
+                                          vals, V, n, (rocblas_int *)(base_ifail(w, n)), (rocblas_int *)(w.d_scal + 40)));
+        }
         else if (variant == 1) TFS_BLAS(rocsolver_dsyev(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, e, w.d_info));
         else {
             double *resid = w.d_scal + 32;
