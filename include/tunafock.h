@@ -158,6 +158,18 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
 /* X = S^-1/2, S^-1 and the smallest overlap eigenvalue (kernel:756-816), host buffers [N,N]. */
 int tf_orthogonaliser(tf_ctx *ctx, int n, const double *S, double *X, double *S_inv, double *smallest_eig);
 
+/* ---- consumers of the resident tensor: AO->MO transformation and RMP2 ------------- */
+
+/* out[p,q,r,s] = sum_{mu nu la si} C1[mu,p] C2[nu,q] C3[la,r] C4[si,s] (mu nu|la si)  -- chemists' (pq|rs), host out
+ * [n1,n2,n3,n4]; C_k are [N, n_k] row-major host matrices (columns = orbitals).  With all four = the full MO matrix
+ * this is transform_ERI_AO_to_MO (tuna_ci.py:204-255); every quarter step is an f64 GEMM (rocBLAS / MFMA). */
+int tf_ao_to_mo(tf_ctx *ctx, int n1, const double *C1, int n2, const double *C2, int n3, const double *C3, int n4, const double *C4,
+                double *out);
+/* Restricted MP2 correlation energy components from canonical orbitals C [N,N], eps [N] (tuna_mp.py:834-906, energy part):
+ * *e_os = sum g^2/D, *e_ss = sum g (g - g^T_ab)/D over (ia|jb) with i,j in [n_frozen, n_occ), a,b >= n_occ;
+ * E_MP2 = e_os + e_ss.  seconds (may be NULL): wall time of transform + energy. */
+int tf_mp2_rhf(tf_ctx *ctx, int n_occ, int n_frozen, const double *C, const double *eps, double *e_os, double *e_ss, double *seconds);
+
 /* eps[N], C[N,N] = eigenpairs of the Fock matrix in the orthogonalised basis, C = X C' (diagonalise_Fock_matrix,
  * scf:222-250): rocBLAS dgemm + rocSOLVER dsyevd; host buffers. */
 int tf_diagonalise(tf_ctx *ctx, int n, const double *F, const double *X, double *eps, double *C);

@@ -104,3 +104,16 @@ def uhf_golden(golden):
         tag, name = key.split("__", 1)
         out.setdefault(tag, {})[name] = z[key]
     return out
+
+
+@pytest.fixture(scope="session")
+def mp2_golden(golden):
+    z = golden("mp2_systems")
+    out = {}
+    for key in z.files:
+        tag, name = key.split("__", 1)
+        out.setdefault(tag, {})[name] = z[key]
+    return out
+
+
+MP2_SYSTEMS = {"n2_sto3g": "n2_sto3g", "n2_ccpvdz": "n2_ccpvdz", "c5_n2_ccpvtz": "c2_n2_ccpvtz", "co_631g": None}

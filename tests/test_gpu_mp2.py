@@ -1,0 +1,58 @@
+"""GPU: AO->MO transformation (rocBLAS f64 GEMMs on the resident tensor) and RMP2 energy -- BASELINE config 5 -- against the
+reference's own transform_ERI_AO_to_MO / run_restricted_MP2 expressions (tests/golden/mp2_systems.npz)."""
+import numpy as np
+import pytest
+
+from conftest import R_CO, make_system
+from oracle import oracle as orc
+from oracle import scf_oracle as so
+from tuna_amd import molecule as mol
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(tag):
+    if tag == "co_631g":
+        atoms = mol.make_atoms(["C", "O"], R_CO)
+        shells = mol.build_shells(atoms, "6-31G")
+        return atoms, shells, mol.expand_cartesian_aos(shells), 7
+    return make_system({"n2_sto3g": "n2_sto3g", "n2_ccpvdz": "n2_ccpvdz", "c5_n2_ccpvtz": "c2_n2_ccpvtz"}[tag])
+
+
+@pytest.mark.parametrize("tag", ["n2_sto3g", "n2_ccpvdz", "c5_n2_ccpvtz", "co_631g"])
+def test_rmp2_energy_and_mo_integrals(engine, mp2_golden, tag):
+    g = mp2_golden[tag]
+    atoms, shells, aos, nocc = _system(tag)
+    engine.set_basis(aos).build_eri(True)
+    r = engine.mp2_rhf(g["C"], g["eps"], nocc)
+    assert abs(r["E_OS"] - float(g["E_OS"])) < 1e-10 and abs(r["E_SS"] - float(g["E_SS"])) < 1e-10
+    assert abs(r["E_MP2"] - (float(g["E_OS"]) + float(g["E_SS"]))) < 1e-10
+    # the full (pq|rs) transformation, sampled against the reference tensor
+    if engine.N <= 60:
+        MO = engine.ao_to_mo(g["C"])
+        idx = g["mo_idx"]
+        assert np.abs(MO[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] - g["mo_val"]).max() < 1e-11
+        for perm in [(1, 0, 2, 3), (2, 3, 0, 1)]:
+            assert np.abs(MO - MO.transpose(perm)).max() < 1e-11
+
+
+def test_mixed_orbital_blocks_against_oracle(engine):
+    """(i a | p q)-type transformation with four different coefficient blocks vs a NumPy einsum of the oracle tensor."""
+    atoms, shells, aos, nocc = make_system("n2_sto3g")
+    engine.set_basis(aos).build_eri(True)
+    Es = so.eri_to_spherical(engine.sph_matrix(), orc.eri(aos))
+    rng = np.random.default_rng(1)
+    N = engine.N
+    C1, C2, C3, C4 = rng.standard_normal((N, 3)), rng.standard_normal((N, 5)), rng.standard_normal((N, 2)), rng.standard_normal((N, N))
+    ref = np.einsum("mnls,mp,nq,lr,st->pqrt", Es, C1, C2, C3, C4, optimize=True)
+    assert np.abs(engine.ao_to_mo(C1, C2, C3, C4) - ref).max() < 1e-11
+
+
+def test_scf_then_mp2_end_to_end(engine, mp2_golden):
+    """Own orbitals (native RHF on the GPU) -> RMP2: total energy of BASELINE config 5, N2 MP2/cc-pVTZ."""
+    from tuna_amd.energy import run
+    g = mp2_golden["c5_n2_ccpvtz"]
+    out = run("SPE : N N 1.0977 : HF CC-PVTZ : EXTREME NODAMP", engine=engine)
+    r = engine.mp2_rhf(out.molecular_orbitals, out.epsilons, 7)
+    assert abs(out.energy - float(g["E_SCF"])) < 1e-9
+    assert abs(r["E_MP2"] - (float(g["E_OS"]) + float(g["E_SS"]))) < 1e-8

@@ -221,6 +221,48 @@ def run_reference_uhf(scf, ortho, atoms, shells, S, T, V, ERI, n_alpha, n_beta, 
                 components=np.array([out.kinetic_energy, out.nuclear_electron_energy, out.coulomb_energy, out.exchange_energy]))
 
 
+def load_reference_ao_to_mo():
+    """transform_ERI_AO_to_MO (tuna_ci.py:204-255) and build_doubles_epsilons_tensor (tuna_ci.py:304-334) from source text."""
+    src = open(os.path.join(REF, "TUNA", "tuna_ci.py")).read()
+    tree = ast.parse(src)
+    stubs = _stub_modules()["tuna_util"]
+    ns = {"np": np, "ndarray": np.ndarray, "Calculation": object, "log": stubs.log, "timer": stubs.timer, "error": stubs.error}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("transform_ERI_AO_to_MO", "build_doubles_epsilons_tensor"):
+            exec(compile(ast.Module([node], []), "tuna_ci.py", "exec"), ns)
+    return ns["transform_ERI_AO_to_MO"], ns["build_doubles_epsilons_tensor"]
+
+
+def make_mp2_golden(scf, blocks, ortho):
+    """Config 5: RMP2 on converged RHF orbitals -- the reference's own AO->MO transformation and the energy expressions of
+    run_restricted_MP2 (tuna_mp.py:874-890: physicists' transpose, [o,o,v,v] slice, E_OS and E_SS einsums)."""
+    ao_to_mo, doubles_eps = load_reference_ao_to_mo()
+    out = {}
+    for tag, (sym, R, basis, nocc) in {
+        "n2_sto3g": (["N", "N"], mol.angstrom_to_bohr(1.0977), "STO-3G", 7),
+        "n2_ccpvdz": (["N", "N"], mol.angstrom_to_bohr(1.0977), "cc-pVDZ", 7),
+        "c5_n2_ccpvtz": (["N", "N"], mol.angstrom_to_bohr(1.0977), "cc-pVTZ", 7),
+        "co_631g": (["C", "O"], mol.angstrom_to_bohr(1.128), "6-31G", 7),
+    }.items():
+        atoms, shells, aos = system(sym, R, basis)
+        S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
+        U = reference_U(shells, blocks)
+        Ss, Ts_, Vs, Es = to_spherical(U, S), to_spherical(U, T), to_spherical(U, V), eri_to_spherical(U, E)
+        r = run_reference_scf(scf, ortho, atoms, shells, Ss, Ts_, Vs, Es, nocc, "extreme", tag.startswith("co"))   # CO needs damping
+        C, eps = r["C"], r["epsilons"]
+        ERI_MO = ao_to_mo(Es, C, None, True)
+        o, v = slice(0, nocc), slice(nocc, len(eps))
+        e_ijab = doubles_eps(eps, eps, o, o, v, v)
+        g = ERI_MO.transpose(0, 2, 1, 3)[o, o, v, v]
+        E_OS = np.einsum("ijab,ijab,ijab->", g, g, e_ijab, optimize=True)
+        E_SS = np.einsum("ijab,ijab,ijab->", g, g - g.swapaxes(2, 3), e_ijab, optimize=True)
+        idx = sample_indices(len(eps), 5000, 9)
+        out[tag] = dict(C=C, eps=eps, E_SCF=r["energy"], E_OS=E_OS, E_SS=E_SS, n_occ=nocc, mo_idx=idx,
+                        mo_val=ERI_MO[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]])
+        print("MP2", tag, len(eps), "E_SCF", r["energy"], "E_MP2", E_OS + E_SS, "OS", E_OS, "SS", E_SS)
+    np.savez_compressed(os.path.join(GOLD, "mp2_systems.npz"), **{f"{t}__{k}": v for t, d in out.items() for k, v in d.items()})
+
+
 def make_uhf_golden(scf, blocks, ortho):
     """Open-shell systems for the unrestricted path: O2 triplet, NO doublet, OH doublet (hetero), Li atom."""
     out = {}
@@ -268,7 +310,7 @@ def run_reference_scf(scf, ortho, atoms, shells, S, T, V, ERI, n_occ, conv="extr
                                                   (P0, P0 / 2, P0 / 2, E0), (None, None, None, None), True)
     finally:
         scf.format_output_line = orig
-    return dict(table=np.array(table), energy=out.energy, epsilons=out.epsilons, P=out.P, X=X, P0=P0, E0=E0,
+    return dict(table=np.array(table), energy=out.energy, epsilons=out.epsilons, C=out.molecular_orbitals, P=out.P, X=X, P0=P0, E0=E0,
                 V_NN=V_NN, components=np.array([out.kinetic_energy, out.nuclear_electron_energy, out.coulomb_energy,
                                                 out.exchange_energy]), smallest_S=smallest)
 
@@ -282,6 +324,9 @@ def main():
     blocks, ortho = load_reference_kernel_bits()
     if "--uhf-only" in sys.argv:
         make_uhf_golden(scf, blocks, ortho)
+        return
+    if "--mp2-only" in sys.argv:
+        make_mp2_golden(scf, blocks, ortho)
         return
     np.savez(os.path.join(GOLD, "sph_blocks.npz"), **{f"L{L}": b for L, b in blocks.items()})
 
@@ -383,6 +428,7 @@ def main():
                         eri_sph_fro=np.sqrt(np.sum(Es * Es)))
     print("high_l", aos.n, U.shape[0])
     make_uhf_golden(scf, blocks, ortho)
+    make_mp2_golden(scf, blocks, ortho)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@
 #include "tf_eri.hip.h"
 #include "tf_oneel.hip.h"
 #include "tf_scf.hip.h"
+#include "tf_mp2.hip.h"
 
 using namespace tfk;
 
@@ -931,6 +932,82 @@ int tf_diagonalise(tf_ctx *ctx, int n, const double *F, const double *X, double 
     int rc = tfscf::diagonalise(ctx->scf, n, F, X, eps, C, msg);
     if (rc) ctx->err = msg;
     return rc;
+}
+
+// ---- AO->MO transformation and RMP2 (next row of the hot path: consumers of the resident tensor) ----------------------
+
+static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const double *C2, int n2, const double *C3, int n3, const double *C4,
+                               int n4, double **d_out, double *seconds)
+{
+    const int N = ctx->N;
+    std::string msg;
+    int rc = tfscf::ensure(ctx->scf, N, 6, msg);
+    if (rc) { ctx->err = msg; return rc; }
+    double *dC[4] = {nullptr, nullptr, nullptr, nullptr};
+    const double *hC[4] = {C1, C2, C3, C4};
+    const int nk[4] = {n1, n2, n3, n4};
+    for (int k = 0; k < 4; ++k) {
+        HIPCHK(ctx, hipMalloc((void **)&dC[k], (size_t)N * nk[k] * sizeof(double)));
+        HIPCHK(ctx, hipMemcpy(dC[k], hC[k], (size_t)N * nk[k] * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPCHK(ctx, hipMalloc((void **)d_out, (size_t)n1 * n2 * n3 * n4 * sizeof(double)));
+    rc = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, ctx->n_rows, N, ctx->ld, dC[0], n1, dC[1], n2, dC[2], n3, dC[3], n4,
+                          *d_out, seconds, msg);
+    for (int k = 0; k < 4; ++k) (void)hipFree(dC[k]);
+    if (rc) { ctx->err = msg; (void)hipFree(*d_out); *d_out = nullptr; }
+    return rc;
+}
+
+int tf_ao_to_mo(tf_ctx *ctx, int n1, const double *C1, int n2, const double *C2, int n3, const double *C3, int n4, const double *C4,
+                double *out)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_ao_to_mo: call tf_build_eri first");
+    if (ctx->world != 1) TF_FAIL(ctx, TF_EINVAL, "tf_ao_to_mo: the tensor must be on one GPU (world = 1) in this build");
+    if (n1 < 1 || n2 < 1 || n3 < 1 || n4 < 1 || !C1 || !C2 || !C3 || !C4 || !out) TF_FAIL(ctx, TF_EINVAL, "tf_ao_to_mo: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *d_out = nullptr;
+    int rc = mo_transform_device(ctx, C1, n1, C2, n2, C3, n3, C4, n4, &d_out, nullptr);
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(out, d_out, (size_t)n1 * n2 * n3 * n4 * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    HIPCHK(ctx, e);
+    return TF_OK;
+}
+
+int tf_mp2_rhf(tf_ctx *ctx, int n_occ, int n_frozen, const double *C, const double *eps, double *e_os, double *e_ss, double *seconds)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_mp2_rhf: call tf_build_eri first");
+    if (ctx->world != 1) TF_FAIL(ctx, TF_EINVAL, "tf_mp2_rhf: the tensor must be on one GPU (world = 1) in this build");
+    const int N = ctx->N;
+    if (!C || !eps || !e_os || !e_ss || n_frozen < 0 || n_occ <= n_frozen || n_occ >= N) TF_FAIL(ctx, TF_EINVAL, "tf_mp2_rhf: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int o = n_occ - n_frozen, v = N - n_occ;
+    std::vector<double> Co((size_t)N * o), Cv((size_t)N * v);
+    for (int m = 0; m < N; ++m) {
+        for (int i = 0; i < o; ++i) Co[(size_t)m * o + i] = C[(size_t)m * N + n_frozen + i];
+        for (int a = 0; a < v; ++a) Cv[(size_t)m * v + a] = C[(size_t)m * N + n_occ + a];
+    }
+    double *d_g = nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = mo_transform_device(ctx, Co.data(), o, Cv.data(), v, Co.data(), o, Cv.data(), v, &d_g, nullptr);   // (ia|jb)
+    if (rc) return rc;
+    double *d_eps = nullptr, *d_part = nullptr;
+    const int nblk = 1024;
+    HIPCHK(ctx, hipMalloc((void **)&d_eps, (size_t)N * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&d_part, (size_t)2 * nblk * sizeof(double)));
+    HIPCHK(ctx, hipMemcpy(d_eps, eps, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(tfmp2::mp2_energy_kernel, dim3(nblk), dim3(256), 0, 0, d_g, d_eps, n_frozen, o, v, n_occ, d_part);
+    std::vector<double> part(2 * nblk);
+    hipError_t e = hipMemcpy(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_g); (void)hipFree(d_eps); (void)hipFree(d_part);
+    HIPCHK(ctx, e);
+    double os = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) { os += part[2 * b]; ss += part[2 * b + 1]; }
+    *e_os = os; *e_ss = ss;
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return TF_OK;
 }
 
 int tf_eigh_probe(tf_ctx *ctx, int n, int variant, int reps, double *seconds)

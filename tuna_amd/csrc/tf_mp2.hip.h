@@ -1,0 +1,134 @@
+// tf_mp2.hip.h -- AO->MO integral transformation on the HBM-resident tensor and the RMP2 energy (SURVEY.md section 8f, rank 1;
+// BASELINE config 5).  This is the one place of the path that is GEMM-shaped: every quarter transformation is a (batched) f64
+// GEMM through rocBLAS (MFMA f64 on gfx950).
+// Reference: transform_ERI_AO_to_MO tuna_ci.py:204-255 (four einsums over the dense N^4 tensor),
+//            build_doubles_epsilons_tensor tuna_ci.py:304-334, run_restricted_MP2 tuna_mp.py:834-906 (energy part).
+// Layout trick: the stored tensor keeps rows (mu >= nu) x full [lambda][sigma], so the ket half-transformation
+//     Q[mu nu][r s] = sum_{lambda sigma} C3[lambda r] (mu nu|lambda sigma) C4[sigma s]
+// is two strided-batched GEMMs with one stored row per batch entry (each stored byte is read once), and the bra half is
+// two more GEMMs on the unpacked Q.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/tunafock.h"
+
+namespace tfmp2 {
+
+#define TFM_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (call);                                                                         \
+        if (_e != hipSuccess) { msg = std::string(#call) + " failed: " + hipGetErrorString(_e); rc = (_e == hipErrorOutOfMemory ? TF_ENOMEM : TF_ENODEVICE); goto done; } \
+    } while (0)
+#define TFM_BLAS(call)                                                                                  \
+    do {                                                                                                \
+        rocblas_status _s = (call);                                                                     \
+        if (_s != rocblas_status_success) { msg = std::string(#call) + " failed (rocBLAS status " + std::to_string((int)_s) + ")"; rc = TF_ELINALG; goto done; } \
+    } while (0)
+
+// Qfull[mu][nu][x] = Q[row(max,min)][x]
+__global__ void unpack_rows_kernel(const double *__restrict__ Q, const int *__restrict__ rowmap, int N, long long width,
+                                   double *__restrict__ Qfull)
+{
+    const long long total = (long long)N * N * width;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long mn = e / width;
+        const long long x = e - mn * width;
+        const int mu = (int)(mn / N), nu = (int)(mn - (long long)mu * N);
+        const int hi = max(mu, nu), lo = min(mu, nu);
+        const int r = rowmap[hi * (hi + 1) / 2 + lo];
+        Qfull[e] = (r >= 0) ? Q[(long long)r * width + x] : 0.0;
+    }
+}
+
+// RMP2 energy from g[i][a][j][b] = (ia|jb):  E_OS = sum g^2 / D,  E_SS = sum g (g - g[i][b][j][a]) / D   (tuna_mp.py:882-890)
+__global__ void mp2_energy_kernel(const double *__restrict__ g, const double *__restrict__ eps, int n_frozen, int o, int v, int n_occ_total,
+                                  double *__restrict__ partial /* [gridDim.x][2] */)
+{
+    __shared__ double s_os[256], s_ss[256];
+    const long long total = (long long)o * v * o * v;
+    double os = 0.0, ss = 0.0;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        long long r = e;
+        const int b = (int)(r % v); r /= v;
+        const int j = (int)(r % o); r /= o;
+        const int a = (int)(r % v);
+        const int i = (int)(r / v);
+        const double gij = g[e];
+        const double gx = g[(((long long)i * v + b) * o + j) * v + a];
+        const double D = eps[n_frozen + i] + eps[n_frozen + j] - eps[n_occ_total + a] - eps[n_occ_total + b];
+        os += gij * gij / D;
+        ss += gij * (gij - gx) / D;
+    }
+    s_os[threadIdx.x] = os; s_ss[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { s_os[threadIdx.x] += s_os[threadIdx.x + s]; s_ss[threadIdx.x] += s_ss[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s_os[0]; partial[2 * blockIdx.x + 1] = s_ss[0]; }
+}
+
+// out[p][q][r][s] = sum C1[mu p] C2[nu q] C3[la r] C4[si s] (mu nu|la si); C_k are [N, n_k] row-major DEVICE matrices;
+// d_out [n1,n2,n3,n4] on the device.  Rows of the stored tensor are processed in slabs to bound the scratch.
+inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowmap, long long n_rows, int N, int ld, const double *dC1,
+                     int n1, const double *dC2, int n2, const double *dC3, int n3, const double *dC4, int n4, double *d_out,
+                     double *gemm_seconds, std::string &msg)
+{
+    int rc = TF_OK;
+    const long long n34 = (long long)n3 * n4;
+    const long long row_len = (long long)N * ld;
+    double *dR = nullptr, *dQ = nullptr, *dQfull = nullptr, *dW = nullptr;
+    const double one = 1.0, zero = 0.0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    // slab of rows for the first quarter transformation: R = C3^T M needs n3*N doubles per row
+    long long slab = std::max<long long>(1, std::min<long long>(n_rows, (long long)((2048LL << 20) / ((long long)n3 * N * sizeof(double)))));
+    if (n34 * N > 0x7fffffffLL || n34 > 0x7fffffffLL) { msg = "AO->MO transformation: dimension overflow"; return TF_EINVAL; }
+    TFM_HIP(hipEventCreate(&e0));
+    TFM_HIP(hipEventCreate(&e1));
+    TFM_HIP(hipMalloc((void **)&dR, (size_t)slab * n3 * N * sizeof(double)));
+    TFM_HIP(hipMalloc((void **)&dQ, (size_t)std::max<long long>(1, n_rows) * n34 * sizeof(double)));
+    TFM_HIP(hipEventRecord(e0, 0));
+    for (long long r0 = 0; r0 < n_rows; r0 += slab) {
+        const int nb = (int)std::min<long long>(slab, n_rows - r0);
+        // R[row] (n3 x N, row-major) = C3^T (n3 x N) * M[row] (N x N, ld)
+        TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, N, n3, N, &one,
+                                               d_eri + r0 * row_len, ld, row_len, dC3, n3, 0, &zero, dR, N, (rocblas_stride)n3 * N, nb));
+        // Q[row] (n3 x n4) = R[row] (n3 x N) * C4 (N x n4)
+        TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, n4, n3, N, &one, dC4, n4, 0, dR, N,
+                                               (rocblas_stride)n3 * N, &zero, dQ + r0 * n34, n4, (rocblas_stride)n34, nb));
+    }
+    (void)hipFree(dR); dR = nullptr;
+    TFM_HIP(hipMalloc((void **)&dQfull, (size_t)N * N * n34 * sizeof(double)));
+    {
+        const long long tot = (long long)N * N * n34;
+        hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 1 << 20)), dim3(256), 0, 0, dQ, d_rowmap, N,
+                           n34, dQfull);
+    }
+    TFM_HIP(hipDeviceSynchronize());
+    (void)hipFree(dQ); dQ = nullptr;
+    TFM_HIP(hipMalloc((void **)&dW, (size_t)n1 * N * n34 * sizeof(double)));
+    // W (n1 x N*n34) = C1^T (n1 x N) * Qfull (N x N*n34)
+    TFM_BLAS(rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)(N * n34), n1, N, &one, dQfull,
+                           (rocblas_int)(N * n34), dC1, n1, &zero, dW, (rocblas_int)(N * n34)));
+    // out[p] (n2 x n34) = C2^T (n2 x N) * W[p] (N x n34)
+    TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)n34, n2, N, &one, dW,
+                                           (rocblas_int)n34, (rocblas_stride)N * n34, dC2, n2, 0, &zero, d_out, (rocblas_int)n34,
+                                           (rocblas_stride)n2 * n34, n1));
+    TFM_HIP(hipEventRecord(e1, 0));
+    TFM_HIP(hipEventSynchronize(e1));
+    if (gemm_seconds) { float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1); *gemm_seconds = ms * 1e-3; }
+done:
+    if (dR) (void)hipFree(dR);
+    if (dQ) (void)hipFree(dQ);
+    if (dQfull) (void)hipFree(dQfull);
+    if (dW) (void)hipFree(dW);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // namespace tfmp2

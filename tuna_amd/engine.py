@@ -165,6 +165,25 @@ class Engine:
         self._check(self._L.tf_orthogonaliser(self._ctx, n, ptr(S), ptr(X), ptr(Si), C.byref(sm)))
         return X, sm.value, Si
 
+    # ---- post-SCF consumers of the resident tensor ------------------------------------------------
+    def ao_to_mo(self, C1, C2=None, C3=None, C4=None) -> np.ndarray:
+        """(pq|rs) = sum C1[mu,p] C2[nu,q] C3[la,r] C4[si,s] (mu nu|la si); all four default to C1 (tuna_ci.py:204-255)."""
+        Cs = [f64(C1)] + [f64(c) if c is not None else None for c in (C2, C3, C4)]
+        Cs = [c if c is not None else Cs[0] for c in Cs]
+        n = [c.shape[1] for c in Cs]
+        out = np.empty(tuple(n))
+        self._check(self._L.tf_ao_to_mo(self._ctx, n[0], ptr(Cs[0]), n[1], ptr(Cs[1]), n[2], ptr(Cs[2]), n[3], ptr(Cs[3]), ptr(out)))
+        return out
+
+    def mp2_rhf(self, C, eps, n_occ, n_frozen=0) -> dict:
+        """RMP2 correlation energy (tuna_mp.py:834-906): {"E_MP2", "E_OS", "E_SS", "seconds"}."""
+        Cm, eps = f64(C), f64(eps)
+        import ctypes
+        os_, ss, t = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(self._L.tf_mp2_rhf(self._ctx, int(n_occ), int(n_frozen), ptr(Cm), ptr(eps), ctypes.byref(os_), ctypes.byref(ss),
+                                       ctypes.byref(t)))
+        return {"E_MP2": os_.value + ss.value, "E_OS": os_.value, "E_SS": ss.value, "seconds": t.value}
+
     def diagonalise(self, F, X):
         """(epsilons, molecular_orbitals) = eigh(sym(X^T F X)), C = X C' on the device (scf:222-250)."""
         F, X = f64(F), f64(X)
