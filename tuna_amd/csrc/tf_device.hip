@@ -752,6 +752,13 @@ static int launch_jk(tf_ctx *ctx, int nd, const double *const *dP, double *const
         // rows per workgroup: share each P tile among JB rows, but keep >= ~2 workgroups per CU in flight
         int JB = (ctx->n_rows >= 4 * 2048) ? 4 : (ctx->n_rows >= 2 * 2048 ? 2 : 1);
         if (nd == 2 && JB == 4) JB = 2;                         // register budget
+        int nlc = (npair <= TF_JK_THREADS) ? 1 : (npair <= 2 * TF_JK_THREADS ? 2 : 4);
+        // test hooks (tests/test_gpu_sharded.py): exercise the variants that only N > 512 would select
+        if (const char *e = getenv("TF_JK_FORCE_NLC")) nlc = std::max(nlc, atoi(e));
+        if (const char *e = getenv("TF_JK_FORCE_JB")) { const int f = atoi(e); if (f == 1 || f == 2 || (f == 4 && nd == 1)) JB = f; }
+        // instantiated combinations: (NLC 4, one density) up to JB 2; (NLC 4, two densities) JB 1 -- the grid below must match
+        if (nlc == 4 && nd == 1 && JB == 4) JB = 2;
+        if (nlc == 4 && nd == 2) JB = 1;
         const size_t smem = (size_t)(2 * nd * JB * N + 4 * TF_JK_THREADS) * sizeof(double);
         const dim3 grid((unsigned)((ctx->n_rows + JB - 1) / JB)), block(TF_JK_THREADS);
         hipEvent_t ev_after = nullptr;
@@ -769,24 +776,22 @@ static int launch_jk(tf_ctx *ctx, int nd, const double *const *dP, double *const
 #define TF_JK_LAUNCH(NLC, JBV, NDV)                                                                                         \
         hipLaunchKernelGGL((jk_rows_kernel<NLC, JBV, NDV>), grid, block, smem, st, ctx->d_eri, ctx->d_row_ij, ctx->n_rows, N, ld, \
                            Ppad[0], Ppad[1], ctx->d_Jrow, ctx->d_Kp)
+        if (npair > 4 * TF_JK_THREADS) TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the J/K kernel's row length limit (2048)", N);
         if (nd == 1) {
-            if (npair <= TF_JK_THREADS) {
+            if (nlc == 1) {
                 if (JB == 4) TF_JK_LAUNCH(1, 4, 1); else if (JB == 2) TF_JK_LAUNCH(1, 2, 1); else TF_JK_LAUNCH(1, 1, 1);
-            } else if (npair <= 2 * TF_JK_THREADS) {
+            } else if (nlc == 2) {
                 if (JB == 4) TF_JK_LAUNCH(2, 4, 1); else if (JB == 2) TF_JK_LAUNCH(2, 2, 1); else TF_JK_LAUNCH(2, 1, 1);
-            } else if (npair <= 4 * TF_JK_THREADS) {
+            } else {
                 if (JB >= 2) TF_JK_LAUNCH(4, 2, 1); else TF_JK_LAUNCH(4, 1, 1);
-            } else
-                TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the J/K kernel's row length limit (2048)", N);
+            }
         } else {
-            if (npair <= TF_JK_THREADS) {
+            if (nlc == 1) {
                 if (JB == 2) TF_JK_LAUNCH(1, 2, 2); else TF_JK_LAUNCH(1, 1, 2);
-            } else if (npair <= 2 * TF_JK_THREADS) {
+            } else if (nlc == 2) {
                 if (JB == 2) TF_JK_LAUNCH(2, 2, 2); else TF_JK_LAUNCH(2, 1, 2);
-            } else if (npair <= 4 * TF_JK_THREADS) {
-                TF_JK_LAUNCH(4, 1, 2);
             } else
-                TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the J/K kernel's row length limit (2048)", N);
+                TF_JK_LAUNCH(4, 1, 2);
         }
 #undef TF_JK_LAUNCH
         if (ev_after) (void)hipEventRecord(ev_after, st);
