@@ -40,10 +40,10 @@ def test_integral_module_mirror(golden):
 
 
 @pytest.mark.parametrize("line,tag,key", [
-    ("SPE : H H 0.74 : HF STO-3G : EXTREME", "h2_sto3g", "scf_energy"),
-    ("SPE : N N 1.0977 : HF CC-PVTZ : EXTREME", "c2_n2_ccpvtz", "scf_energy"),
-    ("SPE : C O 1.128 : HF DEF2-TZVP : EXTREME NODAMP", "c4_co_def2tzvp", "scf_energy_nodamp"),
-    ("SPE : HE : HF 6-31G : TIGHT", "he_631g", "scf_energy"),
+    ("SPE : H H 0.74 : HF STO-3G : EXTREME COREGUESS", "h2_sto3g", "scf_energy"),
+    ("SPE : N N 1.0977 : HF CC-PVTZ : EXTREME COREGUESS", "c2_n2_ccpvtz", "scf_energy"),
+    ("SPE : C O 1.128 : HF DEF2-TZVP : EXTREME NODAMP COREGUESS", "c4_co_def2tzvp", "scf_energy_nodamp"),
+    ("SPE : HE : HF 6-31G : TIGHT COREGUESS", "he_631g", "scf_energy"),
 ])
 def test_input_line_single_points(golden, small, line, tag, key):
     from tuna_amd.energy import run
@@ -64,7 +64,7 @@ def test_scf_function_names_and_python_level_cycle(engine, golden):
     from tuna_amd.engine import SCF_CONVERGENCE
     from tuna_amd import molecule as mol
     g = golden("n2_ccpvdz")
-    calc = Calculation(basis="cc-pVDZ", SCF_conv=SCF_CONVERGENCE["extreme"])
+    calc = Calculation(basis="cc-pVDZ", SCF_conv=SCF_CONVERGENCE["extreme"], core_guess=True)
     molecule, integrals, X, guess, _ = build_molecule_and_integrals(["N", "N"], mol.angstrom_to_bohr(1.0977), calc, engine)
     P0 = guess[0]
     J = scf.calculate_coulomb_matrix(P0, integrals.ERI_AO)
@@ -87,3 +87,29 @@ def test_scf_function_names_and_python_level_cycle(engine, golden):
     assert abs(native.energy - float(g["scf_energy"])) < 1e-9
     assert abs(py["energy"] - native.energy) < 1e-9 and py["n_iter"] == native.n_iterations
     np.testing.assert_allclose(py["table"][:, 6], native.table[:, 6], atol=1e-6)
+
+
+@pytest.mark.parametrize("line,tag", [
+    ("SPE : H H 0.74 : HF STO-3G", "c1_h2_sto3g"),                 # BASELINE configs[0]
+    ("SPE : N N 1.0977 : HF CC-PVDZ", "n2_ccpvdz"),
+    ("SPE : N N 1.0977 : HF CC-PVTZ", "c2_n2_ccpvtz"),             # BASELINE configs[1]
+    ("SPE : C O 1.128 : HF DEF2-TZVP", "c4_co_def2tzvp"),
+    ("SPE : NE : HF 6-31G", "ne_631g"),
+])
+@pytest.mark.parametrize("conv", ["medium", "extreme"])
+def test_default_keywords_reproduce_reference_run(golden, line, tag, conv):
+    """What `python3 TUNA/tuna.py <line>` does by default: SAD guess (tuna_guess.py:247-299), DIIS 6 + dynamic damping, medium
+    thresholds -- guess energy, every printed iteration and the final energy against the reference's own run."""
+    from tuna_amd.energy import run
+    z = golden("sad_default_runs")
+    g = {k.split("__", 1)[1]: z[k] for k in z.files if k.startswith(tag + "__")}
+    out = run(line + ("" if conv == "medium" else " : EXTREME"))
+    ref = g[f"table_{conv}"]
+    assert abs(out.energy - float(g[f"energy_{conv}"])) < 1e-9
+    assert abs(out.n_iterations - len(ref)) <= (1 if conv == "extreme" else 0)
+    n = min(out.n_iterations, len(ref))
+    if tag == "ne_631g":
+        n = 6   # spherical atom in a 9-function basis: the Pulay matrix becomes singular to rounding once the error vectors are
+                # ~1e-6 (they span very few independent directions) and the extrapolated iterate is noise-driven in the reference too
+    np.testing.assert_allclose(out.table[:n, 1], ref[:n, 1], atol=1e-8)       # E_total per iteration
+    np.testing.assert_allclose(out.table[:n, 6], ref[:n, 6], atol=1e-6)       # damping factors

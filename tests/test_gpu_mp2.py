@@ -52,7 +52,7 @@ def test_scf_then_mp2_end_to_end(engine, mp2_golden):
     """Own orbitals (native RHF on the GPU) -> RMP2: total energy of BASELINE config 5, N2 MP2/cc-pVTZ."""
     from tuna_amd.energy import run
     g = mp2_golden["c5_n2_ccpvtz"]
-    out = run("SPE : N N 1.0977 : HF CC-PVTZ : EXTREME NODAMP", engine=engine)
+    out = run("SPE : N N 1.0977 : HF CC-PVTZ : EXTREME", engine=engine)
     r = engine.mp2_rhf(out.molecular_orbitals, out.epsilons, 7)
     assert abs(out.energy - float(g["E_SCF"])) < 1e-9
     assert abs(r["E_MP2"] - (float(g["E_OS"]) + float(g["E_SS"]))) < 1e-8

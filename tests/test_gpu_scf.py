@@ -106,7 +106,7 @@ def test_unrestricted_cycle_matches_reference(engine, uhf_golden, tag, damping):
     from tuna_amd import scf
     g = uhf_golden[tag]
     sym, R, basis, na, nb = UHF_SYSTEMS[tag]
-    calc = Calculation(basis=basis, SCF_conv=SCF_CONVERGENCE["extreme"], multiplicity=na - nb + 1, damping=damping)
+    calc = Calculation(basis=basis, SCF_conv=SCF_CONVERGENCE["extreme"], multiplicity=na - nb + 1, damping=damping, core_guess=True)
     molecule, integrals, X, guess, _ = build_molecule_and_integrals(sym, R, calc, engine)
     assert calc.reference == "UHF" and (molecule.n_alpha, molecule.n_beta) == (na, nb)
     assert abs(guess[3] - float(g["E0"])) < 1e-9
@@ -127,5 +127,5 @@ def test_unrestricted_cycle_matches_reference(engine, uhf_golden, tag, damping):
 
 def test_uhf_input_line(uhf_golden):
     from tuna_amd.energy import run
-    out = run("SPE : O O 1.2075 : UHF CC-PVDZ : EXTREME NODAMP ML 3")
+    out = run("SPE : O O 1.2075 : UHF CC-PVDZ : EXTREME NODAMP ML 3 COREGUESS")
     assert abs(out.energy - float(uhf_golden["o2_triplet_ccpvdz"]["scf_energy_nodamp"])) < 1e-8

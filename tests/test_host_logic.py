@@ -111,3 +111,27 @@ def test_shard_plan_is_balanced_and_complete():
         assert owner.min() == 0 and owner.max() == world - 1
         loads = np.array([w[owner == r].sum() for r in range(world)])
         assert loads.sum() == w.sum() and (loads.max() - loads.min()) <= w.max()
+
+
+def test_sad_guess_host_algebra(golden):
+    """Projection + trace cleaning of the SAD guess (tuna_guess.py:209-236, tuna_dft.py:35-41) with oracle integrals against the
+    density the reference's own functions produced (tests/golden/sad_default_runs.npz)."""
+    from oracle import oracle as orc
+    from oracle import scf_oracle as so
+    from tuna_amd import guess
+    z = golden("sad_default_runs")
+    atoms, shells, aos, nocc = make_system("n2_ccpvdz")
+    U = spherical.transformation_matrix([s.L for s in shells])
+    xyz = [a.origin for a in atoms]; chg = [float(a.charge) for a in atoms]
+    S, T, V, _, _ = orc.one_electron(aos, xyz, chg, [0, 0, 1.0])
+    S, T, V = (so.to_spherical(U, M) for M in (S, T, V))
+    _, _, S_inv = so.orthogonaliser(S)
+
+    class FakeEngine:
+        def cross_overlap(self, other):
+            return orc.cross_overlap(aos, other)
+    P, Pa, Pb, E0 = guess.superposition_guess(FakeEngine(), atoms, S, S_inv, U, nocc, nocc, T + V)
+    assert np.abs(P - z["n2_ccpvdz__P_guess"]).max() < 1e-10
+    assert abs(E0 - float(z["n2_ccpvdz__E_guess"])) < 1e-8
+    assert abs(np.trace(Pa @ S) - nocc) < 1e-12
+    assert abs(guess.centre_of_mass(mol.make_atoms(["C", "O"], 2.0)) - 2.0 * 15.994915 / (12.0 + 15.994915)) < 1e-12

@@ -38,5 +38,37 @@ def main():
     print("wrote", os.path.normpath(OUT), {k: len(v) for k, v in out.items()})
 
 
+def export_atomic_data():
+    """Atomic masses and the spherically averaged HF/STO-3G atomic density matrices of the SAD guess
+    (tuna_util.py:1676-1924, pure data) -> tuna_amd/data/atomic_data.json.  The dict literal contains np.array(...) calls,
+    so it is evaluated with a namespace that only knows `np.array`."""
+    import numpy as np
+    lines = open(os.path.join(REF, "TUNA", "tuna_util.py")).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("atomic_properties = {"))
+    depth, end = 0, start
+    for i in range(start, len(lines)):
+        depth += lines[i].count("{") - lines[i].count("}")
+        if depth == 0:
+            end = i
+            break
+    node = ast.parse("\n".join(lines[start:end + 1])).body[0]
+    table = eval(compile(ast.Expression(node.value), "atomic_properties", "eval"), {"np": types_np(np)})
+    out = {}
+    for sym, d in table.items():
+        if sym == "X":
+            continue
+        out[sym] = {"charge": d["charge"], "mass": d["mass"], "density": None if d["density"] is None else np.asarray(d["density"], dtype=float).tolist()}
+    path = os.path.join(os.path.dirname(OUT), "atomic_data.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote", os.path.normpath(path), len(out), "elements")
+
+
+def types_np(np):
+    import types
+    return types.SimpleNamespace(array=np.array)
+
+
 if __name__ == "__main__":
     main()
+    export_atomic_data()

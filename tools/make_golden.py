@@ -263,6 +263,64 @@ def make_mp2_golden(scf, blocks, ortho):
     np.savez_compressed(os.path.join(GOLD, "mp2_systems.npz"), **{f"{t}__{k}": v for t, d in out.items() for k, v in d.items()})
 
 
+def make_sad_golden(scf, blocks, ortho):
+    """The reference's DEFAULT single-point path: superposition-of-atomic-densities guess (tuna_guess.py functions executed from
+    source text, atomic densities from the literal table of tuna_util.py) followed by the reference SCF with default keywords
+    (DIIS 6 + dynamic damping) at the default "medium" thresholds and at "extreme"."""
+    import json
+    src = open(os.path.join(REF, "TUNA", "tuna_guess.py")).read()
+    tree = ast.parse(src)
+    from scipy.linalg import block_diag
+    ns = {"np": np, "ndarray": np.ndarray, "block_diag": block_diag, "Atom": object}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("project_density_matrix", "form_minimal_basis_superposition_density"):
+            exec(compile(ast.Module([node], []), "tuna_guess.py", "exec"), ns)
+    dens = {k: (None if v["density"] is None else np.array(v["density"])) for k, v in
+            json.load(open(os.path.join(ROOT, "tuna_amd", "data", "atomic_data.json"))).items()}
+    ints_ref = orc.ref_engine()
+    out = {}
+    for tag, (sym, R, basis, nocc) in {
+        "c1_h2_sto3g": (["H", "H"], mol.angstrom_to_bohr(0.74), "STO-3G", 1),
+        "n2_ccpvdz": (["N", "N"], mol.angstrom_to_bohr(1.0977), "cc-pVDZ", 7),
+        "c2_n2_ccpvtz": (["N", "N"], mol.angstrom_to_bohr(1.0977), "cc-pVTZ", 7),
+        "c4_co_def2tzvp": (["C", "O"], mol.angstrom_to_bohr(1.128), "def2-TZVP", 7),
+        "ne_631g": (["NE"], None, "6-31G", 5),
+    }.items():
+        atoms, shells, aos = system(sym, R, basis)
+        S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
+        U = reference_U(shells, blocks)
+        Ss, Ts_, Vs, Es = to_spherical(U, S), to_spherical(U, T), to_spherical(U, V), eri_to_spherical(U, E)
+        X, smallest, S_inv = ortho(Ss, None, True)
+        ref_atoms = [types.SimpleNamespace(density=dens[a.symbol]) for a in atoms]
+        P_min = ns["form_minimal_basis_superposition_density"](ref_atoms)
+        _, _, aos_min = system(sym, R, "STO-3G")
+        S_cross = np.asarray(ints_ref.calculate_cross_basis_overlap_matrix(aos.n, aos_min.n, orc.ref_basis_list(aos), orc.ref_basis_list(aos_min), 4))
+        P_spin = ns["project_density_matrix"](P_min, S_cross, S_inv, U)
+        Pa = P_spin * (nocc / np.trace(P_spin @ Ss))                      # clean_density_matrix, tuna_dft.py:35-41
+        P0 = Pa + Pa
+        E0 = float(np.einsum("mn,mn->", Ts_ + Vs, P0, optimize=True))
+        n_sph = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
+        d = dict(P_guess=P0, E_guess=E0)
+        for conv in ("medium", "extreme"):
+            molecule = types.SimpleNamespace(n_doubly_occ=nocc, partition_ranges=n_sph, atoms=atoms, n_electrons=2 * nocc, n_alpha=nocc, n_beta=nocc)
+            table = []
+            orig = scf.format_output_line
+
+            def rec(E_total, delta_E, max_DP, RMS_DP, damping_factor, step, commutator, calculation, silent=False):
+                table.append([step, E_total, delta_E, RMS_DP, max_DP, commutator, float(damping_factor)])
+            scf.format_output_line = rec
+            try:
+                o = scf.run_self_consistent_field_cycle(molecule, Calc(CONV[conv], damping=True), Ints(Ss, Ts_, Vs, Es), mol.nuclear_repulsion(atoms), X,
+                                                        (P0, Pa, Pa, E0), (None, None, None, None), True)
+            finally:
+                scf.format_output_line = orig
+            d[f"table_{conv}"] = np.array(table)
+            d[f"energy_{conv}"] = o.energy
+        out[tag] = d
+        print("SAD", tag, aos.n, "E_guess", E0, "E", d["energy_medium"], d["energy_extreme"], "iters", len(d["table_medium"]), len(d["table_extreme"]))
+    np.savez_compressed(os.path.join(GOLD, "sad_default_runs.npz"), **{f"{t}__{k}": v for t, d in out.items() for k, v in d.items()})
+
+
 def make_uhf_golden(scf, blocks, ortho):
     """Open-shell systems for the unrestricted path: O2 triplet, NO doublet, OH doublet (hetero), Li atom."""
     out = {}
@@ -324,6 +382,9 @@ def main():
     blocks, ortho = load_reference_kernel_bits()
     if "--uhf-only" in sys.argv:
         make_uhf_golden(scf, blocks, ortho)
+        return
+    if "--sad-only" in sys.argv:
+        make_sad_golden(scf, blocks, ortho)
         return
     if "--mp2-only" in sys.argv:
         make_mp2_golden(scf, blocks, ortho)
@@ -429,6 +490,7 @@ def main():
     print("high_l", aos.n, U.shape[0])
     make_uhf_golden(scf, blocks, ortho)
     make_mp2_golden(scf, blocks, ortho)
+    make_sad_golden(scf, blocks, ortho)
 
 
 if __name__ == "__main__":

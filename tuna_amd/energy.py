@@ -6,9 +6,8 @@
 Input line format `TYPE : A B R : METHOD BASIS : KEYWORDS` (tuna.py:87-99).  Supported here: TYPE = SPE, METHOD = HF
 (restricted) or UHF / any multiplicity via ML (unrestricted), the basis sets shipped in tuna_amd/data, and the SCF keywords of SURVEY.md section 5
 (LOOSE/MEDIUM/TIGHT/EXTREME, MAXITER n, DIIS [n]/NODIIS, DAMP x/NODAMP/MAXDAMP x, SLOWCONV/VERYSLOWCONV, HFX x,
-CARTHARM, DECONTRACT, COREGUESS, CH n).  Everything numerical runs on the GPU through the C ABI.  The initial guess is the
-core-Hamiltonian guess (the reference's COREGUESS; its default SAD tables are data not shipped here) -- converged energies do
-not depend on it.
+CARTHARM, DECONTRACT, COREGUESS/SADGUESS, CH n, ML n).  Everything numerical runs on the GPU through the C ABI.  The initial
+guess is the reference's default for single points, the superposition of atomic densities (tuna_amd/guess.py).
 """
 from __future__ import annotations
 
@@ -41,7 +40,7 @@ class Calculation:
     HFX_prop: float = 1.0               # calc:207
     cartesian_harmonics: bool = False   # CARTHARM, calc:91
     decontract: bool = False            # DECONTRACT, calc:90
-    core_guess: bool = True
+    core_guess: bool = False            # COREGUESS, calc:95; default is the superposition of atomic densities
     DFT_calculation: bool = False
     multiplicity: int = 1               # ML, calc:151
 
@@ -123,7 +122,9 @@ def interpret_keywords(params, calc: Calculation) -> Calculation:
             calc.charge = int(value())
         elif p in ("ML", "MULTIPLICITY"):
             calc.multiplicity = int(value())
-        elif p in ("COREGUESS", "T", "P", "DEBUG"):
+        elif p == "COREGUESS":
+            calc.core_guess = True
+        elif p in ("SADGUESS", "T", "P", "DEBUG"):
             pass
         else:
             raise TunaError(f"Keyword \"{p}\" is not supported on the GPU hot path (SCF keywords only)")
@@ -149,7 +150,8 @@ def build_molecule_and_integrals(symbols, R_bohr, calc: Calculation, engine: Eng
     t0 = time.perf_counter()
     engine.set_basis(aos)
     xyz, chg = [a.origin for a in atoms], [float(a.charge) for a in atoms]
-    com = [0.0, 0.0, 0.5 * atoms[-1].origin[2] if len(atoms) == 2 else 0.0]
+    from . import guess as guess_mod
+    com = [0.0, 0.0, guess_mod.centre_of_mass(atoms) if len(atoms) == 2 else 0.0]     # dipole origin, kernel:312
     S, T, V, D, Q = engine.one_electron(xyz, chg, com, spherical=spherical)
     timings["One-electron integrals"] = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -166,14 +168,18 @@ def build_molecule_and_integrals(symbols, R_bohr, calc: Calculation, engine: Eng
     if smallest < 1e-7:                                   # STHRESH, kernel:887
         raise TunaError("An overlap matrix eigenvalue is too small! Change the basis set or decrease the threshold with STHRESH.")
     t0 = time.perf_counter()
-    _, C0 = engine.diagonalise(integrals.H_core, X)
-    if calc.reference == "UHF":
-        Pa0, Pb0 = construct_density_matrix(C0, n_alpha, 1), construct_density_matrix(C0, n_beta, 1)
-        P0 = Pa0 + Pb0
+    use_core = calc.core_guess or calc.cartesian_harmonics or any(a.charge == 0 for a in atoms)
+    if use_core:
+        _, C0 = engine.diagonalise(integrals.H_core, X)
+        if calc.reference == "UHF":
+            Pa0, Pb0 = construct_density_matrix(C0, n_alpha, 1), construct_density_matrix(C0, n_beta, 1)
+            P0 = Pa0 + Pb0
+        else:
+            P0 = construct_density_matrix(C0, molecule.n_doubly_occ, 2)
+            Pa0 = Pb0 = P0 / 2
+        E0 = float(np.einsum("mn,mn->", integrals.H_core, P0))     # guess energy, tuna_guess.py:429
     else:
-        P0 = construct_density_matrix(C0, molecule.n_doubly_occ, 2)
-        Pa0 = Pb0 = P0 / 2
-    E0 = float(np.einsum("mn,mn->", integrals.H_core, P0))     # guess energy, tuna_guess.py:429
+        P0, Pa0, Pb0, E0 = guess_mod.superposition_guess(engine, atoms, S, S_inv, engine.sph_matrix(), n_alpha, n_beta, integrals.H_core)
     timings["Initial guess"] = time.perf_counter() - t0
     return molecule, integrals, X, (P0, Pa0, Pb0, E0), timings
 
