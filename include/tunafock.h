@@ -158,6 +158,22 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
 /* X = S^-1/2, S^-1 and the smallest overlap eigenvalue (kernel:756-816), host buffers [N,N]. */
 int tf_orthogonaliser(tf_ctx *ctx, int n, const double *S, double *X, double *S_inv, double *smallest_eig);
 
+/* ---- Kohn-Sham exchange-correlation (BASELINE config 4) ------------------------- */
+
+/* Hands the molecular integration grid (built by the caller exactly as set_up_integration_grid / build_molecular_grid,
+ * tuna_dft.py:94-394, do: xyz [3][n_points], weights [n_points]) to the context, which evaluates every AO and its gradient
+ * on it once (construct_basis_functions_on_grid, tuna_dft.py:516-666) and keeps them in HBM.  x_functional: 0 none,
+ * 1 Slater, 2 B88, 3 B3 (0.9 B88 + 0.1 Slater); c_functional: 0 none, 1 VWN5, 2 VWN3, 3 LYP, 4 3P (0.81 LYP + 0.19 VWN5),
+ * 5 3P with VWN3 ("B3LYP/G"); dfx / dfc = DFX_prop / DFC_prop; x_alpha = X_alpha (2/3).  While a grid is set,
+ * tf_scf_rhf runs the restricted Kohn-Sham cycle (opts.hfx = HFX_prop).  Needs tf_build_eri first. */
+int tf_dft_setup(tf_ctx *ctx, int64_t n_points, const double *xyz, const double *weights, int x_functional, int c_functional, double dfx,
+                 double dfc, double x_alpha);
+/* V_XC [N,N] = V_X*DFX + V_C*DFC for the closed-shell density P [N,N] (calculate_restricted_exchange_correlation_matrix,
+ * tuna_scf.py:600-654), the grid integral of the density and the scaled exchange / correlation energies. */
+int tf_dft_vxc(tf_ctx *ctx, const double *P, double *Vxc, double *n_elec, double *e_x, double *e_c);
+/* Back to Hartree-Fock. */
+int tf_dft_clear(tf_ctx *ctx);
+
 /* ---- consumers of the resident tensor: AO->MO transformation and RMP2 ------------- */
 
 /* out[p,q,r,s] = sum_{mu nu la si} C1[mu,p] C2[nu,q] C3[la,r] C4[si,s] (mu nu|la si)  -- chemists' (pq|rs), host out

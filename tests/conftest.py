@@ -117,3 +117,22 @@ def mp2_golden(golden):
 
 
 MP2_SYSTEMS = {"n2_sto3g": "n2_sto3g", "n2_ccpvdz": "n2_ccpvdz", "c5_n2_ccpvtz": "c2_n2_ccpvtz", "co_631g": None}
+
+
+DFT_SYSTEMS = {
+    "h2_lda_sto3g": (["H", "H"], R_H2, "STO-3G", 1, "LDA", "loose"),
+    "n2_blyp_631g": (["N", "N"], R_N2, "6-31G", 7, "BLYP", "loose"),
+    "co_b3lyp_631g": (["C", "O"], R_CO, "6-31G", 7, "B3LYP", "medium"),
+    "co_b3lypg_ccpvdz": (["C", "O"], R_CO, "cc-pVDZ", 7, "B3LYP/G", "loose"),
+    "c4_co_b3lyp_def2tzvp": (["C", "O"], R_CO, "def2-TZVP", 7, "B3LYP", "medium"),
+}
+
+
+@pytest.fixture(scope="session")
+def dft_golden(golden):
+    z = golden("dft_systems")
+    out = {}
+    for key in z.files:
+        tag, name = key.split("__", 1)
+        out.setdefault(tag, {})[name] = z[key]
+    return out

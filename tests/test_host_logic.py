@@ -135,3 +135,21 @@ def test_sad_guess_host_algebra(golden):
     assert abs(E0 - float(z["n2_ccpvdz__E_guess"])) < 1e-8
     assert abs(np.trace(Pa @ S) - nocc) < 1e-12
     assert abs(guess.centre_of_mass(mol.make_atoms(["C", "O"], 2.0)) - 2.0 * 15.994915 / (12.0 + 15.994915)) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["h2_lda_sto3g", "co_b3lyp_631g", "c4_co_b3lyp_def2tzvp"])
+def test_integration_grid_matches_reference(dft_golden, tag):
+    """Gauss-Legendre x Lebedev atomic grids with Becke diatomic weights (tuna_dft.py:94-394) against the reference's grid."""
+    from conftest import DFT_SYSTEMS
+    from tuna_amd import dft
+    g = dft_golden[tag]
+    sym, R, basis, nocc, method, grid = DFT_SYSTEMS[tag]
+    atoms = mol.make_atoms(sym, R)
+    pts, wts, info = dft.integration_grid(atoms, grid)
+    assert info["n_points"] == int(g["n_points"]) and info["n_radial"] == int(g["n_radial"]) and info["lebedev_order"] == int(g["lebedev"])
+    assert abs(wts.sum() - float(g["weights_sum"])) < 1e-9 * abs(float(g["weights_sum"]))
+    pick = g["pick"]
+    np.testing.assert_allclose(pts.reshape(3, -1)[:, pick], g["pts_pick"], atol=1e-13)
+    np.testing.assert_allclose(wts.reshape(-1)[pick], g["w_pick"], rtol=1e-12, atol=1e-300)
+    if tag.startswith("c4"):
+        assert info["n_points"] == 88536          # SURVEY.md section 3.5

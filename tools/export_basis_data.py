@@ -57,7 +57,7 @@ def export_atomic_data():
     for sym, d in table.items():
         if sym == "X":
             continue
-        out[sym] = {"charge": d["charge"], "mass": d["mass"], "density": None if d["density"] is None else np.asarray(d["density"], dtype=float).tolist()}
+        out[sym] = {"charge": d["charge"], "mass": d["mass"], "real_vdw_radius": d["real_vdw_radius"], "density": None if d["density"] is None else np.asarray(d["density"], dtype=float).tolist()}
     path = os.path.join(os.path.dirname(OUT), "atomic_data.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

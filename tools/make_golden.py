@@ -321,6 +321,122 @@ def make_sad_golden(scf, blocks, ortho):
     np.savez_compressed(os.path.join(GOLD, "sad_default_runs.npz"), **{f"{t}__{k}": v for t, d in out.items() for k, v in d.items()})
 
 
+def load_reference_dft():
+    """tuna_xc.py (parses as is) and tuna_dft.py (one PEP-701 log line patched to `pass`), executed from source text against
+    stand-in modules that carry only logging no-ops, `symmetrise`, `check` and the three numerical floors of
+    tuna_util.constants (density_floor 1e-23, sigma_floor 1e-46, exponent_ceiling 600: tuna_util.py:95-99)."""
+    stubs = _stub_modules()
+    tu = stubs["tuna_util"]
+    tu.constants = types.SimpleNamespace(density_floor=1e-23, exponent_ceiling=600, sigma_floor=1e-23 ** 2)
+
+    def check(assertion, message):
+        if not assertion:
+            raise RuntimeError(message)
+    tu.check = check
+    saved = {k: sys.modules.get(k) for k in list(stubs) + ["tuna_xc"]}
+    sys.modules.update(stubs)
+    try:
+        xc = types.ModuleType("tuna_xc")
+        exec(compile(open(os.path.join(REF, "TUNA", "tuna_xc.py")).read(), "tuna_xc.py", "exec"), xc.__dict__)
+        sys.modules["tuna_xc"] = xc
+        lines, patched = _parseable_lines(os.path.join(REF, "TUNA", "tuna_dft.py"))
+        dft = types.ModuleType("tuna_dft")
+        exec(compile("\n".join(lines), "tuna_dft.py", "exec"), dft.__dict__)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return xc, dft, patched
+
+
+def make_dft_golden(scf, blocks, ortho):
+    """BASELINE config 4 (CO B3LYP/def2-TZVP, "medium" grid) and smaller Kohn-Sham cases with the reference's own grid, basis-on-grid,
+    density, functional and V_XC code, and its SCF loop with DFT switched on."""
+    import json
+    xc, dft, patched = load_reference_dft()
+    print("tuna_dft.py lines patched:", patched)
+    scf.dft, scf.xc = dft, xc                                       # tuna_scf.py does `import tuna_dft as dft`, `import tuna_xc as xc`
+    adata = json.load(open(os.path.join(ROOT, "tuna_amd", "data", "atomic_data.json")))
+    GRID = {"loose": (3, 0.7), "medium": (4, 0.9), "tight": (5, 1.0)}            # tuna_util.py:129-137
+    FUN = {"B3LYP": ("B3", "3P", 0.80, 0.20, 1.0, "GGA"), "BLYP": ("B", "LYP", 1.0, 0.0, 1.0, "GGA"), "LDA": ("S", "VWN5", 1.0, 0.0, 1.0, "LDA"),
+           "B3LYP/G": ("B3", "3P", 0.80, 0.20, 1.0, "GGA")}
+    out = {}
+    for tag, (sym, R, basis, nocc, method, grid) in {
+        "h2_lda_sto3g": (["H", "H"], mol.angstrom_to_bohr(0.74), "STO-3G", 1, "LDA", "loose"),
+        "n2_blyp_631g": (["N", "N"], mol.angstrom_to_bohr(1.0977), "6-31G", 7, "BLYP", "loose"),
+        "co_b3lyp_631g": (["C", "O"], mol.angstrom_to_bohr(1.128), "6-31G", 7, "B3LYP", "medium"),
+        "co_b3lypg_ccpvdz": (["C", "O"], mol.angstrom_to_bohr(1.128), "cc-pVDZ", 7, "B3LYP/G", "loose"),
+        "c4_co_b3lyp_def2tzvp": (["C", "O"], mol.angstrom_to_bohr(1.128), "def2-TZVP", 7, "B3LYP", "medium"),
+    }.items():
+        atoms, shells, aos = system(sym, R, basis)
+        S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
+        U = reference_U(shells, blocks)
+        Ss, Ts_, Vs, Es = to_spherical(U, S), to_spherical(U, T), to_spherical(U, V), eri_to_spherical(U, E)
+        X, smallest, S_inv = ortho(Ss, None, True)
+        xname, cname, DFX, HFX, DFC, fclass = FUN[method]
+        acc, mult = GRID[grid]
+        ref_atoms = [types.SimpleNamespace(real_vdw_radius=adata[a.symbol]["real_vdw_radius"], ghost=False, origin=a.origin, charge=a.charge)
+                     for a in atoms]
+        extent = mult * max(a.real_vdw_radius for a in ref_atoms) / 6
+        n = int(acc * 9)
+        LEB = np.array([3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 35, 41, 47, 53, 59, 65, 71, 77, 83, 89, 95, 101, 107, 113, 119, 125, 131])
+        leb = int(LEB[np.abs(LEB - n).argmin()])
+        n_radial = int(extent * acc)
+        points, weights = dft.build_molecular_grid(extent, n_radial, leb, float(R), ref_atoms)
+        bfs = orc.ref_basis_list(aos)
+        bfs_on_grid = dft.construct_basis_functions_on_grid(bfs, points, U)
+        grads = dft.construct_basis_function_gradients_on_grid(bfs, points, U) if fclass == "GGA" else None
+        # core guess
+        eps0, C0 = scf.diagonalise_Fock_matrix(Ts_ + Vs, X)
+        P0 = scf.construct_density_matrix(C0, nocc, 2)
+        E0 = float(np.einsum("mn,mn->", Ts_ + Vs, P0))
+        calc = Calc(CONV["extreme"], damping=True)
+        calc.DFT_calculation = True
+        calc.HFX_prop, calc.DFX_prop, calc.DFC_prop = HFX, DFX, DFC
+        calc.X_alpha = 2 / 3
+        calc.method = types.SimpleNamespace(name=method)
+        calc.functional = types.SimpleNamespace(functional_class=fclass, x_functional=xname, c_functional=cname)
+        saved_tab = scf.exchange_correlation_functionals
+        scf.exchange_correlation_functionals = {method: calc.functional}
+        x_fun = xc.exchange_functionals.get(xname)
+        c_fun = xc.correlation_functionals.get(cname)
+        # one XC evaluation for the guess density (kernel-level golden)
+        V_XC, density, e_X, e_C = scf.calculate_restricted_exchange_correlation_matrix(P0, bfs_on_grid, grads, weights, calc, x_fun, c_fun)
+        n_el = float(np.sum(density * weights))
+        EX = float(np.sum(e_X * density * weights)) * DFX
+        EC = float(np.sum(e_C * density * weights)) * DFC if e_C is not None else 0.0
+        n_sph = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
+        molecule = types.SimpleNamespace(n_doubly_occ=nocc, partition_ranges=n_sph, atoms=atoms, n_electrons=2 * nocc, n_alpha=nocc, n_beta=nocc)
+        table = []
+        orig = scf.format_output_line
+
+        def rec(E_total, delta_E, max_DP, RMS_DP, damping_factor, step, commutator, calculation, silent=False):
+            table.append([step, E_total, delta_E, RMS_DP, max_DP, commutator, float(damping_factor)])
+        scf.format_output_line = rec
+        try:
+            o = scf.run_self_consistent_field_cycle(molecule, calc, Ints(Ss, Ts_, Vs, Es), mol.nuclear_repulsion(atoms), X, (P0, P0 / 2, P0 / 2, E0),
+                                                    (bfs_on_grid, weights, grads, points), True)
+        finally:
+            scf.format_output_line = orig
+            scf.exchange_correlation_functionals = saved_tab
+        G = weights.size
+        rng = np.random.default_rng(5)
+        pick = rng.integers(0, G, 400)
+        flat_pts = points.reshape(3, -1)
+        d = dict(n_points=G, n_radial=n_radial, lebedev=leb, extent=extent, weights_sum=float(weights.sum()), pick=pick,
+                 pts_pick=flat_pts[:, pick], w_pick=weights.reshape(-1)[pick], bfs_pick=bfs_on_grid.reshape(bfs_on_grid.shape[0], -1)[:, pick],
+                 dens_pick=density.reshape(-1)[pick], P0=P0, V_XC0=V_XC, n_el0=n_el, EX0=EX, EC0=EC, table=np.array(table), energy=o.energy,
+                 components=np.array([o.kinetic_energy, o.nuclear_electron_energy, o.coulomb_energy, o.exchange_energy, o.correlation_energy]),
+                 eps=o.epsilons)
+        if grads is not None:
+            d["grad_pick"] = grads.reshape(3, grads.shape[1], -1)[:, :, pick]
+        out[tag] = d
+        print("DFT", tag, method, basis, "grid", n_radial, "x", weights.shape[1], "=", G, "pts  n_el", n_el, "E", o.energy, "iters", len(table))
+    np.savez_compressed(os.path.join(GOLD, "dft_systems.npz"), **{f"{t}__{k}": v for t, d in out.items() for k, v in d.items()})
+
+
 def make_uhf_golden(scf, blocks, ortho):
     """Open-shell systems for the unrestricted path: O2 triplet, NO doublet, OH doublet (hetero), Li atom."""
     out = {}
@@ -382,6 +498,9 @@ def main():
     blocks, ortho = load_reference_kernel_bits()
     if "--uhf-only" in sys.argv:
         make_uhf_golden(scf, blocks, ortho)
+        return
+    if "--dft-only" in sys.argv:
+        make_dft_golden(scf, blocks, ortho)
         return
     if "--sad-only" in sys.argv:
         make_sad_golden(scf, blocks, ortho)
@@ -491,6 +610,7 @@ def main():
     make_uhf_golden(scf, blocks, ortho)
     make_mp2_golden(scf, blocks, ortho)
     make_sad_golden(scf, blocks, ortho)
+    make_dft_golden(scf, blocks, ortho)
 
 
 if __name__ == "__main__":

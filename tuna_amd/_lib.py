@@ -37,7 +37,8 @@ EXPORTS = ["tf_create", "tf_destroy", "tf_last_error", "tf_version", "tf_normali
            "tf_dims", "tf_get_sph_matrix", "tf_one_electron", "tf_cross_overlap", "tf_build_eri", "tf_eri_storage",
            "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf",
            "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts", "tf_shard_plan", "tf_jk_profile",
-           "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_ao_to_mo", "tf_mp2_rhf"]
+           "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_ao_to_mo", "tf_mp2_rhf", "tf_dft_setup", "tf_dft_vxc",
+           "tf_dft_clear"]
 
 _lib = None
 
@@ -88,6 +89,9 @@ def lib():
     L.tf_diagonalise.restype = ci; L.tf_diagonalise.argtypes = [vp, ci, vp, vp, vp, vp]
     L.tf_ao_to_mo.restype = ci; L.tf_ao_to_mo.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp]
     L.tf_mp2_rhf.restype = ci; L.tf_mp2_rhf.argtypes = [vp, ci, ci, vp, vp, dp, dp, dp]
+    L.tf_dft_setup.restype = ci; L.tf_dft_setup.argtypes = [vp, C.c_int64, vp, vp, ci, ci, cd, cd, cd]
+    L.tf_dft_vxc.restype = ci; L.tf_dft_vxc.argtypes = [vp, vp, vp, dp, dp, dp]
+    L.tf_dft_clear.restype = ci; L.tf_dft_clear.argtypes = [vp]
     L.tf_eigh_probe.restype = ci; L.tf_eigh_probe.argtypes = [vp, ci, ci, ci, dp]
     L.tf_jk_profile.restype = ci; L.tf_jk_profile.argtypes = [vp, ci]
     L.tf_jk_profile_read.restype = ci; L.tf_jk_profile_read.argtypes = [vp, dp, lp]

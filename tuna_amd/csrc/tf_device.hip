@@ -20,6 +20,7 @@
 #include "tf_oneel.hip.h"
 #include "tf_scf.hip.h"
 #include "tf_mp2.hip.h"
+#include "tf_dft.hip.h"
 
 using namespace tfk;
 
@@ -59,6 +60,7 @@ struct tf_ctx {
     double eri_seconds[4] = {0, 0, 0, 0};
     long long eri_counts[3] = {0, 0, 0};
     tfscf::Workspace scf;
+    tfdft::Grid grid;                    // Kohn-Sham integration grid with the AOs evaluated on it (tf_dft_setup)
     // persistent helpers of tf_build_eri (creating streams / freeing GiB-sized buffers costs tens of ms per call)
     static const int NSTREAM_MAX = 8;
     hipStream_t streams[NSTREAM_MAX] = {};
@@ -183,6 +185,7 @@ void tf_destroy(tf_ctx *ctx)
     free_eri(ctx);
     free_basis(ctx);
     tfscf::release(ctx->scf);
+    tfdft::release(ctx->grid);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->have_streams)
         for (int k = 0; k < tf_ctx::NSTREAM_MAX; ++k) { (void)hipStreamDestroy(ctx->streams[k]); (void)hipEventDestroy(ctx->sev[k]); }
@@ -208,6 +211,7 @@ int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t
     HIPCHK(ctx, hipSetDevice(ctx->device));
     free_eri(ctx);
     free_basis(ctx);
+    tfdft::release(ctx->grid);
     std::string msg = tf::build_basis(ctx->bs, n_ao_cart, origin, lmn, prim_off, exps, coefs_raw);
     if (!msg.empty()) TF_FAIL(ctx, msg.find("aligned") != std::string::npos ? TF_EGEOM : TF_EINVAL, "%s", msg.c_str());
     const tf::Basis &bs = ctx->bs;
@@ -939,6 +943,79 @@ int tf_diagonalise(tf_ctx *ctx, int n, const double *F, const double *X, double 
     return rc;
 }
 
+// ---- Kohn-Sham exchange-correlation (next row of the hot path: SURVEY.md section 8f rank 2) --------------------------
+
+int tf_dft_clear(tf_ctx *ctx)
+{
+    if (!ctx) return TF_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    tfdft::release(ctx->grid);
+    return TF_OK;
+}
+
+int tf_dft_setup(tf_ctx *ctx, int64_t n_points, const double *xyz, const double *weights, int x_functional, int c_functional, double dfx,
+                 double dfc, double x_alpha)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_dft_setup: call tf_build_eri first (it fixes the AO representation)");
+    if (n_points < 1 || !xyz || !weights || x_functional < 0 || x_functional > 3 || c_functional < 0 || c_functional > 5)
+        TF_FAIL(ctx, TF_EINVAL, "tf_dft_setup: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    tfdft::release(ctx->grid);
+    tfdft::Grid &g = ctx->grid;
+    const tf::Basis &bs = ctx->bs;
+    const int N = ctx->N;
+    const long long G = n_points;
+    g.G = G; g.N = N; g.xid = x_functional; g.cid = c_functional; g.dfx = dfx; g.dfc = dfc; g.x_alpha = x_alpha;
+    g.gga = (x_functional >= tfdft::X_B88) || (c_functional >= tfdft::C_LYP);
+    std::string err;
+    tfone::DevBuf buf;
+    tfone::DAO A = tfone::upload_aos(bs, buf, err);
+    if (!err.empty()) TF_FAIL(ctx, TF_ENODEVICE, "%s", err.c_str());
+    double *d_xyz = buf.alloc<double>((size_t)3 * G, err);
+    if (!err.empty()) TF_FAIL(ctx, TF_ENOMEM, "%s", err.c_str());
+    HIPCHK(ctx, hipMemcpy(d_xyz, xyz, (size_t)3 * G * sizeof(double), hipMemcpyHostToDevice));
+    const size_t GN = (size_t)G * N;
+    HIPCHK(ctx, hipMalloc((void **)&g.w, (size_t)G * sizeof(double)));
+    HIPCHK(ctx, hipMemcpy(g.w, weights, (size_t)G * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&g.phi, GN * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&g.dphi, (g.gga ? 3 : 1) * GN * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&g.B, GN * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&g.D, GN * sizeof(double)));
+    for (double **p : {&g.rho, &g.vrho, &g.vsig, &g.ex, &g.ec}) HIPCHK(ctx, hipMalloc((void **)p, (size_t)G * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&g.grad, (size_t)3 * G * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&g.V, (size_t)N * N * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&g.part, (size_t)3 * tfdft::NPART * sizeof(double)));
+    tfdft::DAOs D{A.z, A.lmn, A.prim_off, A.exps, A.w};
+    hipLaunchKernelGGL(tfdft::ao_on_grid_kernel, dim3((unsigned)((GN + 127) / 128)), dim3(128), 0, 0, D, d_xyz, G, N, ctx->d_csr_ptr,
+                       ctx->d_csr_idx, ctx->d_csr_val, g.phi, g.dphi, g.gga ? 1 : 0);
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipGetLastError());
+    std::string msg;
+    int rc = tfscf::ensure(ctx->scf, N, 6, msg);           // makes sure the rocBLAS handle exists
+    if (rc) { ctx->err = msg; return rc; }
+    return TF_OK;
+}
+
+int tf_dft_vxc(tf_ctx *ctx, const double *P, double *Vxc, double *n_elec, double *e_x, double *e_c)
+{
+    if (!ctx) return TF_EINVAL;
+    if (ctx->grid.G <= 0) TF_FAIL(ctx, TF_EINVAL, "tf_dft_vxc: call tf_dft_setup first");
+    if (!P || !Vxc) TF_FAIL(ctx, TF_EINVAL, "tf_dft_vxc: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)ctx->N * ctx->N;
+    HIPCHK(ctx, hipMemcpy(ctx->d_P, P, nn * sizeof(double), hipMemcpyHostToDevice));
+    std::string msg;
+    double o3[3];
+    int rc = tfdft::vxc(ctx->scf.blas, ctx->grid, ctx->d_P, ctx->d_J, o3, msg);
+    if (rc) { ctx->err = msg; return rc; }
+    HIPCHK(ctx, hipMemcpy(Vxc, ctx->d_J, nn * sizeof(double), hipMemcpyDeviceToHost));
+    if (n_elec) *n_elec = o3[0];
+    if (e_x) *e_x = o3[1];
+    if (e_c) *e_c = o3[2];
+    return TF_OK;
+}
+
 // ---- AO->MO transformation and RMP2 (next row of the hot path: consumers of the resident tensor) ----------------------
 
 static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const double *C2, int n2, const double *C3, int n3, const double *C4,
@@ -1038,7 +1115,12 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
         double *j[2] = {dJ, dJ}, *k[2] = {dK, dK};
         return launch_jk(ctx, 1, p, j, k, st);
     };
-    int rc = tfscf::run_rhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0, E0, n_occ, V_NN, jk, ctx->world, *out, msg);
+    tfscf::XCFn xc;
+    if (ctx->grid.G > 0) {
+        if (ctx->grid.N != ctx->N) TF_FAIL(ctx, TF_EINVAL, "tf_scf_rhf: the DFT grid was set up for a different AO dimension");
+        xc = [&](const double *dP, double *dV, double *o3) { return tfdft::vxc(ctx->scf.blas, ctx->grid, dP, dV, o3, msg); };
+    }
+    int rc = tfscf::run_rhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0, E0, n_occ, V_NN, jk, ctx->world, *out, msg, xc);
     if (rc) ctx->err = msg;
     return rc;
 }

@@ -350,14 +350,16 @@ inline int eigh_probe(Workspace &w, int n, int variant, int reps, double *second
 }
 
 using JKFn = std::function<int(const double *, double *, double *, hipStream_t)>;
+// Kohn-Sham hook: V_XC (device [N,N]) and {n_elec, E_X, E_C} for the device density (tf_dft.hip.h); empty for Hartree-Fock
+using XCFn = std::function<int(const double *, double *, double *)>;
 
 inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, const double *T, const double *V, const double *Fext,
                    const double *X, const double *P0, double E0, int n_occ, double V_NN, const JKFn &jk, int world,
-                   tf_scf_result &out, std::string &msg)
+                   tf_scf_result &out, std::string &msg, const XCFn &xc = XCFn())
 {
     if (world != 1) { msg = "tf_scf_rhf runs on one GPU; use tuna_amd.scf (torch.distributed all-reduce) for sharded tensors"; return TF_EINVAL; }
     const int max_diis = std::max(1, std::min(8, (int)o.max_diis));
-    const int n_mats = 20 + 2 * max_diis;
+    const int n_mats = 21 + 2 * max_diis;
     int rc = ensure(w, n, n_mats, msg);
     if (rc) return rc;
     const size_t nn = (size_t)n * n;
@@ -367,8 +369,8 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     auto mat = [&](int k) { return base + (size_t)k * nn; };
     double *dS = mat(0), *dH = mat(1), *dX = mat(2), *dP = mat(3), *dPold = mat(4), *dPbd = mat(5), *dPvold = mat(6), *dPoldbd = mat(7);
     double *dF = mat(8), *dJ = mat(9), *dK = mat(10), *dT = mat(11), *dV = mat(12), *dFx = mat(13), *t1 = mat(14), *t2 = mat(15);
-    double *dC = mat(16), *dW = mat(17), *dPn = mat(18), *scr = mat(19);
-    double *hist = mat(20);
+    double *dC = mat(16), *dW = mat(17), *dPn = mat(18), *scr = mat(19), *dVxc = mat(20);
+    double *hist = mat(21);
     double *vals = base + (size_t)n_mats * nn, *ework = vals + n;
     auto histF = [&](int k) { return hist + (size_t)(2 * k) * nn; };
     auto histE = [&](int k) { return hist + (size_t)(2 * k + 1) * nn; };
@@ -431,11 +433,18 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         std::swap(dPvold, dPold);            // dPvold <- old P_old ; dPold free to be overwritten
         TFS_HIP(hipMemcpyAsync(dPold, dP, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
         // Fock matrix (scf:497-531)
+        // Kohn-Sham: exchange-correlation matrix and energy densities from the CURRENT (old) density (scf:1121)
+        double xc3[3] = {0.0, 0.0, 0.0};
+        if (xc) {
+            rc = xc(dP, dVxc, xc3);
+            if (rc) { msg = "exchange-correlation evaluation failed"; return rc; }
+        }
         TFS_HIP(hipEventRecord(w.ev0, 0));
         rc = jk(dP, dJ, dK, 0);
         if (rc) { msg = "J/K launch failed"; return rc; }
         TFS_HIP(hipEventRecord(w.ev1, 0));
         hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, 0, dH, dJ, dK, o.hfx, t1, (int)nn);
+        if (xc) hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, t1, 1.0, dVxc, t1, (int)nn);        // + V_XC, scf:525
         hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, dF, n);
         // DIIS error e = X^T (F P S - S P F) X   (scf:906-920)
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dF, dP, 0.0, t1));        // F P
@@ -482,7 +491,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         TFS_BLAS(dot(dPn, dFx, &eF));
         TFS_BLAS(dot(dPn, dJ, &eJ));
         TFS_BLAS(dot(dPn, dK, &eK));
-        comps[0] = eT; comps[1] = eV; comps[2] = (1.0 / 2.0) * eJ; comps[3] = -(1.0 / 4.0) * eK * o.hfx; comps[4] = 0.0;
+        comps[0] = eT; comps[1] = eV; comps[2] = (1.0 / 2.0) * eJ; comps[3] = -(1.0 / 4.0) * eK * o.hfx + xc3[1]; comps[4] = xc3[2];   // scf:380-394
         comps[5] = eF; comps[6] = 0.0;
         E = comps[0] + comps[1] + comps[2] + comps[3] + comps[4] + comps[5] + comps[6];
         if (out.eps) TFS_HIP(hipMemcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));

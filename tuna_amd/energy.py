@@ -43,6 +43,9 @@ class Calculation:
     core_guess: bool = False            # COREGUESS, calc:95; default is the superposition of atomic densities
     DFT_calculation: bool = False
     multiplicity: int = 1               # ML, calc:151
+    functional: str | None = None       # Kohn-Sham functional name (tuna_amd.dft.FUNCTIONALS) or None for Hartree-Fock
+    grid_conv: str = "medium"           # LOOSEGRID/MEDIUMGRID/TIGHTGRID..., util:129-137
+    X_alpha: float = 2 / 3              # XA, calc:156
 
 
 @dataclass
@@ -122,6 +125,10 @@ def interpret_keywords(params, calc: Calculation) -> Calculation:
             calc.charge = int(value())
         elif p in ("ML", "MULTIPLICITY"):
             calc.multiplicity = int(value())
+        elif p in ("LOOSEGRID", "MEDIUMGRID", "TIGHTGRID", "EXTREMEGRID"):
+            calc.grid_conv = p[:-4].lower()
+        elif p == "XA":
+            calc.X_alpha = float(value())
         elif p == "COREGUESS":
             calc.core_guess = True
         elif p in ("SADGUESS", "T", "P", "DEBUG"):
@@ -159,6 +166,17 @@ def build_molecule_and_integrals(symbols, R_bohr, calc: Calculation, engine: Eng
     timings["Two-electron integrals"] = time.perf_counter() - t0
     fock = sharded_fock_factory(engine) if sharded_fock_factory is not None and engine.world > 1 else None
     integrals = Integrals(S, T, V, D, Q, DeviceERI(engine, fock))
+    if calc.functional is not None:                         # Kohn-Sham: grid + AOs on the grid (tuna_dft.py:94-208)
+        from . import dft as dft_mod
+        if calc.reference == "UHF":
+            raise TunaError("unrestricted Kohn-Sham is not on the GPU path in this build")
+        t0 = time.perf_counter()
+        pts, wts, ginfo = dft_mod.integration_grid(atoms, calc.grid_conv)
+        f = engine.dft_setup(pts, wts, calc.functional, calc.X_alpha)
+        calc.HFX_prop, calc.DFT_calculation = f["hfx"], True
+        timings["Integration grid setup"] = time.perf_counter() - t0
+    else:
+        engine.dft_clear()
     dim = (lambda s: s.n_sph) if spherical else (lambda s: s.n_cart)
     ranges = [sum(dim(s) for s in shells if s.atom == a) for a in range(len(atoms))]
     molecule = Molecule(atoms, shells, aos, n_el, n_el // 2, n_alpha, n_beta, ranges, engine.N, aos.n)
@@ -197,8 +215,12 @@ def calculate_energy(symbols, R_bohr, calc: Calculation, engine: Engine | None =
         timings["Self-consistent field"] = time.perf_counter() - t0
         out.timings.update(timings)
         if not silent:
-            label = "\n Unrestricted Hartree-Fock energy: " if calc.reference == "UHF" else "\n Restricted Hartree-Fock energy:   "
-            log(label + f"{out.energy:16.10f}")                                          # kernel:846-850
+            if calc.functional is not None:
+                space = " " * max(0, 8 - len(calc.functional))
+                log(f"\n Restricted {calc.functional} energy: {space}      " + f"{out.energy:16.10f}")     # kernel:854
+            else:
+                label = "\n Unrestricted Hartree-Fock energy: " if calc.reference == "UHF" else "\n Restricted Hartree-Fock energy:   "
+                log(label + f"{out.energy:16.10f}")                                      # kernel:846-850
             log("\n Final single point energy: " + f"{out.energy:16.10f}")              # kernel:1305
         out.integrals = integrals if not own else None      # the device tensor dies with an engine we own
         return out
@@ -212,9 +234,12 @@ def run(input_line: str, silent: bool = True, engine: Engine | None = None, log=
     ctype, method, basis, symbols, R, params = parse_input(input_line)
     if ctype != "SPE":
         raise TunaError(f"Calculation type \"{ctype}\" is not supported.")
-    if method not in ("HF", "RHF", "UHF"):
+    from . import dft as dft_mod
+    if method not in ("HF", "RHF", "UHF") and method not in dft_mod.FUNCTIONALS:
         raise TunaError(f"Electronic structure method \"{method}\" is not supported.")
-    calc = interpret_keywords(params, Calculation(ctype, "HF", basis))
+    calc = interpret_keywords(params, Calculation(ctype, method if method in dft_mod.FUNCTIONALS else "HF", basis))
     if method == "UHF":
         calc.reference = "UHF"
+    if method in dft_mod.FUNCTIONALS:
+        calc.functional = method
     return calculate_energy(symbols, R, calc, engine, silent, log)

@@ -165,6 +165,34 @@ class Engine:
         self._check(self._L.tf_orthogonaliser(self._ctx, n, ptr(S), ptr(X), ptr(Si), C.byref(sm)))
         return X, sm.value, Si
 
+    # ---- Kohn-Sham exchange-correlation ------------------------------------------------------------
+    def dft_setup(self, points, weights, functional: str, x_alpha: float = 2 / 3) -> dict:
+        """Puts the grid on the device, evaluates the AOs on it and selects the functional (tuna_amd.dft.FUNCTIONALS).
+        While set, scf_rhf runs restricted Kohn-Sham; returns {"hfx": HFX_prop, ...} to pass on."""
+        from . import dft
+        name = functional.upper()
+        if name not in dft.FUNCTIONALS:
+            raise TunaError(f"Electronic structure method \"{functional}\" is not supported.")
+        xn, cn, dfx, hfx, dfc = dft.FUNCTIONALS[name]
+        pts = f64(np.asarray(points).reshape(3, -1))
+        wts = f64(np.asarray(weights).reshape(-1))
+        self._check(self._L.tf_dft_setup(self._ctx, wts.size, ptr(pts), ptr(wts), dft.X_ID[xn], dft.C_ID[cn], dfx, dfc, float(x_alpha)))
+        self.functional = {"name": name, "hfx": hfx, "dfx": dfx, "dfc": dfc, "n_points": int(wts.size)}
+        return self.functional
+
+    def dft_vxc(self, P):
+        """(V_XC, n_electrons_on_grid, E_X * DFX, E_C * DFC) for a closed-shell density (tuna_scf.py:600-654)."""
+        import ctypes
+        P = f64(P)
+        V = np.zeros_like(P)
+        n, ex, ec = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(self._L.tf_dft_vxc(self._ctx, ptr(P), ptr(V), ctypes.byref(n), ctypes.byref(ex), ctypes.byref(ec)))
+        return V, n.value, ex.value, ec.value
+
+    def dft_clear(self):
+        self._check(self._L.tf_dft_clear(self._ctx))
+        self.functional = None
+
     # ---- post-SCF consumers of the resident tensor ------------------------------------------------
     def ao_to_mo(self, C1, C2=None, C3=None, C4=None) -> np.ndarray:
         """(pq|rs) = sum C1[mu,p] C2[nu,q] C3[la,r] C4[si,s] (mu nu|la si); all four default to C1 (tuna_ci.py:204-255)."""
