@@ -89,8 +89,18 @@ int tf_cross_overlap(tf_ctx *ctx, int n_ao2, const double *origin2, const int32_
  *      + transform_to_spherical_harmonics (kernel:454-529) -------------------------------- */
 
 /* Build this rank's rows of the (ij|kl) tensor on the device.  spherical = 0 is CARTHARM
- * (kernel:481).  The tensor stays resident in HBM: rows (i >= j) x full (k,l). */
+ * (kernel:481).  The tensor stays resident in HBM in one of two layouts:
+ *   TF_LAYOUT_PACKED (default): the 8-fold unique values, row (i >= j) = all pairs (k >= l) <= (i,j)
+ *                               -- N^4 bytes instead of the reference's 8 N^4 (kernel:349);
+ *   TF_LAYOUT_ROWS:             rows (i >= j) x full [k][l] -- 4 N^4 bytes. */
 int tf_build_eri(tf_ctx *ctx, int spherical);
+#define TF_LAYOUT_AUTO (-1)
+#define TF_LAYOUT_ROWS 0
+#define TF_LAYOUT_PACKED 1
+/* Layout for the next tf_build_eri (TF_LAYOUT_AUTO = packed when the J/K kernel covers N, i.e. N <= 1024). */
+int tf_set_eri_layout(tf_ctx *ctx, int layout);
+/* Layout of the stored tensor (TF_LAYOUT_ROWS / TF_LAYOUT_PACKED), or TF_EINVAL before tf_build_eri. */
+int tf_eri_layout(const tf_ctx *ctx);
 /* Bytes of HBM holding the stored rows, number of stored rows, row length (leading dimension). */
 int tf_eri_storage(const tf_ctx *ctx, int64_t *bytes, int64_t *n_rows, int32_t *n, int32_t *ld);
 /* Dense N^4 tensor with all 8 images, as the reference leaves it in `ERI_AO` (caller-allocated,
@@ -112,7 +122,9 @@ int tf_eri_element(tf_ctx *ctx, const double *origin, const int32_t *lmn, const 
  * full matrices); the caller all-reduces (RCCL) -- see tuna_amd/distributed.py. */
 int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K);
 /* Same with device pointers, asynchronous on `stream` (a hipStream_t, may be NULL for the
- * default stream).  Inputs already in HBM; nothing is synchronised or copied. */
+ * default stream).  Inputs already in HBM; nothing is synchronised or copied.  With the packed
+ * layout the densities must be symmetric here (every SCF density is); tf_fock_jk itself also
+ * accepts general matrices (it checks on the host and takes a second pass for them). */
 int tf_fock_jk_device(tf_ctx *ctx, int n_dens, const double *dP, double *dJ, double *dK, void *stream);
 
 /* ---- SCF: replaces run_self_consistent_field_cycle (scf:1292-1435) for RHF ---------------- */

@@ -16,6 +16,7 @@
 #include "../../include/tunafock.h"
 #include "tf_internal.h"
 #include "tf_kernels.hip.h"
+#include "tf_jkpacked.hip.h"
 #include "tf_eri.hip.h"
 #include "tf_oneel.hip.h"
 #include "tf_scf.hip.h"
@@ -53,6 +54,15 @@ struct tf_ctx {
     std::vector<std::vector<int>> class_pairs;   // pairs of each class, ascending
     // J/K scratch
     double *d_Jrow = nullptr, *d_Kp = nullptr, *d_Ppad = nullptr, *d_J = nullptr, *d_K = nullptr, *d_P = nullptr;
+    // packed (8-fold unique) layout: tf_jkpacked.hip.h
+    int layout_req = -1;                // -1 auto, 0 rows (i >= j) x [k][l], 1 packed
+    int layout = 0;
+    long long n_elems = 0;              // stored doubles
+    long long *d_rowoff = nullptr;
+    JKGroup *d_groups = nullptr;
+    int n_groups = 0, nseg = 1;
+    int *d_gfirst = nullptr;            // [2][N]: first / one-past-last group with i == a
+    double *d_Psym = nullptr, *d_Pp = nullptr, *d_ypart = nullptr, *d_DI = nullptr, *d_DJ = nullptr, *d_Jt = nullptr, *d_D = nullptr;
     // instrumentation
     bool prof_jk = false;
     std::vector<hipEvent_t> prof_ev;     // pairs (before, after) around the row kernel, on the launch stream
@@ -109,10 +119,15 @@ static int upload(tf_ctx *ctx, const std::vector<T> &h, T **d, bool track = true
 static void free_eri(tf_ctx *ctx)
 {
     for (void *p : {(void *)ctx->d_eri, (void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
-                    (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P})
+                    (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_groups,
+                    (void *)ctx->d_gfirst, (void *)ctx->d_Psym, (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ,
+                    (void *)ctx->d_Jt, (void *)ctx->d_D})
         if (p) (void)hipFree(p);
     ctx->d_eri = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
     ctx->d_Ppad = nullptr; ctx->d_J = nullptr; ctx->d_K = nullptr; ctx->d_P = nullptr;
+    ctx->d_rowoff = nullptr; ctx->d_groups = nullptr; ctx->d_gfirst = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
+    ctx->d_ypart = nullptr; ctx->d_DI = nullptr; ctx->d_DJ = nullptr; ctx->d_Jt = nullptr; ctx->d_D = nullptr;
+    ctx->n_groups = 0; ctx->n_elems = 0;
     ctx->have_eri = false;
 }
 
@@ -360,14 +375,28 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         ctx->host_pairs[p].outoff_b = out_off(bs.shells[bs.pairs[p].B]);
     }
     HIPCHK(ctx, hipMemcpy(ctx->d_pairs, ctx->host_pairs.data(), (size_t)npairs * sizeof(DPair), hipMemcpyHostToDevice));
-    std::vector<long long> pair_rows(npairs);
+    // layout: packed (8-fold unique, tf_jkpacked.hip.h) unless asked otherwise; its J/K kernel covers N <= 1024
+    int layout = ctx->layout_req;
+    if (const char *e = getenv("TF_ERI_LAYOUT")) layout = (e[0] == 'p') ? 1 : (e[0] == 'r' ? 0 : layout);
+    if (layout < 0) layout = 1;
+    if (N > 1024) layout = 0;
+    ctx->layout = layout;
+    const bool packed = layout == 1;
+    std::vector<long long> pair_rows(npairs), pair_weight(npairs);
     for (int p = 0; p < npairs; ++p) {
         const tf::Shell &a = bs.shells[bs.pairs[p].A], &b = bs.shells[bs.pairs[p].B];
         pair_rows[p] = (bs.pairs[p].A == bs.pairs[p].B) ? (long long)out_dim(a) * (out_dim(a) + 1) / 2
                                                         : (long long)out_dim(a) * out_dim(b);
+        long long w = 0;                                         // stored elements of the block's rows
+        for (int x = 0; x < out_dim(a); ++x)
+            for (int y = 0; y < out_dim(b); ++y) {
+                const long long i = out_off(a) + x, j = out_off(b) + y;
+                if (i >= j) w += packed ? i * (i + 1) / 2 + j + 1 : 1;
+            }
+        pair_weight[p] = w;
     }
     std::vector<int> owner;
-    shard_plan(pair_rows, ctx->world, owner);
+    shard_plan(pair_weight, ctx->world, owner);
     ctx->my_pairs.clear();
     for (int p = 0; p < npairs; ++p)
         if (owner[p] == ctx->rank) ctx->my_pairs.push_back(p);
@@ -387,11 +416,54 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 row_ij.push_back(make_int2(i, j));
             }
     }
+    std::vector<long long> rowoff;
+    std::vector<JKGroup> groups;
+    std::vector<int> gfirst(2 * (size_t)N, 0);
+    long long ypart_len = 0;
+    if (packed) {
+        // owned rows in ascending pair index; row p holds the p + 1 pairs q <= p
+        std::sort(row_ij.begin(), row_ij.end(), [](const int2 &u, const int2 &v) { return u.x != v.x ? u.x < v.x : u.y < v.y; });
+        rowoff.resize(row_ij.size() + 1);
+        long long off = 0;
+        for (size_t r = 0; r < row_ij.size(); ++r) {
+            const long long pidx = (long long)row_ij[r].x * (row_ij[r].x + 1) / 2 + row_ij[r].y;
+            rowmap[(size_t)pidx] = (int)r;
+            rowoff[r] = off;
+            off += pidx + 1;
+        }
+        rowoff[row_ij.size()] = off;
+        ctx->n_elems = off;
+        // workgroups: runs of consecutive j with the same i, longest rows first (they are dispatched in this order)
+        for (long long r = (long long)row_ij.size() - 1; r >= 0;) {
+            long long r0 = r;
+            while (r0 > 0 && row_ij[r0 - 1].x == row_ij[r].x && row_ij[r0 - 1].y == row_ij[r0].y - 1 && r - r0 + 1 < TF_JKP_JBB) --r0;
+            JKGroup g{};
+            g.i = row_ij[r].x; g.j0 = row_ij[r0].y; g.nr = (int)(r - r0 + 1); g.r0 = (int)r0;
+            g.yoff = ypart_len;
+            g.ylen = (long long)g.i * (g.i + 1) / 2 + row_ij[r].y + 1;
+            ypart_len += g.ylen;
+            groups.push_back(g);
+            r = r0 - 1;
+        }
+        for (int a = 0; a < N; ++a) gfirst[a] = gfirst[N + a] = 0;
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const int a = groups[gi].i;
+            if (gfirst[N + a] == gfirst[a]) gfirst[a] = (int)gi;
+            gfirst[N + a] = (int)gi + 1;
+        }
+    }
     ctx->n_rows = (long long)row_ij.size();
     const long long row_len = (long long)N * ld;
+    if (!packed) ctx->n_elems = ctx->n_rows * row_len;
     if (ctx->n_rows > 0x7fffffffLL) TF_FAIL(ctx, TF_EINVAL, "too many tensor rows for this build");
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_eri, std::max<size_t>(1, (size_t)ctx->n_rows * row_len * sizeof(double))));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_eri, std::max<size_t>(1, (size_t)ctx->n_elems * sizeof(double))));
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
+    if (packed) {
+        if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, groups, &ctx->d_groups, false)) ||
+            (rc = upload(ctx, gfirst, &ctx->d_gfirst, false)))
+            return rc;
+        ctx->n_groups = (int)groups.size();
+    }
 
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
     // ---- slabs of bra pairs: Cartesian block -> ket transform -> bra transform -> tensor rows
@@ -472,6 +544,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         q.fused = 1; q.spherical = spherical ? 1 : 0;
         q.nsc = spherical ? sc.nsph : sc.ncomp; q.nsd = spherical ? sd.nsph : sd.ncomp;
         q.Nout = N; q.ld = ld;
+        q.tri = packed ? 1 : 0;
         double *d_out_slab = d_T2;                               // fused kernels write the half-transformed slab directly
         const int *d_ket = d_kets + ket_off[kcls];
         hipStream_t st = streams[launch_count++ % NSTREAM];
@@ -558,6 +631,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         q.lds_doubles = o;
         q.offBlk = o;                                            // unused (unfused)
         q.G = 1; q.n_ket = npairs; q.fused = 0;
+        q.tri = packed ? 1 : 0;
         hipLaunchKernelGGL((eri_class_kernel<true, true>), dim3(npairs, n_bra), dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), streams[0],
                            ctx->db, q, d_bra, d_braoff, d_kets_all, Nc, d_C);
     };
@@ -570,6 +644,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     const size_t cap_bra = std::min<size_t>(mine_sorted.size(), 65535) + 1;
     const size_t cap_out = (size_t)std::min<long long>(ctx->n_rows, max_rows_c * 2 + (long long)max_out) + 1;
     int *d_bra = nullptr; long long *d_braoff = nullptr; OutRow *d_out = nullptr;
+    static_assert(sizeof(OutRow) == sizeof(OutRowP), "the two row descriptors share one device buffer");
     HIPCHK(ctx, hipMalloc((void **)&d_bra, cap_bra * sizeof(int)));
     HIPCHK(ctx, hipMalloc((void **)&d_braoff, cap_bra * sizeof(long long)));
     HIPCHK(ctx, hipMalloc((void **)&d_out, cap_out * sizeof(OutRow)));
@@ -589,7 +664,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 for (int y = 0; y < out_dim(b); ++y) {
                     const int i = out_off(a) + x, j = out_off(b) + y;
                     if (i < j) continue;
-                    outs.push_back(OutRow{i, j, a.cart_off, b.cart_off, b.ncomp, 0, rows_c, r++});
+                    // packed: dst_row carries the element offset of the row (OutRowP::dst_off)
+                    const long long dst = packed ? rowoff[rowmap[(size_t)i * (i + 1) / 2 + j]] : r++;
+                    outs.push_back(OutRow{i, j, a.cart_off, b.cart_off, b.ncomp, 0, rows_c, dst});
                 }
             rows_c += nr;
             n_quart += npairs;
@@ -640,8 +717,13 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             const unsigned gx = (unsigned)std::min<long long>((row_len + 255) / 256, 4096);
             for (size_t o0 = 0; o0 < outs.size(); o0 += 65535) {
                 const unsigned ny = (unsigned)std::min<size_t>(65535, outs.size() - o0);
-                hipLaunchKernelGGL(xform_bra_store, dim3(gx, ny), dim3(256), 0, 0, d_T2, ctx->d_eri, d_out + o0, row_len,
-                                   ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val);
+                if (packed)
+                    hipLaunchKernelGGL(xform_bra_store_packed, dim3(std::max(1u, gx / 2), ny), dim3(256), 0, 0, d_T2, ctx->d_eri,
+                                       reinterpret_cast<const OutRowP *>(d_out + o0), row_len, ld, ctx->d_csr_ptr, ctx->d_csr_idx,
+                                       ctx->d_csr_val);
+                else
+                    hipLaunchKernelGGL(xform_bra_store, dim3(gx, ny), dim3(256), 0, 0, d_T2, ctx->d_eri, d_out + o0, row_len,
+                                       ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val);
             }
         }
         HIPCHK(ctx, hipEventRecord(e4[3], 0));
@@ -666,8 +748,21 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // ---- J/K scratch
     const size_t nn = (size_t)N * N;
     // (sized for two densities per pass)
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Kp, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * 2 * ld * sizeof(double)));
+    const int Wjk = ((N + 63) / 64 + 1) / 2;                        // waves per workgroup of jk_packed_kernel
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, std::max(2, Wjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
+    if (packed) {
+        const size_t npr = (size_t)N * (N + 1) / 2;
+        ctx->nseg = std::max(1, std::min(TF_JKP_SEG, ctx->n_groups / 32));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Psym, nn * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Pp, npr * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_ypart, std::max<size_t>(1, (size_t)ypart_len) * sizeof(double)));
+        // column parts [.][N] followed by the per-wave row parts [.][W][N]
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, std::max<size_t>(1, (size_t)ctx->n_groups) * (1 + Wjk) * N * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, std::max<size_t>(1, (size_t)ctx->n_rows) * (1 + Wjk) * N * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jt, (size_t)ctx->nseg * npr * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_D, 2 * nn * sizeof(double)));
+    } else
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Kp, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * 2 * ld * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_Ppad, 2 * (size_t)N * ld * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_J, 2 * nn * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_K, 2 * nn * sizeof(double)));
@@ -680,12 +775,21 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
 int tf_eri_storage(const tf_ctx *ctx, int64_t *bytes, int64_t *n_rows, int32_t *n, int32_t *ld)
 {
     if (!ctx || !ctx->have_eri) return TF_EINVAL;
-    if (bytes) *bytes = (int64_t)ctx->n_rows * ctx->N * ctx->ld * (int64_t)sizeof(double);
+    if (bytes) *bytes = (int64_t)ctx->n_elems * (int64_t)sizeof(double);
     if (n_rows) *n_rows = ctx->n_rows;
     if (n) *n = ctx->N;
     if (ld) *ld = ctx->ld;
     return TF_OK;
 }
+
+int tf_set_eri_layout(tf_ctx *ctx, int layout)
+{
+    if (!ctx || layout < -1 || layout > 1) return TF_EINVAL;
+    ctx->layout_req = layout;
+    return TF_OK;
+}
+
+int tf_eri_layout(const tf_ctx *ctx) { return (ctx && ctx->have_eri) ? ctx->layout : TF_EINVAL; }
 
 int tf_eri_timings(const tf_ctx *ctx, double *s4)
 {
@@ -710,7 +814,10 @@ int tf_copy_eri(tf_ctx *ctx, double *host_out)
     double *d_dense = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&d_dense, total * sizeof(double)));
     const unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 1 << 20);
-    hipLaunchKernelGGL(expand_dense_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N, ctx->ld, d_dense);
+    if (ctx->layout == 1)
+        hipLaunchKernelGGL(expand_dense_packed_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->d_rowoff, ctx->N, d_dense);
+    else
+        hipLaunchKernelGGL(expand_dense_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N, ctx->ld, d_dense);
     hipError_t e = hipMemcpy(host_out, d_dense, total * sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(d_dense);
     HIPCHK(ctx, e);
@@ -729,8 +836,12 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
     HIPCHK(ctx, hipMalloc((void **)&d_idx, (size_t)n_idx * 4 * sizeof(int)));
     HIPCHK(ctx, hipMalloc((void **)&d_val, (size_t)n_idx * sizeof(double)));
     HIPCHK(ctx, hipMemcpy(d_idx, idx, (size_t)n_idx * 4 * sizeof(int), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N,
-                       ctx->ld, (long long)n_idx, d_idx, d_val);
+    if (ctx->layout == 1)
+        hipLaunchKernelGGL(sample_packed_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap,
+                           ctx->d_rowoff, (long long)n_idx, d_idx, d_val);
+    else
+        hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N,
+                           ctx->ld, (long long)n_idx, d_idx, d_val);
     hipError_t e = hipMemcpy(values, d_val, (size_t)n_idx * sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(d_idx); (void)hipFree(d_val);
     HIPCHK(ctx, e);
@@ -740,8 +851,57 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
 // ---- J/K ------------------------------------------------------------------------------------------
 
 // nd = 1 or 2 densities in one pass over the tensor.  dP/dJ/dK: nd dense [N,N] device matrices each.
-static int launch_jk(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st)
+// nonsym[d] != 0: density d is not symmetric -- two passes (K = D(P^T) + D(P)^T); nullptr = all symmetric.
+static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st,
+                            const int *nonsym)
 {
+    const int N = ctx->N, NW = (N + 63) / 64, W = (NW + 1) / 2;
+    const long long npr = (long long)N * (N + 1) / 2;
+    const size_t smem = (size_t)(TF_JKP_JBB + 1) * N * sizeof(double);
+    static size_t smem_set = 0;
+    if (smem > smem_set) {
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        smem_set = smem;
+    }
+    for (int d = 0; d < nd; ++d)                                 // one density per pass over the packed tensor
+      for (int pass = 0; pass < ((nonsym && nonsym[d]) ? 2 : 1); ++pass) {
+        const bool general = nonsym && nonsym[d];
+        double *dD = (pass == 0) ? ctx->d_D : ctx->d_D + (size_t)N * N;
+        hipLaunchKernelGGL(pack_density_kernel, dim3((N * N + 255) / 256), dim3(256), 0, st, dP[d], N, (general && pass == 0) ? 1 : 0,
+                           ctx->d_Psym, ctx->d_Pp);
+        if (ctx->n_groups > 0) {
+            hipEvent_t ev_after = nullptr;
+            if (ctx->prof_jk) {
+                if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+                    hipEvent_t a, b;
+                    if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { ctx->prof_ev.push_back(a); ctx->prof_ev.push_back(b); }
+                }
+                if (ctx->prof_used + 2 <= ctx->prof_ev.size()) {
+                    (void)hipEventRecord(ctx->prof_ev[ctx->prof_used], st);
+                    ev_after = ctx->prof_ev[ctx->prof_used + 1];
+                    ctx->prof_used += 2;
+                }
+            }
+            hipLaunchKernelGGL(jk_packed_kernel, dim3((unsigned)ctx->n_groups), dim3(64 * W), smem, st, ctx->d_eri, ctx->d_rowoff, ctx->d_groups,
+                               N, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, ctx->d_DI, ctx->d_DI + (size_t)ctx->n_groups * N, ctx->d_DJ,
+                               ctx->d_DJ + (size_t)ctx->n_rows * N);
+            if (ev_after) (void)hipEventRecord(ev_after, st);
+        }
+        hipLaunchKernelGGL(jt_reduce_kernel, dim3((unsigned)((npr + 255) / 256), ctx->nseg), dim3(256), 0, st, ctx->d_ypart, ctx->d_groups,
+                           ctx->n_groups, npr, ctx->d_Jt);
+        hipLaunchKernelGGL(kd_reduce_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, st, ctx->d_DI, ctx->d_DI + (size_t)ctx->n_groups * N,
+                           ctx->d_DJ, ctx->d_DJ + (size_t)ctx->n_rows * N, W, ctx->d_gfirst, ctx->d_rowmap, N, dD);
+        if (general && pass == 0) continue;
+        hipLaunchKernelGGL(jk_packed_final_kernel, dim3((N * N + 255) / 256), dim3(256), 0, st, ctx->d_D, dD, ctx->d_Jrow, W, ctx->d_Jt,
+                           ctx->nseg, ctx->d_rowmap, N, dJ[d], dK[d]);
+      }
+    return TF_OK;
+}
+
+static int launch_jk(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st,
+                     const int *nonsym = nullptr)
+{
+    if (ctx->layout == 1) return launch_jk_packed(ctx, nd, dP, dJ, dK, st, nonsym);
     const int N = ctx->N, ld = ctx->ld;
     const double *Ppad[2] = {dP[0], nd > 1 ? dP[1] : dP[0]};
     if (ld != N) {
@@ -834,7 +994,15 @@ int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K)
         HIPCHK(ctx, hipMemcpy(ctx->d_P, P + d * nn, nd * nn * sizeof(double), hipMemcpyHostToDevice));
         const double *p[2] = {ctx->d_P, ctx->d_P + (nd - 1) * nn};
         double *j[2] = {ctx->d_J, ctx->d_J + (nd - 1) * nn}, *k[2] = {ctx->d_K, ctx->d_K + (nd - 1) * nn};
-        int rc = launch_jk(ctx, nd, p, j, k, 0);
+        int nonsym[2] = {0, 0};                                  // the packed layout needs a second pass for a non-symmetric density
+        const int N = ctx->N;
+        for (int q = 0; q < nd; ++q) {
+            const double *Pq = P + (d + q) * nn;
+            for (int a = 0; a < N && !nonsym[q]; ++a)
+                for (int b = 0; b < a; ++b)
+                    if (Pq[(size_t)a * N + b] != Pq[(size_t)b * N + a]) { nonsym[q] = 1; break; }
+        }
+        int rc = launch_jk(ctx, nd, p, j, k, 0, nonsym);
         if (rc) return rc;
         HIPCHK(ctx, hipMemcpy(J + d * nn, ctx->d_J, nd * nn * sizeof(double), hipMemcpyDeviceToHost));
         HIPCHK(ctx, hipMemcpy(K + d * nn, ctx->d_K, nd * nn * sizeof(double), hipMemcpyDeviceToHost));
@@ -1033,7 +1201,8 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
         HIPCHK(ctx, hipMemcpy(dC[k], hC[k], (size_t)N * nk[k] * sizeof(double), hipMemcpyHostToDevice));
     }
     HIPCHK(ctx, hipMalloc((void **)d_out, (size_t)n1 * n2 * n3 * n4 * sizeof(double)));
-    rc = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, ctx->n_rows, N, ctx->ld, dC[0], n1, dC[1], n2, dC[2], n3, dC[3], n4,
+    rc = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, ctx->layout == 1 ? ctx->d_rowoff : nullptr, ctx->d_row_ij, ctx->n_rows, N,
+                          ctx->ld, dC[0], n1, dC[1], n2, dC[2], n3, dC[3], n4,
                           *d_out, seconds, msg);
     for (int k = 0; k < 4; ++k) (void)hipFree(dC[k]);
     if (rc) { ctx->err = msg; (void)hipFree(*d_out); *d_out = nullptr; }

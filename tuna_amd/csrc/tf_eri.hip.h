@@ -24,6 +24,7 @@ struct QClass {
     int G, ncp;            // multi kernel: shell quartets per workgroup, padded components per quartet
     int n_ket;             // ket pairs in this launch
     int fused, spherical, nsc, nsd, Nout, ld, offBlk;   // fused ket transform: output dims of shells C, D; T2 geometry; LDS block buffer
+    int tri;               // packed layout: only kets with first shell <= the bra's first shell are needed ((kl) <= (ij))
     // LDS carve-out, offsets in doubles
     int offR, offPref, offPQ, offRed, offEab, offEcd, offScale, offLmn, lds_doubles;
 };
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_class_kernel(DBasis B, QCl
     const int tid = threadIdx.x;
     const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
     const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
+    if (qc_in.tri && cd.A > ab.A) return;                      // every (kl) of this ket lies above every (ij) of the bra
     QClass qc = qc_in;
     bool stage_ok = true;
     if (GENERIC) {
@@ -339,7 +341,12 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_multi_kernel(DBasis B, QCl
     const long long row0 = bra_rowoff[blockIdx.y];
     const size_t NcNc = (size_t)Nc * Nc;
     const int ket0 = blockIdx.x * G;
-    const int nsub = min(G, qc.n_ket - ket0);
+    int nsub = min(G, qc.n_ket - ket0);
+    if (qc.tri) {                                              // ket lists ascend in the first shell: the needed ones are a prefix
+        const int ok = (tid < nsub) && (B.pairs[ket_pairs[ket0 + tid]].A <= ab.A);
+        nsub = __syncthreads_count(ok);
+        if (nsub == 0) return;
+    }
 
     // ---- staging: bra tables once, ket tables per sub-quartet ----
     stage_components(B, ab.compoff_a, qc.nca, sLmn, sScale, tid, TF_ERI_THREADS);
@@ -429,6 +436,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     const int tid = threadIdx.x;
     const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
     const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
+    if (qc.tri && cd.A > ab.A) return;
     const int L = qc.L, nEab = qc.nEab, nEcd = qc.nEcd;
     const int La1 = qc.La + 1, Lb1 = qc.Lb + 1, Lc1 = qc.Lc + 1, Ld1 = qc.Ld + 1;
     const int nT = La1 * Lb1 * Lc1 * Ld1, nM = L / 2 + 1;

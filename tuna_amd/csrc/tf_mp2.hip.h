@@ -15,6 +15,7 @@
 #include <string>
 
 #include "../../include/tunafock.h"
+#include "tf_jkpacked.hip.h"
 
 namespace tfmp2 {
 
@@ -74,14 +75,16 @@ __global__ void mp2_energy_kernel(const double *__restrict__ g, const double *__
 
 // out[p][q][r][s] = sum C1[mu p] C2[nu q] C3[la r] C4[si s] (mu nu|la si); C_k are [N, n_k] row-major DEVICE matrices;
 // d_out [n1,n2,n3,n4] on the device.  Rows of the stored tensor are processed in slabs to bound the scratch.
-inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowmap, long long n_rows, int N, int ld, const double *dC1,
-                     int n1, const double *dC2, int n2, const double *dC3, int n3, const double *dC4, int n4, double *d_out,
-                     double *gemm_seconds, std::string &msg)
+// Packed layout (d_rowoff != nullptr): the rows of a slab are first materialised as full [N][ld] matrices (unpack_full_rows_kernel).
+inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowmap, const long long *d_rowoff, const int2 *d_row_ij,
+                     long long n_rows, int N, int ld, const double *dC1, int n1, const double *dC2, int n2, const double *dC3, int n3,
+                     const double *dC4, int n4, double *d_out, double *gemm_seconds, std::string &msg)
 {
     int rc = TF_OK;
     const long long n34 = (long long)n3 * n4;
     const long long row_len = (long long)N * ld;
-    double *dR = nullptr, *dQ = nullptr, *dQfull = nullptr, *dW = nullptr;
+    double *dR = nullptr, *dQ = nullptr, *dQfull = nullptr, *dW = nullptr, *dM = nullptr;
+    const bool packed = d_rowoff != nullptr;
     const double one = 1.0, zero = 0.0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     // slab of rows for the first quarter transformation: R = C3^T M needs n3*N doubles per row
@@ -89,19 +92,31 @@ inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowm
     if (n34 * N > 0x7fffffffLL || n34 > 0x7fffffffLL) { msg = "AO->MO transformation: dimension overflow"; return TF_EINVAL; }
     TFM_HIP(hipEventCreate(&e0));
     TFM_HIP(hipEventCreate(&e1));
+    if (packed) {
+        slab = std::max<long long>(1, std::min<long long>(slab, (long long)((2048LL << 20) / (row_len * (long long)sizeof(double)))));
+        TFM_HIP(hipMalloc((void **)&dM, (size_t)slab * row_len * sizeof(double)));
+    }
     TFM_HIP(hipMalloc((void **)&dR, (size_t)slab * n3 * N * sizeof(double)));
     TFM_HIP(hipMalloc((void **)&dQ, (size_t)std::max<long long>(1, n_rows) * n34 * sizeof(double)));
     TFM_HIP(hipEventRecord(e0, 0));
     for (long long r0 = 0; r0 < n_rows; r0 += slab) {
         const int nb = (int)std::min<long long>(slab, n_rows - r0);
+        const double *Mrows = d_eri + r0 * row_len;
+        if (packed) {
+            const long long tot = (long long)nb * row_len;
+            hipLaunchKernelGGL(unpack_full_rows_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 1 << 20)), dim3(256), 0, 0, d_eri,
+                               d_rowmap, d_rowoff, d_row_ij, r0, nb, N, ld, dM);
+            Mrows = dM;
+        }
         // R[row] (n3 x N, row-major) = C3^T (n3 x N) * M[row] (N x N, ld)
-        TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, N, n3, N, &one,
-                                               d_eri + r0 * row_len, ld, row_len, dC3, n3, 0, &zero, dR, N, (rocblas_stride)n3 * N, nb));
+        TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, N, n3, N, &one, Mrows, ld, row_len,
+                                               dC3, n3, 0, &zero, dR, N, (rocblas_stride)n3 * N, nb));
         // Q[row] (n3 x n4) = R[row] (n3 x N) * C4 (N x n4)
         TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, n4, n3, N, &one, dC4, n4, 0, dR, N,
                                                (rocblas_stride)n3 * N, &zero, dQ + r0 * n34, n4, (rocblas_stride)n34, nb));
     }
     (void)hipFree(dR); dR = nullptr;
+    if (dM) { (void)hipFree(dM); dM = nullptr; }
     TFM_HIP(hipMalloc((void **)&dQfull, (size_t)N * N * n34 * sizeof(double)));
     {
         const long long tot = (long long)N * N * n34;
@@ -123,6 +138,7 @@ inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowm
     if (gemm_seconds) { float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1); *gemm_seconds = ms * 1e-3; }
 done:
     if (dR) (void)hipFree(dR);
+    if (dM) (void)hipFree(dM);
     if (dQ) (void)hipFree(dQ);
     if (dQfull) (void)hipFree(dQfull);
     if (dW) (void)hipFree(dW);

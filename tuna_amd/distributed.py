@@ -14,19 +14,23 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def shell_pair_rows(shells, spherical: bool = True) -> np.ndarray:
-    """Row count of every bra shell pair (A >= B, A-major), the weights of the shard plan (tf_build_eri)."""
+def shell_pair_rows(shells, spherical: bool = True, layout: str = "packed") -> np.ndarray:
+    """Weight of every bra shell pair (A >= B, A-major) in the shard plan of tf_build_eri: the stored elements of its rows --
+    row (i,j) holds i(i+1)/2 + j + 1 values in the packed layout, and a constant number (so: the row count) in the rows layout."""
     dim = [(s.n_sph if spherical else s.n_cart) for s in shells]
+    off = np.concatenate([[0], np.cumsum(dim)]).astype(np.int64)
     w = []
     for A in range(len(shells)):
         for B in range(A + 1):
-            w.append(dim[A] * (dim[A] + 1) // 2 if A == B else dim[A] * dim[B])
+            i, j = np.meshgrid(np.arange(off[A], off[A + 1]), np.arange(off[B], off[B + 1]), indexing="ij")
+            keep = i >= j
+            w.append(int((i * (i + 1) // 2 + j + 1)[keep].sum()) if layout == "packed" else int(keep.sum()))
     return np.asarray(w, dtype=np.int64)
 
 
-def shard_owner(shells, world: int, spherical: bool = True) -> np.ndarray:
+def shard_owner(shells, world: int, spherical: bool = True, layout: str = "packed") -> np.ndarray:
     """owner[p] = rank that generates and keeps the rows of shell pair p -- the library's own plan (tf_shard_plan)."""
-    w = shell_pair_rows(shells, spherical)
+    w = shell_pair_rows(shells, spherical, layout)
     owner = np.zeros(len(w), dtype=np.int32)
     rc = _lib.lib().tf_shard_plan(len(w), _lib.ptr(w), int(world), _lib.ptr(owner))
     if rc != 0:
@@ -34,9 +38,9 @@ def shard_owner(shells, world: int, spherical: bool = True) -> np.ndarray:
     return owner
 
 
-def row_owner_matrix(shells, world: int, spherical: bool = True) -> np.ndarray:
+def row_owner_matrix(shells, world: int, spherical: bool = True, layout: str = "packed") -> np.ndarray:
     """owner[i, j] (i >= j) of every AO-pair row; -1 above the diagonal."""
-    owner = shard_owner(shells, world, spherical)
+    owner = shard_owner(shells, world, spherical, layout)
     dim = [(s.n_sph if spherical else s.n_cart) for s in shells]
     off = np.concatenate([[0], np.cumsum(dim)])
     N = int(off[-1])

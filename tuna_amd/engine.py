@@ -93,7 +93,13 @@ class Engine:
         return S
 
     # ---- two-electron ------------------------------------------------------------------------
-    def build_eri(self, spherical: bool = True):
+    LAYOUTS = {"auto": -1, "rows": 0, "packed": 1}
+
+    def build_eri(self, spherical: bool = True, layout: str | None = None):
+        """layout: "packed" (8-fold unique values, the default where the J/K kernel covers N), "rows" ((i >= j) x full [k][l])
+        or None / "auto"."""
+        if layout is not None:
+            self._check(self._L.tf_set_eri_layout(self._ctx, self.LAYOUTS[layout]))
         self._check(self._L.tf_build_eri(self._ctx, int(spherical)))
         self.spherical = spherical
         self.N = self.n_sph if spherical else self.n_cart
@@ -103,7 +109,8 @@ class Engine:
         b, r = C.c_int64(), C.c_int64()
         n, ld = C.c_int32(), C.c_int32()
         self._check(self._L.tf_eri_storage(self._ctx, b, r, n, ld))
-        return {"bytes": b.value, "rows": r.value, "N": n.value, "ld": ld.value}
+        return {"bytes": b.value, "rows": r.value, "N": n.value, "ld": ld.value,
+                "layout": "packed" if self._L.tf_eri_layout(self._ctx) == 1 else "rows"}
 
     def eri_timings(self) -> dict:
         t = np.zeros(4)
