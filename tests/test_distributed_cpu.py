@@ -83,7 +83,7 @@ def _worker(rank, world, port, tag, layout, ret):
         Jf, Kf = jk.numpy()
         errJ = float(np.abs(Jf - so.coulomb(P, Es)).max()); errK = float(np.abs(Kf - so.exchange(P, Es)).max())
         ii, jj = np.nonzero(owner >= 0)
-        load = (ii * (ii + 1) // 2 + jj + 1) if layout == "packed" else np.ones(len(ii), dtype=np.int64)   # stored values per row
+        load = tdist.packed_row_length(ii, jj) if layout == "packed" else np.ones(len(ii), dtype=np.int64)   # stored values per row
         mine = int(load[owner[ii, jj] == rank].sum()); total = int(load.sum())
         ret[rank] = (errJ, errK, mine, total)
     finally:
@@ -113,7 +113,8 @@ def test_shard_plan_deterministic_and_consistent_with_rows(layout):
     w = tdist.shell_pair_rows(shells, layout=layout)
     N = sum(s.n_sph for s in shells)
     npair = N * (N + 1) // 2
-    assert w.sum() == (npair * (npair + 1) // 2 if layout == "packed" else npair)
+    ii, jj = np.tril_indices(N)
+    assert w.sum() == (int(tdist.packed_row_length(ii, jj).sum()) if layout == "packed" else npair)
     for world in (1, 2, 4, 8):
         o1, o2 = tdist.shard_owner(shells, world, layout=layout), tdist.shard_owner(shells, world, layout=layout)
         assert np.array_equal(o1, o2)

@@ -60,7 +60,8 @@ struct tf_ctx {
     long long n_elems = 0;              // stored doubles
     long long *d_rowoff = nullptr;
     JKGroup *d_groups = nullptr;
-    int n_groups = 0, nseg = 1;
+    JKTask *d_tasks = nullptr;
+    int n_groups = 0, n_tasks = 0, nseg = 1;
     int *d_gfirst = nullptr;            // [2][N]: first / one-past-last group with i == a
     double *d_Psym = nullptr, *d_Pp = nullptr, *d_ypart = nullptr, *d_DI = nullptr, *d_DJ = nullptr, *d_Jt = nullptr, *d_D = nullptr;
     // instrumentation
@@ -120,14 +121,14 @@ static void free_eri(tf_ctx *ctx)
 {
     for (void *p : {(void *)ctx->d_eri, (void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
                     (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_groups,
-                    (void *)ctx->d_gfirst, (void *)ctx->d_Psym, (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ,
+                    (void *)ctx->d_gfirst, (void *)ctx->d_tasks, (void *)ctx->d_Psym, (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ,
                     (void *)ctx->d_Jt, (void *)ctx->d_D})
         if (p) (void)hipFree(p);
     ctx->d_eri = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
     ctx->d_Ppad = nullptr; ctx->d_J = nullptr; ctx->d_K = nullptr; ctx->d_P = nullptr;
-    ctx->d_rowoff = nullptr; ctx->d_groups = nullptr; ctx->d_gfirst = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
+    ctx->d_rowoff = nullptr; ctx->d_groups = nullptr; ctx->d_tasks = nullptr; ctx->d_gfirst = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
     ctx->d_ypart = nullptr; ctx->d_DI = nullptr; ctx->d_DJ = nullptr; ctx->d_Jt = nullptr; ctx->d_D = nullptr;
-    ctx->n_groups = 0; ctx->n_elems = 0;
+    ctx->n_groups = 0; ctx->n_tasks = 0; ctx->n_elems = 0;
     ctx->have_eri = false;
 }
 
@@ -375,11 +376,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         ctx->host_pairs[p].outoff_b = out_off(bs.shells[bs.pairs[p].B]);
     }
     HIPCHK(ctx, hipMemcpy(ctx->d_pairs, ctx->host_pairs.data(), (size_t)npairs * sizeof(DPair), hipMemcpyHostToDevice));
-    // layout: packed (8-fold unique, tf_jkpacked.hip.h) unless asked otherwise; its J/K kernel covers N <= 1024
+    // layout: packed (8-fold unique, tf_jkpacked.hip.h) unless asked otherwise
     int layout = ctx->layout_req;
     if (const char *e = getenv("TF_ERI_LAYOUT")) layout = (e[0] == 'p') ? 1 : (e[0] == 'r' ? 0 : layout);
     if (layout < 0) layout = 1;
-    if (N > 1024) layout = 0;
     ctx->layout = layout;
     const bool packed = layout == 1;
     std::vector<long long> pair_rows(npairs), pair_weight(npairs);
@@ -391,7 +391,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         for (int x = 0; x < out_dim(a); ++x)
             for (int y = 0; y < out_dim(b); ++y) {
                 const long long i = out_off(a) + x, j = out_off(b) + y;
-                if (i >= j) w += packed ? i * (i + 1) / 2 + j + 1 : 1;
+                if (i >= j) w += packed ? packed_row_len(i, j) : 1;
             }
         pair_weight[p] = w;
     }
@@ -418,39 +418,45 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     }
     std::vector<long long> rowoff;
     std::vector<JKGroup> groups;
+    std::vector<JKTask> tasks;
     std::vector<int> gfirst(2 * (size_t)N, 0);
     long long ypart_len = 0;
     if (packed) {
-        // owned rows in ascending pair index; row p holds the p + 1 pairs q <= p
+        // owned rows in ascending (i,j); row (i,j) holds the pairs (k,l) <= (i,j) at their padded indices (tf_jkpacked.hip.h)
         std::sort(row_ij.begin(), row_ij.end(), [](const int2 &u, const int2 &v) { return u.x != v.x ? u.x < v.x : u.y < v.y; });
         rowoff.resize(row_ij.size() + 1);
         long long off = 0;
         for (size_t r = 0; r < row_ij.size(); ++r) {
-            const long long pidx = (long long)row_ij[r].x * (row_ij[r].x + 1) / 2 + row_ij[r].y;
-            rowmap[(size_t)pidx] = (int)r;
+            rowmap[(size_t)row_ij[r].x * (row_ij[r].x + 1) / 2 + row_ij[r].y] = (int)r;
             rowoff[r] = off;
-            off += pidx + 1;
+            off += packed_row_len(row_ij[r].x, row_ij[r].y);
         }
         rowoff[row_ij.size()] = off;
         ctx->n_elems = off;
-        // workgroups: runs of consecutive j with the same i, longest rows first (they are dispatched in this order)
+        // groups: runs of consecutive j with the same i, longest rows first
         for (long long r = (long long)row_ij.size() - 1; r >= 0;) {
             long long r0 = r;
             while (r0 > 0 && row_ij[r0 - 1].x == row_ij[r].x && row_ij[r0 - 1].y == row_ij[r0].y - 1 && r - r0 + 1 < TF_JKP_JBB) --r0;
             JKGroup g{};
             g.i = row_ij[r].x; g.j0 = row_ij[r0].y; g.nr = (int)(r - r0 + 1); g.r0 = (int)r0;
+            for (int q = 0; q < TF_JKP_JBB; ++q) g.roff[q] = (int)(rowoff[r0 + std::min<long long>(q, r - r0)] - rowoff[r0]);
             g.yoff = ypart_len;
-            g.ylen = (long long)g.i * (g.i + 1) / 2 + row_ij[r].y + 1;
+            g.ylen = packed_row_len(row_ij[r].x, row_ij[r].y);
             ypart_len += g.ylen;
             groups.push_back(g);
             r = r0 - 1;
         }
-        for (int a = 0; a < N; ++a) gfirst[a] = gfirst[N + a] = 0;
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const int a = groups[gi].i;
             if (gfirst[N + a] == gfirst[a]) gfirst[a] = (int)gi;
             gfirst[N + a] = (int)gi + 1;
         }
+        // tasks (group, 128-column chunk), longest first: the hardware dispatches workgroups in this order
+        for (size_t gi = 0; gi < groups.size(); ++gi)
+            for (int c = 0; c * TF_JKP_CW <= groups[gi].i; ++c) tasks.push_back(JKTask{(int)gi, c});
+        std::stable_sort(tasks.begin(), tasks.end(), [&](const JKTask &u, const JKTask &v) {
+            return groups[u.group].i - u.chunk * TF_JKP_CW > groups[v.group].i - v.chunk * TF_JKP_CW;
+        });
     }
     ctx->n_rows = (long long)row_ij.size();
     const long long row_len = (long long)N * ld;
@@ -460,9 +466,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
     if (packed) {
         if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, groups, &ctx->d_groups, false)) ||
-            (rc = upload(ctx, gfirst, &ctx->d_gfirst, false)))
+            (rc = upload(ctx, gfirst, &ctx->d_gfirst, false)) || (rc = upload(ctx, tasks, &ctx->d_tasks, false)))
             return rc;
         ctx->n_groups = (int)groups.size();
+        ctx->n_tasks = (int)tasks.size();
     }
 
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
@@ -748,17 +755,18 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // ---- J/K scratch
     const size_t nn = (size_t)N * N;
     // (sized for two densities per pass)
-    const int Wjk = ((N + 63) / 64 + 1) / 2;                        // waves per workgroup of jk_packed_kernel
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, std::max(2, Wjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
+    const int NWjk = (N + TF_JKP_CW - 1) / TF_JKP_CW;               // column chunks of jk_packed_kernel
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, std::max(2, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     if (packed) {
-        const size_t npr = (size_t)N * (N + 1) / 2;
+        const size_t npr = (size_t)tri_off(N);                      // padded pair index space
         ctx->nseg = std::max(1, std::min(TF_JKP_SEG, ctx->n_groups / 32));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Psym, nn * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Pp, npr * sizeof(double)));
+        HIPCHK(ctx, hipMemset(ctx->d_Pp, 0, npr * sizeof(double)));   // pad slots stay zero
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_ypart, std::max<size_t>(1, (size_t)ypart_len) * sizeof(double)));
-        // column parts [.][N] followed by the per-wave row parts [.][W][N]
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, std::max<size_t>(1, (size_t)ctx->n_groups) * (1 + Wjk) * N * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, std::max<size_t>(1, (size_t)ctx->n_rows) * (1 + Wjk) * N * sizeof(double)));
+        // column parts [.][N] followed by the per-chunk row parts [.][NW][N]
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, std::max<size_t>(1, (size_t)ctx->n_groups) * (1 + NWjk) * N * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, std::max<size_t>(1, (size_t)ctx->n_rows) * (1 + NWjk) * N * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jt, (size_t)ctx->nseg * npr * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_D, 2 * nn * sizeof(double)));
     } else
@@ -855,21 +863,15 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
 static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st,
                             const int *nonsym)
 {
-    const int N = ctx->N, NW = (N + 63) / 64, W = (NW + 1) / 2;
-    const long long npr = (long long)N * (N + 1) / 2;
-    const size_t smem = (size_t)(TF_JKP_JBB + 1) * N * sizeof(double);
-    static size_t smem_set = 0;
-    if (smem > smem_set) {
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        smem_set = smem;
-    }
+    const int N = ctx->N, NW = (N + TF_JKP_CW - 1) / TF_JKP_CW;
+    const long long npr = tri_off(N);
     for (int d = 0; d < nd; ++d)                                 // one density per pass over the packed tensor
       for (int pass = 0; pass < ((nonsym && nonsym[d]) ? 2 : 1); ++pass) {
         const bool general = nonsym && nonsym[d];
         double *dD = (pass == 0) ? ctx->d_D : ctx->d_D + (size_t)N * N;
         hipLaunchKernelGGL(pack_density_kernel, dim3((N * N + 255) / 256), dim3(256), 0, st, dP[d], N, (general && pass == 0) ? 1 : 0,
                            ctx->d_Psym, ctx->d_Pp);
-        if (ctx->n_groups > 0) {
+        if (ctx->n_tasks > 0) {
             hipEvent_t ev_after = nullptr;
             if (ctx->prof_jk) {
                 if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
@@ -882,17 +884,17 @@ static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double
                     ctx->prof_used += 2;
                 }
             }
-            hipLaunchKernelGGL(jk_packed_kernel, dim3((unsigned)ctx->n_groups), dim3(64 * W), smem, st, ctx->d_eri, ctx->d_rowoff, ctx->d_groups,
-                               N, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, ctx->d_DI, ctx->d_DI + (size_t)ctx->n_groups * N, ctx->d_DJ,
-                               ctx->d_DJ + (size_t)ctx->n_rows * N);
+            hipLaunchKernelGGL(jk_packed_kernel, dim3((unsigned)ctx->n_tasks), dim3(64), 0, st, ctx->d_eri, ctx->d_rowoff, ctx->d_groups,
+                               ctx->d_tasks, N, NW, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, ctx->d_DI,
+                               ctx->d_DI + (size_t)ctx->n_groups * N, ctx->d_DJ, ctx->d_DJ + (size_t)ctx->n_rows * N);
             if (ev_after) (void)hipEventRecord(ev_after, st);
         }
         hipLaunchKernelGGL(jt_reduce_kernel, dim3((unsigned)((npr + 255) / 256), ctx->nseg), dim3(256), 0, st, ctx->d_ypart, ctx->d_groups,
                            ctx->n_groups, npr, ctx->d_Jt);
         hipLaunchKernelGGL(kd_reduce_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, st, ctx->d_DI, ctx->d_DI + (size_t)ctx->n_groups * N,
-                           ctx->d_DJ, ctx->d_DJ + (size_t)ctx->n_rows * N, W, ctx->d_gfirst, ctx->d_rowmap, N, dD);
+                           ctx->d_DJ, ctx->d_DJ + (size_t)ctx->n_rows * N, NW, ctx->d_gfirst, ctx->d_rowmap, N, dD);
         if (general && pass == 0) continue;
-        hipLaunchKernelGGL(jk_packed_final_kernel, dim3((N * N + 255) / 256), dim3(256), 0, st, ctx->d_D, dD, ctx->d_Jrow, W, ctx->d_Jt,
+        hipLaunchKernelGGL(jk_packed_final_kernel, dim3((N * N + 255) / 256), dim3(256), 0, st, ctx->d_D, dD, ctx->d_Jrow, NW, ctx->d_Jt,
                            ctx->nseg, ctx->d_rowmap, N, dJ[d], dK[d]);
       }
     return TF_OK;

@@ -2,9 +2,10 @@
 // Reference: calculate_coulomb_matrix tuna_scf.py:55-72 ("ijkl,kl->ij"), calculate_exchange_matrix tuna_scf.py:27-44
 // ("ilkj,kl->ij"); the reference keeps all 8 images of every (ij|kl) (pyx:1335-1342), here each unique value is stored once.
 //
-// Layout: pair index p = i(i+1)/2 + j (i >= j).  Row p of the tensor holds (ij|kl) for every pair q = k(k+1)/2 + l <= p,
-// contiguously, i.e. the tensor is the packed lower triangle of the symmetric npair x npair matrix; a rank stores the rows it owns
-// in ascending p with a row-offset table.  8 N^4 / 8 bytes instead of the reference's 8 N^4.
+// Layout: a pair (k >= l) has the padded index tri_off(k) + l, where every row k of the triangle starts at an EVEN index
+// (tri_off(k) = sum of the row lengths 1, 2, 3, ... each rounded up to even), so that 16-byte loads stay aligned; pad slots hold 0.
+// Row (i >= j) of the tensor holds (ij|kl) for every pair (k,l) <= (i,j) at [tri_off(k) + l], its length rounded up to even;
+// a rank stores the rows it owns in ascending (i,j) with a row-offset table.  N^4 bytes instead of the reference's 8 N^4.
 //
 // One pass over row (i,j) has to feed six outputs per element m = (ij|kl):
 //     Jd[ij] += m Pp[kl]                      (Pp[kl] = P[k][l] + P[l][k], or P[k][k])
@@ -13,25 +14,49 @@
 // (the four D terms at half weight when kl == ij), and K = D + D^T covers the transposed images when P is symmetric, as every SCF
 // density is.  A general P takes two passes: K = D(P^T) + D(P)^T (the einsum of scf:42 exactly).
 //
-// Kernel shape: a workgroup owns up to JBB rows (i; j0..j0+nr-1) sharing i; a wave owns two 64-column chunks of every triangle
-// row k (chunk c and its mirror NW-1-c, so all waves do the same work) and walks k up to i.  Lane-local accumulators: the
-// "column" sums (outputs indexed by l); the "row" sums (outputs indexed by k) are reduced across the wave with a transposing
-// butterfly on permlane swaps / DPP (no LDS) and written per wave.  Jt partials are written once per workgroup and column
-// (1/JBB of the tensor's bytes) and summed by jt_reduce_kernel.  No atomics anywhere: results are bitwise reproducible.
+// Kernel shape: a task = (group of up to JBB rows (i; j0..j0+nr-1) sharing i) x (one chunk of 128 columns); one wave per task, a
+// lane owns two adjacent columns (one 16-byte load per row and triangle row k) and walks k up to i.  Tasks are dispatched longest
+// first, so the triangle balances itself.  Lane-local accumulators: the "column" sums (outputs indexed by l); the "row" sums
+// (outputs indexed by k) are reduced across the wave with a transposing butterfly on permlane swaps / DPP (no LDS) and written
+// per task.  Jt partials are written once per group and column (1/JBB of the tensor's bytes) and summed by jt_reduce_kernel.
+// No atomics anywhere: results are bitwise reproducible.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #define TF_JKP_JBB 8
+#define TF_JKP_CW 128            // columns per chunk (2 per lane)
 #define TF_JKP_SEG 64            // segments of the group list in the Jt reduction
+
+// padded triangle: first index of row k, and the stored length of tensor row (i,j)
+__host__ __device__ inline long long tri_off(long long k) { const long long h = k >> 1; return 2 * h * (h + 1) + ((k & 1) ? k + 1 : 0); }
+__host__ __device__ inline long long packed_row_len(long long i, long long j) { return (tri_off(i) + j + 2) & ~1LL; }
 
 struct JKGroup {
     int i, j0, nr, r0;           // rows r0..r0+nr-1 (local numbering) = pairs (i, j0..j0+nr-1)
-    long long yoff;              // first element of this group's Jt partial (length = pair(i, j0+nr-1) + 1)
-    long long ylen;
+    long long yoff, ylen;        // this group's Jt partial: first element, length (= stored length of its last row)
+    int roff[TF_JKP_JBB];        // start of row r relative to row 0, in doubles
 };
+struct JKTask { int group, chunk; };
 
 __device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void st_stream(double *p, double v) { __builtin_nontemporal_store(v, p); }
+
+// Buffer addressing for the streaming loop: a wave-uniform descriptor (base in SGPRs), a wave-uniform byte offset (SGPR) and the
+// lane's 32-bit byte offset (one VGPR) -- no per-lane 64-bit address arithmetic.  AUX 2 = non-temporal (touched once).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <int AUX>
+__device__ __forceinline__ double2 buf_load2(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, unsigned uniform_off)
+{
+    return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, (int)uniform_off, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, unsigned uniform_off, double2 v)
+{
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs, (int)lane_off, (int)uniform_off, AUX);
+}
 
 // ---- wave-level sums without LDS traffic -----------------------------------------------------------------------------
 // gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even 16-lane rows between two registers: one
@@ -99,7 +124,8 @@ __device__ __forceinline__ double wave_sum1(double t)                   // every
     return sum8(t);
 }
 
-// X = P or P^T (dense [N][N], what the exchange terms contract with); Pp[k(k+1)/2+l] = P[k][l] + P[l][k] (k != l), P[k][k]
+// X = P or P^T (dense [N][N], what the exchange terms contract with); Pp[tri_off(k)+l] = P[k][l] + P[l][k] (k != l), P[k][k];
+// the pad slots of Pp stay zero (set once at allocation).
 __global__ void pack_density_kernel(const double *__restrict__ P, int N, int transpose, double *__restrict__ X, double *__restrict__ Pp)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,192 +133,254 @@ __global__ void pack_density_kernel(const double *__restrict__ P, int N, int tra
     const int k = e / N, l = e - k * N;
     const double a = P[e], b = P[(size_t)l * N + k];
     X[e] = transpose ? b : a;
-    if (l <= k) Pp[(size_t)k * (k + 1) / 2 + l] = (k == l) ? a : a + b;
+    if (l <= k) Pp[tri_off(k) + l] = (k == l) ? a : a + b;
 }
 
-// Per-wave state of one 64-column chunk: lane-local column sums and the P values of the lane's column.
-struct JKChunk {
-    int l;                               // column of this lane
-    double pil, pjl[TF_JKP_JBB];         // P[i][l], P[j_r][l]
-    double colI, colJ[TF_JKP_JBB];       // D[i][l], D[j_r][l] accumulators
+// Wave-uniform description of a task (lives in SGPRs).
+struct JKWave {
+    const double *T0, *Pp, *Pi, *Pj0;    // first row of the group; packed density; P[i][.]; P[j0][.]
+    int N, i, j0, nr, c0;                // c0 = first column of the chunk
+    unsigned roff8[TF_JKP_JBB];          // byte offset of row r from row 0
+    double *yg, *DIr_w, *DJr_w;
+    size_t rowW;
+    double ppij[TF_JKP_JBB];
 };
 
-enum { JKP_OFF = 0, JKP_DIAG = 1, JKP_FULL = 2 };
+// Per-lane state: the two columns l0, l0 + 1 of the lane
+struct JKLane {
+    int l0;
+    double2 pil, pjl[TF_JKP_JBB];        // P[i][l], P[j_r][l]
+    double2 colI, colJ[TF_JKP_JBB];      // D[i][l], D[j_r][l] accumulators
+};
 
-// One triangle row k < i of one chunk.  MODE FULL: every lane has l < k (no masks); DIAG: the 64x64 tile on the diagonal.
-template <int MODE>
-__device__ __forceinline__ void jkp_chunk_row(JKChunk &C, const double *const (&Tr)[TF_JKP_JBB], const double *__restrict__ Pp,
-                                              double *__restrict__ yrow, long long bk, int k, const double (&pjk)[TF_JKP_JBB], double pik,
-                                              const double (&ppij)[TF_JKP_JBB], double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double &rI)
+enum { JKP_DIAG = 1, JKP_FULL = 2 };
+
+// The values a lane needs from triangle row k < i: the JBB tensor elements of its two columns and Pp[kl].
+struct JKLoad { double2 m[TF_JKP_JBB], pp; };
+
+// MODE FULL: every lane has l < k (no masks); DIAG: the 128-column tile on the diagonal (a pair is present iff l0 <= k; the pad
+// slot after an odd-length row reads 0).  ALL8: the group has all JBB rows.
+template <bool ALL8, int MODE>
+__device__ __forceinline__ void jkp_load(JKLoad &L, int l0, int lane, const JKWave &U, int k)
 {
-    if (MODE == JKP_OFF) return;
-    const bool v = (MODE == JKP_FULL) || C.l <= k;
-    const double offd = (MODE == JKP_FULL || C.l < k) ? 1.0 : 0.0;
-    double m[TF_JKP_JBB];
+    const long long bk = tri_off(k) + U.c0;
+    const bool v = (MODE == JKP_FULL) || l0 <= k;
+    const __amdgpu_buffer_rsrc_t rt = buf_rsrc(U.T0 + bk), rp = buf_rsrc(U.Pp + bk);
+    const double2 zero = make_double2(0.0, 0.0);
 #pragma unroll
-    for (int r = 0; r < TF_JKP_JBB; ++r) m[r] = v ? ld_stream(Tr[r] + bk + C.l) : 0.0;
-    const double pp = v ? Pp[bk + C.l] : 0.0;
-    double jt = 0.0;
+    for (int r = 0; r < TF_JKP_JBB; ++r) L.m[r] = (v && (ALL8 || r < U.nr)) ? buf_load2<2>(rt, 16u * (unsigned)lane, U.roff8[r]) : zero;
+    L.pp = v ? buf_load2<0>(rp, 16u * (unsigned)lane, 0u) : zero;
+}
+
+// part 1: everything that needs only the lane's own P values (Jd, Jt, the row sums); part 2: the column sums, which need the
+// wave-uniform P[j_r][k], P[i][k] -- fetched through the scalar unit while part 1 runs.
+template <int MODE>
+__device__ __forceinline__ void jkp_row1(const JKLane &C, const JKLoad &L, const JKWave &U, int lane, int k, double (&jd)[TF_JKP_JBB],
+                                         double (&rJ)[TF_JKP_JBB], double &rI)
+{
+    const bool v = (MODE == JKP_FULL) || C.l0 <= k;
+    double2 jt = make_double2(0.0, 0.0);
+    rI = 0.0;
 #pragma unroll
     for (int r = 0; r < TF_JKP_JBB; ++r) {
-        const double mr = m[r];
-        jd[r] += mr * pp;
-        jt += mr * ppij[r];
-        rI += mr * C.pjl[r];
-        rJ[r] += mr * C.pil;
-        const double mc = (MODE == JKP_FULL) ? mr : mr * offd;
-        C.colI += mc * pjk[r];
-        C.colJ[r] += mc * pik;
+        const double2 m = L.m[r];
+        jd[r] += m.x * L.pp.x + m.y * L.pp.y;
+        jt.x += m.x * U.ppij[r]; jt.y += m.y * U.ppij[r];
+        const double2 pj = C.pjl[r];
+        rI += m.x * pj.x + m.y * pj.y;
+        rJ[r] = m.x * C.pil.x + m.y * C.pil.y;
     }
-    if (v) st_stream(yrow + C.l, jt);
+#if !defined(TF_JKP_EXP) || (TF_JKP_EXP != 1 && TF_JKP_EXP != 3)
+    if (v) buf_store2<2>(buf_rsrc(U.yg + tri_off(k) + U.c0), 16u * (unsigned)lane, 0u, jt);
+#else
+    if (jt.x == 1.2345e300) buf_store2<2>(buf_rsrc(U.yg + tri_off(k) + U.c0), 16u * (unsigned)lane, 0u, jt);
+#endif
+}
+
+template <int MODE>
+__device__ __forceinline__ void jkp_row2(JKLane &C, const JKLoad &L, int k, const double (&pjk)[TF_JKP_JBB], double pik)
+{
+    const double o0 = (MODE == JKP_FULL || C.l0 < k) ? 1.0 : 0.0, o1 = (MODE == JKP_FULL || C.l0 + 1 < k) ? 1.0 : 0.0;
+#pragma unroll
+    for (int r = 0; r < TF_JKP_JBB; ++r) {
+        const double mx = (MODE == JKP_FULL) ? L.m[r].x : L.m[r].x * o0, my = (MODE == JKP_FULL) ? L.m[r].y : L.m[r].y * o1;
+        C.colI.x += mx * pjk[r]; C.colI.y += my * pjk[r];
+        C.colJ[r].x += mx * pik; C.colJ[r].y += my * pik;
+    }
 }
 
 // The last triangle row k == i: row r ends at l == j_r, where the element (ij|ij) counts half in K and not at all in Jt.
-__device__ __forceinline__ void jkp_chunk_last(JKChunk &C, const JKGroup &g, const double *const (&Tr)[TF_JKP_JBB],
-                                               const double *__restrict__ Pp, double *__restrict__ yrow, long long bk,
-                                               const double (&pjk)[TF_JKP_JBB], double pik, const double (&ppij)[TF_JKP_JBB],
-                                               double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double &rI)
+__device__ __forceinline__ void jkp_last(JKLane &C, const JKWave &U, const double (&pjk)[TF_JKP_JBB], double pik,
+                                         double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double &rI)
 {
-    const int i = g.i, jlast = g.j0 + g.nr - 1;
-    const bool v = C.l <= jlast;
-    const double pp = v ? Pp[bk + C.l] : 0.0;
-    double jt = 0.0;
+    const int i = U.i, jlast = U.j0 + U.nr - 1;
+    const long long bk = tri_off(i);
+    rI = 0.0;
 #pragma unroll
-    for (int r = 0; r < TF_JKP_JBB; ++r) {
-        const int jr = g.j0 + r;
-        const bool vr = r < g.nr && C.l <= jr;
-        const double mr = vr ? ld_stream(Tr[r] + bk + C.l) : 0.0;
-        const bool diag = (C.l == jr);
-        jd[r] += mr * pp;
-        jt += diag ? 0.0 : mr * ppij[r];
-        const double mk = diag ? 0.5 * mr : mr;
-        rI += mk * C.pjl[r];
-        rJ[r] += mk * C.pil;
-        const double mc = (C.l < i) ? mk : 0.0;
-        C.colI += mc * pjk[r];
-        C.colJ[r] += mc * pik;
+    for (int r = 0; r < TF_JKP_JBB; ++r) rJ[r] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int l = C.l0 + e;
+        const bool v = l <= jlast;
+        const double pp = v ? U.Pp[bk + l] : 0.0;
+        const double pil = e ? C.pil.y : C.pil.x;
+        double jt = 0.0, cI = 0.0;
+#pragma unroll
+        for (int r = 0; r < TF_JKP_JBB; ++r) {
+            const int jr = U.j0 + r;
+            const bool vr = r < U.nr && l <= jr;
+            const double mr = vr ? ld_stream(U.T0 + (U.roff8[r] >> 3) + bk + l) : 0.0;
+            const bool diag = (l == jr);
+            jd[r] += mr * pp;
+            jt += diag ? 0.0 : mr * U.ppij[r];
+            const double mk = diag ? 0.5 * mr : mr;
+            rI += mk * (e ? C.pjl[r].y : C.pjl[r].x);
+            rJ[r] += mk * pil;
+            const double mc = (l < i) ? mk : 0.0;
+            cI += mc * pjk[r];
+            if (e) C.colJ[r].y += mc * pik; else C.colJ[r].x += mc * pik;
+        }
+        if (e) C.colI.y += cI; else C.colI.x += cI;
+        if (v) U.yg[bk + l] = jt;
+        else if (l == jlast + 1 && (l & 1)) U.yg[bk + l] = 0.0;        // pad slot of the group's last (odd-length) row
     }
-    if (v) st_stream(yrow + C.l, jt);
 }
 
-// Workgroup = W = ceil(NW / 2) waves (NW = ceil(N / 64) column chunks); wave w owns chunks cA = w and cB = NW - 1 - w, which
-// balances the triangle (chunk c is only populated for k >= 64 c).  After the P rows are staged in LDS the waves never meet again.
-// Outputs: Jd [n_rows][W] per-wave partials; ypart: Jt partials; DIc [G][N], DJc [n_rows][N]: column parts (l-indexed);
-// DIr [G][W][N], DJr [n_rows][W][N]: row parts per wave (k-indexed, written for 64 w <= k <= i).
-__global__ __launch_bounds__(512) void jk_packed_kernel(const double *__restrict__ T, const long long *__restrict__ rowoff,
-                                                        const JKGroup *__restrict__ groups, int N, const double *__restrict__ P,
-                                                        const double *__restrict__ Pp, double *__restrict__ Jd,
-                                                        double *__restrict__ ypart, double *__restrict__ DIc, double *__restrict__ DIr,
-                                                        double *__restrict__ DJc, double *__restrict__ DJr)
+template <bool ALL8>
+__device__ __forceinline__ void jkp_row_sums(const JKWave &U, int k, int lane, double (&rJ)[TF_JKP_JBB], double rI)
+{
+#if defined(TF_JKP_EXP) && TF_JKP_EXP >= 2
+    double t = rI;
+    for (int r = 0; r < TF_JKP_JBB; ++r) t += rJ[r];
+    if (t == 1.2345e300) U.DIr_w[k] = t;
+#else
+    const double tJ = wave_sum8(rJ);
+    const double tI = wave_sum1(rI);
+    if ((lane & 7) == 0 && (ALL8 || (lane >> 3) < U.nr)) U.DJr_w[(size_t)(lane >> 3) * U.rowW + k] = tJ;
+    if (lane == 0) U.DIr_w[k] = tI;
+#endif
+}
+
+// Rows k0 <= k < k1 of a task in one mode.  The loads of row k + 1 are issued before row k is consumed, so a wave always has a
+// full row of requests in flight; the wave-uniform P[j_r][k], P[i][k] come through the scalar unit while part 1 runs.
+template <bool ALL8, int MODE>
+__device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane &C, double (&jd)[TF_JKP_JBB], int k0, int k1, int lane)
 {
     constexpr int JBB = TF_JKP_JBB;
-    extern __shared__ double smem[];
-    const JKGroup g = groups[blockIdx.x];
-    const int W = blockDim.x >> 6, NW = (N + 63) >> 6;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // w in an SGPR: uniform loop control
-    const int i = g.i;
-    double *sPi = smem;                                  // P[i][.]
-    double *sPj = smem + N;                              // [JBB][N]  P[j_r][.]
-    for (int x = threadIdx.x; x < N; x += blockDim.x) {
-        sPi[x] = P[(size_t)i * N + x];
+    if (k0 >= k1) return;
+    JKLoad L, Nx;
+#if !defined(TF_JKP_EXP) || TF_JKP_EXP != 4
+    jkp_load<ALL8, MODE>(L, C.l0, lane, U, k0);
+#endif
+    for (int k = k0; k < k1; ++k) {
+#if defined(TF_JKP_EXP) && TF_JKP_EXP == 4
+        jkp_load<ALL8, MODE>(L, C.l0, lane, U, k);
+#else
+        jkp_load<ALL8, MODE>(Nx, C.l0, lane, U, min(k + 1, k1 - 1));
+#endif
+        double pjk[JBB];
 #pragma unroll
-        for (int r = 0; r < JBB; ++r) sPj[r * N + x] = (r < g.nr) ? P[(size_t)(g.j0 + r) * N + x] : 0.0;
+        for (int r = 0; r < JBB; ++r) pjk[r] = (ALL8 || r < U.nr) ? U.Pj0[(size_t)r * U.N + k] : 0.0;
+        const double pik = U.Pi[k];
+        double rJ[JBB], rI;
+        jkp_row1<MODE>(C, L, U, lane, k, jd, rJ, rI);
+        jkp_row_sums<ALL8>(U, k, lane, rJ, rI);
+        jkp_row2<MODE>(C, L, k, pjk, pik);
+#if !defined(TF_JKP_EXP) || TF_JKP_EXP != 4
+        L = Nx;
+#endif
     }
-    __syncthreads();
+}
 
-    const int cA = w, cB = NW - 1 - w;
-    const bool haveB = cB > cA;
-    JKChunk A, B;
-    A.l = cA * 64 + lane; B.l = cB * 64 + lane;
+template <bool ALL8>
+__device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lane, int group, int r0, double *__restrict__ Jd,
+                                         double *__restrict__ DIc, double *__restrict__ DJc)
+{
+    constexpr int JBB = TF_JKP_JBB;
+    const int N = U.N, i = U.i;
+    JKLane C;
+    C.l0 = U.c0 + 2 * lane;
     {
-        const bool inA = A.l < N, inB = haveB && B.l < N;
-        A.pil = inA ? sPi[A.l] : 0.0; B.pil = inB ? sPi[B.l] : 0.0;
-        A.colI = 0.0; B.colI = 0.0;
+        const bool in0 = C.l0 < N, in1 = C.l0 + 1 < N;
+        C.pil = make_double2(in0 ? U.Pi[C.l0] : 0.0, in1 ? U.Pi[C.l0 + 1] : 0.0);
+        C.colI = make_double2(0.0, 0.0);
 #pragma unroll
         for (int r = 0; r < JBB; ++r) {
-            A.pjl[r] = inA ? sPj[r * N + A.l] : 0.0; B.pjl[r] = inB ? sPj[r * N + B.l] : 0.0;
-            A.colJ[r] = 0.0; B.colJ[r] = 0.0;
+            const bool have = ALL8 || r < U.nr;
+            C.pjl[r] = make_double2((in0 && have) ? U.Pj0[(size_t)r * N + C.l0] : 0.0, (in1 && have) ? U.Pj0[(size_t)r * N + C.l0 + 1] : 0.0);
+            C.colJ[r] = make_double2(0.0, 0.0);
         }
     }
-    double ppij[JBB], jd[JBB];
-    const double *Tr[JBB];
+    double jd[JBB];
 #pragma unroll
-    for (int r = 0; r < JBB; ++r) {
-        const bool have = r < g.nr;                      // missing rows alias row 0 with zero weights everywhere
-        ppij[r] = have ? Pp[(size_t)i * (i + 1) / 2 + g.j0 + r] : 0.0;
-        Tr[r] = T + rowoff[g.r0 + (have ? r : 0)];
-        jd[r] = 0.0;
-    }
-    double *yg = ypart + g.yoff;
-    double *DIr_w = DIr + ((size_t)blockIdx.x * W + w) * N;
-    const size_t rowW = (size_t)W * N;
-    double *DJr_w = DJr + ((size_t)g.r0 * W + w) * N;     // + r * rowW
+    for (int r = 0; r < JBB; ++r) jd[r] = 0.0;
 
-    // one k-row of the wave: both chunks, then the row sums
-#define JKP_ROW(MA, MB)                                                                                                        \
-    {                                                                                                                          \
-        const long long bk = (long long)k * (k + 1) / 2;                                                                       \
-        double pjk[JBB], rJ[JBB], rI = 0.0;                                                                                    \
-        _Pragma("unroll") for (int r = 0; r < JBB; ++r) { pjk[r] = sPj[r * N + k]; rJ[r] = 0.0; }                            \
-        const double pik = sPi[k];                                                                                             \
-        jkp_chunk_row<MA>(A, Tr, Pp, yg + bk, bk, k, pjk, pik, ppij, jd, rJ, rI);                                              \
-        jkp_chunk_row<MB>(B, Tr, Pp, yg + bk, bk, k, pjk, pik, ppij, jd, rJ, rI);                                              \
-        const double tJ = wave_sum8(rJ);                                                                                       \
-        const double tI = wave_sum1(rI);                                                                                       \
-        if ((lane & 7) == 0 && (lane >> 3) < g.nr) DJr_w[(size_t)(lane >> 3) * rowW + k] = tJ;                                 \
-        if (lane == 0) DIr_w[k] = tI;                                                                                          \
-    }
-
-    if (64 * cA <= i) {
-        const int kA1 = min(64 * cA + 64, i);                          // end of A's diagonal tile (exclusive), rows k < i only
-        const int kB0 = haveB ? min(64 * cB, i) : i;                   // B joins here
-        const int kB1 = haveB ? min(64 * cB + 64, i) : i;
-        int k = 64 * cA;
-        for (; k < kA1; ++k) JKP_ROW(JKP_DIAG, JKP_OFF)
-        for (; k < kB0; ++k) JKP_ROW(JKP_FULL, JKP_OFF)
-        for (; k < kB1; ++k) JKP_ROW(JKP_FULL, JKP_DIAG)
-        for (; k < i; ++k) JKP_ROW(JKP_FULL, JKP_FULL)
-        {   // k == i
-            const long long bk = (long long)i * (i + 1) / 2;
-            double pjk[JBB], rJ[JBB], rI = 0.0;
+    const int kd1 = min(U.c0 + TF_JKP_CW, i);                         // end of the diagonal tile (exclusive), rows k < i only
+    jkp_segment<ALL8, JKP_DIAG>(U, C, jd, U.c0, kd1, lane);
+    jkp_segment<ALL8, JKP_FULL>(U, C, jd, kd1, i, lane);
+    {   // k == i
+        double pjk[JBB], rJ[JBB], rI;
 #pragma unroll
-            for (int r = 0; r < JBB; ++r) { pjk[r] = sPj[r * N + i]; rJ[r] = 0.0; }
-            const double pik = sPi[i];
-            jkp_chunk_last(A, g, Tr, Pp, yg + bk, bk, pjk, pik, ppij, jd, rJ, rI);
-            if (haveB && 64 * cB <= i) jkp_chunk_last(B, g, Tr, Pp, yg + bk, bk, pjk, pik, ppij, jd, rJ, rI);
-            const double tJ = wave_sum8(rJ);
-            const double tI = wave_sum1(rI);
-            if ((lane & 7) == 0 && (lane >> 3) < g.nr) DJr_w[(size_t)(lane >> 3) * rowW + i] = tJ;
-            if (lane == 0) DIr_w[i] = tI;
+        for (int r = 0; r < JBB; ++r) pjk[r] = (ALL8 || r < U.nr) ? U.Pj0[(size_t)r * N + i] : 0.0;
+        const double pik = U.Pi[i];
+        jkp_last(C, U, pjk, pik, jd, rJ, rI);
+        jkp_row_sums<ALL8>(U, i, lane, rJ, rI);
+    }
+    // column parts (every column l < N of the group belongs to exactly one task)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int l = C.l0 + e;
+        if (l < N) {
+            DIc[(size_t)group * N + l] = e ? C.colI.y : C.colI.x;
+#pragma unroll
+            for (int r = 0; r < JBB; ++r)
+                if (ALL8 || r < U.nr) DJc[(size_t)(r0 + r) * N + l] = e ? C.colJ[r].y : C.colJ[r].x;
         }
-    }
-#undef JKP_ROW
-    // column parts (every column l < N belongs to exactly one wave)
-    if (A.l < N) {
-        DIc[(size_t)blockIdx.x * N + A.l] = A.colI;
-#pragma unroll
-        for (int r = 0; r < JBB; ++r)
-            if (r < g.nr) DJc[(size_t)(g.r0 + r) * N + A.l] = A.colJ[r];
-    }
-    if (haveB && B.l < N) {
-        DIc[(size_t)blockIdx.x * N + B.l] = B.colI;
-#pragma unroll
-        for (int r = 0; r < JBB; ++r)
-            if (r < g.nr) DJc[(size_t)(g.r0 + r) * N + B.l] = B.colJ[r];
     }
     {
         const double t = wave_sum8(jd);
-        if ((lane & 7) == 0 && (lane >> 3) < g.nr) Jd[(size_t)(g.r0 + (lane >> 3)) * W + w] = t;
+        if ((lane & 7) == 0 && (ALL8 || (lane >> 3) < U.nr)) Jd[(size_t)(r0 + (lane >> 3)) * NW + c] = t;
     }
 }
 
-// Jt partial sums: groups are sorted by descending partial length, so the groups that cover column q are a prefix of the list.
-// grid (ceil(npair/256), SEG): segment s sums its slice of that prefix; out[s][q].
+// One wave per task (group, chunk); NW = ceil(N / 128) chunks; only tasks with 128 chunk <= i exist.
+// Outputs: Jd [n_rows][NW] per-task partials; ypart: Jt partials; DIc [G][N], DJc [n_rows][N]: column parts (l-indexed);
+// DIr [G][NW][N], DJr [n_rows][NW][N]: row parts per task (k-indexed, written for 128 chunk <= k <= i).
+__global__ __launch_bounds__(64) void jk_packed_kernel(const double *__restrict__ T, const long long *__restrict__ rowoff,
+                                                       const JKGroup *__restrict__ groups, const JKTask *__restrict__ tasks, int N,
+                                                       int NW, const double *__restrict__ P, const double *__restrict__ Pp,
+                                                       double *__restrict__ Jd, double *__restrict__ ypart, double *__restrict__ DIc,
+                                                       double *__restrict__ DIr, double *__restrict__ DJc, double *__restrict__ DJr)
+{
+    constexpr int JBB = TF_JKP_JBB;
+    const JKTask t = tasks[blockIdx.x];
+    const JKGroup g = groups[t.group];
+    const int lane = threadIdx.x;
+    JKWave U;
+    U.T0 = T + rowoff[g.r0]; U.Pp = Pp; U.Pi = P + (size_t)g.i * N; U.Pj0 = P + (size_t)g.j0 * N;
+    U.N = N; U.i = g.i; U.j0 = g.j0; U.nr = g.nr; U.c0 = t.chunk * TF_JKP_CW;
+    U.yg = ypart + g.yoff;
+    U.DIr_w = DIr + ((size_t)t.group * NW + t.chunk) * N;
+    U.rowW = (size_t)NW * N;
+    U.DJr_w = DJr + ((size_t)g.r0 * NW + t.chunk) * N;
+#pragma unroll
+    for (int r = 0; r < JBB; ++r) {
+        U.roff8[r] = 8u * (unsigned)g.roff[r];
+        U.ppij[r] = (r < g.nr) ? Pp[tri_off(g.i) + g.j0 + r] : 0.0;
+    }
+    if (g.nr == JBB)
+        jkp_task<true>(U, NW, t.chunk, lane, t.group, g.r0, Jd, DIc, DJc);
+    else
+        jkp_task<false>(U, NW, t.chunk, lane, t.group, g.r0, Jd, DIc, DJc);
+}
+
+// Jt partial sums over the padded pair index q: groups are sorted by descending partial length, so the groups that cover q are
+// a prefix of the list.  grid (ceil(NP/256), SEG): segment s sums its slice of that prefix; out[s][q].
 __global__ __launch_bounds__(256) void jt_reduce_kernel(const double *__restrict__ ypart, const JKGroup *__restrict__ groups, int n_groups,
-                                                        long long npair, double *__restrict__ out)
+                                                        long long NP, double *__restrict__ out)
 {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= npair) return;
+    if (q >= NP) return;
     const int per = (n_groups + gridDim.y - 1) / gridDim.y;
     const int g0 = blockIdx.y * per, g1 = min(n_groups, g0 + per);
     double s = 0.0;
@@ -301,13 +389,13 @@ __global__ __launch_bounds__(256) void jt_reduce_kernel(const double *__restrict
         if (groups[g].ylen <= q) break;
         s += ypart[groups[g].yoff + q];
     }
-    out[(size_t)blockIdx.y * npair + q] = s;
+    out[(size_t)blockIdx.y * NP + q] = s;
 }
 
-// D[a][x] = sum over groups with i == a of (column part + row parts of the waves)[x] + the same over owned rows (i > a, j == a).
+// D[a][x] = sum over groups with i == a of (column part + row parts of the chunks)[x] + the same over owned rows (i > a, j == a).
 // grid (N, ceil(N/64)), 256 threads = 4 slices x 64 columns; gfirst[a]..gfirst[N+a] are the groups with i == a.
 __global__ __launch_bounds__(256) void kd_reduce_kernel(const double *__restrict__ DIc, const double *__restrict__ DIr,
-                                                        const double *__restrict__ DJc, const double *__restrict__ DJr, int W,
+                                                        const double *__restrict__ DJc, const double *__restrict__ DJr, int NW,
                                                         const int *__restrict__ gfirst, const int *__restrict__ rowmap, int N,
                                                         double *__restrict__ D)
 {
@@ -315,20 +403,20 @@ __global__ __launch_bounds__(256) void kd_reduce_kernel(const double *__restrict
     const int a = blockIdx.x;
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int x = blockIdx.y * 64 + lane;
-    const int nw = min(W, (x >> 6) + 1);                  // waves whose first chunk starts at or before x
+    const int nw = min(NW, x / TF_JKP_CW + 1);            // chunks that start at or before x
     double s = 0.0;
     if (x < N) {
         if (x <= a)
             for (int g = gfirst[a] + sl; g < gfirst[N + a]; g += 4) {
                 double t = DIc[(size_t)g * N + x];
-                for (int w = 0; w < nw; ++w) t += DIr[((size_t)g * W + w) * N + x];
+                for (int w = 0; w < nw; ++w) t += DIr[((size_t)g * NW + w) * N + x];
                 s += t;
             }
         for (int i = max(a + 1, x) + sl; i < N; i += 4) {
             const int r = rowmap[(size_t)i * (i + 1) / 2 + a];
             if (r < 0) continue;
             double t = DJc[(size_t)r * N + x];
-            for (int w = 0; w < nw; ++w) t += DJr[((size_t)r * W + w) * N + x];
+            for (int w = 0; w < nw; ++w) t += DJr[((size_t)r * NW + w) * N + x];
             s += t;
         }
     }
@@ -338,8 +426,8 @@ __global__ __launch_bounds__(256) void kd_reduce_kernel(const double *__restrict
 }
 
 // K = D + D2^T (D2 = D for a symmetric density; for a general one D = D(P^T), D2 = D(P));
-// J[i][j] = sum_w Jd[row(ij)][w] (owned rows) + sum_s Jt_s[pair(ij)]
-__global__ void jk_packed_final_kernel(const double *__restrict__ D, const double *__restrict__ D2, const double *__restrict__ Jd, int W,
+// J[a][b] = sum over the chunks of Jd[row(ab)] (owned rows) + sum_s Jt_s[pair(ab)]
+__global__ void jk_packed_final_kernel(const double *__restrict__ D, const double *__restrict__ D2, const double *__restrict__ Jd, int NW,
                                        const double *__restrict__ Jt, int nseg, const int *__restrict__ rowmap, int N,
                                        double *__restrict__ J, double *__restrict__ K)
 {
@@ -348,22 +436,24 @@ __global__ void jk_packed_final_kernel(const double *__restrict__ D, const doubl
     const int a = e / N, b = e - a * N;
     K[e] = D[e] + D2[(size_t)b * N + a];
     const int hi = max(a, b), lo = min(a, b);
-    const long long p = (long long)hi * (hi + 1) / 2 + lo, npair = (long long)N * (N + 1) / 2;
-    const int r = rowmap[p];
+    const long long NP = tri_off(N), q = tri_off(hi) + lo;
+    const int r = rowmap[(size_t)hi * (hi + 1) / 2 + lo];
     double s = 0.0;
     if (r >= 0)
-        for (int w = 0; w < W; ++w) s += Jd[(size_t)r * W + w];
-    for (int t = 0; t < nseg; ++t) s += Jt[(size_t)t * npair + p];
+        for (int w = 0; w <= hi / TF_JKP_CW; ++w) s += Jd[(size_t)r * NW + w];
+    for (int t = 0; t < nseg; ++t) s += Jt[(size_t)t * NP + q];
     J[e] = s;
 }
 
-__device__ __forceinline__ void unpair(long long q, int &k, int &l)
+// padded index -> (k, l); l > k marks a pad slot
+__device__ __forceinline__ void unpair_padded(long long x, int &k, int &l)
 {
-    long long kk = (long long)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-    while (kk * (kk + 1) / 2 > q) --kk;
-    while ((kk + 1) * (kk + 2) / 2 <= q) ++kk;
+    long long kk = (long long)(sqrt(2.0 * (double)x + 1.0)) - 1;
+    if (kk < 0) kk = 0;
+    while (tri_off(kk) > x) --kk;
+    while (tri_off(kk + 1) <= x) ++kk;
     k = (int)kk;
-    l = (int)(q - kk * (kk + 1) / 2);
+    l = (int)(x - tri_off(kk));
 }
 
 struct OutRowP {
@@ -374,7 +464,7 @@ struct OutRowP {
     long long dst_off;     // offset of the packed row in the stored tensor
 };
 
-// packed tensor row (i,j) = bra transform of the ket-transformed slab, keeping only pairs (k >= l) up to (i,j)
+// packed tensor row (i,j) = bra transform of the ket-transformed slab, keeping only pairs (k >= l) up to (i,j); pad slots <- 0
 __global__ void xform_bra_store_packed(const double *__restrict__ in, double *__restrict__ eri, const OutRowP *__restrict__ rows,
                                        long long row_len, int ld, const int *__restrict__ ptr, const int *__restrict__ idx,
                                        const double *__restrict__ val)
@@ -382,17 +472,19 @@ __global__ void xform_bra_store_packed(const double *__restrict__ in, double *__
     const OutRowP R = rows[blockIdx.y];
     const double *__restrict__ src = in + R.slab_off * row_len;
     double *__restrict__ dst = eri + R.dst_off;
-    const long long len = (long long)R.i * (R.i + 1) / 2 + R.j + 1;
+    const long long len = packed_row_len(R.i, R.j);
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < len; q += (long long)gridDim.x * blockDim.x) {
         int k, l;
-        unpair(q, k, l);
-        const long long x = (long long)k * ld + l;
+        unpair_padded(q, k, l);
         double s = 0.0;
-        for (int qa = ptr[R.i]; qa < ptr[R.i + 1]; ++qa) {
-            const long long ra = (long long)(idx[qa] - R.cartA) * R.ncb;
-            double t = 0.0;
-            for (int qb = ptr[R.j]; qb < ptr[R.j + 1]; ++qb) t += val[qb] * src[(ra + (idx[qb] - R.cartB)) * row_len + x];
-            s += val[qa] * t;
+        if (l <= k && (k < R.i || l <= R.j)) {
+            const long long x = (long long)k * ld + l;
+            for (int qa = ptr[R.i]; qa < ptr[R.i + 1]; ++qa) {
+                const long long ra = (long long)(idx[qa] - R.cartA) * R.ncb;
+                double t = 0.0;
+                for (int qb = ptr[R.j]; qb < ptr[R.j + 1]; ++qb) t += val[qb] * src[(ra + (idx[qb] - R.cartB)) * row_len + x];
+                s += val[qa] * t;
+            }
         }
         dst[q] = s;
     }
@@ -401,10 +493,11 @@ __global__ void xform_bra_store_packed(const double *__restrict__ in, double *__
 __device__ __forceinline__ double packed_element(const double *__restrict__ eri, const int *__restrict__ rowmap,
                                                  const long long *__restrict__ rowoff, int i, int j, int k, int l)
 {
-    const long long p = (long long)max(i, j) * (max(i, j) + 1) / 2 + min(i, j);
-    const long long q = (long long)max(k, l) * (max(k, l) + 1) / 2 + min(k, l);
+    const int ih = max(i, j), il = min(i, j), kh = max(k, l), kl = min(k, l);
+    const long long p = (long long)ih * (ih + 1) / 2 + il, q = (long long)kh * (kh + 1) / 2 + kl;
     const int r = rowmap[max(p, q)];
-    return (r >= 0) ? eri[rowoff[r] + min(p, q)] : 0.0;
+    if (r < 0) return 0.0;
+    return eri[rowoff[r] + (p >= q ? tri_off(kh) + kl : tri_off(ih) + il)];
 }
 
 // packed -> dense N^4 with all images (what the reference leaves in ERI_AO, pyx:1335-1342).  On several ranks an element

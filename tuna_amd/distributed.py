@@ -14,9 +14,21 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def packed_tri_offset(k):
+    """First padded index of row k of the (k >= l) triangle: every row starts at an even index (tf_jkpacked.hip.h: tri_off)."""
+    k = np.asarray(k, dtype=np.int64)
+    h = k >> 1
+    return 2 * h * (h + 1) + np.where(k & 1, k + 1, 0)
+
+
+def packed_row_length(i, j):
+    """Stored doubles of tensor row (i >= j) in the packed layout: the pairs (k,l) <= (i,j), rounded up to even."""
+    return (packed_tri_offset(i) + np.asarray(j, dtype=np.int64) + 2) & ~np.int64(1)
+
+
 def shell_pair_rows(shells, spherical: bool = True, layout: str = "packed") -> np.ndarray:
-    """Weight of every bra shell pair (A >= B, A-major) in the shard plan of tf_build_eri: the stored elements of its rows --
-    row (i,j) holds i(i+1)/2 + j + 1 values in the packed layout, and a constant number (so: the row count) in the rows layout."""
+    """Weight of every bra shell pair (A >= B, A-major) in the shard plan of tf_build_eri: the stored elements of its rows
+    (packed layout), or its row count (rows layout, every row has the same length)."""
     dim = [(s.n_sph if spherical else s.n_cart) for s in shells]
     off = np.concatenate([[0], np.cumsum(dim)]).astype(np.int64)
     w = []
@@ -24,7 +36,7 @@ def shell_pair_rows(shells, spherical: bool = True, layout: str = "packed") -> n
         for B in range(A + 1):
             i, j = np.meshgrid(np.arange(off[A], off[A + 1]), np.arange(off[B], off[B + 1]), indexing="ij")
             keep = i >= j
-            w.append(int((i * (i + 1) // 2 + j + 1)[keep].sum()) if layout == "packed" else int(keep.sum()))
+            w.append(int(packed_row_length(i, j)[keep].sum()) if layout == "packed" else int(keep.sum()))
     return np.asarray(w, dtype=np.int64)
 
 
