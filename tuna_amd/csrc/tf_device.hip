@@ -61,7 +61,8 @@ struct tf_ctx {
     long long *d_rowoff = nullptr;
     JKGroup *d_groups = nullptr;
     JKTask *d_tasks = nullptr;
-    int n_groups = 0, n_tasks = 0, nseg = 1;
+    JKSuper *d_supers = nullptr;
+    int n_groups = 0, n_tasks = 0, n_supers = 0, nseg = 1;
     int *d_gfirst = nullptr;            // [2][N]: first / one-past-last group with i == a
     double *d_Psym = nullptr, *d_Pp = nullptr, *d_ypart = nullptr, *d_DI = nullptr, *d_DJ = nullptr, *d_Jt = nullptr, *d_D = nullptr;
     // instrumentation
@@ -121,14 +122,14 @@ static void free_eri(tf_ctx *ctx)
 {
     for (void *p : {(void *)ctx->d_eri, (void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
                     (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_groups,
-                    (void *)ctx->d_gfirst, (void *)ctx->d_tasks, (void *)ctx->d_Psym, (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ,
+                    (void *)ctx->d_gfirst, (void *)ctx->d_tasks, (void *)ctx->d_supers, (void *)ctx->d_Psym, (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ,
                     (void *)ctx->d_Jt, (void *)ctx->d_D})
         if (p) (void)hipFree(p);
     ctx->d_eri = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
     ctx->d_Ppad = nullptr; ctx->d_J = nullptr; ctx->d_K = nullptr; ctx->d_P = nullptr;
-    ctx->d_rowoff = nullptr; ctx->d_groups = nullptr; ctx->d_tasks = nullptr; ctx->d_gfirst = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
+    ctx->d_rowoff = nullptr; ctx->d_groups = nullptr; ctx->d_tasks = nullptr; ctx->d_supers = nullptr; ctx->d_gfirst = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
     ctx->d_ypart = nullptr; ctx->d_DI = nullptr; ctx->d_DJ = nullptr; ctx->d_Jt = nullptr; ctx->d_D = nullptr;
-    ctx->n_groups = 0; ctx->n_tasks = 0; ctx->n_elems = 0;
+    ctx->n_groups = 0; ctx->n_tasks = 0; ctx->n_supers = 0; ctx->n_elems = 0;
     ctx->have_eri = false;
 }
 
@@ -419,6 +420,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     std::vector<long long> rowoff;
     std::vector<JKGroup> groups;
     std::vector<JKTask> tasks;
+    std::vector<JKSuper> supers;
     std::vector<int> gfirst(2 * (size_t)N, 0);
     long long ypart_len = 0;
     if (packed) {
@@ -440,9 +442,6 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             JKGroup g{};
             g.i = row_ij[r].x; g.j0 = row_ij[r0].y; g.nr = (int)(r - r0 + 1); g.r0 = (int)r0;
             for (int q = 0; q < TF_JKP_JBB; ++q) g.roff[q] = (int)(rowoff[r0 + std::min<long long>(q, r - r0)] - rowoff[r0]);
-            g.yoff = ypart_len;
-            g.ylen = packed_row_len(row_ij[r].x, row_ij[r].y);
-            ypart_len += g.ylen;
             groups.push_back(g);
             r = r0 - 1;
         }
@@ -451,11 +450,23 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             if (gfirst[N + a] == gfirst[a]) gfirst[a] = (int)gi;
             gfirst[N + a] = (int)gi + 1;
         }
-        // tasks (group, 128-column chunk), longest first: the hardware dispatches workgroups in this order
-        for (size_t gi = 0; gi < groups.size(); ++gi)
-            for (int c = 0; c * TF_JKP_CW <= groups[gi].i; ++c) tasks.push_back(JKTask{(int)gi, c});
+        // super-groups: up to TF_JKP_W adjacent groups with the same i share a workgroup and one Jt partial
+        for (size_t gi = 0; gi < groups.size();) {
+            size_t ge = gi + 1;
+            while (ge < groups.size() && groups[ge].i == groups[gi].i && ge - gi < TF_JKP_W) ++ge;
+            JKSuper sg{};
+            sg.g0 = (int)gi; sg.ng = (int)(ge - gi);
+            sg.yoff = ypart_len;
+            sg.ylen = packed_row_len(groups[gi].i, groups[gi].j0 + groups[gi].nr - 1);   // the first group ends last
+            ypart_len += sg.ylen;
+            supers.push_back(sg);
+            gi = ge;
+        }
+        // tasks (super-group, 128-column chunk), longest first: the hardware dispatches workgroups in this order
+        for (size_t si = 0; si < supers.size(); ++si)
+            for (int c = 0; c * TF_JKP_CW <= groups[supers[si].g0].i; ++c) tasks.push_back(JKTask{(int)si, c});
         std::stable_sort(tasks.begin(), tasks.end(), [&](const JKTask &u, const JKTask &v) {
-            return groups[u.group].i - u.chunk * TF_JKP_CW > groups[v.group].i - v.chunk * TF_JKP_CW;
+            return groups[supers[u.super].g0].i - u.chunk * TF_JKP_CW > groups[supers[v.super].g0].i - v.chunk * TF_JKP_CW;
         });
     }
     ctx->n_rows = (long long)row_ij.size();
@@ -466,10 +477,12 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
     if (packed) {
         if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, groups, &ctx->d_groups, false)) ||
-            (rc = upload(ctx, gfirst, &ctx->d_gfirst, false)) || (rc = upload(ctx, tasks, &ctx->d_tasks, false)))
+            (rc = upload(ctx, gfirst, &ctx->d_gfirst, false)) || (rc = upload(ctx, tasks, &ctx->d_tasks, false)) ||
+            (rc = upload(ctx, supers, &ctx->d_supers, false)))
             return rc;
         ctx->n_groups = (int)groups.size();
         ctx->n_tasks = (int)tasks.size();
+        ctx->n_supers = (int)supers.size();
     }
 
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
@@ -759,7 +772,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, std::max(2, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     if (packed) {
         const size_t npr = (size_t)tri_off(N);                      // padded pair index space
-        ctx->nseg = std::max(1, std::min(TF_JKP_SEG, ctx->n_groups / 32));
+        ctx->nseg = std::max(1, std::min(TF_JKP_SEG, ctx->n_supers / 32));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Psym, nn * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Pp, npr * sizeof(double)));
         HIPCHK(ctx, hipMemset(ctx->d_Pp, 0, npr * sizeof(double)));   // pad slots stay zero
@@ -884,13 +897,13 @@ static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double
                     ctx->prof_used += 2;
                 }
             }
-            hipLaunchKernelGGL(jk_packed_kernel, dim3((unsigned)ctx->n_tasks), dim3(64), 0, st, ctx->d_eri, ctx->d_rowoff, ctx->d_groups,
-                               ctx->d_tasks, N, NW, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, ctx->d_DI,
+            hipLaunchKernelGGL(jk_packed_kernel, dim3((unsigned)ctx->n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, ctx->d_rowoff,
+                               ctx->d_groups, ctx->d_supers, ctx->d_tasks, N, NW, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, ctx->d_DI,
                                ctx->d_DI + (size_t)ctx->n_groups * N, ctx->d_DJ, ctx->d_DJ + (size_t)ctx->n_rows * N);
             if (ev_after) (void)hipEventRecord(ev_after, st);
         }
-        hipLaunchKernelGGL(jt_reduce_kernel, dim3((unsigned)((npr + 255) / 256), ctx->nseg), dim3(256), 0, st, ctx->d_ypart, ctx->d_groups,
-                           ctx->n_groups, npr, ctx->d_Jt);
+        hipLaunchKernelGGL(jt_reduce_kernel, dim3((unsigned)((npr + 255) / 256), ctx->nseg), dim3(256), 0, st, ctx->d_ypart, ctx->d_supers,
+                           ctx->n_supers, npr, ctx->d_Jt);
         hipLaunchKernelGGL(kd_reduce_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, st, ctx->d_DI, ctx->d_DI + (size_t)ctx->n_groups * N,
                            ctx->d_DJ, ctx->d_DJ + (size_t)ctx->n_rows * N, NW, ctx->d_gfirst, ctx->d_rowmap, N, dD);
         if (general && pass == 0) continue;

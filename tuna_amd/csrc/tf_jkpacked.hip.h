@@ -33,10 +33,14 @@ __host__ __device__ inline long long packed_row_len(long long i, long long j) { 
 
 struct JKGroup {
     int i, j0, nr, r0;           // rows r0..r0+nr-1 (local numbering) = pairs (i, j0..j0+nr-1)
-    long long yoff, ylen;        // this group's Jt partial: first element, length (= stored length of its last row)
     int roff[TF_JKP_JBB];        // start of row r relative to row 0, in doubles
 };
-struct JKTask { int group, chunk; };
+#define TF_JKP_W 4                // groups (waves) per workgroup: their Jt partials are merged in LDS before they are written
+#define TF_JKP_KB 4               // triangle rows per merge block
+static_assert(TF_JKP_KB <= TF_JKP_W, "one wave per merged row");
+// up to TF_JKP_W adjacent groups with the same i share one Jt partial (length = stored length of the first, longest group)
+struct JKSuper { int g0, ng; long long yoff, ylen; };
+struct JKTask { int super, chunk; };
 
 __device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
 
@@ -175,10 +179,9 @@ __device__ __forceinline__ void jkp_load(JKLoad &L, int l0, int lane, const JKWa
 // part 1: everything that needs only the lane's own P values (Jd, Jt, the row sums); part 2: the column sums, which need the
 // wave-uniform P[j_r][k], P[i][k] -- fetched through the scalar unit while part 1 runs.
 template <int MODE>
-__device__ __forceinline__ void jkp_row1(const JKLane &C, const JKLoad &L, const JKWave &U, int lane, int k, double (&jd)[TF_JKP_JBB],
-                                         double (&rJ)[TF_JKP_JBB], double &rI)
+__device__ __forceinline__ double2 jkp_row1(const JKLane &C, const JKLoad &L, const JKWave &U, double (&jd)[TF_JKP_JBB],
+                                            double (&rJ)[TF_JKP_JBB], double &rI)
 {
-    const bool v = (MODE == JKP_FULL) || C.l0 <= k;
     double2 jt = make_double2(0.0, 0.0);
     rI = 0.0;
 #pragma unroll
@@ -190,11 +193,7 @@ __device__ __forceinline__ void jkp_row1(const JKLane &C, const JKLoad &L, const
         rI += m.x * pj.x + m.y * pj.y;
         rJ[r] = m.x * C.pil.x + m.y * C.pil.y;
     }
-#if !defined(TF_JKP_EXP) || (TF_JKP_EXP != 1 && TF_JKP_EXP != 3)
-    if (v) buf_store2<2>(buf_rsrc(U.yg + tri_off(k) + U.c0), 16u * (unsigned)lane, 0u, jt);
-#else
-    if (jt.x == 1.2345e300) buf_store2<2>(buf_rsrc(U.yg + tri_off(k) + U.c0), 16u * (unsigned)lane, 0u, jt);
-#endif
+    return jt;                                              // masked lanes loaded zeros: their jt is 0
 }
 
 template <int MODE>
@@ -210,11 +209,12 @@ __device__ __forceinline__ void jkp_row2(JKLane &C, const JKLoad &L, int k, cons
 }
 
 // The last triangle row k == i: row r ends at l == j_r, where the element (ij|ij) counts half in K and not at all in Jt.
-__device__ __forceinline__ void jkp_last(JKLane &C, const JKWave &U, const double (&pjk)[TF_JKP_JBB], double pik,
-                                         double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double &rI)
+__device__ __forceinline__ double2 jkp_last(JKLane &C, const JKWave &U, const double (&pjk)[TF_JKP_JBB], double pik,
+                                            double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double &rI)
 {
     const int i = U.i, jlast = U.j0 + U.nr - 1;
     const long long bk = tri_off(i);
+    double2 jt2 = make_double2(0.0, 0.0);
     rI = 0.0;
 #pragma unroll
     for (int r = 0; r < TF_JKP_JBB; ++r) rJ[r] = 0.0;
@@ -241,9 +241,9 @@ __device__ __forceinline__ void jkp_last(JKLane &C, const JKWave &U, const doubl
             if (e) C.colJ[r].y += mc * pik; else C.colJ[r].x += mc * pik;
         }
         if (e) C.colI.y += cI; else C.colI.x += cI;
-        if (v) U.yg[bk + l] = jt;
-        else if (l == jlast + 1 && (l & 1)) U.yg[bk + l] = 0.0;        // pad slot of the group's last (odd-length) row
+        if (e) jt2.y = jt; else jt2.x = jt;                               // 0 beyond the group's last column
     }
+    return jt2;
 }
 
 template <bool ALL8>
@@ -261,40 +261,55 @@ __device__ __forceinline__ void jkp_row_sums(const JKWave &U, int k, int lane, d
 #endif
 }
 
+// Jt of the rows kb..kb+KB-1: the waves of the workgroup have left their partials in slots[kk][wave][lane]; wave w adds up
+// row kb + w and writes it (fixed order: bitwise reproducible).  Two barriers per block.
+template <int MODE>
+__device__ __forceinline__ void jkp_merge_jt(const JKWave &U, double2 *slots, int ng, int w, int lane, int kb, int k1)
+{
+    __syncthreads();
+    const int k = kb + w;
+    if (w < TF_JKP_KB && k < k1) {
+        double2 t = slots[(w * TF_JKP_W) * 64 + lane];
+        for (int u = 1; u < ng; ++u) { const double2 x = slots[(w * TF_JKP_W + u) * 64 + lane]; t.x += x.x; t.y += x.y; }
+        if (MODE == JKP_FULL || U.c0 + 2 * lane <= k) buf_store2<2>(buf_rsrc(U.yg + tri_off(k) + U.c0), 16u * (unsigned)lane, 0u, t);
+    }
+    __syncthreads();
+}
+
 // Rows k0 <= k < k1 of a task in one mode.  The loads of row k + 1 are issued before row k is consumed, so a wave always has a
 // full row of requests in flight; the wave-uniform P[j_r][k], P[i][k] come through the scalar unit while part 1 runs.
+// Every wave of the workgroup runs the same k range (idle waves included): the barriers of the Jt merge must match.
 template <bool ALL8, int MODE>
-__device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane &C, double (&jd)[TF_JKP_JBB], int k0, int k1, int lane)
+__device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane &C, double (&jd)[TF_JKP_JBB], int k0, int k1, int lane, bool active,
+                                            double2 *slots, int ng, int w)
 {
     constexpr int JBB = TF_JKP_JBB;
     if (k0 >= k1) return;
     JKLoad L, Nx;
-#if !defined(TF_JKP_EXP) || TF_JKP_EXP != 4
-    jkp_load<ALL8, MODE>(L, C.l0, lane, U, k0);
-#endif
-    for (int k = k0; k < k1; ++k) {
-#if defined(TF_JKP_EXP) && TF_JKP_EXP == 4
-        jkp_load<ALL8, MODE>(L, C.l0, lane, U, k);
-#else
-        jkp_load<ALL8, MODE>(Nx, C.l0, lane, U, min(k + 1, k1 - 1));
-#endif
-        double pjk[JBB];
+    if (active) jkp_load<ALL8, MODE>(L, C.l0, lane, U, k0);
+    for (int kb = k0; kb < k1; kb += TF_JKP_KB) {
+        if (active) {
+            const int ke = min(kb + TF_JKP_KB, k1);
+            for (int k = kb; k < ke; ++k) {
+                jkp_load<ALL8, MODE>(Nx, C.l0, lane, U, min(k + 1, k1 - 1));
+                double pjk[JBB];
 #pragma unroll
-        for (int r = 0; r < JBB; ++r) pjk[r] = (ALL8 || r < U.nr) ? U.Pj0[(size_t)r * U.N + k] : 0.0;
-        const double pik = U.Pi[k];
-        double rJ[JBB], rI;
-        jkp_row1<MODE>(C, L, U, lane, k, jd, rJ, rI);
-        jkp_row_sums<ALL8>(U, k, lane, rJ, rI);
-        jkp_row2<MODE>(C, L, k, pjk, pik);
-#if !defined(TF_JKP_EXP) || TF_JKP_EXP != 4
-        L = Nx;
-#endif
+                for (int r = 0; r < JBB; ++r) pjk[r] = (ALL8 || r < U.nr) ? U.Pj0[(size_t)r * U.N + k] : 0.0;
+                const double pik = U.Pi[k];
+                double rJ[JBB], rI;
+                slots[((k - kb) * TF_JKP_W + w) * 64 + lane] = jkp_row1<MODE>(C, L, U, jd, rJ, rI);
+                jkp_row_sums<ALL8>(U, k, lane, rJ, rI);
+                jkp_row2<MODE>(C, L, k, pjk, pik);
+                L = Nx;
+            }
+        }
+        jkp_merge_jt<MODE>(U, slots, ng, w, lane, kb, k1);
     }
 }
 
 template <bool ALL8>
-__device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lane, int group, int r0, double *__restrict__ Jd,
-                                         double *__restrict__ DIc, double *__restrict__ DJc)
+__device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lane, int group, int r0, bool active, double2 *slots, int ng,
+                                         int w, double *__restrict__ Jd, double *__restrict__ DIc, double *__restrict__ DJc)
 {
     constexpr int JBB = TF_JKP_JBB;
     const int N = U.N, i = U.i;
@@ -316,16 +331,27 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lan
     for (int r = 0; r < JBB; ++r) jd[r] = 0.0;
 
     const int kd1 = min(U.c0 + TF_JKP_CW, i);                         // end of the diagonal tile (exclusive), rows k < i only
-    jkp_segment<ALL8, JKP_DIAG>(U, C, jd, U.c0, kd1, lane);
-    jkp_segment<ALL8, JKP_FULL>(U, C, jd, kd1, i, lane);
-    {   // k == i
-        double pjk[JBB], rJ[JBB], rI;
+    jkp_segment<ALL8, JKP_DIAG>(U, C, jd, U.c0, kd1, lane, active, slots, ng, w);
+    jkp_segment<ALL8, JKP_FULL>(U, C, jd, kd1, i, lane, active, slots, ng, w);
+    {   // k == i: the groups end at different columns; the first group of the workgroup is the longest
+        double2 jt = make_double2(0.0, 0.0);
+        if (active) {
+            double pjk[JBB], rJ[JBB], rI;
 #pragma unroll
-        for (int r = 0; r < JBB; ++r) pjk[r] = (ALL8 || r < U.nr) ? U.Pj0[(size_t)r * N + i] : 0.0;
-        const double pik = U.Pi[i];
-        jkp_last(C, U, pjk, pik, jd, rJ, rI);
-        jkp_row_sums<ALL8>(U, i, lane, rJ, rI);
+            for (int r = 0; r < JBB; ++r) pjk[r] = (ALL8 || r < U.nr) ? U.Pj0[(size_t)r * N + i] : 0.0;
+            const double pik = U.Pi[i];
+            jt = jkp_last(C, U, pjk, pik, jd, rJ, rI);
+            jkp_row_sums<ALL8>(U, i, lane, rJ, rI);
+        }
+        slots[w * 64 + lane] = jt;
+        __syncthreads();
+        if (w == 0) {                                                  // wave 0 holds the first group: its last column bounds the row
+            double2 t = slots[lane];
+            for (int u = 1; u < ng; ++u) { const double2 x = slots[u * 64 + lane]; t.x += x.x; t.y += x.y; }
+            if (C.l0 <= U.j0 + U.nr - 1) buf_store2<2>(buf_rsrc(U.yg + tri_off(i) + U.c0), 16u * (unsigned)lane, 0u, t);
+        }
     }
+    if (!active) return;
     // column parts (every column l < N of the group belongs to exactly one task)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -343,24 +369,31 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lan
     }
 }
 
-// One wave per task (group, chunk); NW = ceil(N / 128) chunks; only tasks with 128 chunk <= i exist.
-// Outputs: Jd [n_rows][NW] per-task partials; ypart: Jt partials; DIc [G][N], DJc [n_rows][N]: column parts (l-indexed);
-// DIr [G][NW][N], DJr [n_rows][NW][N]: row parts per task (k-indexed, written for 128 chunk <= k <= i).
-__global__ __launch_bounds__(64) void jk_packed_kernel(const double *__restrict__ T, const long long *__restrict__ rowoff,
-                                                       const JKGroup *__restrict__ groups, const JKTask *__restrict__ tasks, int N,
-                                                       int NW, const double *__restrict__ P, const double *__restrict__ Pp,
-                                                       double *__restrict__ Jd, double *__restrict__ ypart, double *__restrict__ DIc,
-                                                       double *__restrict__ DIr, double *__restrict__ DJc, double *__restrict__ DJr)
+// One workgroup per task (super-group, chunk): wave w owns group g0 + w (idle if the super-group has fewer).  NW = ceil(N / 128)
+// chunks; only tasks with 128 chunk <= i exist.
+// Outputs: Jd [n_rows][NW] per-task partials; ypart: Jt partials per super-group; DIc [G][N], DJc [n_rows][N]: column parts
+// (l-indexed); DIr [G][NW][N], DJr [n_rows][NW][N]: row parts per task (k-indexed, written for 128 chunk <= k <= i).
+__global__ __launch_bounds__(64 * TF_JKP_W) void jk_packed_kernel(const double *__restrict__ T, const long long *__restrict__ rowoff,
+                                                                  const JKGroup *__restrict__ groups, const JKSuper *__restrict__ supers,
+                                                                  const JKTask *__restrict__ tasks, int N, int NW,
+                                                                  const double *__restrict__ P, const double *__restrict__ Pp,
+                                                                  double *__restrict__ Jd, double *__restrict__ ypart,
+                                                                  double *__restrict__ DIc, double *__restrict__ DIr,
+                                                                  double *__restrict__ DJc, double *__restrict__ DJr)
 {
     constexpr int JBB = TF_JKP_JBB;
+    __shared__ double2 slots[TF_JKP_KB * TF_JKP_W * 64];
     const JKTask t = tasks[blockIdx.x];
-    const JKGroup g = groups[t.group];
-    const int lane = threadIdx.x;
+    const JKSuper sg = supers[t.super];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool active = w < sg.ng;
+    const int gi = sg.g0 + (active ? w : 0);
+    const JKGroup g = groups[gi];
     JKWave U;
     U.T0 = T + rowoff[g.r0]; U.Pp = Pp; U.Pi = P + (size_t)g.i * N; U.Pj0 = P + (size_t)g.j0 * N;
     U.N = N; U.i = g.i; U.j0 = g.j0; U.nr = g.nr; U.c0 = t.chunk * TF_JKP_CW;
-    U.yg = ypart + g.yoff;
-    U.DIr_w = DIr + ((size_t)t.group * NW + t.chunk) * N;
+    U.yg = ypart + sg.yoff;
+    U.DIr_w = DIr + ((size_t)gi * NW + t.chunk) * N;
     U.rowW = (size_t)NW * N;
     U.DJr_w = DJr + ((size_t)g.r0 * NW + t.chunk) * N;
 #pragma unroll
@@ -369,14 +402,14 @@ __global__ __launch_bounds__(64) void jk_packed_kernel(const double *__restrict_
         U.ppij[r] = (r < g.nr) ? Pp[tri_off(g.i) + g.j0 + r] : 0.0;
     }
     if (g.nr == JBB)
-        jkp_task<true>(U, NW, t.chunk, lane, t.group, g.r0, Jd, DIc, DJc);
+        jkp_task<true>(U, NW, t.chunk, lane, gi, g.r0, active, slots, sg.ng, w, Jd, DIc, DJc);
     else
-        jkp_task<false>(U, NW, t.chunk, lane, t.group, g.r0, Jd, DIc, DJc);
+        jkp_task<false>(U, NW, t.chunk, lane, gi, g.r0, active, slots, sg.ng, w, Jd, DIc, DJc);
 }
 
-// Jt partial sums over the padded pair index q: groups are sorted by descending partial length, so the groups that cover q are
+// Jt partial sums over the padded pair index q: super-groups are sorted by descending partial length, so those that cover q are
 // a prefix of the list.  grid (ceil(NP/256), SEG): segment s sums its slice of that prefix; out[s][q].
-__global__ __launch_bounds__(256) void jt_reduce_kernel(const double *__restrict__ ypart, const JKGroup *__restrict__ groups, int n_groups,
+__global__ __launch_bounds__(256) void jt_reduce_kernel(const double *__restrict__ ypart, const JKSuper *__restrict__ groups, int n_groups,
                                                         long long NP, double *__restrict__ out)
 {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
