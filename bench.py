@@ -91,17 +91,20 @@ def cpu_baseline_eri(aos, limit_s: float = 20.0):
     return {"seconds": time.perf_counter() - t0, "kind": kind, "cores": os.cpu_count()}
 
 
-def pmc_traffic(workload: str, world: int):
-    """HBM bytes per launch of the row kernel from the committed rocprofv3 PMC passes (profiles/), corrected as
+JK_KERNEL = {"packed": "jk_packed_kernel", "rows": "tfk::jk_rows_kernel"}
+
+
+def pmc_traffic(workload: str, world: int, layout: str):
+    """HBM bytes per launch of the J/K kernel from the committed rocprofv3 PMC passes (profiles/), corrected as
     MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB) x 1024 x 2 for 16-byte coalesced streaming reads, plus
     WRITE_SIZE (KB) x 1024.  Counters cannot be collected from inside an un-profiled run, so this is the figure of the
     profiled run of the same workload; null when no such profile is committed."""
     if world != 1:
         return None, None
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_{workload.replace('-', '')}.json")
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_{workload.replace('-', '')}_{layout}.json")
     try:
         d = json.load(open(path))
-        k = [v for name, v in d.items() if "jk_rows_kernel" in name][0]
+        k = [v for name, v in d.items() if JK_KERNEL[layout] in name][0]
         return (k["FETCH_SIZE"]["mean_KB"] * 1024.0 * 2.0 + k["WRITE_SIZE"]["mean_KB"] * 1024.0), os.path.relpath(path, ROOT)
     except Exception:
         return None, None
@@ -115,6 +118,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("TUNA_BENCH_WORKLOAD", "synth-400"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scf", action="store_true")
+    ap.add_argument("--layout", choices=["packed", "rows"], default="packed", help="ERI storage layout (tunafock.h: tf_set_eri_layout)")
     args = ap.parse_args()
 
     import torch
@@ -138,7 +142,7 @@ def main():
     eng = Engine(local_rank, rank, world)
     eng.set_basis(aos)
     t0 = time.perf_counter()
-    eng.build_eri(True)
+    eng.build_eri(True, layout=args.layout)
     torch.cuda.synchronize()
     eri_wall = time.perf_counter() - t0
     N = eng.N
@@ -191,27 +195,31 @@ def main():
     ok = bool(np.isfinite(Jh).all() and np.abs(Jh - Jh.T).max() < 1e-8 * max(1.0, np.abs(Jh).max()))
 
     if rank == 0:
-        traffic, traffic_src = pmc_traffic(args.workload, world)
+        layout = st["layout"]
+        traffic, traffic_src = pmc_traffic(args.workload, world, layout)
         alg_bytes = 8.0 * N ** 4 / world                    # 8 N^4 bytes per build, per GPU 8 N^4 / G
         stored_bytes = float(st["bytes"])
         achieved = alg_bytes / kernel_avg_s / 1e9
+        storage = {"packed": "8-fold symmetry-unique values of the spherical tensor, row (i>=j) = pairs (k>=l) <= (i,j), f64, "
+                             "sharded by (ij) shell pair over ranks",
+                   "rows": "rows (i>=j) x full (k,l) of the spherical tensor, f64, sharded by (ij) shell pair over ranks"}[layout]
         out = {
             "metric": "Fock builds/sec (J+K from the HBM-resident ERI tensor, one density) + SCF wall time",
             "value": args.steps / elapsed, "unit": "Fock builds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "n_ao_spherical": N, "n_ao_cartesian": eng.n_cart,
-                       "n_shells": eng.n_shell, "n_densities": 1,
-                       "storage": "rows (i>=j) x full (k,l) of the spherical tensor, f64, sharded by (ij) shell pair over ranks",
+                       "n_shells": eng.n_shell, "n_densities": 1, "layout": layout, "storage": storage,
                        "stored_bytes_per_gpu": stored_bytes, "parallelism": f"ij-row shards x{world} + RCCL all-reduce of [J;K]" if world > 1 else "1 GPU",
                        "result_ok": ok},
-            "roofline": {"bound": "hbm", "kernel": "tfk::jk_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": JK_KERNEL[layout], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_avg_ms": 1e3 * kernel_avg_s,
                          "stored_bytes_per_launch": stored_bytes, "achieved_on_stored_bytes": stored_bytes / kernel_avg_s / 1e9,
                          "frac_on_stored_bytes": stored_bytes / kernel_avg_s / 1e9 / HBM_PEAK_GBS,
-                         "note": "achieved prices the 8*N^4 algorithmic bytes of SURVEY 8d; the kernel physically reads the (i>=j) half "
-                                 "(stored_bytes), so frac can exceed what the physical stream alone would give"},
+                         "note": "achieved prices the 8*N^4 algorithmic bytes of SURVEY 8d; the kernel physically streams the stored "
+                                 "symmetry-unique part once (stored_bytes: 1/8 of them in the packed layout, 1/2 in the rows layout) plus its "
+                                 "partial sums, so frac exceeds 1; frac_on_stored_bytes and traffic are the physical figures"},
             "eri_build": {"wall_s": eri_wall, "device_s": {k: float(v) for k, v in eri_t.items() if k.endswith("_s")},
                           "shell_quartets": eri_t["shell_quartets"], "primitive_shell_quartets": eri_t["primitive_shell_quartets"],
                           "component_quartets": eri_t["component_quartets"]},

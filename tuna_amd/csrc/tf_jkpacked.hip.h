@@ -25,7 +25,7 @@
 
 #define TF_JKP_JBB 8
 #define TF_JKP_CW 128            // columns per chunk (2 per lane)
-#define TF_JKP_SEG 64            // segments of the group list in the Jt reduction
+#define TF_JKP_SEG 16            // segments of the group list in the Jt reduction
 
 // padded triangle: first index of row k, and the stored length of tensor row (i,j)
 __host__ __device__ inline long long tri_off(long long k) { const long long h = k >> 1; return 2 * h * (h + 1) + ((k & 1) ? k + 1 : 0); }
