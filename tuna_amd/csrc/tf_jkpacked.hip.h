@@ -249,16 +249,10 @@ __device__ __forceinline__ double2 jkp_last(JKLane &C, const JKWave &U, const do
 template <bool ALL8>
 __device__ __forceinline__ void jkp_row_sums(const JKWave &U, int k, int lane, double (&rJ)[TF_JKP_JBB], double rI)
 {
-#if defined(TF_JKP_EXP) && TF_JKP_EXP >= 2
-    double t = rI;
-    for (int r = 0; r < TF_JKP_JBB; ++r) t += rJ[r];
-    if (t == 1.2345e300) U.DIr_w[k] = t;
-#else
     const double tJ = wave_sum8(rJ);
     const double tI = wave_sum1(rI);
     if ((lane & 7) == 0 && (ALL8 || (lane >> 3) < U.nr)) U.DJr_w[(size_t)(lane >> 3) * U.rowW + k] = tJ;
     if (lane == 0) U.DIr_w[k] = tI;
-#endif
 }
 
 // Jt of the rows kb..kb+KB-1: the waves of the workgroup have left their partials in slots[kk][wave][lane]; wave w adds up
