@@ -1,0 +1,33 @@
+"""GPU: RHF on the synthetic N-AO even-tempered Ar2-like diatomic of the bench: where the wall time of an
+SCF iteration goes at the north-star size.  usage: python tools/gpu_scf_synth.py [N=400] [reps=2]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from tuna_amd import molecule as mol
+from tuna_amd.engine import Engine
+from oracle import scf_oracle as so
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+counts = mol.synthetic_counts(N)
+atoms = mol.make_atoms(["AR", "AR"], 7.1)
+sh = mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)})
+aos = mol.expand_cartesian_aos(sh)
+eng = Engine(0)
+for rep in range(reps):
+    t0 = time.perf_counter(); eng.set_basis(aos).build_eri(True); t1 = time.perf_counter()
+    xyz = [a.origin for a in atoms]; chg = [float(a.charge) for a in atoms]
+    S, T, V, _, _ = eng.one_electron(xyz, chg, [0, 0, 0.5 * atoms[1].origin[2]]); t2 = time.perf_counter()
+    X, smin, _ = eng.orthogonaliser(S); t3 = time.perf_counter()
+    P0, E0 = so.core_guess(T, V, X, 18)
+    nao = [sum(s.n_sph for s in sh if s.atom == a) for a in range(2)]
+    t4 = time.perf_counter()
+    r = eng.scf_rhf(S, T, V, P0, E0, 18, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping="none", n_atom_ao=nao, max_iter=200)
+    t5 = time.perf_counter()
+    it = r["n_iter"]
+    print(f"synth-{eng.N} rep{rep}: eri {t1-t0:.3f} s, 1e {t2-t1:.3f}, ortho {t3-t2:.3f} (min S eig {smin:.2e}), scf {t5-t4:.3f} s = {it} iterations x "
+          f"{1e3*(t5-t4)/it:.2f} ms [fock kernels {1e3*r['fock_seconds']/it:.2f} ms/it, eigen {1e3*r['eig_seconds']/it:.2f} ms/it]  E = {r['energy']:.8f}")

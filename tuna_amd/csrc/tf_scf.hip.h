@@ -19,6 +19,7 @@
 
 #include "../../include/tunafock.h"
 #include "tf_jacobi.hip.h"
+#include <cstdio>
 
 namespace tfscf {
 
@@ -36,6 +37,11 @@ struct Workspace {
     size_t jac_prev_cap = 0;
     int jac_prev_n = 0;              // 0 = no valid warm start
     bool warm_ok = false;            // set by run_rhf for the duration of one SCF cycle
+    // eigenvector refinement (n > 64): rows of ref_X are the current orthonormal approximate eigenvectors, ref_lam their values
+    double *ref_buf = nullptr;       // [7][n][n] + n doubles: X, Xnew, G, Y, S, E, scaled X; lambda
+    size_t ref_cap = 0;
+    int ref_n = 0;                   // 0 = no valid start
+    long long ref_solves = 0, ref_steps = 0, ref_fallbacks = 0;
 };
 
 inline void release(Workspace &w)
@@ -48,6 +54,7 @@ inline void release(Workspace &w)
     if (w.ev1) (void)hipEventDestroy(w.ev1);
     if (w.jac_scratch) (void)hipFree(w.jac_scratch);
     if (w.jac_prev) (void)hipFree(w.jac_prev);
+    if (w.ref_buf) (void)hipFree(w.ref_buf);
     w = Workspace();
 }
 
@@ -205,6 +212,160 @@ inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, st
 }
 
 // dense solve A x = b for the (m <= 9) DIIS system; false if A is exactly singular (np.linalg.solve -> LinAlgError)
+// ---- warm-started eigenvector refinement ------------------------------------------------------------------------------------
+// Inside an SCF cycle successive Fock matrices differ little, and what the cycle needs from a diagonalisation is the projector on
+// the n_occ lowest eigenvectors (scf:183-211, 222-250).  Given the eigenvectors X of the previous solve, one step of the
+// first-order refinement of Ogita & Aishima (Japan J. Indust. Appl. Math. 35 (2018) 1007), in the form used here:
+//     X <- X (3/2 I - 1/2 X^T X)                     (Newton-Schulz: orthonormal to the square of the previous defect)
+//     S = X^T A X,  lambda_i = s_ii,  e_ij = s_ij / (lambda_j - lambda_i),  X <- X + X E
+// is five n^3 GEMMs on the matrix cores and converges quadratically.  Every occupied-virtual pair is rotated (its denominator is at
+// least the gap); a pair inside the occupied or inside the virtual space is rotated only where that is well conditioned
+// (|s_ij| <= 0.05 |lambda_j - lambda_i| and the difference above rounding level) -- the rotation inside a (near-)degenerate cluster
+// does not change the projector, and diatomics are full of exact degeneracies (pi, delta, g/u pairs of separated atoms).
+// Converged when the largest occupied-virtual rotation is below 1e-9.  No convergence in 16 steps, a rotation above 0.3 or a closed
+// gap: the caller diagonalises (rocsolver_dsyevd) and restarts from those vectors.  At n = 400 a step costs ~0.15 ms against 9 ms
+// for dsyevd (`tools/gpu_eigh_probe.py`); orbitals and orbital energies for the caller are produced once at the end of the cycle by a
+// real eigensolve.  Storage: rows of Xr are the eigenvectors (Xr = X^T).
+
+// lam[i] = s_ii, occupation weights w[i] (1 for the n_occ lowest), scal = {homo, lumo}; single block
+__global__ void k_ref_diag(const double *__restrict__ S, int n, int n_occ, double *__restrict__ lam, double *__restrict__ wocc,
+                           double *__restrict__ scal)
+{
+    __shared__ double s0[1024], s1[1024];
+    for (int i = threadIdx.x; i < n; i += 1024) lam[i] = S[(size_t)i * n + i];
+    __syncthreads();
+    // ranks: the n_occ lowest values are occupied (ties broken by index, as a stable sort would)
+    double homo = -1e300, lumo = 1e300;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double li = lam[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const double lj = lam[j]; rank += (lj < li || (lj == li && j < i)) ? 1 : 0; }
+        const bool occ = rank < n_occ;
+        wocc[i] = occ ? 1.0 : 0.0;
+        if (occ) homo = fmax(homo, li); else lumo = fmin(lumo, li);
+    }
+    s0[threadIdx.x] = homo; s1[threadIdx.x] = lumo;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { s0[threadIdx.x] = fmax(s0[threadIdx.x], s0[threadIdx.x + st]); s1[threadIdx.x] = fmin(s1[threadIdx.x], s1[threadIdx.x + st]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { scal[0] = s0[0]; scal[1] = s1[0]; }
+}
+
+// E (row-major, antisymmetric) and per block: max |e_ij| over all pairs, and over the occupied-virtual pairs
+__global__ void k_ref_E(const double *__restrict__ S, const double *__restrict__ lam, const double *__restrict__ wocc, int n,
+                        double *__restrict__ E, double *__restrict__ blockmax)
+{
+    __shared__ double sm[256], so[256];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0.0;
+    bool ov = false;
+    if (e < n * n) {
+        const int i = e / n, j = e - i * n;
+        if (i != j) {
+            const double sij = 0.5 * (S[e] + S[(size_t)j * n + i]);
+            const double dl = lam[j] - lam[i];
+            ov = wocc[i] != wocc[j];
+            if (ov || (fabs(sij) <= 0.05 * fabs(dl) && fabs(dl) > 1e-5)) v = sij / dl;
+        }
+        E[e] = v;
+    }
+    sm[threadIdx.x] = fabs(v); so[threadIdx.x] = ov ? fabs(v) : 0.0;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + st]); so[threadIdx.x] = fmax(so[threadIdx.x], so[threadIdx.x + st]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { blockmax[2 * blockIdx.x] = sm[0]; blockmax[2 * blockIdx.x + 1] = so[0]; }
+}
+
+// out[i][:] = w[i] * X[i][:]
+__global__ void k_scale_rows(const double *__restrict__ X, const double *__restrict__ w, double *__restrict__ out, int n)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * n) out[e] = w[e / n] * X[e];
+}
+
+inline int ref_ensure(Workspace &w, int n, std::string &msg)
+{
+    const size_t need = 6 * (size_t)n * n + 2 * (size_t)n + 2 * (((size_t)n * n + 255) / 256) + 8;
+    if (need > w.ref_cap) {
+        if (w.ref_buf) (void)hipFree(w.ref_buf);
+        w.ref_buf = nullptr; w.ref_cap = 0; w.ref_n = 0;
+        TFS_HIP(hipMalloc((void **)&w.ref_buf, need * sizeof(double)));
+        w.ref_cap = need;
+    }
+    return TF_OK;
+}
+
+// Refines the stored vectors against the symmetric A (device, row-major n x n).  TF_OK: *Xocc (a buffer of the workspace) holds the
+// rows of the n_occ lowest eigenvectors (other rows zero).  TF_ELINALG: no convergence -- the caller diagonalises and calls ref_store.
+inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **Xocc, std::string &msg)
+{
+    if (w.ref_n != n || !w.ref_buf) return TF_ELINALG;
+    static const bool dbg = getenv("TF_DEBUG") != nullptr;
+    const size_t nn = (size_t)n * n;
+    double *X = w.ref_buf, *Xn = X + nn, *G = Xn + nn, *Y = G + nn, *S = Y + nn, *E = S + nn;
+    double *lam = E + nn, *wocc = lam + n, *bmax = wocc + n;
+    const int g = (int)((nn + 255) / 256);
+    std::vector<double> hb(2 * (size_t)g);
+    // X <- (3/2 I - 1/2 G) X with G = X X^T (rows are the vectors)
+    auto orthonormalise = [&]() -> int {
+        TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, X, X, 0.0, G));
+        TFS_HIP(hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, -0.5, G, X, 1.5, Xn));
+        std::swap(X, Xn);
+        return TF_OK;
+    };
+    ++w.ref_solves;
+    int rc = TF_OK;
+    bool ok = false;
+    for (int step = 0; step < 16 && !ok; ++step) {
+        if ((rc = orthonormalise())) return rc;
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, X, A, 0.0, Y));         // rows A x_i
+        TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Y, X, 0.0, S));          // S = X^T A X
+        hipLaunchKernelGGL(k_ref_diag, dim3(1), dim3(1024), 0, 0, S, n, n_occ, lam, wocc, w.d_scal + 40);
+        hipLaunchKernelGGL(k_ref_E, dim3(g), dim3(256), 0, 0, S, lam, wocc, n, E, bmax);
+        double h[2];
+        TFS_HIP(hipMemcpy(h, w.d_scal + 40, 2 * sizeof(double), hipMemcpyDeviceToHost));
+        TFS_HIP(hipMemcpy(hb.data(), bmax, 2 * (size_t)g * sizeof(double), hipMemcpyDeviceToHost));
+        double emax = 0.0, eov = 0.0;
+        for (int b = 0; b < g; ++b) { emax = std::max(emax, hb[2 * b]); eov = std::max(eov, hb[2 * b + 1]); }
+        if (dbg) fprintf(stderr, "[tf refine] step %d: homo %.6f lumo %.6f max|E| %.3e max|E_ov| %.3e\n", step, h[0], h[1], emax, eov);
+        if (!std::isfinite(emax) || !(h[1] > h[0]) || emax > 0.3) break;
+        TFS_HIP(hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, E, X, 1.0, Xn));         // X + E^T X   (rows)
+        std::swap(X, Xn);
+        w.ref_steps += 1;
+        ok = eov < 1e-9 && emax < 1e-3;
+    }
+    if (ok) {
+        if ((rc = orthonormalise())) return rc;
+        if (X != w.ref_buf) {                                                  // keep the vectors in the first slot for the next solve
+            TFS_HIP(hipMemcpyAsync(w.ref_buf, X, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            X = w.ref_buf;
+        }
+        double *Xw = w.ref_buf + 2 * nn;                                       // G's slot: free now
+        hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, 0, X, wocc, Xw, n);
+        *Xocc = Xw;
+        return TF_OK;
+    }
+    ++w.ref_fallbacks;
+    w.ref_n = 0;
+    return TF_ELINALG;
+}
+
+// after a real eigensolve: rows of V (row-major, as eigh() leaves them) become the refinement start
+inline int ref_store(Workspace &w, int n, const double *V, std::string &msg)
+{
+    int rc = ref_ensure(w, n, msg);
+    if (rc) return rc;
+    TFS_HIP(hipMemcpyAsync(w.ref_buf, V, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, 0));
+    w.ref_n = n;
+    return TF_OK;
+}
+
 inline bool small_solve(int m, std::vector<double> A, std::vector<double> b, std::vector<double> &x)
 {
     for (int c = 0; c < m; ++c) {
@@ -335,6 +496,10 @@ inline int eigh_probe(Workspace &w, int n, int variant, int reps, double *second
                 TFS_BLAS(rocsolver_dsyevx(w.blas, rocblas_evect_original, rocblas_erange_index, rocblas_fill_upper, n, A, n, 0.0, 0.0, 1, k, 0.0, nev,
                                           vals, V, n, (rocblas_int *)(base_ifail(w, n)), (rocblas_int *)(w.d_scal + 40)));
         }
+        else if (variant == 6) TFS_BLAS(rocsolver_dsyevdj(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, w.d_info));
+        else if (variant == 7) {                                  // four n x n GEMMs: the cost of one eigenvector refinement step
+            for (int q = 0; q < 4; ++q) TFS_BLAS(gemm_rm(w.blas, q & 1, false, n, 1.0, A0, A, 0.0, V));
+        }
         else if (variant == 1) TFS_BLAS(rocsolver_dsyev(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, e, w.d_info));
         else {
             double *resid = w.d_scal + 32;
@@ -398,13 +563,48 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     auto dot = [&](const double *a, const double *b, double *res) { return rocblas_ddot(w.blas, (int)nn, a, 1, b, 1, res); };
 
     // diagonalise F (AO) -> eps, C ; P = 2 C_occ C_occ^T symmetrised      (scf:222-250, 183-211)
+    // n > 64 (where the eigensolver is rocsolver_dsyevd): after the first solve the density comes from refined eigenvectors
+    static const bool no_refine = getenv("TF_EIGH") != nullptr;
+    const bool refining = !no_refine && n > 64 && n_occ > 0 && n_occ < n;
+    bool orbitals_current = false, orbitals_final = false;
+    w.ref_n = 0;
     auto diag_density = [&](const double *Fao, double *Pout) -> int {
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, Fao, 0.0, t1));     // X^T F
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));     // (X^T F) X
         hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
         auto te = std::chrono::steady_clock::now();
+        orbitals_current = false;
+        if (refining && w.ref_n == n) {
+            double *Xocc = nullptr;
+            std::string rmsg;
+            const int rr = ref_refine(w, n, n_occ, dW, &Xocc, rmsg);
+            if (rr == TF_OK) {
+                const double two = 2.0, zero = 0.0;
+                TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Xocc, dX, 0.0, t1));    // rows: occupied orbitals in the AO basis (others 0)
+                TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &two, t1, n, t1, n, &zero, t2, n));
+                hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, Pout, n);
+                TFS_HIP(hipDeviceSynchronize());
+                out.eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - te).count();
+                if (getenv("TF_REFINE_CHECK")) {                 // debugging aid: the same density from a real eigensolve
+                    std::vector<double> hp(nn), hq(nn);
+                    TFS_HIP(hipMemcpy(hp.data(), Pout, nn * sizeof(double), hipMemcpyDeviceToHost));
+                    int r2 = eigh(w, n, dW, vals, ework, msg);
+                    if (r2) return r2;
+                    TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
+                    TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, n_occ, &two, dC, n, dC, n, &zero, t1, n));
+                    hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, t2, n);
+                    TFS_HIP(hipMemcpy(hq.data(), t2, nn * sizeof(double), hipMemcpyDeviceToHost));
+                    double dmax = 0.0;
+                    for (size_t q = 0; q < nn; ++q) dmax = std::max(dmax, std::fabs(hp[q] - hq[q]));
+                    fprintf(stderr, "[tf refine] max |P_refined - P_eigh| = %.3e\n", dmax);
+                }
+                return TF_OK;
+            }
+            if (rr != TF_ELINALG) { msg = rmsg; return rr; }
+        }
         int r = eigh(w, n, dW, vals, ework, msg);
         if (r) return r;
+        if (refining) { r = ref_store(w, n, dW, msg); if (r) return r; }
         TFS_HIP(hipDeviceSynchronize());
         out.eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - te).count();
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));      // C = X V   (dW rows = eigenvectors)
@@ -412,6 +612,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         // col-major view of dC is C^T: P = sum_{k<nocc} C[:,k] C[:,k]^T = M[:nocc,:]^T M[:nocc,:]
         TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, n_occ, &two, dC, n, dC, n, &zero, t1, n));
         hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, Pout, n);
+        orbitals_current = true;
         return TF_OK;
     };
 
@@ -494,8 +695,9 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         comps[0] = eT; comps[1] = eV; comps[2] = (1.0 / 2.0) * eJ; comps[3] = -(1.0 / 4.0) * eK * o.hfx + xc3[1]; comps[4] = xc3[2];   // scf:380-394
         comps[5] = eF; comps[6] = 0.0;
         E = comps[0] + comps[1] + comps[2] + comps[3] + comps[4] + comps[5] + comps[6];
-        if (out.eps) TFS_HIP(hipMemcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
-        if (out.C) TFS_HIP(hipMemcpy(out.C, dC, nn * sizeof(double), hipMemcpyDeviceToHost));
+        orbitals_final = orbitals_current;                            // of THIS iteration's Fock matrix (the DIIS solve below reuses dC)
+        if (orbitals_final && out.eps) TFS_HIP(hipMemcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (orbitals_final && out.C) TFS_HIP(hipMemcpy(out.C, dC, nn * sizeof(double), hipMemcpyDeviceToHost));
         // DIIS extrapolation (scf:991-1059)
         double *Pcur = dPn;
         if (step > 2 && o.use_diis && commutator < 0.3) {
@@ -557,6 +759,21 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             break;
         }
     }
+    if (!orbitals_final && (out.eps || out.C) && out.n_iter > 0) {
+        // orbitals and orbital energies of the last Fock matrix (what the reference's last diagonalisation leaves, scf:1133)
+        TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, dF, 0.0, t1));
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+        auto te = std::chrono::steady_clock::now();
+        rc = eigh(w, n, dW, vals, ework, msg);
+        if (rc) return rc;
+        TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
+        TFS_HIP(hipDeviceSynchronize());
+        out.eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - te).count();
+        if (out.eps) TFS_HIP(hipMemcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (out.C) TFS_HIP(hipMemcpy(out.C, dC, nn * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    w.ref_n = 0;
     out.energy = E + V_NN;
     std::memcpy(out.components, comps, sizeof(comps));
     if (out.P) TFS_HIP(hipMemcpy(out.P, dP, nn * sizeof(double), hipMemcpyDeviceToHost));
