@@ -50,9 +50,15 @@ const char *tf_last_error(const tf_ctx *ctx);
 /* ABI version of the library (major*100 + minor). */
 int tf_version(void);
 
-/* Stateless, host only: the row-block -> rank plan tf_build_eri uses (longest-processing-time on
- * weight[b] = rows of block b).  Replaces the `schedule="dynamic"` load balancing of pyx:1314.  owner[n_blocks]. */
+/* Stateless, host only: longest-processing-time assignment of weighted blocks to ranks (a generic
+ * helper; replaces the `schedule="dynamic"` load balancing of pyx:1314).  owner[n_blocks]. */
 int tf_shard_plan(int n_blocks, const int64_t *weight, int world, int32_t *owner);
+/* Stateless, host only: the plan tf_build_eri uses.  Bra shell pairs (A >= B, index A(A+1)/2 + B) of
+ * n_shells shells with dim[s] output functions each: for every A the B range is cut into `world`
+ * contiguous segments of equal weight (stored values of their rows in `layout`), the heaviest
+ * segment going to the least loaded rank -- every rank keeps, for each row index i, long runs of
+ * consecutive j, which is what the J/K kernel's 8-row groups want.  owner[n_shells (n_shells+1)/2]. */
+int tf_shard_plan_pairs(int n_shells, const int32_t *dim, int layout, int world, int32_t *owner);
 
 /* ---- basis: replaces `Basis.__cinit__` / `Basis.normalize` (pyx:144-210) ------------------ */
 

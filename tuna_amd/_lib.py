@@ -38,7 +38,7 @@ EXPORTS = ["tf_create", "tf_destroy", "tf_last_error", "tf_version", "tf_normali
            "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf",
            "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts", "tf_shard_plan", "tf_jk_profile",
            "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_ao_to_mo", "tf_mp2_rhf", "tf_dft_setup", "tf_dft_vxc",
-           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout"]
+           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs"]
 
 _lib = None
 
@@ -88,6 +88,7 @@ def lib():
     L.tf_eri_timings.restype = ci; L.tf_eri_timings.argtypes = [vp, vp]
     L.tf_eri_counts.restype = ci; L.tf_eri_counts.argtypes = [vp, vp]
     L.tf_shard_plan.restype = ci; L.tf_shard_plan.argtypes = [ci, vp, ci, vp]
+    L.tf_shard_plan_pairs.restype = ci; L.tf_shard_plan_pairs.argtypes = [ci, vp, ci, ci, vp]
     L.tf_diagonalise.restype = ci; L.tf_diagonalise.argtypes = [vp, ci, vp, vp, vp, vp]
     L.tf_ao_to_mo.restype = ci; L.tf_ao_to_mo.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp]
     L.tf_mp2_rhf.restype = ci; L.tf_mp2_rhf.argtypes = [vp, ci, ci, vp, vp, dp, dp, dp]

@@ -160,9 +160,60 @@ static void shard_plan(const std::vector<long long> &weight, int world, std::vec
     }
 }
 
+// The plan of tf_build_eri (include/tunafock.h: tf_shard_plan_pairs).  Deterministic: every rank computes the same plan.
+static void shard_plan_pairs(const std::vector<int> &dim, bool packed, int world, std::vector<int> &owner)
+{
+    const int ns = (int)dim.size();
+    std::vector<long long> off(ns + 1, 0);
+    for (int s = 0; s < ns; ++s) off[s + 1] = off[s] + dim[s];
+    owner.assign((size_t)ns * (ns + 1) / 2, 0);
+    std::vector<long long> load(world, 0);
+    std::vector<long long> w;
+    for (int A = ns - 1; A >= 0; --A) {                           // heaviest rows first
+        w.assign(A + 1, 0);
+        long long total = 0;
+        for (int B = 0; B <= A; ++B) {
+            long long wb = 0;
+            for (long long i = off[A]; i < off[A + 1]; ++i)
+                for (long long j = off[B]; j < off[B + 1] && j <= i; ++j) wb += packed ? packed_row_len(i, j) : 1;
+            w[B] = wb; total += wb;
+        }
+        // `world` contiguous segments of B with (nearly) equal weight
+        struct Seg { int b0, b1; long long wt; };
+        std::vector<Seg> segs;
+        int b = 0;
+        long long cum = 0;
+        for (int sgi = 1; sgi <= world; ++sgi) {
+            const long long target = (long long)((__int128)total * sgi / world);
+            Seg sg{b, b, 0};
+            while (b <= A && (sgi == world || cum + w[b] / 2 <= target)) { cum += w[b]; sg.wt += w[b]; ++b; }
+            sg.b1 = b;
+            segs.push_back(sg);
+        }
+        std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.wt > y.wt; });
+        std::vector<int> ranks(world);
+        std::iota(ranks.begin(), ranks.end(), 0);
+        std::stable_sort(ranks.begin(), ranks.end(), [&](int x, int y) { return load[x] < load[y]; });
+        for (int k = 0; k < world; ++k) {
+            const Seg &sg = segs[k];
+            for (int B = sg.b0; B < sg.b1; ++B) owner[(size_t)A * (A + 1) / 2 + B] = ranks[k];
+            load[ranks[k]] += sg.wt;
+        }
+    }
+}
+
 extern "C" {
 
 int tf_version(void) { return 100; }
+
+int tf_shard_plan_pairs(int n_shells, const int32_t *dim, int layout, int world, int32_t *owner)
+{
+    if (n_shells < 0 || world < 1 || !dim || !owner || layout < 0 || layout > 1) return TF_EINVAL;
+    std::vector<int> d(dim, dim + n_shells), o;
+    shard_plan_pairs(d, layout == 1, world, o);
+    std::copy(o.begin(), o.end(), owner);
+    return TF_OK;
+}
 
 int tf_shard_plan(int n_blocks, const int64_t *weight, int world, int32_t *owner)
 {
@@ -397,7 +448,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         pair_weight[p] = w;
     }
     std::vector<int> owner;
-    shard_plan(pair_weight, ctx->world, owner);
+    {
+        std::vector<int> dims(bs.shells.size());
+        for (size_t q = 0; q < dims.size(); ++q) dims[q] = out_dim(bs.shells[q]);
+        shard_plan_pairs(dims, packed, ctx->world, owner);           // pair index A(A+1)/2 + B = position in bs.pairs
+    }
     ctx->my_pairs.clear();
     for (int p = 0; p < npairs; ++p)
         if (owner[p] == ctx->rank) ctx->my_pairs.push_back(p);

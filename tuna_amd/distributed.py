@@ -41,12 +41,13 @@ def shell_pair_rows(shells, spherical: bool = True, layout: str = "packed") -> n
 
 
 def shard_owner(shells, world: int, spherical: bool = True, layout: str = "packed") -> np.ndarray:
-    """owner[p] = rank that generates and keeps the rows of shell pair p -- the library's own plan (tf_shard_plan)."""
-    w = shell_pair_rows(shells, spherical, layout)
-    owner = np.zeros(len(w), dtype=np.int32)
-    rc = _lib.lib().tf_shard_plan(len(w), _lib.ptr(w), int(world), _lib.ptr(owner))
+    """owner[p] = rank that generates and keeps the rows of shell pair p (A >= B, A-major) -- the library's own plan
+    (tf_shard_plan_pairs): for every A the B range is cut into `world` contiguous segments of equal weight."""
+    dim = np.asarray([(s.n_sph if spherical else s.n_cart) for s in shells], dtype=np.int32)
+    owner = np.zeros(len(dim) * (len(dim) + 1) // 2, dtype=np.int32)
+    rc = _lib.lib().tf_shard_plan_pairs(len(dim), _lib.ptr(dim), 1 if layout == "packed" else 0, int(world), _lib.ptr(owner))
     if rc != 0:
-        raise _lib.TunaError("tf_shard_plan failed", rc)
+        raise _lib.TunaError("tf_shard_plan_pairs failed", rc)
     return owner
 
 
