@@ -222,7 +222,10 @@ def main():
                                  "partial sums, so frac exceeds 1; frac_on_stored_bytes and traffic are the physical figures"},
             "eri_build": {"wall_s": eri_wall, "device_s": {k: float(v) for k, v in eri_t.items() if k.endswith("_s")},
                           "shell_quartets": eri_t["shell_quartets"], "primitive_shell_quartets": eri_t["primitive_shell_quartets"],
-                          "component_quartets": eri_t["component_quartets"]},
+                          "component_quartets": eri_t["component_quartets"],
+                          "component_quartets_per_s": eri_t["component_quartets"] / max(eri_t["total_s"], 1e-12),
+                          "note": "quartets actually evaluated on this rank (packed layout: ket shell pairs up to the bra's first shell); "
+                                  "FP64-vector / latency-bound work (DESIGN.md section 4.2), not priced against HBM or MFMA"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fock(N)

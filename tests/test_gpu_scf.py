@@ -129,3 +129,56 @@ def test_uhf_input_line(uhf_golden):
     from tuna_amd.energy import run
     out = run("SPE : O O 1.2075 : UHF CC-PVDZ : EXTREME NODAMP ML 3 COREGUESS")
     assert abs(out.energy - float(uhf_golden["o2_triplet_ccpvdz"]["scf_energy_nodamp"])) < 1e-8
+
+
+@pytest.mark.parametrize("symbols,R,basis,nocc", [(["C", "O"], 1.128, "cc-pVQZ", 7), (["AR", "AR"], 3.76, "cc-pVQZ", 18),
+                                                 (["F", "H"], 0.917, "aug-cc-pVQZ", 5)])
+def test_eigenvector_refinement_matches_the_exact_eigensolver(symbols, R, basis, nocc):
+    """n > 64: inside the cycle the density comes from refined eigenvectors (tf_scf.hip.h); the same run with every
+    diagonalisation done by rocsolver_dsyevd (TF_EIGH=rocsolver) must give the same table, orbitals and energy."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from tuna_amd import molecule as mol
+from tuna_amd.engine import Engine
+from oracle import scf_oracle as so
+symbols, R, basis, nocc = %r, %r, %r, %r
+atoms = mol.make_atoms(symbols, mol.angstrom_to_bohr(R)); sh = mol.build_shells(atoms, basis); aos = mol.expand_cartesian_aos(sh)
+with Engine(0) as eng:
+    eng.set_basis(aos).build_eri(True)
+    S, T, V, _, _ = eng.one_electron([a.origin for a in atoms], [float(a.charge) for a in atoms], [0, 0, 0.5 * atoms[1].origin[2]])
+    X, _, _ = eng.orthogonaliser(S)
+    P0, E0 = so.core_guess(T, V, X, nocc)
+    nao = [sum(s.n_sph for s in sh if s.atom == a) for a in range(2)]
+    r = eng.scf_rhf(S, T, V, P0, E0, nocc, mol.nuclear_repulsion(atoms), X=X, conv="extreme", damping="dynamic", n_atom_ao=nao)
+    C = r["C"]; proj = C[:, :nocc] @ C[:, :nocc].T
+    print(json.dumps({"N": eng.N, "E": r["energy"], "n_iter": r["n_iter"], "table": np.asarray(r["table"])[:r["n_iter"]].tolist(),
+                      "eps": np.asarray(r["epsilons"]).tolist(), "proj_norm": float(np.abs(proj).sum()), "P_sum": float(np.abs(r["P"]).sum()),
+                      "orth": float(np.abs(C.T @ S @ C - np.eye(eng.N)).max())}))
+''' % (os.path.join(os.path.dirname(__file__), ".."), symbols, R, basis, nocc)
+    res = {}
+    for mode in ("refine", "rocsolver"):
+        env = dict(os.environ)
+        env.pop("TF_EIGH", None)
+        if mode == "rocsolver":
+            env["TF_EIGH"] = "rocsolver"
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+    a, b = res["refine"], res["rocsolver"]
+    assert a["N"] > 64
+    assert abs(a["E"] - b["E"]) < 1e-9
+    # the last iterations sit at the EXTREME thresholds (max dP ~ 1e-11) within rounding noise: the stopping iteration may differ
+    assert abs(a["n_iter"] - b["n_iter"]) <= 3
+    n = min(a["n_iter"], b["n_iter"])
+    ta, tb = np.asarray(a["table"])[:n], np.asarray(b["table"])[:n]
+    assert np.abs(ta[:, 1] - tb[:, 1]).max() < 1e-8                       # energies of every iteration
+    big = tb[:, 5] > 1e-9
+    assert np.abs(ta[big, 5] / tb[big, 5] - 1.0).max() < 1e-3              # commutator norms while they are above the noise
+    assert np.abs(ta[big, 6] - tb[big, 6]).max() < 1e-6                    # same damping factors
+    assert np.abs(np.asarray(a["eps"]) - np.asarray(b["eps"])).max() < 1e-8   # final orbital energies come from a real eigensolve
+    assert a["orth"] < 1e-10 and abs(a["P_sum"] - b["P_sum"]) < 1e-6 * b["P_sum"]

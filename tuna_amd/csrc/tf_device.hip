@@ -542,7 +542,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
 
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
     // ---- slabs of bra pairs: Cartesian block -> ket transform -> bra transform -> tensor rows
-    size_t slab_bytes = (size_t)1 << 30;
+    // Cartesian slab: 1 GiB, more (up to 4 GiB) for big tensors -- fewer, larger class launches (N = 500: 0.52 -> 0.44 s)
+    size_t slab_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>((size_t)1 << 30, (size_t)ctx->n_elems));
     if (const char *e = getenv("TF_SLAB_MB")) slab_bytes = (size_t)std::max(1, atoi(e)) << 20;
     const size_t cart_row_bytes = (size_t)Nc * Nc * sizeof(double);
     long long max_rows_c = std::max<long long>(1, (long long)(slab_bytes / cart_row_bytes));
@@ -562,11 +563,17 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     double *d_C = ctx->scr[0], *d_T1 = ctx->scr[1], *d_T2 = ctx->scr[2];
     double t_stage[4] = {0, 0, 0, 0};
     long long n_quart = 0, n_primq = 0, n_compq = 0;
-    long long tot_pp = 0, tot_comp = 0;
+    // work counters: ket pairs / primitive pairs / component pairs with first shell <= A (the pair list is A-major).  The packed
+    // layout computes exactly the kets whose first shell does not exceed the bra's; the rows layout all of them.
+    const int nsh = (int)bs.shells.size();
+    std::vector<long long> cum_pairs(nsh + 1, 0), cum_pp(nsh + 1, 0), cum_comp(nsh + 1, 0);
     for (int p = 0; p < npairs; ++p) {
-        tot_pp += bs.pairs[p].npp;
-        tot_comp += (long long)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
+        const int A = bs.pairs[p].A;
+        cum_pairs[A + 1] += 1;
+        cum_pp[A + 1] += bs.pairs[p].npp;
+        cum_comp[A + 1] += (long long)bs.shells[A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
     }
+    for (int a = 0; a < nsh; ++a) { cum_pairs[a + 1] += cum_pairs[a]; cum_pp[a + 1] += cum_pp[a]; cum_comp[a + 1] += cum_comp[a]; }
     DBG("slab buffers allocated");
     auto t_wall0 = std::chrono::steady_clock::now();
     // class-sorted ket lists on the device (one contiguous range per class)
@@ -744,9 +751,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                     outs.push_back(OutRow{i, j, a.cart_off, b.cart_off, b.ncomp, 0, rows_c, dst});
                 }
             rows_c += nr;
-            n_quart += npairs;
-            n_primq += (long long)bs.pairs[p].npp * tot_pp;
-            n_compq += nr * tot_comp;
+            const int Alim = packed ? bs.pairs[p].A + 1 : nsh;
+            n_quart += cum_pairs[Alim];
+            n_primq += (long long)bs.pairs[p].npp * cum_pp[Alim];
+            n_compq += nr * cum_comp[Alim];
             ++cursor;
         }
         // the previous slab's kernels (stream 0 and the class streams) read these buffers: drain before overwriting
