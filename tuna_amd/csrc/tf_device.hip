@@ -611,7 +611,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     int launch_count = 0;
     DBG("streams created");
 
-    auto class_launch = [&](int bcls, int kcls, int max_npp_bra, unsigned n_bra, const int *d_bra, const long long *d_braoff) {
+    // bra_Amax: largest first shell among the bra pairs of the run -- in the packed layout only kets with first shell <= it are needed
+    // (the class ket lists ascend in the first shell, so that is a prefix: workgroups beyond it are not even launched)
+    auto class_launch = [&](int bcls, int kcls, int max_npp_bra, unsigned n_bra, const int *d_bra, const long long *d_braoff, int bra_Amax) {
         const tf::Pair &pb = bs.pairs[ctx->class_pairs[bcls][0]], &pk = bs.pairs[ctx->class_pairs[kcls][0]];
         const tf::Shell &sa = bs.shells[pb.A], &sb = bs.shells[pb.B], &sc = bs.shells[pk.A], &sd = bs.shells[pk.B];
         QClass q{};
@@ -623,6 +625,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         q.npp_ab = max_npp_bra; q.npp_cd = cls_maxnpp[kcls]; q.npq = q.npp_ab * q.npp_cd;      // class maxima (LDS sizing)
         q.nEab = pb.nE; q.nEcd = pk.nE;
         q.n_ket = ket_off[kcls + 1] - ket_off[kcls];
+        if (packed) {
+            const std::vector<int> &kl = ctx->class_pairs[kcls];
+            q.n_ket = (int)(std::upper_bound(kl.begin(), kl.end(), bra_Amax, [&](int a, int p) { return a < bs.pairs[p].A; }) - kl.begin());
+            if (q.n_ket == 0) return;
+        }
         q.fused = 1; q.spherical = spherical ? 1 : 0;
         q.nsc = spherical ? sc.nsph : sc.ncomp; q.nsd = spherical ? sd.nsph : sd.ncomp;
         q.Nout = N; q.ld = ld;
@@ -648,6 +655,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             q.offScale = o; o += 42 + kc * q.G;
             q.offLmn = o; o += (42 + kc * q.G + q.G + 1) / 2;
             q.offBlk = o; o += q.G * q.ncomp;
+            q.offCsr = o; o += TF_CSR_DOUBLES;
             q.lds_doubles = o;
             const dim3 grid((q.n_ket + q.G - 1) / q.G, n_bra);
             hipLaunchKernelGGL(eri_multi_kernel, grid, dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q, d_bra, d_braoff,
@@ -666,6 +674,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             q.offLmn = o; o += 42;
             q.offRed = o; o += 2 * nT * nM;                      // X and Z tables
             q.offBlk = o; o += TF_BLK_DOUBLES;
+            q.offTab = o; o += 3 * (q.nca * q.ncb + q.ncc * q.ncd + 1) / 2 + 1;
+            q.offG = o; o += (q.Lc + 1) * (q.Ld + 1) * (q.La + q.Lb + 1) * nM;
+            q.offCsr = o; o += TF_CSR_DOUBLES;
             q.lds_doubles = o;
             hipLaunchKernelGGL(eri_fact_kernel, dim3(q.n_ket, n_bra), dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q, d_bra,
                                d_braoff, d_ket, Nc, d_out_slab);
@@ -686,6 +697,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             q.offScale = o; o += 84;
             q.offLmn = o; o += 42;
             q.offBlk = o; o += TF_BLK_DOUBLES;
+            q.offCsr = o; o += TF_CSR_DOUBLES;
             q.lds_doubles = o;
             const dim3 grid(q.n_ket, n_bra);
             if (stage)
@@ -774,10 +786,14 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         while (r0 < bra.size()) {
             const int bcls = ctx->pair_class[bra[r0]];
             size_t r1 = r0;
-            int max_npp = 1;
-            while (r1 < bra.size() && ctx->pair_class[bra[r1]] == bcls) { max_npp = std::max(max_npp, bs.pairs[bra[r1]].npp); ++r1; }
+            int max_npp = 1, Amax = 0;
+            while (r1 < bra.size() && ctx->pair_class[bra[r1]] == bcls) {
+                max_npp = std::max(max_npp, bs.pairs[bra[r1]].npp);
+                Amax = std::max(Amax, bs.pairs[bra[r1]].A);
+                ++r1;
+            }
             for (int kcls = 0; kcls < ncls; ++kcls)
-                class_launch(bcls, kcls, max_npp, (unsigned)(r1 - r0), d_bra + r0, d_braoff + r0);
+                class_launch(bcls, kcls, max_npp, (unsigned)(r1 - r0), d_bra + r0, d_braoff + r0, Amax);
             r0 = r1;
         }
         for (int k = 0; k < NSTREAM; ++k) {

@@ -24,6 +24,9 @@ struct QClass {
     int G, ncp;            // multi kernel: shell quartets per workgroup, padded components per quartet
     int n_ket;             // ket pairs in this launch
     int fused, spherical, nsc, nsd, Nout, ld, offBlk;   // fused ket transform: output dims of shells C, D; T2 geometry; LDS block buffer
+    int offG;              // factorised kernel: ket half of the z tables, (Lc+1)(Ld+1)(La+Lb+1) nM doubles
+    int offTab;            // factorised kernel: per-pair component tables, (nab + ncc*ncd) * 3/2 doubles
+    int offCsr;            // fused spherical ket transform: LDS copy of the two shells' Cartesian->spherical CSR rows (TF_CSR_DOUBLES)
     int tri;               // packed layout: only kets with first shell <= the bra's first shell are needed ((kl) <= (ij))
     // LDS carve-out, offsets in doubles
     int offR, offPref, offPQ, offRed, offEab, offEcd, offScale, offLmn, lds_doubles;
@@ -108,11 +111,34 @@ __device__ __forceinline__ double hermite_sum(const CompQuartet &Q, const double
 
 #define TF_BLK_DOUBLES 1024   // LDS doubles of the Cartesian (cc,cd) sub-block buffer of the fused ket transform
 
+// LDS copy of the Cartesian->spherical rows of shell types C and D (the global CSR is a chain of dependent L2 loads per output)
+#define TF_CSR_CAP 144                                     // entries per shell type (h shells: 11 rows)
+#define TF_CSR_DOUBLES (2 * TF_CSR_CAP + (2 * TF_CSR_CAP + 32) / 2)
+struct KetCsr { const double *valC, *valD; const int *ptrC, *ptrD, *idxC, *idxD; bool ok; };
+
+__device__ __forceinline__ KetCsr stage_ket_csr(const DBasis &B, const QClass &qc, double *sCsr, int tid, int nthreads)
+{
+    double *vC = sCsr, *vD = sCsr + TF_CSR_CAP;
+    int *ints = reinterpret_cast<int *>(sCsr + 2 * TF_CSR_CAP);
+    int *pC = ints, *pD = ints + 16, *iC = ints + 32, *iD = ints + 32 + TF_CSR_CAP;
+    const int baseC = B.sphL_base[qc.Lc], baseD = B.sphL_base[qc.Ld];
+    const int c0 = B.sphL_ptr[baseC], d0 = B.sphL_ptr[baseD];
+    const int nC = B.sphL_ptr[baseC + qc.nsc] - c0, nD = B.sphL_ptr[baseD + qc.nsd] - d0;
+    KetCsr K{vC, vD, pC, pD, iC, iD, nC <= TF_CSR_CAP && nD <= TF_CSR_CAP && qc.nsc < 16 && qc.nsd < 16};
+    if (!K.ok) return K;
+    for (int k = tid; k <= qc.nsc; k += nthreads) pC[k] = B.sphL_ptr[baseC + k] - c0;
+    for (int k = tid; k <= qc.nsd; k += nthreads) pD[k] = B.sphL_ptr[baseD + k] - d0;
+    for (int k = tid; k < nC; k += nthreads) { iC[k] = B.sphL_idx[c0 + k]; vC[k] = B.sphL_val[c0 + k]; }
+    for (int k = tid; k < nD; k += nthreads) { iD[k] = B.sphL_idx[d0 + k]; vD[k] = B.sphL_val[d0 + k]; }
+    return K;                                              // the caller's next barrier publishes it
+}
+
 // Fused ket transform (reference: the ket half of transform_to_spherical_harmonics, kernel:504-523): the Cartesian values of
 // `nblk` complete (cc,cd) sub-blocks sit in LDS (sBlk[b][cc][cd]); every thread produces outputs (b, sc, sd) as short CSR dot
-// products and writes them straight into the half-transformed slab T2[row(ca,cb)][k_out][l_out] (and the mirror image).
-__device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, const double *sBlk, int nblk, long long row_first,
-                                             const DPair &cd, double *__restrict__ T2, int tid, int nthreads)
+// products and writes them straight into the half-transformed slab T2[row(ca,cb)][k_out][l_out] (and, for the rows layout, the
+// mirror image).
+__device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, const KetCsr &K, const double *sBlk, int nblk,
+                                             long long row_first, const DPair &cd, double *__restrict__ T2, int tid, int nthreads)
 {
     const int per = qc.nsc * qc.nsd;
     const size_t row_len = (size_t)qc.Nout * qc.ld;
@@ -122,7 +148,14 @@ __device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, 
         const int sc = r / qc.nsd, sd = r - sc * qc.nsd;
         const double *blk = sBlk + (size_t)b * qc.ncc * qc.ncd;
         double s = 0.0;
-        if (qc.spherical) {
+        if (qc.spherical && K.ok) {
+            for (int qa = K.ptrC[sc]; qa < K.ptrC[sc + 1]; ++qa) {
+                const double *rowp = blk + K.idxC[qa] * qc.ncd;
+                double t = 0.0;
+                for (int qb = K.ptrD[sd]; qb < K.ptrD[sd + 1]; ++qb) t += K.valD[qb] * rowp[K.idxD[qb]];
+                s += K.valC[qa] * t;
+            }
+        } else if (qc.spherical) {
             for (int qa = B.sphL_ptr[baseC + sc]; qa < B.sphL_ptr[baseC + sc + 1]; ++qa) {
                 const double *rowp = blk + B.sphL_idx[qa] * qc.ncd;
                 double t = 0.0;
@@ -134,7 +167,7 @@ __device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, 
         const int k = cd.outoff_a + sc, l = cd.outoff_b + sd;
         double *dst = T2 + (size_t)(row_first + b) * row_len;
         dst[(size_t)k * qc.ld + l] = s;
-        if (cd.A != cd.B) dst[(size_t)l * qc.ld + k] = s;
+        if (cd.A != cd.B && !qc.tri) dst[(size_t)l * qc.ld + k] = s;   // the packed layout keeps k >= l only: no mirror image
     }
 }
 
@@ -212,6 +245,8 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_class_kernel(DBasis B, QCl
     stage_components(B, ab.compoff_b, qc.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
     stage_components(B, cd.compoff_a, qc.ncc, sLmn + 42, sScale + 42, tid, TF_ERI_THREADS);
     stage_components(B, cd.compoff_b, qc.ncd, sLmn + 63, sScale + 63, tid, TF_ERI_THREADS);
+    KetCsr kcsr{};
+    if (qc.fused && qc.spherical) kcsr = stage_ket_csr(B, qc, smem + qc.offCsr, tid, TF_ERI_THREADS);
     const double *__restrict__ gEab = B.epool + ab.e_off;
     const double *__restrict__ gEcd = B.epool + cd.e_off;
     const bool staged = STAGE_E && stage_ok;
@@ -307,13 +342,13 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_class_kernel(DBasis B, QCl
                     const size_t row = (size_t)(row0 + (long long)Q.ca * qc.ncb + Q.cb);
                     const int k = cd.cartoff_a + Q.cc, l = cd.cartoff_b + Q.cd;
                     Cslab[row * NcNc + (size_t)k * Nc + l] = val;
-                    if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+                    if (cd.A != cd.B && !qc.tri) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
                 }
             }
         }
         if (qc.fused) {
             __syncthreads();
-            ket_epilogue(B, qc, sBlk, nblk, row0 + blk0, cd, Cslab, tid, TF_ERI_THREADS);
+            ket_epilogue(B, qc, kcsr, sBlk, nblk, row0 + blk0, cd, Cslab, tid, TF_ERI_THREADS);
             __syncthreads();
         }
     }
@@ -351,6 +386,8 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_multi_kernel(DBasis B, QCl
     // ---- staging: bra tables once, ket tables per sub-quartet ----
     stage_components(B, ab.compoff_a, qc.nca, sLmn, sScale, tid, TF_ERI_THREADS);
     stage_components(B, ab.compoff_b, qc.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
+    KetCsr kcsr{};
+    if (qc.fused && qc.spherical) kcsr = stage_ket_csr(B, qc, smem + qc.offCsr, tid, TF_ERI_THREADS);
     {
         const double *__restrict__ gEab = B.epool + ab.e_off;
         for (int k = tid; k < 2 * nEab; k += TF_ERI_THREADS) sEab[k] = gEab[k];
@@ -397,7 +434,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_multi_kernel(DBasis B, QCl
             const size_t row = (size_t)(row0 + (long long)Q.ca * qc.ncb + Q.cb);
             const int k = cd.cartoff_a + Q.cc, l = cd.cartoff_b + Q.cd;
             Cslab[row * NcNc + (size_t)k * Nc + l] = val;
-            if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+            if (cd.A != cd.B && !qc.tri) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
         }
     }
     if (qc.fused) {
@@ -409,7 +446,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_multi_kernel(DBasis B, QCl
         if (lanes > 0 && sq < nsub) {
             const DPair cd = B.pairs[sKet[sq]];
             (void)per;
-            ket_epilogue(B, qc, smem + qc.offBlk + (size_t)sq * qc.ncomp, nab, row0, cd, Cslab, lt, lanes);
+            ket_epilogue(B, qc, kcsr, smem + qc.offBlk + (size_t)sq * qc.ncomp, nab, row0, cd, Cslab, lt, lanes);
         }
     }
 }
@@ -423,6 +460,48 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_multi_kernel(DBasis B, QCl
 // There are only (La+1)(Lb+1)(Lc+1)(Ld+1) tuples (256 for ffff), so the tables are built once per shell quartet in LDS and
 // every Cartesian component costs a handful of multiply-adds instead of ~150 (same terms, different association order:
 // results agree with the reference's order to rounding).
+// sum_{m + m' <= NM-1} X[m] Y[m'] Z[m + m'] with the three table rows in registers (rows are zero-padded beyond their degree)
+template <int NM>
+__device__ __forceinline__ double fact_sum(const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z)
+{
+    double x[NM], y[NM], z[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) { x[m] = X[m]; y[m] = Y[m]; z[m] = Z[m]; }
+    double sum = 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        double t = 0.0;
+#pragma unroll
+        for (int mp = 0; mp + m < NM; ++mp) t += y[mp] * z[m + mp];
+        sum += x[m] * t;
+    }
+    return sum;
+}
+
+__device__ __forceinline__ double fact_sum_any(int nM, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z)
+{
+    switch (nM) {
+    case 1: return fact_sum<1>(X, Y, Z);
+    case 2: return fact_sum<2>(X, Y, Z);
+    case 3: return fact_sum<3>(X, Y, Z);
+    case 4: return fact_sum<4>(X, Y, Z);
+    case 5: return fact_sum<5>(X, Y, Z);
+    case 6: return fact_sum<6>(X, Y, Z);
+    case 7: return fact_sum<7>(X, Y, Z);
+    case 8: return fact_sum<8>(X, Y, Z);
+    case 9: return fact_sum<9>(X, Y, Z);
+    default: {
+        double sum = 0.0;
+        for (int m = 0; m < nM; ++m) {
+            double t = 0.0;
+            for (int mp = 0; mp + m < nM; ++mp) t += Y[mp] * Z[m + mp];
+            sum += X[m] * t;
+        }
+        return sum;
+    }
+    }
+}
+
 __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QClass qc, const int *__restrict__ bra_pairs,
                                                                   const long long *__restrict__ bra_rowoff,
                                                                   const int *__restrict__ ket_pairs, int Nc,
@@ -449,6 +528,8 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     stage_components(B, ab.compoff_b, qc.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
     stage_components(B, cd.compoff_a, qc.ncc, sLmn + 42, sScale + 42, tid, TF_ERI_THREADS);
     stage_components(B, cd.compoff_b, qc.ncd, sLmn + 63, sScale + 63, tid, TF_ERI_THREADS);
+    KetCsr kcsr{};
+    if (qc.fused && qc.spherical) kcsr = stage_ket_csr(B, qc, smem + qc.offCsr, tid, TF_ERI_THREADS);
     {
         const double *__restrict__ gEab = B.epool + ab.e_off;
         const double *__restrict__ gEcd = B.epool + cd.e_off;
@@ -456,6 +537,25 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
         for (int k = tid; k < 2 * nEcd; k += TF_ERI_THREADS) sEcd[k] = gEcd[k];
     }
     coop_tables(B, L, 1, 1, sR, sPref, sPQ, [&](int, int &ppab, int &ppcd) { ppab = ab.pp_off; ppcd = cd.pp_off; }, tid);
+    __syncthreads();
+    // ---- ket half of the z tables: G[c,d][v][n], v <= La + Lb, n <= L - v - (c + d) (zero beyond) ----
+    double *sG = smem + qc.offG;
+    for (int e = tid; e < Lc1 * Ld1 * Lab1 * nM; e += TF_ERI_THREADS) {
+        const int n = e % nM;
+        int r = e / nM;
+        const int v = r % Lab1; r /= Lab1;
+        const int d = r % Ld1, c = r / Ld1;
+        const int l34 = c + d;
+        double gsum = 0.0;
+        if (n <= L - v - l34) {
+            const double *Ez34 = sEcd + nEcd + (c * Ld1 + d) * Lcd1;
+            for (int phi = 0; phi <= l34; ++phi) {
+                const double term = Ez34[phi] * sR[tri_index(v + phi, n, L)];
+                gsum += (phi & 1) ? -term : term;
+            }
+        }
+        sG[e] = gsum;
+    }
     __syncthreads();
     // ---- per-axis tables ----
     for (int e = tid; e < nT * nM; e += TF_ERI_THREADS) {
@@ -478,67 +578,69 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
             x *= c_dfact[m];
         }
         sX[e] = x;
-        // Z: all v, phi; n = m
+        // Z in two stages (below): first the ket half G[c,d][v][n] = sum_phi (-1)^phi Ez34[phi] R[v + phi][n], then the bra half
         double z = 0.0;
         if (m <= L - l12 - l34) {
-            const double *Ez12 = sEab + nEab + (a * Lb1 + b) * Lab1, *Ez34 = sEcd + nEcd + (c * Ld1 + d) * Lcd1;
-            for (int v = 0; v <= l12; ++v) {
-                double zphi = 0.0;
-                for (int phi = 0; phi <= l34; ++phi) {
-                    const double term = Ez34[phi] * sR[tri_index(v + phi, m, L)];
-                    zphi += (phi & 1) ? -term : term;
-                }
-                z += Ez12[v] * zphi;
-            }
+            const double *Ez12 = sEab + nEab + (a * Lb1 + b) * Lab1;
+            const double *G = sG + ((c * Ld1 + d) * Lab1) * nM + m;
+            for (int v = 0; v <= l12; ++v) z += Ez12[v] * G[v * nM];
         }
         sZ[e] = z;
     }
     __syncthreads();
     // ---- components, in groups of complete (cc,cd) sub-blocks ----
+    // Per bra component pair and per ket component pair (class constants, tabulated once per workgroup): the pair's part of the three
+    // table indices, the parities of its x and y exponent sums, and its normalisation ratio.  A component is then two table lookups,
+    // one parity test and one unrolled triple-table sum -- no integer division by runtime shell sizes, no per-component lmn decode.
     const double pref = sPref[0];
     const int *lmnA = sLmn, *lmnB = sLmn + 21, *lmnC = sLmn + 42, *lmnD = sLmn + 63;
     double *sBlk = smem + qc.offBlk;
     const int nsubc = qc.ncc * qc.ncd, nab = qc.nca * qc.ncb;
+    double *sScAB = smem + qc.offTab, *sScCD = sScAB + nab;
+    int *sIxAB = reinterpret_cast<int *>(sScCD + nsubc), *sIxCD = sIxAB + nab;
+    for (int e = tid; e < nab + nsubc; e += TF_ERI_THREADS) {
+        const bool bra = e < nab;
+        const int f = bra ? e : e - nab;
+        const int n2 = bra ? qc.ncb : qc.ncd, L2 = bra ? Lb1 : Ld1;
+        const int i1 = f / n2, i2 = f - i1 * n2;
+        const int u = bra ? lmnA[i1] : lmnC[i1], w = bra ? lmnB[i2] : lmnD[i2];
+        const int ux = u & 255, uy = (u >> 8) & 255, uz = (u >> 16) & 255, wx = w & 255, wy = (w >> 8) & 255, wz = (w >> 16) & 255;
+        const int packed = (ux * L2 + wx) | ((uy * L2 + wy) << 8) | ((uz * L2 + wz) << 16) | (((ux + wx) & 1) << 24) | (((uy + wy) & 1) << 25);
+        if (bra) { sIxAB[f] = packed; sScAB[f] = sScale[i1] * sScale[21 + i2]; }
+        else { sIxCD[f] = packed; sScCD[f] = sScale[42 + i1] * sScale[63 + i2]; }
+    }
+    __syncthreads();
+    const int LcLd = Lc1 * Ld1;
+    const float inv_nsubc = 1.0f / (float)nsubc;
     const int GB = qc.fused ? max(1, min(nab, TF_BLK_DOUBLES / nsubc)) : nab;
     for (int blk0 = 0; blk0 < nab; blk0 += GB) {
         const int nblk = min(GB, nab - blk0), ncg = nblk * nsubc;
         for (int cl = tid; cl < ncg; cl += TF_ERI_THREADS) {
-            int c = blk0 * nsubc + cl;
-            const int id = c % qc.ncd; c /= qc.ncd;
-            const int ic = c % qc.ncc; c /= qc.ncc;
-            const int ib = c % qc.ncb; const int ia = c / qc.ncb;
-            const int a = lmnA[ia], b = lmnB[ib], cc = lmnC[ic], d = lmnD[id];
-            const int ax = a & 255, ay = (a >> 8) & 255, az = (a >> 16) & 255;
-            const int bx = b & 255, by = (b >> 8) & 255, bz = (b >> 16) & 255;
-            const int cx = cc & 255, cy = (cc >> 8) & 255, cz = (cc >> 16) & 255;
-            const int dx = d & 255, dy = (d >> 8) & 255, dz = (d >> 16) & 255;
-            const int lxs = ax + bx + cx + dx, lys = ay + by + cy + dy;
+            int abl = (int)((float)cl * inv_nsubc);                     // cl / nsubc without an integer division
+            if ((abl + 1) * nsubc <= cl) ++abl;
+            if (abl * nsubc > cl) --abl;
+            const int icd = cl - abl * nsubc, iab = blk0 + abl;
+            const int pa = sIxAB[iab], pc = sIxCD[icd];
             double val = 0.0;
-            if (!((lxs & 1) || (lys & 1))) {                          // x/y parity, pyx:1324-1327
-                const double *X = sX + (((ax * Lb1 + bx) * Lc1 + cx) * Ld1 + dx) * nM;
-                const double *Y = sX + (((ay * Lb1 + by) * Lc1 + cy) * Ld1 + dy) * nM;
-                const double *Z = sZ + (((az * Lb1 + bz) * Lc1 + cz) * Ld1 + dz) * nM;
-                double sum = 0.0;
-                for (int m = 0; m <= lxs / 2; ++m) {
-                    const double xm = X[m];
-                    double t = 0.0;
-                    for (int mp = 0; mp <= lys / 2; ++mp) t += Y[mp] * Z[m + mp];
-                    sum += xm * t;
-                }
-                val = pref * sum * (sScale[ia] * sScale[21 + ib] * sScale[42 + ic] * sScale[63 + id]);
+            if ((((pa ^ pc) >> 24) & 3) == 0) {                          // x and y exponent sums both even, pyx:1324-1327
+                const double *X = sX + ((pa & 255) * LcLd + (pc & 255)) * nM;
+                const double *Y = sX + (((pa >> 8) & 255) * LcLd + ((pc >> 8) & 255)) * nM;
+                const double *Z = sZ + (((pa >> 16) & 255) * LcLd + ((pc >> 16) & 255)) * nM;
+                val = pref * fact_sum_any(nM, X, Y, Z) * (sScAB[iab] * sScCD[icd]);
             }
             if (qc.fused)
                 sBlk[cl] = val;
             else {
+                const int ia = iab / qc.ncb, ib = iab - ia * qc.ncb, ic = icd / qc.ncd, id = icd - ic * qc.ncd;
                 const size_t row = (size_t)(row0 + (long long)ia * qc.ncb + ib);
                 const int k = cd.cartoff_a + ic, l = cd.cartoff_b + id;
                 Cslab[row * NcNc + (size_t)k * Nc + l] = val;
-                if (cd.A != cd.B) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+                if (cd.A != cd.B && !qc.tri) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
             }
         }
         if (qc.fused) {
             __syncthreads();
-            ket_epilogue(B, qc, sBlk, nblk, row0 + blk0, cd, Cslab, tid, TF_ERI_THREADS);
+            ket_epilogue(B, qc, kcsr, sBlk, nblk, row0 + blk0, cd, Cslab, tid, TF_ERI_THREADS);
             __syncthreads();
         }
     }
