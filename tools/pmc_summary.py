@@ -19,10 +19,17 @@ def main():
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0]
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    res = {k: {c: {"dispatches": len(v), "mean_KB": sum(v) / len(v), "max_KB": max(v)} for c, v in cs.items()} for k, cs in agg.items()}
+    res = {}
+    for k, cs in agg.items():
+        res[k] = {}
+        for c, v in cs.items():
+            e = {"dispatches": len(v), "mean": sum(v) / len(v), "max": max(v), "sum": sum(v)}
+            if c.endswith("_SIZE"):                      # FETCH_SIZE / WRITE_SIZE count KB
+                e["mean_KB"], e["max_KB"] = e["mean"], e["max"]
+            res[k][c] = e
     json.dump(res, open(out, "w"), indent=1)
     for k, cs in res.items():
-        print(k, {c: round(v["mean_KB"], 1) for c, v in cs.items()})
+        print(k, {c: round(v["mean"], 1) for c, v in cs.items()})
 
 
 if __name__ == "__main__":
