@@ -676,13 +676,16 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             q.offPQ = o; o += 2;
             q.offEab = o; o += 2 * q.nEab;
             q.offEcd = o; o += 2 * q.nEcd;
+            const int tables_end = o;                            // R, prefactors and E tables: dead once X and Z are built
             q.offScale = o; o += 84;
             q.offLmn = o; o += 42;
             q.offRed = o; o += 2 * nT * nM;                      // X and Z tables
-            q.offBlk = o; o += TF_BLK_DOUBLES;
+            const int nG = (q.Lc + 1) * (q.Ld + 1) * (q.La + q.Lb + 1) * nM;
+            q.offBlk = o; o += std::max((int)TF_BLK_DOUBLES, nG);   // the ket half of the z tables lives here until the components start
+            q.offG = q.offBlk;
             q.offTab = o; o += 3 * (q.nca * q.ncb + q.ncc * q.ncd + 1) / 2 + 1;
-            q.offG = o; o += (q.Lc + 1) * (q.Ld + 1) * (q.La + q.Lb + 1) * nM;
-            q.offCsr = o; o += TF_CSR_DOUBLES;
+            if (tables_end >= TF_CSR_DOUBLES) q.offCsr = 0;      // staged over the dead tables (after the X/Z barrier)
+            else { q.offCsr = o; o += TF_CSR_DOUBLES; }
             q.lds_doubles = o;
             hipLaunchKernelGGL(eri_fact_kernel, dim3(q.n_ket, n_bra), dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q, d_bra,
                                d_braoff, d_ket, Nc, d_out_slab);
@@ -718,7 +721,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // Small problems: one launch per slab mixing every class (LDS carved by launch-wide capacities).
     auto generic_launch = [&](unsigned n_bra, const int *d_bra, const long long *d_braoff) {
         QClass q{};
-        const int RB = 3584, EBa = 1536, EBc = 1536;       // (doubling the E capacities halves the occupancy: Ar2 build 0.084 -> 0.18 s)
+        const int RB = 2048, EBa = 1024, EBc = 1024;       // (doubling the E capacities halves the occupancy: Ar2 build 0.084 -> 0.18 s)
         int o = 0;
         q.offR = o; o += RB;
         q.offPref = o; o += TF_ERI_THREADS;

@@ -528,8 +528,6 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     stage_components(B, ab.compoff_b, qc.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
     stage_components(B, cd.compoff_a, qc.ncc, sLmn + 42, sScale + 42, tid, TF_ERI_THREADS);
     stage_components(B, cd.compoff_b, qc.ncd, sLmn + 63, sScale + 63, tid, TF_ERI_THREADS);
-    KetCsr kcsr{};
-    if (qc.fused && qc.spherical) kcsr = stage_ket_csr(B, qc, smem + qc.offCsr, tid, TF_ERI_THREADS);
     {
         const double *__restrict__ gEab = B.epool + ab.e_off;
         const double *__restrict__ gEcd = B.epool + cd.e_off;
@@ -588,6 +586,9 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
         sZ[e] = z;
     }
     __syncthreads();
+    // the R / E tables are dead from here on: the spherical CSR rows of the ket shells may be staged over them (host: offCsr)
+    KetCsr kcsr{};
+    if (qc.fused && qc.spherical) kcsr = stage_ket_csr(B, qc, smem + qc.offCsr, tid, TF_ERI_THREADS);
     // ---- components, in groups of complete (cc,cd) sub-blocks ----
     // Per bra component pair and per ket component pair (class constants, tabulated once per workgroup): the pair's part of the three
     // table indices, the parities of its x and y exponent sums, and its normalisation ratio.  A component is then two table lookups,
