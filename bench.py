@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("TUNA_BENCH_WORKLOAD", "synth-400"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scf", action="store_true")
+    ap.add_argument("--n-dens", type=int, choices=[1, 2], default=1, help="densities per Fock build (2 = a UHF build: alpha and beta in one pass)")
     ap.add_argument("--layout", choices=["packed", "rows"], default="packed", help="ERI storage layout (tunafock.h: tf_set_eri_layout)")
     args = ap.parse_args()
 
@@ -155,12 +156,13 @@ def main():
     A = np.random.default_rng(0).standard_normal((N, N))
     P = A + A.T
     P *= 2 * nocc / np.trace(P @ S)
-    dP = torch.from_numpy(P).to(dev)
-    dJK = torch.zeros((2, N, N), dtype=torch.float64, device=dev)
+    nd = args.n_dens
+    dP = torch.from_numpy(np.stack([P, 0.5 * P + 0.25 * np.diag(np.diag(P))][:nd])).to(dev)       # [nd, N, N], symmetric
+    dJK = torch.zeros((2, nd, N, N), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, stream)
+        eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), nd, stream)
         if world > 1:
             dist.all_reduce(dJK)
 
@@ -191,7 +193,7 @@ def main():
     kernel_avg_s = float(k_max.item())
 
     # sanity of the timed result: J symmetric, tr-type identity <P|J> > 0
-    Jh = dJK[0].cpu().numpy()
+    Jh = dJK[0, 0].cpu().numpy()
     ok = bool(np.isfinite(Jh).all() and np.abs(Jh - Jh.T).max() < 1e-8 * max(1.0, np.abs(Jh).max()))
 
     if rank == 0:
@@ -209,7 +211,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "n_ao_spherical": N, "n_ao_cartesian": eng.n_cart,
-                       "n_shells": eng.n_shell, "n_densities": 1, "layout": layout, "storage": storage,
+                       "n_shells": eng.n_shell, "n_densities": nd, "layout": layout, "storage": storage,
                        "stored_bytes_per_gpu": stored_bytes, "parallelism": f"ij-row shards x{world} + RCCL all-reduce of [J;K]" if world > 1 else "1 GPU",
                        "result_ok": ok},
             "roofline": {"bound": "hbm", "kernel": JK_KERNEL[layout], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

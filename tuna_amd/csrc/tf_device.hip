@@ -59,11 +59,15 @@ struct tf_ctx {
     int layout = 0;
     long long n_elems = 0;              // stored doubles
     long long *d_rowoff = nullptr;
-    JKGroup *d_groups = nullptr;
-    JKTask *d_tasks = nullptr;
-    JKSuper *d_supers = nullptr;
-    int n_groups = 0, n_tasks = 0, n_supers = 0, nseg = 1;
-    int *d_gfirst = nullptr;            // [2][N]: first / one-past-last group with i == a
+    // work tables of jk_packed_kernel: set 0 for one density per pass (groups of 8 rows), set 1 for two (groups of 4 rows)
+    struct JKTables {
+        JKGroup *d_groups = nullptr;
+        JKTask *d_tasks = nullptr;
+        JKSuper *d_supers = nullptr;
+        int *d_gfirst = nullptr;        // [2][N]: first / one-past-last group with i == a
+        int n_groups = 0, n_tasks = 0, n_supers = 0, nseg = 1;
+        long long ypart_len = 0;
+    } jkt[2];
     double *d_Psym = nullptr, *d_Pp = nullptr, *d_ypart = nullptr, *d_DI = nullptr, *d_DJ = nullptr, *d_Jt = nullptr, *d_D = nullptr;
     // instrumentation
     bool prof_jk = false;
@@ -121,15 +125,19 @@ static int upload(tf_ctx *ctx, const std::vector<T> &h, T **d, bool track = true
 static void free_eri(tf_ctx *ctx)
 {
     for (void *p : {(void *)ctx->d_eri, (void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
-                    (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_groups,
-                    (void *)ctx->d_gfirst, (void *)ctx->d_tasks, (void *)ctx->d_supers, (void *)ctx->d_Psym, (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ,
-                    (void *)ctx->d_Jt, (void *)ctx->d_D})
+                    (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_Psym,
+                    (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ, (void *)ctx->d_Jt, (void *)ctx->d_D})
         if (p) (void)hipFree(p);
+    for (auto &t : ctx->jkt) {
+        for (void *p : {(void *)t.d_groups, (void *)t.d_tasks, (void *)t.d_supers, (void *)t.d_gfirst})
+            if (p) (void)hipFree(p);
+        t = tf_ctx::JKTables();
+    }
     ctx->d_eri = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
     ctx->d_Ppad = nullptr; ctx->d_J = nullptr; ctx->d_K = nullptr; ctx->d_P = nullptr;
-    ctx->d_rowoff = nullptr; ctx->d_groups = nullptr; ctx->d_tasks = nullptr; ctx->d_supers = nullptr; ctx->d_gfirst = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
+    ctx->d_rowoff = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
     ctx->d_ypart = nullptr; ctx->d_DI = nullptr; ctx->d_DJ = nullptr; ctx->d_Jt = nullptr; ctx->d_D = nullptr;
-    ctx->n_groups = 0; ctx->n_tasks = 0; ctx->n_supers = 0; ctx->n_elems = 0;
+    ctx->n_elems = 0;
     ctx->have_eri = false;
 }
 
@@ -473,11 +481,6 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             }
     }
     std::vector<long long> rowoff;
-    std::vector<JKGroup> groups;
-    std::vector<JKTask> tasks;
-    std::vector<JKSuper> supers;
-    std::vector<int> gfirst(2 * (size_t)N, 0);
-    long long ypart_len = 0;
     if (packed) {
         // owned rows in ascending (i,j); row (i,j) holds the pairs (k,l) <= (i,j) at their padded indices (tf_jkpacked.hip.h)
         std::sort(row_ij.begin(), row_ij.end(), [](const int2 &u, const int2 &v) { return u.x != v.x ? u.x < v.x : u.y < v.y; });
@@ -490,10 +493,18 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
         rowoff[row_ij.size()] = off;
         ctx->n_elems = off;
+    }
+    // work tables of the J/K kernel for groups of RB rows (8: one density per pass; 4: two)
+    auto build_jk_tables = [&](int RB, tf_ctx::JKTables &T) -> int {
+        std::vector<JKGroup> groups;
+        std::vector<JKTask> tasks;
+        std::vector<JKSuper> supers;
+        std::vector<int> gfirst(2 * (size_t)N, 0);
+        long long ypart_len = 0;
         // groups: runs of consecutive j with the same i, longest rows first
         for (long long r = (long long)row_ij.size() - 1; r >= 0;) {
             long long r0 = r;
-            while (r0 > 0 && row_ij[r0 - 1].x == row_ij[r].x && row_ij[r0 - 1].y == row_ij[r0].y - 1 && r - r0 + 1 < TF_JKP_JBB) --r0;
+            while (r0 > 0 && row_ij[r0 - 1].x == row_ij[r].x && row_ij[r0 - 1].y == row_ij[r0].y - 1 && r - r0 + 1 < RB) --r0;
             JKGroup g{};
             g.i = row_ij[r].x; g.j0 = row_ij[r0].y; g.nr = (int)(r - r0 + 1); g.r0 = (int)r0;
             for (int q = 0; q < TF_JKP_JBB; ++q) g.roff[q] = (int)(rowoff[r0 + std::min<long long>(q, r - r0)] - rowoff[r0]);
@@ -523,7 +534,15 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         std::stable_sort(tasks.begin(), tasks.end(), [&](const JKTask &u, const JKTask &v) {
             return groups[supers[u.super].g0].i - u.chunk * TF_JKP_CW > groups[supers[v.super].g0].i - v.chunk * TF_JKP_CW;
         });
-    }
+        int rc2;
+        if ((rc2 = upload(ctx, groups, &T.d_groups, false)) || (rc2 = upload(ctx, gfirst, &T.d_gfirst, false)) ||
+            (rc2 = upload(ctx, tasks, &T.d_tasks, false)) || (rc2 = upload(ctx, supers, &T.d_supers, false)))
+            return rc2;
+        T.n_groups = (int)groups.size(); T.n_tasks = (int)tasks.size(); T.n_supers = (int)supers.size();
+        T.nseg = std::max(1, std::min(TF_JKP_SEG, T.n_supers / 32));
+        T.ypart_len = ypart_len;
+        return TF_OK;
+    };
     ctx->n_rows = (long long)row_ij.size();
     const long long row_len = (long long)N * ld;
     if (!packed) ctx->n_elems = ctx->n_rows * row_len;
@@ -531,13 +550,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_eri, std::max<size_t>(1, (size_t)ctx->n_elems * sizeof(double))));
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
     if (packed) {
-        if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, groups, &ctx->d_groups, false)) ||
-            (rc = upload(ctx, gfirst, &ctx->d_gfirst, false)) || (rc = upload(ctx, tasks, &ctx->d_tasks, false)) ||
-            (rc = upload(ctx, supers, &ctx->d_supers, false)))
+        if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = build_jk_tables(TF_JKP_JBB, ctx->jkt[0])) ||
+            (rc = build_jk_tables(TF_JKP_JBB / 2, ctx->jkt[1])))
             return rc;
-        ctx->n_groups = (int)groups.size();
-        ctx->n_tasks = (int)tasks.size();
-        ctx->n_supers = (int)supers.size();
     }
 
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
@@ -858,18 +873,21 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     const size_t nn = (size_t)N * N;
     // (sized for two densities per pass)
     const int NWjk = (N + TF_JKP_CW - 1) / TF_JKP_CW;               // column chunks of jk_packed_kernel
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, std::max(2, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     if (packed) {
+        // everything sized for a two-density pass (second density behind the first)
         const size_t npr = (size_t)tri_off(N);                      // padded pair index space
-        ctx->nseg = std::max(1, std::min(TF_JKP_SEG, ctx->n_supers / 32));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Psym, nn * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Pp, npr * sizeof(double)));
-        HIPCHK(ctx, hipMemset(ctx->d_Pp, 0, npr * sizeof(double)));   // pad slots stay zero
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_ypart, std::max<size_t>(1, (size_t)ypart_len) * sizeof(double)));
+        const size_t ny = (size_t)std::max(ctx->jkt[0].ypart_len, 2 * ctx->jkt[1].ypart_len);
+        const size_t ng = (size_t)std::max(ctx->jkt[0].n_groups, 2 * ctx->jkt[1].n_groups);
+        const int nsegmax = std::max(ctx->jkt[0].nseg, ctx->jkt[1].nseg);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Psym, 2 * nn * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Pp, 2 * npr * sizeof(double)));
+        HIPCHK(ctx, hipMemset(ctx->d_Pp, 0, 2 * npr * sizeof(double)));   // pad slots stay zero
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_ypart, std::max<size_t>(1, ny) * sizeof(double)));
         // column parts [.][N] followed by the per-chunk row parts [.][NW][N]
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, std::max<size_t>(1, (size_t)ctx->n_groups) * (1 + NWjk) * N * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, std::max<size_t>(1, (size_t)ctx->n_rows) * (1 + NWjk) * N * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jt, (size_t)ctx->nseg * npr * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, std::max<size_t>(1, ng) * (1 + NWjk) * N * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * (1 + NWjk) * N * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jt, 2 * (size_t)nsegmax * npr * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_D, 2 * nn * sizeof(double)));
     } else
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Kp, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * 2 * ld * sizeof(double)));
@@ -961,43 +979,80 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
 // ---- J/K ------------------------------------------------------------------------------------------
 
 // nd = 1 or 2 densities in one pass over the tensor.  dP/dJ/dK: nd dense [N,N] device matrices each.
+// One pass of jk_packed_kernel over ND densities (device, symmetric for the exchange part; X = what the D terms contract with) and the
+// reductions; dDout[d]: the D matrix of density d.  Tables: set ND - 1.
+extern "C++" {
+template <int ND>
+static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
+{
+    const int N = ctx->N, NW = (N + TF_JKP_CW - 1) / TF_JKP_CW;
+    const size_t nn = (size_t)N * N, npr = (size_t)tri_off(N), nrows = (size_t)std::max<long long>(1, ctx->n_rows);
+    const tf_ctx::JKTables &T = ctx->jkt[ND - 1];
+    const size_t ng = (size_t)std::max(1, T.n_groups);
+    // layout of the partial arrays: [column parts of density 0 | .. density 1 | row parts of density 0 | .. density 1]
+    JKStrides S{};
+    S.P = nn; S.Pp = npr; S.y = (size_t)T.ypart_len; S.Jd = nrows * NW;
+    S.DIc = ng * N; S.DIr = ng * NW * N; S.DJc = nrows * N; S.DJr = nrows * NW * N;
+    double *DIc = ctx->d_DI, *DIr = ctx->d_DI + ND * S.DIc, *DJc = ctx->d_DJ, *DJr = ctx->d_DJ + ND * S.DJc;
+    if (T.n_tasks > 0) {
+        hipEvent_t ev_after = nullptr;
+        if (ctx->prof_jk) {
+            if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { ctx->prof_ev.push_back(a); ctx->prof_ev.push_back(b); }
+            }
+            if (ctx->prof_used + 2 <= ctx->prof_ev.size()) {
+                (void)hipEventRecord(ctx->prof_ev[ctx->prof_used], st);
+                ev_after = ctx->prof_ev[ctx->prof_used + 1];
+                ctx->prof_used += 2;
+            }
+        }
+        hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)T.n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, ctx->d_rowoff, T.d_groups,
+                           T.d_supers, T.d_tasks, N, NW, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+        if (ev_after) (void)hipEventRecord(ev_after, st);
+    }
+    for (int d = 0; d < ND; ++d) {
+        hipLaunchKernelGGL(jt_reduce_kernel, dim3((unsigned)((npr + 255) / 256), T.nseg), dim3(256), 0, st, ctx->d_ypart + d * S.y, T.d_supers,
+                           T.n_supers, (long long)npr, ctx->d_Jt + (size_t)d * T.nseg * npr);
+        hipLaunchKernelGGL(kd_reduce_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, st, DIc + d * S.DIc, DIr + d * S.DIr, DJc + d * S.DJc,
+                           DJr + d * S.DJr, NW, T.d_gfirst, ctx->d_rowmap, N, dDout[d]);
+    }
+    return TF_OK;
+}
+}  // extern "C++"
+
 // nonsym[d] != 0: density d is not symmetric -- two passes (K = D(P^T) + D(P)^T); nullptr = all symmetric.
 static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st,
                             const int *nonsym)
 {
     const int N = ctx->N, NW = (N + TF_JKP_CW - 1) / TF_JKP_CW;
-    const long long npr = tri_off(N);
+    const size_t nn = (size_t)N * N, npr = (size_t)tri_off(N), nrows = (size_t)std::max<long long>(1, ctx->n_rows);
+    const dim3 gN((N * N + 255) / 256), b256(256);
+    static const bool no_fuse = getenv("TF_JK_NOFUSE") != nullptr;
+    if (nd == 2 && !no_fuse && !(nonsym && (nonsym[0] || nonsym[1]))) {
+        // two symmetric densities (UHF alpha / beta): one pass over the tensor, groups of 4 rows x 2 densities
+        for (int d = 0; d < 2; ++d)
+            hipLaunchKernelGGL(pack_density_kernel, gN, b256, 0, st, dP[d], N, 0, ctx->d_Psym + d * nn, ctx->d_Pp + d * npr);
+        double *dD[2] = {ctx->d_D, ctx->d_D + nn};
+        int rc = jk_packed_pass<2>(ctx, st, dD);
+        if (rc) return rc;
+        const int nseg = ctx->jkt[1].nseg;
+        for (int d = 0; d < 2; ++d)
+            hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, dD[d], dD[d], ctx->d_Jrow + d * nrows * NW, NW,
+                               ctx->d_Jt + (size_t)d * nseg * npr, nseg, ctx->d_rowmap, N, dJ[d], dK[d]);
+        return TF_OK;
+    }
     for (int d = 0; d < nd; ++d)                                 // one density per pass over the packed tensor
       for (int pass = 0; pass < ((nonsym && nonsym[d]) ? 2 : 1); ++pass) {
         const bool general = nonsym && nonsym[d];
-        double *dD = (pass == 0) ? ctx->d_D : ctx->d_D + (size_t)N * N;
-        hipLaunchKernelGGL(pack_density_kernel, dim3((N * N + 255) / 256), dim3(256), 0, st, dP[d], N, (general && pass == 0) ? 1 : 0,
-                           ctx->d_Psym, ctx->d_Pp);
-        if (ctx->n_tasks > 0) {
-            hipEvent_t ev_after = nullptr;
-            if (ctx->prof_jk) {
-                if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
-                    hipEvent_t a, b;
-                    if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { ctx->prof_ev.push_back(a); ctx->prof_ev.push_back(b); }
-                }
-                if (ctx->prof_used + 2 <= ctx->prof_ev.size()) {
-                    (void)hipEventRecord(ctx->prof_ev[ctx->prof_used], st);
-                    ev_after = ctx->prof_ev[ctx->prof_used + 1];
-                    ctx->prof_used += 2;
-                }
-            }
-            hipLaunchKernelGGL(jk_packed_kernel, dim3((unsigned)ctx->n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, ctx->d_rowoff,
-                               ctx->d_groups, ctx->d_supers, ctx->d_tasks, N, NW, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, ctx->d_DI,
-                               ctx->d_DI + (size_t)ctx->n_groups * N, ctx->d_DJ, ctx->d_DJ + (size_t)ctx->n_rows * N);
-            if (ev_after) (void)hipEventRecord(ev_after, st);
-        }
-        hipLaunchKernelGGL(jt_reduce_kernel, dim3((unsigned)((npr + 255) / 256), ctx->nseg), dim3(256), 0, st, ctx->d_ypart, ctx->d_supers,
-                           ctx->n_supers, npr, ctx->d_Jt);
-        hipLaunchKernelGGL(kd_reduce_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, st, ctx->d_DI, ctx->d_DI + (size_t)ctx->n_groups * N,
-                           ctx->d_DJ, ctx->d_DJ + (size_t)ctx->n_rows * N, NW, ctx->d_gfirst, ctx->d_rowmap, N, dD);
+        double *dD = (pass == 0) ? ctx->d_D : ctx->d_D + nn;
+        hipLaunchKernelGGL(pack_density_kernel, gN, b256, 0, st, dP[d], N, (general && pass == 0) ? 1 : 0, ctx->d_Psym, ctx->d_Pp);
+        double *dDp[1] = {dD};
+        int rc = jk_packed_pass<1>(ctx, st, dDp);
+        if (rc) return rc;
         if (general && pass == 0) continue;
-        hipLaunchKernelGGL(jk_packed_final_kernel, dim3((N * N + 255) / 256), dim3(256), 0, st, ctx->d_D, dD, ctx->d_Jrow, NW, ctx->d_Jt,
-                           ctx->nseg, ctx->d_rowmap, N, dJ[d], dK[d]);
+        hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, ctx->d_D, dD, ctx->d_Jrow, NW, ctx->d_Jt, ctx->jkt[0].nseg, ctx->d_rowmap, N,
+                           dJ[d], dK[d]);
       }
     return TF_OK;
 }

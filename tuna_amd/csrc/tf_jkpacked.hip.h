@@ -140,209 +140,265 @@ __global__ void pack_density_kernel(const double *__restrict__ P, int N, int tra
     if (l <= k) Pp[tri_off(k) + l] = (k == l) ? a : a + b;
 }
 
+// The kernel handles ND = 1 or 2 densities per pass.  Its eight "virtual rows" v = d * RB + r are RB = 8 / ND tensor rows times
+// ND densities: the loads of a tensor row are shared by the densities, all per-row state is indexed by v.  Arrays of the second
+// density follow those of the first at the strides given in JKWave.
+
 // Wave-uniform description of a task (lives in SGPRs).
 struct JKWave {
-    const double *T0, *Pp, *Pi, *Pj0;    // first row of the group; packed density; P[i][.]; P[j0][.]
+    const double *T0, *P, *Pp;           // first row of the group; density matrices [ND][N][N]; packed densities [ND][NP]
+    long long NP;
     int N, i, j0, nr, c0;                // c0 = first column of the chunk
     unsigned roff8[TF_JKP_JBB];          // byte offset of row r from row 0
-    double *yg, *DIr_w, *DJr_w;
-    size_t rowW;
-    double ppij[TF_JKP_JBB];
+    double *yg, *DIr_w, *DJr_w;          // density d: + d * ystride / dstrideI / dstrideJ
+    size_t rowW, ystride, dstrideI, dstrideJ;
+    double ppij[TF_JKP_JBB];             // Pp_d[(i, j_r)] by virtual row
 };
 
 // Per-lane state: the two columns l0, l0 + 1 of the lane
+template <int ND>
 struct JKLane {
     int l0;
-    double2 pil, pjl[TF_JKP_JBB];        // P[i][l], P[j_r][l]
-    double2 colI, colJ[TF_JKP_JBB];      // D[i][l], D[j_r][l] accumulators
+    double2 pil[ND], pjl[TF_JKP_JBB];    // P_d[i][l];  P_d[j_r][l] by virtual row
+    double2 colI[ND], colJ[TF_JKP_JBB];  // D_d[i][l], D_d[j_r][l] accumulators
 };
 
 enum { JKP_DIAG = 1, JKP_FULL = 2 };
 
-// The values a lane needs from triangle row k < i: the JBB tensor elements of its two columns and Pp[kl].
-struct JKLoad { double2 m[TF_JKP_JBB], pp; };
+// The values a lane needs from triangle row k < i: the tensor elements of its two columns and Pp_d[kl].
+template <int ND>
+struct JKLoad { double2 m[TF_JKP_JBB / ND], pp[ND]; };
 
 // MODE FULL: every lane has l < k (no masks); DIAG: the 128-column tile on the diagonal (a pair is present iff l0 <= k; the pad
-// slot after an odd-length row reads 0).  ALL8: the group has all JBB rows.
-template <bool ALL8, int MODE>
-__device__ __forceinline__ void jkp_load(JKLoad &L, int l0, int lane, const JKWave &U, int k)
+// slot after an odd-length row reads 0).  ALLR: the group has all RB rows.
+template <int ND, bool ALLR, int MODE>
+__device__ __forceinline__ void jkp_load(JKLoad<ND> &L, int l0, int lane, const JKWave &U, int k)
 {
+    constexpr int RB = TF_JKP_JBB / ND;
     const long long bk = tri_off(k) + U.c0;
     const bool v = (MODE == JKP_FULL) || l0 <= k;
-    const __amdgpu_buffer_rsrc_t rt = buf_rsrc(U.T0 + bk), rp = buf_rsrc(U.Pp + bk);
+    const __amdgpu_buffer_rsrc_t rt = buf_rsrc(U.T0 + bk);
     const double2 zero = make_double2(0.0, 0.0);
 #pragma unroll
-    for (int r = 0; r < TF_JKP_JBB; ++r) L.m[r] = (v && (ALL8 || r < U.nr)) ? buf_load2<2>(rt, 16u * (unsigned)lane, U.roff8[r]) : zero;
-    L.pp = v ? buf_load2<0>(rp, 16u * (unsigned)lane, 0u) : zero;
+    for (int r = 0; r < RB; ++r) L.m[r] = (v && (ALLR || r < U.nr)) ? buf_load2<2>(rt, 16u * (unsigned)lane, U.roff8[r]) : zero;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) L.pp[d] = v ? buf_load2<0>(buf_rsrc(U.Pp + d * U.NP + bk), 16u * (unsigned)lane, 0u) : zero;
 }
 
 // part 1: everything that needs only the lane's own P values (Jd, Jt, the row sums); part 2: the column sums, which need the
 // wave-uniform P[j_r][k], P[i][k] -- fetched through the scalar unit while part 1 runs.
-template <int MODE>
-__device__ __forceinline__ double2 jkp_row1(const JKLane &C, const JKLoad &L, const JKWave &U, double (&jd)[TF_JKP_JBB],
-                                            double (&rJ)[TF_JKP_JBB], double &rI)
+template <int ND>
+__device__ __forceinline__ void jkp_row1(const JKLane<ND> &C, const JKLoad<ND> &L, const JKWave &U, double (&jd)[TF_JKP_JBB],
+                                         double (&rJ)[TF_JKP_JBB], double (&rI)[ND], double2 (&jt)[ND])
 {
-    double2 jt = make_double2(0.0, 0.0);
-    rI = 0.0;
+    constexpr int RB = TF_JKP_JBB / ND;
 #pragma unroll
-    for (int r = 0; r < TF_JKP_JBB; ++r) {
-        const double2 m = L.m[r];
-        jd[r] += m.x * L.pp.x + m.y * L.pp.y;
-        jt.x += m.x * U.ppij[r]; jt.y += m.y * U.ppij[r];
-        const double2 pj = C.pjl[r];
-        rI += m.x * pj.x + m.y * pj.y;
-        rJ[r] = m.x * C.pil.x + m.y * C.pil.y;
-    }
-    return jt;                                              // masked lanes loaded zeros: their jt is 0
+    for (int d = 0; d < ND; ++d) {
+        jt[d] = make_double2(0.0, 0.0);
+        rI[d] = 0.0;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int v = d * RB + r;
+            const double2 m = L.m[r];
+            jd[v] += m.x * L.pp[d].x + m.y * L.pp[d].y;
+            jt[d].x += m.x * U.ppij[v]; jt[d].y += m.y * U.ppij[v];
+            const double2 pj = C.pjl[v];
+            rI[d] += m.x * pj.x + m.y * pj.y;
+            rJ[v] = m.x * C.pil[d].x + m.y * C.pil[d].y;
+        }
+    }                                                       // masked lanes loaded zeros: their jt is 0
 }
 
-template <int MODE>
-__device__ __forceinline__ void jkp_row2(JKLane &C, const JKLoad &L, int k, const double (&pjk)[TF_JKP_JBB], double pik)
+template <int ND, int MODE>
+__device__ __forceinline__ void jkp_row2(JKLane<ND> &C, const JKLoad<ND> &L, int k, const double (&pjk)[TF_JKP_JBB], const double (&pik)[ND])
 {
+    constexpr int RB = TF_JKP_JBB / ND;
     const double o0 = (MODE == JKP_FULL || C.l0 < k) ? 1.0 : 0.0, o1 = (MODE == JKP_FULL || C.l0 + 1 < k) ? 1.0 : 0.0;
 #pragma unroll
-    for (int r = 0; r < TF_JKP_JBB; ++r) {
+    for (int r = 0; r < RB; ++r) {
         const double mx = (MODE == JKP_FULL) ? L.m[r].x : L.m[r].x * o0, my = (MODE == JKP_FULL) ? L.m[r].y : L.m[r].y * o1;
-        C.colI.x += mx * pjk[r]; C.colI.y += my * pjk[r];
-        C.colJ[r].x += mx * pik; C.colJ[r].y += my * pik;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int v = d * RB + r;
+            C.colI[d].x += mx * pjk[v]; C.colI[d].y += my * pjk[v];
+            C.colJ[v].x += mx * pik[d]; C.colJ[v].y += my * pik[d];
+        }
     }
 }
 
 // The last triangle row k == i: row r ends at l == j_r, where the element (ij|ij) counts half in K and not at all in Jt.
-__device__ __forceinline__ double2 jkp_last(JKLane &C, const JKWave &U, const double (&pjk)[TF_JKP_JBB], double pik,
-                                            double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double &rI)
+template <int ND>
+__device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const double (&pjk)[TF_JKP_JBB], const double (&pik)[ND],
+                                         double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double (&rI)[ND], double2 (&jt2)[ND])
 {
+    constexpr int RB = TF_JKP_JBB / ND;
     const int i = U.i, jlast = U.j0 + U.nr - 1;
     const long long bk = tri_off(i);
-    double2 jt2 = make_double2(0.0, 0.0);
-    rI = 0.0;
 #pragma unroll
-    for (int r = 0; r < TF_JKP_JBB; ++r) rJ[r] = 0.0;
+    for (int d = 0; d < ND; ++d) { rI[d] = 0.0; jt2[d] = make_double2(0.0, 0.0); }
+#pragma unroll
+    for (int v = 0; v < TF_JKP_JBB; ++v) rJ[v] = 0.0;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int l = C.l0 + e;
-        const bool v = l <= jlast;
-        const double pp = v ? U.Pp[bk + l] : 0.0;
-        const double pil = e ? C.pil.y : C.pil.x;
-        double jt = 0.0, cI = 0.0;
+        const bool valid = l <= jlast;
+        double mrow[RB];
 #pragma unroll
-        for (int r = 0; r < TF_JKP_JBB; ++r) {
-            const int jr = U.j0 + r;
-            const bool vr = r < U.nr && l <= jr;
-            const double mr = vr ? ld_stream(U.T0 + (U.roff8[r] >> 3) + bk + l) : 0.0;
-            const bool diag = (l == jr);
-            jd[r] += mr * pp;
-            jt += diag ? 0.0 : mr * U.ppij[r];
-            const double mk = diag ? 0.5 * mr : mr;
-            rI += mk * (e ? C.pjl[r].y : C.pjl[r].x);
-            rJ[r] += mk * pil;
-            const double mc = (l < i) ? mk : 0.0;
-            cI += mc * pjk[r];
-            if (e) C.colJ[r].y += mc * pik; else C.colJ[r].x += mc * pik;
+        for (int r = 0; r < RB; ++r) mrow[r] = (r < U.nr && l <= U.j0 + r) ? ld_stream(U.T0 + (U.roff8[r] >> 3) + bk + l) : 0.0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const double pp = valid ? U.Pp[d * U.NP + bk + l] : 0.0;
+            const double pil = e ? C.pil[d].y : C.pil[d].x;
+            double jt = 0.0, cI = 0.0;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int v = d * RB + r;
+                const double mr = mrow[r];
+                const bool diag = (l == U.j0 + r);
+                jd[v] += mr * pp;
+                jt += diag ? 0.0 : mr * U.ppij[v];
+                const double mk = diag ? 0.5 * mr : mr;
+                rI[d] += mk * (e ? C.pjl[v].y : C.pjl[v].x);
+                rJ[v] += mk * pil;
+                const double mc = (l < i) ? mk : 0.0;
+                cI += mc * pjk[v];
+                if (e) C.colJ[v].y += mc * pik[d]; else C.colJ[v].x += mc * pik[d];
+            }
+            if (e) { C.colI[d].y += cI; jt2[d].y = jt; } else { C.colI[d].x += cI; jt2[d].x = jt; }   // jt: 0 beyond the group's last column
         }
-        if (e) C.colI.y += cI; else C.colI.x += cI;
-        if (e) jt2.y = jt; else jt2.x = jt;                               // 0 beyond the group's last column
     }
-    return jt2;
 }
 
-template <bool ALL8>
-__device__ __forceinline__ void jkp_row_sums(const JKWave &U, int k, int lane, double (&rJ)[TF_JKP_JBB], double rI)
+template <int ND, bool ALLR>
+__device__ __forceinline__ void jkp_row_sums(const JKWave &U, int k, int lane, double (&rJ)[TF_JKP_JBB], const double (&rI)[ND])
 {
+    constexpr int RB = TF_JKP_JBB / ND;
     const double tJ = wave_sum8(rJ);
-    const double tI = wave_sum1(rI);
-    if ((lane & 7) == 0 && (ALL8 || (lane >> 3) < U.nr)) U.DJr_w[(size_t)(lane >> 3) * U.rowW + k] = tJ;
-    if (lane == 0) U.DIr_w[k] = tI;
+    const int v = lane >> 3, d = v / RB, r = v - d * RB;
+    if ((lane & 7) == 0 && (ALLR || r < U.nr)) U.DJr_w[d * U.dstrideJ + (size_t)r * U.rowW + k] = tJ;
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+        const double tI = wave_sum1(rI[dd]);
+        if (lane == 0) U.DIr_w[dd * U.dstrideI + k] = tI;
+    }
 }
 
-// Jt of the rows kb..kb+KB-1: the waves of the workgroup have left their partials in slots[kk][wave][lane]; wave w adds up
+// Jt of the rows kb..kb+KB-1: the waves of the workgroup have left their partials in slots[kk][wave][d][lane]; wave w adds up
 // row kb + w and writes it (fixed order: bitwise reproducible).  Two barriers per block.
-template <int MODE>
+template <int ND, int MODE>
 __device__ __forceinline__ void jkp_merge_jt(const JKWave &U, double2 *slots, int ng, int w, int lane, int kb, int k1)
 {
     __syncthreads();
     const int k = kb + w;
     if (w < TF_JKP_KB && k < k1) {
-        double2 t = slots[(w * TF_JKP_W) * 64 + lane];
-        for (int u = 1; u < ng; ++u) { const double2 x = slots[(w * TF_JKP_W + u) * 64 + lane]; t.x += x.x; t.y += x.y; }
-        if (MODE == JKP_FULL || U.c0 + 2 * lane <= k) buf_store2<2>(buf_rsrc(U.yg + tri_off(k) + U.c0), 16u * (unsigned)lane, 0u, t);
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            double2 t = slots[((w * TF_JKP_W) * ND + d) * 64 + lane];
+            for (int u = 1; u < ng; ++u) { const double2 x = slots[((w * TF_JKP_W + u) * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
+            if (MODE == JKP_FULL || U.c0 + 2 * lane <= k)
+                buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + tri_off(k) + U.c0), 16u * (unsigned)lane, 0u, t);
+        }
     }
     __syncthreads();
+}
+
+template <int ND, bool ALLR>
+__device__ __forceinline__ void jkp_uniform_p(const JKWave &U, int k, double (&pjk)[TF_JKP_JBB], double (&pik)[ND])
+{
+    constexpr int RB = TF_JKP_JBB / ND;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const double *Pd = U.P + (size_t)d * U.N * U.N;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) pjk[d * RB + r] = (ALLR || r < U.nr) ? Pd[(size_t)(U.j0 + r) * U.N + k] : 0.0;
+        pik[d] = Pd[(size_t)U.i * U.N + k];
+    }
 }
 
 // Rows k0 <= k < k1 of a task in one mode.  The loads of row k + 1 are issued before row k is consumed, so a wave always has a
 // full row of requests in flight; the wave-uniform P[j_r][k], P[i][k] come through the scalar unit while part 1 runs.
 // Every wave of the workgroup runs the same k range (idle waves included): the barriers of the Jt merge must match.
-template <bool ALL8, int MODE>
-__device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane &C, double (&jd)[TF_JKP_JBB], int k0, int k1, int lane, bool active,
+template <int ND, bool ALLR, int MODE>
+__device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane<ND> &C, double (&jd)[TF_JKP_JBB], int k0, int k1, int lane, bool active,
                                             double2 *slots, int ng, int w)
 {
     constexpr int JBB = TF_JKP_JBB;
     if (k0 >= k1) return;
-    JKLoad L, Nx;
-    if (active) jkp_load<ALL8, MODE>(L, C.l0, lane, U, k0);
+    JKLoad<ND> L, Nx;
+    if (active) jkp_load<ND, ALLR, MODE>(L, C.l0, lane, U, k0);
     for (int kb = k0; kb < k1; kb += TF_JKP_KB) {
         if (active) {
             const int ke = min(kb + TF_JKP_KB, k1);
             for (int k = kb; k < ke; ++k) {
-                jkp_load<ALL8, MODE>(Nx, C.l0, lane, U, min(k + 1, k1 - 1));
-                double pjk[JBB];
+                jkp_load<ND, ALLR, MODE>(Nx, C.l0, lane, U, min(k + 1, k1 - 1));
+                double pjk[JBB], pik[ND], rJ[JBB], rI[ND];
+                double2 jt[ND];
+                jkp_uniform_p<ND, ALLR>(U, k, pjk, pik);
+                jkp_row1<ND>(C, L, U, jd, rJ, rI, jt);
 #pragma unroll
-                for (int r = 0; r < JBB; ++r) pjk[r] = (ALL8 || r < U.nr) ? U.Pj0[(size_t)r * U.N + k] : 0.0;
-                const double pik = U.Pi[k];
-                double rJ[JBB], rI;
-                slots[((k - kb) * TF_JKP_W + w) * 64 + lane] = jkp_row1<MODE>(C, L, U, jd, rJ, rI);
-                jkp_row_sums<ALL8>(U, k, lane, rJ, rI);
-                jkp_row2<MODE>(C, L, k, pjk, pik);
+                for (int d = 0; d < ND; ++d) slots[(((k - kb) * TF_JKP_W + w) * ND + d) * 64 + lane] = jt[d];
+                jkp_row_sums<ND, ALLR>(U, k, lane, rJ, rI);
+                jkp_row2<ND, MODE>(C, L, k, pjk, pik);
                 L = Nx;
             }
         }
-        jkp_merge_jt<MODE>(U, slots, ng, w, lane, kb, k1);
+        jkp_merge_jt<ND, MODE>(U, slots, ng, w, lane, kb, k1);
     }
 }
 
-template <bool ALL8>
+template <int ND, bool ALLR>
 __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lane, int group, int r0, bool active, double2 *slots, int ng,
-                                         int w, double *__restrict__ Jd, double *__restrict__ DIc, double *__restrict__ DJc)
+                                         int w, double *__restrict__ Jd, size_t strideJd, double *__restrict__ DIc, size_t strideDIc,
+                                         double *__restrict__ DJc, size_t strideDJc)
 {
-    constexpr int JBB = TF_JKP_JBB;
+    constexpr int JBB = TF_JKP_JBB, RB = JBB / ND;
     const int N = U.N, i = U.i;
-    JKLane C;
+    JKLane<ND> C;
     C.l0 = U.c0 + 2 * lane;
     {
         const bool in0 = C.l0 < N, in1 = C.l0 + 1 < N;
-        C.pil = make_double2(in0 ? U.Pi[C.l0] : 0.0, in1 ? U.Pi[C.l0 + 1] : 0.0);
-        C.colI = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int r = 0; r < JBB; ++r) {
-            const bool have = ALL8 || r < U.nr;
-            C.pjl[r] = make_double2((in0 && have) ? U.Pj0[(size_t)r * N + C.l0] : 0.0, (in1 && have) ? U.Pj0[(size_t)r * N + C.l0 + 1] : 0.0);
-            C.colJ[r] = make_double2(0.0, 0.0);
+        for (int d = 0; d < ND; ++d) {
+            const double *Pd = U.P + (size_t)d * N * N;
+            const double *Pi = Pd + (size_t)i * N;
+            C.pil[d] = make_double2(in0 ? Pi[C.l0] : 0.0, in1 ? Pi[C.l0 + 1] : 0.0);
+            C.colI[d] = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const bool have = ALLR || r < U.nr;
+                const double *Pj = Pd + (size_t)(U.j0 + r) * N;
+                C.pjl[d * RB + r] = make_double2((in0 && have) ? Pj[C.l0] : 0.0, (in1 && have) ? Pj[C.l0 + 1] : 0.0);
+                C.colJ[d * RB + r] = make_double2(0.0, 0.0);
+            }
         }
     }
     double jd[JBB];
 #pragma unroll
-    for (int r = 0; r < JBB; ++r) jd[r] = 0.0;
+    for (int v = 0; v < JBB; ++v) jd[v] = 0.0;
 
     const int kd1 = min(U.c0 + TF_JKP_CW, i);                         // end of the diagonal tile (exclusive), rows k < i only
-    jkp_segment<ALL8, JKP_DIAG>(U, C, jd, U.c0, kd1, lane, active, slots, ng, w);
-    jkp_segment<ALL8, JKP_FULL>(U, C, jd, kd1, i, lane, active, slots, ng, w);
+    jkp_segment<ND, ALLR, JKP_DIAG>(U, C, jd, U.c0, kd1, lane, active, slots, ng, w);
+    jkp_segment<ND, ALLR, JKP_FULL>(U, C, jd, kd1, i, lane, active, slots, ng, w);
     {   // k == i: the groups end at different columns; the first group of the workgroup is the longest
-        double2 jt = make_double2(0.0, 0.0);
-        if (active) {
-            double pjk[JBB], rJ[JBB], rI;
+        double2 jt[ND];
 #pragma unroll
-            for (int r = 0; r < JBB; ++r) pjk[r] = (ALL8 || r < U.nr) ? U.Pj0[(size_t)r * N + i] : 0.0;
-            const double pik = U.Pi[i];
-            jt = jkp_last(C, U, pjk, pik, jd, rJ, rI);
-            jkp_row_sums<ALL8>(U, i, lane, rJ, rI);
+        for (int d = 0; d < ND; ++d) jt[d] = make_double2(0.0, 0.0);
+        if (active) {
+            double pjk[JBB], pik[ND], rJ[JBB], rI[ND];
+            jkp_uniform_p<ND, ALLR>(U, i, pjk, pik);
+            jkp_last<ND>(C, U, pjk, pik, jd, rJ, rI, jt);
+            jkp_row_sums<ND, ALLR>(U, i, lane, rJ, rI);
         }
-        slots[w * 64 + lane] = jt;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) slots[(w * ND + d) * 64 + lane] = jt[d];
         __syncthreads();
         if (w == 0) {                                                  // wave 0 holds the first group: its last column bounds the row
-            double2 t = slots[lane];
-            for (int u = 1; u < ng; ++u) { const double2 x = slots[u * 64 + lane]; t.x += x.x; t.y += x.y; }
-            if (C.l0 <= U.j0 + U.nr - 1) buf_store2<2>(buf_rsrc(U.yg + tri_off(i) + U.c0), 16u * (unsigned)lane, 0u, t);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                double2 t = slots[d * 64 + lane];
+                for (int u = 1; u < ng; ++u) { const double2 x = slots[(u * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
+                if (C.l0 <= U.j0 + U.nr - 1) buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + tri_off(i) + U.c0), 16u * (unsigned)lane, 0u, t);
+            }
         }
     }
     if (!active) return;
@@ -351,32 +407,40 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lan
     for (int e = 0; e < 2; ++e) {
         const int l = C.l0 + e;
         if (l < N) {
-            DIc[(size_t)group * N + l] = e ? C.colI.y : C.colI.x;
 #pragma unroll
-            for (int r = 0; r < JBB; ++r)
-                if (ALL8 || r < U.nr) DJc[(size_t)(r0 + r) * N + l] = e ? C.colJ[r].y : C.colJ[r].x;
+            for (int d = 0; d < ND; ++d) {
+                DIc[d * strideDIc + (size_t)group * N + l] = e ? C.colI[d].y : C.colI[d].x;
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    if (ALLR || r < U.nr) DJc[d * strideDJc + (size_t)(r0 + r) * N + l] = e ? C.colJ[d * RB + r].y : C.colJ[d * RB + r].x;
+            }
         }
     }
     {
         const double t = wave_sum8(jd);
-        if ((lane & 7) == 0 && (ALL8 || (lane >> 3) < U.nr)) Jd[(size_t)(r0 + (lane >> 3)) * NW + c] = t;
+        const int v = lane >> 3, d = v / RB, r = v - d * RB;
+        if ((lane & 7) == 0 && (ALLR || r < U.nr)) Jd[d * strideJd + (size_t)(r0 + r) * NW + c] = t;
     }
 }
 
+// Strides (in doubles) between the arrays of density 0 and density 1 of a two-density pass
+struct JKStrides { size_t P, Pp, y, Jd, DIc, DIr, DJc, DJr; };
+
 // One workgroup per task (super-group, chunk): wave w owns group g0 + w (idle if the super-group has fewer).  NW = ceil(N / 128)
-// chunks; only tasks with 128 chunk <= i exist.
+// chunks; only tasks with 128 chunk <= i exist.  ND densities per pass: groups of 8 / ND rows.
 // Outputs: Jd [n_rows][NW] per-task partials; ypart: Jt partials per super-group; DIc [G][N], DJc [n_rows][N]: column parts
 // (l-indexed); DIr [G][NW][N], DJr [n_rows][NW][N]: row parts per task (k-indexed, written for 128 chunk <= k <= i).
+template <int ND>
 __global__ __launch_bounds__(64 * TF_JKP_W) void jk_packed_kernel(const double *__restrict__ T, const long long *__restrict__ rowoff,
                                                                   const JKGroup *__restrict__ groups, const JKSuper *__restrict__ supers,
                                                                   const JKTask *__restrict__ tasks, int N, int NW,
                                                                   const double *__restrict__ P, const double *__restrict__ Pp,
                                                                   double *__restrict__ Jd, double *__restrict__ ypart,
                                                                   double *__restrict__ DIc, double *__restrict__ DIr,
-                                                                  double *__restrict__ DJc, double *__restrict__ DJr)
+                                                                  double *__restrict__ DJc, double *__restrict__ DJr, JKStrides S)
 {
-    constexpr int JBB = TF_JKP_JBB;
-    __shared__ double2 slots[TF_JKP_KB * TF_JKP_W * 64];
+    constexpr int JBB = TF_JKP_JBB, RB = JBB / ND;
+    __shared__ double2 slots[TF_JKP_KB * TF_JKP_W * ND * 64];
     const JKTask t = tasks[blockIdx.x];
     const JKSuper sg = supers[t.super];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -384,21 +448,22 @@ __global__ __launch_bounds__(64 * TF_JKP_W) void jk_packed_kernel(const double *
     const int gi = sg.g0 + (active ? w : 0);
     const JKGroup g = groups[gi];
     JKWave U;
-    U.T0 = T + rowoff[g.r0]; U.Pp = Pp; U.Pi = P + (size_t)g.i * N; U.Pj0 = P + (size_t)g.j0 * N;
+    U.T0 = T + rowoff[g.r0]; U.P = P; U.Pp = Pp; U.NP = (long long)S.Pp;
     U.N = N; U.i = g.i; U.j0 = g.j0; U.nr = g.nr; U.c0 = t.chunk * TF_JKP_CW;
-    U.yg = ypart + sg.yoff;
-    U.DIr_w = DIr + ((size_t)gi * NW + t.chunk) * N;
+    U.yg = ypart + sg.yoff; U.ystride = S.y;
+    U.DIr_w = DIr + ((size_t)gi * NW + t.chunk) * N; U.dstrideI = S.DIr;
     U.rowW = (size_t)NW * N;
-    U.DJr_w = DJr + ((size_t)g.r0 * NW + t.chunk) * N;
+    U.DJr_w = DJr + ((size_t)g.r0 * NW + t.chunk) * N; U.dstrideJ = S.DJr;
 #pragma unroll
-    for (int r = 0; r < JBB; ++r) {
-        U.roff8[r] = 8u * (unsigned)g.roff[r];
-        U.ppij[r] = (r < g.nr) ? Pp[tri_off(g.i) + g.j0 + r] : 0.0;
-    }
-    if (g.nr == JBB)
-        jkp_task<true>(U, NW, t.chunk, lane, gi, g.r0, active, slots, sg.ng, w, Jd, DIc, DJc);
+    for (int r = 0; r < JBB; ++r) U.roff8[r] = 8u * (unsigned)g.roff[r < RB ? r : 0];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < RB; ++r) U.ppij[d * RB + r] = (r < g.nr) ? Pp[d * S.Pp + tri_off(g.i) + g.j0 + r] : 0.0;
+    if (g.nr == RB)
+        jkp_task<ND, true>(U, NW, t.chunk, lane, gi, g.r0, active, slots, sg.ng, w, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
     else
-        jkp_task<false>(U, NW, t.chunk, lane, gi, g.r0, active, slots, sg.ng, w, Jd, DIc, DJc);
+        jkp_task<ND, false>(U, NW, t.chunk, lane, gi, g.r0, active, slots, sg.ng, w, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
 }
 
 // Jt partial sums over the padded pair index q: super-groups are sorted by descending partial length, so those that cover q are
