@@ -162,9 +162,10 @@ def test_error_behaviour(engine):
         engine.fock_jk(np.eye(2))   # no tensor built yet
 
 
-@pytest.mark.parametrize("n_sph", [120, 200])
+@pytest.mark.parametrize("n_sph", [120, 200, 400])
 def test_synthetic_series_properties(engine, n_sph):
-    """Synthetic even-tempered Ar2-like diatomic: properties that hold at any size."""
+    """Synthetic even-tempered Ar2-like diatomic: properties that hold at any size -- up to the 400-AO
+    workload of bench.py (25.8 GB of stored tensor)."""
     counts = mol.synthetic_counts(n_sph)
     atoms = mol.make_atoms(["AR", "AR"], 7.1)
     aos = mol.expand_cartesian_aos(mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)}))
@@ -195,3 +196,30 @@ def test_synthetic_series_properties(engine, n_sph):
     rows = np.array([[i, j, k, l] for k in range(N) for l in range(N)], dtype=np.int32)
     M = engine.sample_eri(rows).reshape(N, N)
     assert abs(J1[i, j] - np.sum(M * P1)) < 1e-10 * scale
+
+
+def test_packed_and_rows_layouts_agree(engine):
+    """The 8-fold packed tensor + jk_packed_kernel against the (i >= j) x [k][l] rows layout + jk_rows_kernel: same tensor values,
+    same J and K for one and for two densities (the fused two-density pass included)."""
+    counts = mol.synthetic_counts(200)
+    atoms = mol.make_atoms(["AR", "AR"], 7.1)
+    aos = mol.expand_cartesian_aos(mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)}))
+    rng = np.random.default_rng(3)
+    N = 200
+    A = rng.standard_normal((2, N, N)); P = A + A.transpose(0, 2, 1)
+    idx = rng.integers(0, N, size=(5000, 4)).astype(np.int32)
+    res = {}
+    for layout in ("rows", "packed"):
+        engine.set_basis(aos).build_eri(True, layout=layout)
+        st = engine.eri_storage()
+        assert st["layout"] == layout
+        J1, K1 = engine.fock_jk(P[0])
+        J2, K2 = engine.fock_jk(P)                                   # two densities in one call
+        res[layout] = (engine.sample_eri(idx), J1, K1, J2, K2, st["bytes"])
+    a, b = res["rows"], res["packed"]
+    assert np.abs(a[0] - b[0]).max() < 1e-13
+    scale = np.abs(a[1]).max()
+    for q in (1, 2, 3, 4):
+        assert np.abs(a[q] - b[q]).max() < 1e-11 * scale
+    assert np.abs(b[3][0] - b[1]).max() < 1e-11 * scale and np.abs(b[4][0] - b[2]).max() < 1e-11 * scale   # fused pass = single pass
+    assert b[5] < 0.27 * a[5]                                         # N^4 bytes against 4 N^4
