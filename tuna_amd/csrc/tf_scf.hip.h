@@ -20,6 +20,7 @@
 #include "../../include/tunafock.h"
 #include "tf_jacobi.hip.h"
 #include <cstdio>
+#include <vector>
 
 namespace tfscf {
 
@@ -42,6 +43,7 @@ struct Workspace {
     size_t ref_cap = 0;
     int ref_n = 0;                   // 0 = no valid start
     long long ref_solves = 0, ref_steps = 0, ref_fallbacks = 0;
+    std::vector<hipEvent_t> tev;     // timing events, read after the cycle (no synchronisation inside it)
 };
 
 inline void release(Workspace &w)
@@ -55,6 +57,7 @@ inline void release(Workspace &w)
     if (w.jac_scratch) (void)hipFree(w.jac_scratch);
     if (w.jac_prev) (void)hipFree(w.jac_prev);
     if (w.ref_buf) (void)hipFree(w.ref_buf);
+    for (hipEvent_t e : w.tev) (void)hipEventDestroy(e);
     w = Workspace();
 }
 
@@ -130,6 +133,32 @@ __global__ void k_lincomb(Ptr8 a, int m, double *__restrict__ out, int nn)     /
     double s = 0.0;
     for (int k = 0; k < m; ++k) s += a.c[k] * a.p[k][e];
     out[e] = s;
+}
+
+// out[k] = <x, a.p[k]> for k < m (m <= 8): all the scalar products of one SCF step in one launch and one read-back instead of one
+// synchronising rocblas_ddot each (at N = 60 the cycle is bound by such round trips).  Single block, fixed summation tree.
+__global__ void k_multi_dot(const double *__restrict__ x, Ptr8 a, int m, int nn, double *__restrict__ out)
+{
+    __shared__ double sm[8][256];
+    double acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+    for (int e = threadIdx.x; e < nn; e += 256) {
+        const double xv = x[e];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < m) acc[k] += xv * a.p[k][e];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sm[k][threadIdx.x] += sm[k][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < m) out[threadIdx.x] = sm[threadIdx.x][0];
 }
 
 // res[0] = max |a-b|, res[1] = sum (a-b)^2       (scf:285-286), single block
@@ -524,7 +553,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
 {
     if (world != 1) { msg = "tf_scf_rhf runs on one GPU; use tuna_amd.scf (torch.distributed all-reduce) for sharded tensors"; return TF_EINVAL; }
     const int max_diis = std::max(1, std::min(8, (int)o.max_diis));
-    const int n_mats = 21 + 2 * max_diis;
+    const int n_mats = 22 + 2 * max_diis;
     int rc = ensure(w, n, n_mats, msg);
     if (rc) return rc;
     const size_t nn = (size_t)n * n;
@@ -534,9 +563,9 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     auto mat = [&](int k) { return base + (size_t)k * nn; };
     double *dS = mat(0), *dH = mat(1), *dX = mat(2), *dP = mat(3), *dPold = mat(4), *dPbd = mat(5), *dPvold = mat(6), *dPoldbd = mat(7);
     double *dF = mat(8), *dJ = mat(9), *dK = mat(10), *dT = mat(11), *dV = mat(12), *dFx = mat(13), *t1 = mat(14), *t2 = mat(15);
-    double *dC = mat(16), *dW = mat(17), *dPn = mat(18), *scr = mat(19), *dVxc = mat(20);
-    double *hist = mat(21);
-    double *vals = base + (size_t)n_mats * nn, *ework = vals + n;
+    double *dC = mat(16), *dW = mat(17), *dPn = mat(18), *scr = mat(19), *dVxc = mat(20), *dCsave = mat(21);
+    double *hist = mat(22);
+    double *vals = base + (size_t)n_mats * nn, *ework = vals + n, *vals_save = ework + n;
     auto histF = [&](int k) { return hist + (size_t)(2 * k) * nn; };
     auto histE = [&](int k) { return hist + (size_t)(2 * k + 1) * nn; };
 
@@ -560,7 +589,21 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     TFS_HIP(hipMemset(dPoldbd, 0, nn * sizeof(double)));
 
     TFS_BLAS(rocblas_set_pointer_mode(w.blas, rocblas_pointer_mode_host));
-    auto dot = [&](const double *a, const double *b, double *res) { return rocblas_ddot(w.blas, (int)nn, a, 1, b, 1, res); };
+    // device-time spans without synchronising inside the cycle: events from a pool, read after the last iteration
+    size_t tev_used = 0;
+    std::vector<std::pair<size_t, int>> spans;                    // (first event index, 0 = Fock build, 1 = eigensolver)
+    auto span_begin = [&](int kind) -> int {
+        while (w.tev.size() < tev_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            w.tev.push_back(e);
+        }
+        spans.emplace_back(tev_used, kind);
+        (void)hipEventRecord(w.tev[tev_used], 0);
+        tev_used += 2;
+        return (int)tev_used - 1;
+    };
+    auto span_end = [&](int idx) { if (idx >= 0) (void)hipEventRecord(w.tev[idx], 0); };
 
     // diagonalise F (AO) -> eps, C ; P = 2 C_occ C_occ^T symmetrised      (scf:222-250, 183-211)
     // n > 64 (where the eigensolver is rocsolver_dsyevd): after the first solve the density comes from refined eigenvectors
@@ -572,7 +615,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, Fao, 0.0, t1));     // X^T F
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));     // (X^T F) X
         hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
-        auto te = std::chrono::steady_clock::now();
+        const int te = span_begin(1);
         orbitals_current = false;
         if (refining && w.ref_n == n) {
             double *Xocc = nullptr;
@@ -583,8 +626,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                 TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Xocc, dX, 0.0, t1));    // rows: occupied orbitals in the AO basis (others 0)
                 TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &two, t1, n, t1, n, &zero, t2, n));
                 hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, Pout, n);
-                TFS_HIP(hipDeviceSynchronize());
-                out.eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - te).count();
+                span_end(te);
                 if (getenv("TF_REFINE_CHECK")) {                 // debugging aid: the same density from a real eigensolve
                     std::vector<double> hp(nn), hq(nn);
                     TFS_HIP(hipMemcpy(hp.data(), Pout, nn * sizeof(double), hipMemcpyDeviceToHost));
@@ -605,8 +647,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         int r = eigh(w, n, dW, vals, ework, msg);
         if (r) return r;
         if (refining) { r = ref_store(w, n, dW, msg); if (r) return r; }
-        TFS_HIP(hipDeviceSynchronize());
-        out.eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - te).count();
+        span_end(te);
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));      // C = X V   (dW rows = eigenvectors)
         const double two = 2.0, zero = 0.0;
         // col-major view of dC is C^T: P = sum_{k<nocc} C[:,k] C[:,k]^T = M[:nocc,:]^T M[:nocc,:]
@@ -640,10 +681,10 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             rc = xc(dP, dVxc, xc3);
             if (rc) { msg = "exchange-correlation evaluation failed"; return rc; }
         }
-        TFS_HIP(hipEventRecord(w.ev0, 0));
+        const int tf = span_begin(0);
         rc = jk(dP, dJ, dK, 0);
         if (rc) { msg = "J/K launch failed"; return rc; }
-        TFS_HIP(hipEventRecord(w.ev1, 0));
+        span_end(tf);
         hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, 0, dH, dJ, dK, o.hfx, t1, (int)nn);
         if (xc) hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, t1, 1.0, dVxc, t1, (int)nn);        // + V_XC, scf:525
         hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, dF, n);
@@ -670,34 +711,41 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         TFS_HIP(hipMemcpyAsync(histF(n_hist), dF, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
         ++n_hist;
         double ee = 0.0;
-        for (int k = 0; k < n_hist; ++k) {
-            double d = 0.0;
-            TFS_BLAS(dot(histE(n_hist - 1), histE(k), &d));
-            // the reference stores the error twice (alpha and beta copies, scf:934), hence the factor 2
-            B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = 2.0 * d;
-            if (k == n_hist - 1) ee = d;
+        {
+            Ptr8 a;
+            for (int k = 0; k < 8; ++k) { a.p[k] = histE(0); a.c[k] = 0.0; }
+            for (int k = 0; k < n_hist; ++k) a.p[k] = histE(k);
+            double hd[8];
+            hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, histE(n_hist - 1), a, n_hist, (int)nn, w.d_scal + 48);
+            TFS_HIP(hipMemcpy(hd, w.d_scal + 48, n_hist * sizeof(double), hipMemcpyDeviceToHost));
+            for (int k = 0; k < n_hist; ++k) {
+                // the reference stores the error twice (alpha and beta copies, scf:934), hence the factor 2
+                B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = 2.0 * hd[k];
+                if (k == n_hist - 1) ee = hd[k];
+            }
         }
         commutator = std::sqrt(ee / (double)nn);                                       // scf:918
-        {
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, w.ev0, w.ev1);
-            out.fock_seconds += ms * 1e-3;
-        }
         // diagonalise, new density, energy with the NEW P and the OLD J,K   (scf:1133-1141)
         rc = diag_density(dF, dPn);
         if (rc) return rc;
         double eT, eV, eF, eJ, eK;
-        TFS_BLAS(dot(dPn, dT, &eT));
-        TFS_BLAS(dot(dPn, dV, &eV));
-        TFS_BLAS(dot(dPn, dFx, &eF));
-        TFS_BLAS(dot(dPn, dJ, &eJ));
-        TFS_BLAS(dot(dPn, dK, &eK));
+        {
+            Ptr8 a;
+            for (int k = 0; k < 8; ++k) { a.p[k] = dT; a.c[k] = 0.0; }
+            a.p[0] = dT; a.p[1] = dV; a.p[2] = dFx; a.p[3] = dJ; a.p[4] = dK;
+            double hd[5];
+            hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, dPn, a, 5, (int)nn, w.d_scal + 56);
+            TFS_HIP(hipMemcpy(hd, w.d_scal + 56, 5 * sizeof(double), hipMemcpyDeviceToHost));
+            eT = hd[0]; eV = hd[1]; eF = hd[2]; eJ = hd[3]; eK = hd[4];
+        }
         comps[0] = eT; comps[1] = eV; comps[2] = (1.0 / 2.0) * eJ; comps[3] = -(1.0 / 4.0) * eK * o.hfx + xc3[1]; comps[4] = xc3[2];   // scf:380-394
         comps[5] = eF; comps[6] = 0.0;
         E = comps[0] + comps[1] + comps[2] + comps[3] + comps[4] + comps[5] + comps[6];
         orbitals_final = orbitals_current;                            // of THIS iteration's Fock matrix (the DIIS solve below reuses dC)
-        if (orbitals_final && out.eps) TFS_HIP(hipMemcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
-        if (orbitals_final && out.C) TFS_HIP(hipMemcpy(out.C, dC, nn * sizeof(double), hipMemcpyDeviceToHost));
+        if (orbitals_final && (out.eps || out.C)) {                  // kept on the device; copied out after the cycle
+            TFS_HIP(hipMemcpyAsync(vals_save, vals, n * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            TFS_HIP(hipMemcpyAsync(dCsave, dC, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        }
         // DIIS extrapolation (scf:991-1059)
         double *Pcur = dPn;
         if (step > 2 && o.use_diis && commutator < 0.3) {
@@ -759,21 +807,29 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             break;
         }
     }
+    if (orbitals_final) {
+        if (out.eps) TFS_HIP(hipMemcpy(out.eps, vals_save, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (out.C) TFS_HIP(hipMemcpy(out.C, dCsave, nn * sizeof(double), hipMemcpyDeviceToHost));
+    }
     if (!orbitals_final && (out.eps || out.C) && out.n_iter > 0) {
         // orbitals and orbital energies of the last Fock matrix (what the reference's last diagonalisation leaves, scf:1133)
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, dF, 0.0, t1));
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
         hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
-        auto te = std::chrono::steady_clock::now();
+        const int te = span_begin(1);
         rc = eigh(w, n, dW, vals, ework, msg);
         if (rc) return rc;
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
-        TFS_HIP(hipDeviceSynchronize());
-        out.eig_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - te).count();
+        span_end(te);
         if (out.eps) TFS_HIP(hipMemcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
         if (out.C) TFS_HIP(hipMemcpy(out.C, dC, nn * sizeof(double), hipMemcpyDeviceToHost));
     }
     w.ref_n = 0;
+    TFS_HIP(hipDeviceSynchronize());
+    for (const auto &sp : spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, w.tev[sp.first], w.tev[sp.first + 1]) == hipSuccess) (sp.second == 0 ? out.fock_seconds : out.eig_seconds) += ms * 1e-3;
+    }
     out.energy = E + V_NN;
     std::memcpy(out.components, comps, sizeof(comps));
     if (out.P) TFS_HIP(hipMemcpy(out.P, dP, nn * sizeof(double), hipMemcpyDeviceToHost));
