@@ -1,0 +1,150 @@
+// tf_refine.hip.h -- eigenvector refinement for the small matrices of the SCF cycle (n <= 64) in ONE launch, everything in LDS.
+// Same algorithm as tfscf::ref_refine (tf_scf.hip.h: Newton-Schulz orthonormalisation + first-order rotation, after Ogita &
+// Aishima 2018), but the five matrix products of a step run inside one workgroup on LDS-resident matrices -- one 16 x 16 tile per
+// wave on the FP64 matrix core (V_MFMA_F64_16X16X4_F64) -- and the convergence
+// test stays on the device: a whole solve is one kernel and one 4-byte status read, against ~60 rotation rounds with a barrier each
+// for a warm-started Jacobi sweep.  Role in the reference: np.linalg.eigh in diagonalise_Fock_matrix (scf:244), of which the SCF
+// iteration only needs the projector on the n_occ lowest eigenvectors (scf:183-211).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tfref {
+
+#define TFR_THREADS 1024
+#define TFR_NMAX 64
+
+typedef double tfr_v4d __attribute__((ext_vector_type(4)));
+
+// matrices are padded to NP = a multiple of 16 (the MFMA tile) and stored with row stride NP + 2: even (aligned pairs) and, for
+// NP <= 64, never a multiple of 32 -- the operand reads below (16 rows x 4 columns per instruction) are then bank-conflict free
+__host__ __device__ inline int tfr_np(int n) { return (n + 15) & ~15; }
+__host__ __device__ inline int tfr_stride(int np) { return np + 2; }
+inline size_t lds_bytes(int n)
+{
+    const int np = tfr_np(n);
+    return ((size_t)4 * np * tfr_stride(np) + 2 * TFR_NMAX + 2 * TFR_THREADS) * sizeof(double);
+}
+
+// One 16 x 16 output tile per wave on the FP64 matrix core: V_MFMA_F64_16X16X4_F64 takes A[i = lane % 16][k = lane / 16] and
+// B[k = lane / 16][j = lane % 16] and leaves D[i = 4 v + lane / 16][j = lane % 16] in accumulator v (checked on gfx950).
+// C = beta D + alpha A B^T (NT) or alpha A B (NN); tile (I, J) of this wave, or nothing if the wave has none.
+template <bool NT>
+__device__ __forceinline__ void mm_tile(double *C, const double *A, const double *B, double alpha, double beta, const double *D, int np, int ns,
+                                        int I, int J, int lane, bool on)
+{
+    if (!on) return;
+    const int r = lane & 15, q = lane >> 4;
+    const double *ap = A + (16 * I + r) * ns + q;
+    const double *bp = NT ? B + (16 * J + r) * ns + q : B + q * ns + 16 * J + r;
+    const int bstep = NT ? 4 : 4 * ns;
+    tfr_v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < np / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[kk * bstep], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int idx = (16 * I + 4 * v + q) * ns + 16 * J + r;
+        C[idx] = (beta != 0.0 ? beta * D[idx] : 0.0) + alpha * acc[v];
+    }
+}
+
+// A: symmetric n x n (global, row-major); X: rows = orthonormal approximate eigenvectors (global, in/out).
+// status[0] = 1: converged (X, lam, wocc written; wocc[i] = 1 for the n_occ lowest), 0: not (X untouched); status[1] = steps taken.
+__global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_occ, const double *__restrict__ A, double *__restrict__ X,
+                                                                 double *__restrict__ lam_out, double *__restrict__ wocc_out, int max_steps,
+                                                                 int *__restrict__ status)
+{
+    extern __shared__ double sm[];
+    const int np = tfr_np(n), ns = tfr_stride(np);
+    double *sX = sm, *sA = sX + np * ns, *sT1 = sA + np * ns, *sT2 = sT1 + np * ns;
+    double *sLam = sT2 + np * ns, *sOcc = sLam + TFR_NMAX, *sRed = sOcc + TFR_NMAX;       // sRed: 2 * TFR_THREADS
+    __shared__ int sFlag;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = np / 16;
+    const bool on = w < nt * nt;
+    const int I = on ? w / nt : 0, J = on ? w - I * nt : 0;
+    // load; the padding dimensions are decoupled vectors far up in the virtual space
+    for (int e = tid; e < np * np; e += TFR_THREADS) {
+        const int i = e / np, j = e - i * np;
+        const bool in = i < n && j < n;
+        sX[i * ns + j] = in ? X[(size_t)i * n + j] : ((i == j) ? 1.0 : 0.0);
+        sA[i * ns + j] = in ? 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]) : ((i == j) ? 1.0e6 : 0.0);
+    }
+    __syncthreads();
+    int steps = 0;
+    bool ok = false;
+    for (int step = 0; step < max_steps; ++step) {
+        // X <- (3/2 I - 1/2 X X^T) X
+        mm_tile<true>(sT1, sX, sX, 1.0, 0.0, sX, np, ns, I, J, lane, on);
+        __syncthreads();
+        mm_tile<false>(sT2, sT1, sX, -0.5, 1.5, sX, np, ns, I, J, lane, on);
+        __syncthreads();
+        { double *t = sX; sX = sT2; sT2 = t; }
+        if (ok) break;                                         // that was the closing orthonormalisation
+        // S = X A X^T
+        mm_tile<false>(sT1, sX, sA, 1.0, 0.0, sX, np, ns, I, J, lane, on);
+        __syncthreads();
+        mm_tile<true>(sT2, sT1, sX, 1.0, 0.0, sX, np, ns, I, J, lane, on);
+        __syncthreads();
+        if (tid < np) sLam[tid] = sT2[tid * ns + tid];
+        __syncthreads();
+        if (tid < np) {                                        // the n_occ lowest are occupied (ties by index, like a stable sort)
+            const double li = sLam[tid];
+            int rank = 0;
+            for (int j = 0; j < np; ++j) { const double lj = sLam[j]; rank += (lj < li || (lj == li && j < tid)) ? 1 : 0; }
+            sOcc[tid] = rank < n_occ ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        // E (antisymmetric) into T1; largest rotation overall and between occupied and virtual vectors
+        double emax = 0.0, eov = 0.0;
+        for (int e = tid; e < np * np; e += TFR_THREADS) {
+            const int i = e / np, j = e - i * np;
+            double v = 0.0;
+            if (i != j) {
+                const double sij = 0.5 * (sT2[i * ns + j] + sT2[j * ns + i]);
+                const double dl = sLam[j] - sLam[i];
+                const bool ov = sOcc[i] != sOcc[j];
+                if (ov || (fabs(sij) <= 0.05 * fabs(dl) && fabs(dl) > 1e-5)) v = sij / dl;
+                emax = fmax(emax, fabs(v));
+                if (ov) eov = fmax(eov, fabs(v));
+            }
+            sT1[i * ns + j] = v;
+        }
+        sRed[tid] = emax; sRed[TFR_THREADS + tid] = eov;
+        __syncthreads();
+        for (int st = TFR_THREADS / 2; st > 0; st >>= 1) {
+            if (tid < st) { sRed[tid] = fmax(sRed[tid], sRed[tid + st]); sRed[TFR_THREADS + tid] = fmax(sRed[TFR_THREADS + tid], sRed[TFR_THREADS + tid + st]); }
+            __syncthreads();
+        }
+        emax = sRed[0]; eov = sRed[TFR_THREADS];
+        __syncthreads();
+        if (!(emax <= 0.3)) break;                             // NaN, or not in the quadratic regime: the caller diagonalises
+        // X <- X + E^T X = X - E X
+        mm_tile<false>(sT2, sT1, sX, -1.0, 1.0, sX, np, ns, I, J, lane, on);
+        __syncthreads();
+        { double *t = sX; sX = sT2; sT2 = t; }
+        ++steps;
+        ok = eov < 1e-9 && emax < 1e-3;
+    }
+    if (tid == 0) sFlag = ok ? 1 : 0;
+    __syncthreads();
+    if (sFlag) {
+        for (int e = tid; e < n * n; e += TFR_THREADS) { const int i = e / n, j = e - i * n; X[e] = sX[i * ns + j]; }
+        if (tid < n) { lam_out[tid] = sLam[tid]; wocc_out[tid] = sOcc[tid]; }
+    }
+    if (tid == 0) { status[0] = sFlag; status[1] = steps; }
+}
+
+inline bool launch(int n, int n_occ, const double *A, double *X, double *lam, double *wocc, int *status, hipStream_t st, hipError_t *err)
+{
+    static bool attr_set = false;
+    if (n < 2 || n > TFR_NMAX) return false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)refine_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(refine_lds_kernel, dim3(1), dim3(TFR_THREADS), lds_bytes(n), st, n, n_occ, A, X, lam, wocc, 12, status);
+    *err = hipGetLastError();
+    return *err == hipSuccess;
+}
+
+}  // namespace tfref

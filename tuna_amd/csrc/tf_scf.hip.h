@@ -19,6 +19,7 @@
 
 #include "../../include/tunafock.h"
 #include "tf_jacobi.hip.h"
+#include "tf_refine.hip.h"
 #include <cstdio>
 #include <vector>
 
@@ -385,6 +386,31 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
     return TF_ELINALG;
 }
 
+// n <= 64: the same refinement in one launch with every matrix in LDS (tf_refine.hip.h); one 8-byte status read per solve.
+inline int ref_refine_lds(Workspace &w, int n, int n_occ, const double *A, double **Xocc, std::string &msg)
+{
+    if (w.ref_n != n || !w.ref_buf || n > TFR_NMAX) return TF_ELINALG;
+    const size_t nn = (size_t)n * n;
+    double *X = w.ref_buf, *Xw = X + 2 * nn, *lam = X + 6 * nn, *wocc = lam + n;
+    int *status = reinterpret_cast<int *>(w.d_scal + 62);
+    hipError_t e = hipSuccess;
+    ++w.ref_solves;
+    if (!tfref::launch(n, n_occ, A, X, lam, wocc, status, 0, &e)) {
+        if (e != hipSuccess) { msg = std::string("refinement kernel launch failed: ") + hipGetErrorString(e); return TF_ENODEVICE; }
+        return TF_ELINALG;
+    }
+    int h[2] = {0, 0};
+    TFS_HIP(hipMemcpy(h, status, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    static const bool dbg = getenv("TF_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[tf refine/lds] n %d: %s after %d steps\n", n, h[0] ? "converged" : "NOT converged", h[1]);
+    if (!h[0]) { ++w.ref_fallbacks; w.ref_n = 0; return TF_ELINALG; }
+    w.ref_steps += h[1];
+    const int g = (int)((nn + 255) / 256);
+    hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, 0, X, wocc, Xw, n);
+    *Xocc = Xw;
+    return TF_OK;
+}
+
 // after a real eigensolve: rows of V (row-major, as eigh() leaves them) become the refinement start
 inline int ref_store(Workspace &w, int n, const double *V, std::string &msg)
 {
@@ -606,9 +632,10 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     auto span_end = [&](int idx) { if (idx >= 0) (void)hipEventRecord(w.tev[idx], 0); };
 
     // diagonalise F (AO) -> eps, C ; P = 2 C_occ C_occ^T symmetrised      (scf:222-250, 183-211)
-    // n > 64 (where the eigensolver is rocsolver_dsyevd): after the first solve the density comes from refined eigenvectors
+    // After the first solve of a cycle the density comes from refined eigenvectors: GEMM-based for n > 64 (where the eigensolver
+    // would be rocsolver_dsyevd), one LDS-resident launch for n <= 64 (where it would be the Jacobi kernel).
     static const bool no_refine = getenv("TF_EIGH") != nullptr;
-    const bool refining = !no_refine && n > 64 && n_occ > 0 && n_occ < n;
+    const bool refining = !no_refine && n >= 2 && n_occ > 0 && n_occ < n;
     bool orbitals_current = false, orbitals_final = false;
     w.ref_n = 0;
     auto diag_density = [&](const double *Fao, double *Pout) -> int {
@@ -620,7 +647,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         if (refining && w.ref_n == n) {
             double *Xocc = nullptr;
             std::string rmsg;
-            const int rr = ref_refine(w, n, n_occ, dW, &Xocc, rmsg);
+            const int rr = (n <= TFR_NMAX) ? ref_refine_lds(w, n, n_occ, dW, &Xocc, rmsg) : ref_refine(w, n, n_occ, dW, &Xocc, rmsg);
             if (rr == TF_OK) {
                 const double two = 2.0, zero = 0.0;
                 TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Xocc, dX, 0.0, t1));    // rows: occupied orbitals in the AO basis (others 0)
