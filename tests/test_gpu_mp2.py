@@ -56,3 +56,16 @@ def test_scf_then_mp2_end_to_end(engine, mp2_golden):
     r = engine.mp2_rhf(out.molecular_orbitals, out.epsilons, 7)
     assert abs(out.energy - float(g["E_SCF"])) < 1e-9
     assert abs(r["E_MP2"] - (float(g["E_OS"]) + float(g["E_SS"]))) < 1e-8
+
+
+def test_mp2_input_line(engine, mp2_golden):
+    """The reference-style input line of BASELINE config 5: `SPE : N N 1.0977 : MP2 CC-PVTZ`."""
+    from tuna_amd import energy
+    g = mp2_golden["c5_n2_ccpvtz"]
+    lines = []
+    out = energy.run("SPE : N N 1.0977 : MP2 CC-PVTZ : EXTREME", silent=False, engine=engine, log=lines.append)
+    e_corr = float(g["E_OS"]) + float(g["E_SS"])
+    assert abs(out.correlation_energy_mp2 - e_corr) < 1e-8
+    assert abs(out.energy - (float(g["E_SCF"]) + e_corr)) < 1e-8
+    text = "\n".join(lines)
+    assert "MP2 correlation energy:" in text and "Final single point energy:" in text

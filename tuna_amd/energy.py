@@ -221,6 +221,23 @@ def calculate_energy(symbols, R_bohr, calc: Calculation, engine: Engine | None =
             else:
                 label = "\n Unrestricted Hartree-Fock energy: " if calc.reference == "UHF" else "\n Restricted Hartree-Fock energy:   "
                 log(label + f"{out.energy:16.10f}")                                      # kernel:846-850
+        if calc.method == "MP2":
+            # second-order Moller-Plesset correlation energy on the device-resident tensor (tuna_mp.py:834-906; all-electron,
+            # SURVEY.md section 8d config 5): AO->MO of the (ia|jb) block + the energy sums, tf_mp2_rhf
+            if calc.reference == "UHF":
+                raise TunaError("MP2 is available for a restricted reference only in this build.")
+            t0 = time.perf_counter()
+            r = engine.mp2_rhf(out.molecular_orbitals, out.epsilons, molecule.n_doubly_occ, 0)
+            out.timings["MP2 energy"] = time.perf_counter() - t0
+            out.mp2 = r
+            E_SCF = out.energy
+            out.correlation_energy_mp2 = r["E_MP2"]
+            out.energy = E_SCF + r["E_MP2"]
+            if not silent:
+                log(f"\n  Same spin contribution:             {r['E_SS']:13.10f}")       # mp:904-906
+                log(f"  Opposite spin contribution:         {r['E_OS']:13.10f}")
+                log(f"\n  MP2 correlation energy:             {r['E_MP2']:13.10f}")
+        if not silent:
             log("\n Final single point energy: " + f"{out.energy:16.10f}")              # kernel:1305
         out.integrals = integrals if not own else None      # the device tensor dies with an engine we own
         return out
@@ -235,9 +252,9 @@ def run(input_line: str, silent: bool = True, engine: Engine | None = None, log=
     if ctype != "SPE":
         raise TunaError(f"Calculation type \"{ctype}\" is not supported.")
     from . import dft as dft_mod
-    if method not in ("HF", "RHF", "UHF") and method not in dft_mod.FUNCTIONALS:
+    if method not in ("HF", "RHF", "UHF", "MP2", "RMP2") and method not in dft_mod.FUNCTIONALS:
         raise TunaError(f"Electronic structure method \"{method}\" is not supported.")
-    calc = interpret_keywords(params, Calculation(ctype, method if method in dft_mod.FUNCTIONALS else "HF", basis))
+    calc = interpret_keywords(params, Calculation(ctype, method if method in dft_mod.FUNCTIONALS else ("MP2" if "MP2" in method else "HF"), basis))
     if method == "UHF":
         calc.reference = "UHF"
     if method in dft_mod.FUNCTIONALS:
