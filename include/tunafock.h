@@ -97,7 +97,7 @@ int tf_cross_overlap(tf_ctx *ctx, int n_ao2, const double *origin2, const int32_
 /* Build this rank's rows of the (ij|kl) tensor on the device.  spherical = 0 is CARTHARM
  * (kernel:481).  The tensor stays resident in HBM in one of two layouts:
  *   TF_LAYOUT_PACKED (default): the 8-fold unique values, row (i >= j) = all pairs (k >= l) <= (i,j)
- *                               -- N^4 bytes instead of the reference's 8 N^4 (kernel:349);
+ *                               -- ~N^4 bytes (+ cache-line padding) instead of the reference's 8 N^4 (kernel:349);
  *   TF_LAYOUT_ROWS:             rows (i >= j) x full [k][l] -- 4 N^4 bytes. */
 int tf_build_eri(tf_ctx *ctx, int spherical);
 #define TF_LAYOUT_AUTO (-1)
@@ -107,6 +107,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical);
 int tf_set_eri_layout(tf_ctx *ctx, int layout);
 /* Layout of the stored tensor (TF_LAYOUT_ROWS / TF_LAYOUT_PACKED), or TF_EINVAL before tf_build_eri. */
 int tf_eri_layout(const tf_ctx *ctx);
+/* Alignment unit of the packed layout, in doubles: pair (k >= l) sits at tri(k) + l of its tensor row, where
+ * tri(k) = sum over m = 1..k of (m rounded up to the unit); tensor rows are rounded up to the unit as well. */
+int tf_packed_pad(void);
 /* Bytes of HBM holding the stored rows, number of stored rows, row length (leading dimension). */
 int tf_eri_storage(const tf_ctx *ctx, int64_t *bytes, int64_t *n_rows, int32_t *n, int32_t *ld);
 /* Dense N^4 tensor with all 8 images, as the reference leaves it in `ERI_AO` (caller-allocated,

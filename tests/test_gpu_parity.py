@@ -165,7 +165,7 @@ def test_error_behaviour(engine):
 @pytest.mark.parametrize("n_sph", [120, 200, 400])
 def test_synthetic_series_properties(engine, n_sph):
     """Synthetic even-tempered Ar2-like diatomic: properties that hold at any size -- up to the 400-AO
-    workload of bench.py (25.8 GB of stored tensor)."""
+    workload of bench.py (27 GB of stored tensor)."""
     counts = mol.synthetic_counts(n_sph)
     atoms = mol.make_atoms(["AR", "AR"], 7.1)
     aos = mol.expand_cartesian_aos(mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)}))
@@ -222,4 +222,4 @@ def test_packed_and_rows_layouts_agree(engine):
     for q in (1, 2, 3, 4):
         assert np.abs(a[q] - b[q]).max() < 1e-11 * scale
     assert np.abs(b[3][0] - b[1]).max() < 1e-11 * scale and np.abs(b[4][0] - b[2]).max() < 1e-11 * scale   # fused pass = single pass
-    assert b[5] < 0.27 * a[5]                                         # N^4 bytes against 4 N^4
+    assert b[5] < 0.30 * a[5]                                         # ~N^4 bytes (+ cache-line padding: 11 % at N = 200) against 4 N^4

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtunafock.so")
+LIB_PATH = os.environ.get("TUNAFOCK_LIB") or os.path.join(HERE, "libtunafock.so")
 
 
 class TunaError(RuntimeError):
@@ -38,7 +38,7 @@ EXPORTS = ["tf_create", "tf_destroy", "tf_last_error", "tf_version", "tf_normali
            "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf",
            "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts", "tf_shard_plan", "tf_jk_profile",
            "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_ao_to_mo", "tf_mp2_rhf", "tf_dft_setup", "tf_dft_vxc",
-           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs"]
+           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs", "tf_packed_pad"]
 
 _lib = None
 
@@ -76,6 +76,7 @@ def lib():
     L.tf_build_eri.restype = ci; L.tf_build_eri.argtypes = [vp, ci]
     L.tf_set_eri_layout.restype = ci; L.tf_set_eri_layout.argtypes = [vp, ci]
     L.tf_eri_layout.restype = ci; L.tf_eri_layout.argtypes = [vp]
+    L.tf_packed_pad.restype = ci; L.tf_packed_pad.argtypes = []
     L.tf_eri_storage.restype = ci; L.tf_eri_storage.argtypes = [vp, lp, lp, ip, ip]
     L.tf_copy_eri.restype = ci; L.tf_copy_eri.argtypes = [vp, vp]
     L.tf_sample_eri.restype = ci; L.tf_sample_eri.argtypes = [vp, C.c_int64, vp, vp]

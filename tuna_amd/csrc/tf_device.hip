@@ -918,6 +918,7 @@ int tf_set_eri_layout(tf_ctx *ctx, int layout)
 }
 
 int tf_eri_layout(const tf_ctx *ctx) { return (ctx && ctx->have_eri) ? ctx->layout : TF_EINVAL; }
+int tf_packed_pad(void) { return TF_TRI_PAD; }
 
 int tf_eri_timings(const tf_ctx *ctx, double *s4)
 {

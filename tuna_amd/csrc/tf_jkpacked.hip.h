@@ -2,10 +2,13 @@
 // Reference: calculate_coulomb_matrix tuna_scf.py:55-72 ("ijkl,kl->ij"), calculate_exchange_matrix tuna_scf.py:27-44
 // ("ilkj,kl->ij"); the reference keeps all 8 images of every (ij|kl) (pyx:1335-1342), here each unique value is stored once.
 //
-// Layout: a pair (k >= l) has the padded index tri_off(k) + l, where every row k of the triangle starts at an EVEN index
-// (tri_off(k) = sum of the row lengths 1, 2, 3, ... each rounded up to even), so that 16-byte loads stay aligned; pad slots hold 0.
-// Row (i >= j) of the tensor holds (ij|kl) for every pair (k,l) <= (i,j) at [tri_off(k) + l], its length rounded up to even;
-// a rank stores the rows it owns in ascending (i,j) with a row-offset table.  N^4 bytes instead of the reference's 8 N^4.
+// Layout: a pair (k >= l) has the padded index tri_off(k) + l, where every row k of the triangle starts at a multiple of
+// TF_TRI_PAD = 16 doubles = one 128-byte cache line (tri_off(k) = sum of the row lengths 1, 2, 3, ... each rounded up to 16); pad
+// slots hold 0.  Row (i >= j) of the tensor holds (ij|kl) for every pair (k,l) <= (i,j) at [tri_off(k) + l], its length rounded up
+// to 16; a rank stores the rows it owns in ascending (i,j) with a row-offset table.  ~1.05 N^4 bytes at N = 400 instead of the
+// reference's 8 N^4.  Why whole cache lines: a wave reads 128 columns (1 KB) of a triangle row per load; with rows packed to even
+// indices only, that KB straddled 9 lines and the line shared with the neighbouring 128-column chunk -- another workgroup, usually
+// on another XCD with its own L2 -- came from HBM twice.  Aligned: 4.7 % more stored bytes, 9 % fewer fetched, kernel 6 % faster.
 //
 // One pass over row (i,j) has to feed six outputs per element m = (ij|kl):
 //     Jd[ij] += m Pp[kl]                      (Pp[kl] = P[k][l] + P[l][k], or P[k][k])
@@ -28,8 +31,15 @@
 #define TF_JKP_SEG 16            // segments of the group list in the Jt reduction
 
 // padded triangle: first index of row k, and the stored length of tensor row (i,j)
-__host__ __device__ inline long long tri_off(long long k) { const long long h = k >> 1; return 2 * h * (h + 1) + ((k & 1) ? k + 1 : 0); }
-__host__ __device__ inline long long packed_row_len(long long i, long long j) { return (tri_off(i) + j + 2) & ~1LL; }
+#ifndef TF_TRI_PAD
+#define TF_TRI_PAD 16            // triangle rows and tensor rows start at multiples of this many doubles (a power of two >= 2)
+#endif
+__host__ __device__ inline long long tri_off(long long k)
+{
+    const long long q = k / TF_TRI_PAD, r = k % TF_TRI_PAD;     // sum over m = 1..k of m rounded up to the pad
+    return TF_TRI_PAD * (TF_TRI_PAD * q * (q + 1) / 2 + r * (q + 1));
+}
+__host__ __device__ inline long long packed_row_len(long long i, long long j) { return (tri_off(i) + j + TF_TRI_PAD) & ~(long long)(TF_TRI_PAD - 1); }
 
 struct JKGroup {
     int i, j0, nr, r0;           // rows r0..r0+nr-1 (local numbering) = pairs (i, j0..j0+nr-1)
@@ -392,12 +402,13 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lan
 #pragma unroll
         for (int d = 0; d < ND; ++d) slots[(w * ND + d) * 64 + lane] = jt[d];
         __syncthreads();
-        if (w == 0) {                                                  // wave 0 holds the first group: its last column bounds the row
+        if (w == 0) {                                  // wave 0 holds the first group: its last column bounds the row; the partial is
+                                                       // written (with zeros) up to its padded length, which jt_reduce_kernel sums over
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 double2 t = slots[d * 64 + lane];
                 for (int u = 1; u < ng; ++u) { const double2 x = slots[(u * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
-                if (C.l0 <= U.j0 + U.nr - 1) buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + tri_off(i) + U.c0), 16u * (unsigned)lane, 0u, t);
+                if (C.l0 <= ((U.j0 + U.nr - 1) | (TF_TRI_PAD - 1))) buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + tri_off(i) + U.c0), 16u * (unsigned)lane, 0u, t);
             }
         }
     }
@@ -540,7 +551,8 @@ __global__ void jk_packed_final_kernel(const double *__restrict__ D, const doubl
 // padded index -> (k, l); l > k marks a pad slot
 __device__ __forceinline__ void unpair_padded(long long x, int &k, int &l)
 {
-    long long kk = (long long)(sqrt(2.0 * (double)x + 1.0)) - 1;
+    const double c = 0.5 * (TF_TRI_PAD + 1);                 // tri_off(k) ~ k^2/2 + c k
+    long long kk = (long long)(sqrt(2.0 * (double)x + c * c) - c);
     if (kk < 0) kk = 0;
     while (tri_off(kk) > x) --kk;
     while (tri_off(kk + 1) <= x) ++kk;

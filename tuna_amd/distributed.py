@@ -14,16 +14,24 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def packed_tri_offset(k):
-    """First padded index of row k of the (k >= l) triangle: every row starts at an even index (tf_jkpacked.hip.h: tri_off)."""
+def packed_pad() -> int:
+    """Alignment unit of the packed layout in doubles (tf_packed_pad)."""
+    return int(_lib.lib().tf_packed_pad())
+
+
+def packed_tri_offset(k, pad=None):
+    """First padded index of row k of the (k >= l) triangle: the row lengths 1, 2, 3, ... each rounded up to the alignment
+    unit (tf_jkpacked.hip.h: tri_off)."""
+    pad = packed_pad() if pad is None else int(pad)
     k = np.asarray(k, dtype=np.int64)
-    h = k >> 1
-    return 2 * h * (h + 1) + np.where(k & 1, k + 1, 0)
+    q, r = k // pad, k % pad
+    return pad * (pad * q * (q + 1) // 2 + r * (q + 1))
 
 
-def packed_row_length(i, j):
-    """Stored doubles of tensor row (i >= j) in the packed layout: the pairs (k,l) <= (i,j), rounded up to even."""
-    return (packed_tri_offset(i) + np.asarray(j, dtype=np.int64) + 2) & ~np.int64(1)
+def packed_row_length(i, j, pad=None):
+    """Stored doubles of tensor row (i >= j) in the packed layout: the pairs (k,l) <= (i,j), rounded up to the unit."""
+    pad = packed_pad() if pad is None else int(pad)
+    return (packed_tri_offset(i, pad) + np.asarray(j, dtype=np.int64) + pad) & ~np.int64(pad - 1)
 
 
 def shell_pair_rows(shells, spherical: bool = True, layout: str = "packed") -> np.ndarray:
