@@ -176,6 +176,20 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
                const double *Fext, const double *X, const double *P0, double E0, int n_occ, double V_NN,
                tf_scf_result *out);
 
+/* Unrestricted cycle: run_unrestricted_SCF_cycle (scf:1165-1281) inside the same outer loop.  Both spin densities go
+ * through the tensor in one fused pass per iteration.  `common` as for tf_scf_rhf (P = total density; C, eps, F unused);
+ * the *_spin arrays are the alpha ([0]) and beta ([1]) quantities, caller-allocated, each may be NULL. */
+typedef struct {
+    tf_scf_result common;
+    double *P_spin[2];          /* [N,N]                                           */
+    double *C_spin[2];          /* [N,N]                                           */
+    double *eps_spin[2];        /* [N]                                             */
+    double *F_spin[2];          /* [N,N]                                           */
+} tf_scf_uhf_result;
+int tf_scf_uhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const double *T, const double *V,
+               const double *Fext, const double *X, const double *P0_alpha, const double *P0_beta, double E0,
+               int n_alpha, int n_beta, double V_NN, tf_scf_uhf_result *out);
+
 /* X = S^-1/2, S^-1 and the smallest overlap eigenvalue (kernel:756-816), host buffers [N,N]. */
 int tf_orthogonaliser(tf_ctx *ctx, int n, const double *S, double *X, double *S_inv, double *smallest_eig);
 

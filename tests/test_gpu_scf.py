@@ -125,6 +125,30 @@ def test_unrestricted_cycle_matches_reference(engine, uhf_golden, tag, damping):
     np.testing.assert_allclose(out.table[:n, 6], ref[:n, 6], atol=1e-6)
 
 
+def test_native_and_host_orchestrated_unrestricted_cycles_agree(engine, monkeypatch):
+    """tf_scf_uhf (whole cycle in the library) against the host-orchestrated loop (the path a sharded tensor takes): same
+    trajectory, same orbitals."""
+    from conftest import UHF_SYSTEMS
+    from tuna_amd.energy import Calculation, build_molecule_and_integrals
+    from tuna_amd.engine import SCF_CONVERGENCE
+    from tuna_amd import scf
+    sym, R, basis, na, nb = UHF_SYSTEMS["oh_doublet_ccpvdz"]
+    calc = Calculation(basis=basis, SCF_conv=SCF_CONVERGENCE["extreme"], multiplicity=na - nb + 1, damping=True, core_guess=True)
+    molecule, integrals, X, guess, _ = build_molecule_and_integrals(sym, R, calc, engine)
+    outs = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("TUNA_AMD_HOST_UHF", "1")
+        outs.append(scf.run_self_consistent_field_cycle(molecule, calc, integrals, 0.0, X, guess))
+    a, b = outs
+    assert a.n_iterations == b.n_iterations and abs(a.energy - b.energy) < 1e-10
+    np.testing.assert_allclose(a.table[:, 1:], b.table[:, 1:], atol=1e-8)
+    np.testing.assert_allclose(a.epsilons_alpha, b.epsilons_alpha, atol=1e-8)
+    np.testing.assert_allclose(a.epsilons_beta, b.epsilons_beta, atol=1e-8)
+    assert np.abs(a.P_alpha - b.P_alpha).max() < 1e-8 and np.abs(a.P_beta - b.P_beta).max() < 1e-8
+    assert np.abs(a.F_alpha - b.F_alpha).max() < 1e-8
+
+
 def test_uhf_input_line(uhf_golden):
     from tuna_amd.energy import run
     out = run("SPE : O O 1.2075 : UHF CC-PVDZ : EXTREME NODAMP ML 3 COREGUESS")

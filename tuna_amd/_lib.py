@@ -33,9 +33,14 @@ class ScfResult(C.Structure):
                 ("fock_seconds", C.c_double), ("eig_seconds", C.c_double), ("wall_seconds", C.c_double)]
 
 
+class ScfUhfResult(C.Structure):                          # tf_scf_uhf_result
+    _fields_ = [("common", ScfResult), ("P_spin", C.c_void_p * 2), ("C_spin", C.c_void_p * 2), ("eps_spin", C.c_void_p * 2),
+                ("F_spin", C.c_void_p * 2)]
+
+
 EXPORTS = ["tf_create", "tf_destroy", "tf_last_error", "tf_version", "tf_normalize", "tf_set_basis", "tf_get_norms",
            "tf_dims", "tf_get_sph_matrix", "tf_one_electron", "tf_cross_overlap", "tf_build_eri", "tf_eri_storage",
-           "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf",
+           "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf", "tf_scf_uhf",
            "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts", "tf_shard_plan", "tf_jk_profile",
            "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_ao_to_mo", "tf_mp2_rhf", "tf_dft_setup", "tf_dft_vxc",
            "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs", "tf_packed_pad"]
@@ -85,6 +90,8 @@ def lib():
     L.tf_fock_jk_device.restype = ci; L.tf_fock_jk_device.argtypes = [vp, ci, vp, vp, vp, vp]
     L.tf_scf_rhf.restype = ci
     L.tf_scf_rhf.argtypes = [vp, C.POINTER(ScfOpts), vp, vp, vp, vp, vp, vp, cd, ci, cd, C.POINTER(ScfResult)]
+    L.tf_scf_uhf.restype = ci
+    L.tf_scf_uhf.argtypes = [vp, C.POINTER(ScfOpts), vp, vp, vp, vp, vp, vp, vp, cd, ci, ci, cd, C.POINTER(ScfUhfResult)]
     L.tf_orthogonaliser.restype = ci; L.tf_orthogonaliser.argtypes = [vp, ci, vp, vp, vp, dp]
     L.tf_eri_timings.restype = ci; L.tf_eri_timings.argtypes = [vp, vp]
     L.tf_eri_counts.restype = ci; L.tf_eri_counts.argtypes = [vp, vp]

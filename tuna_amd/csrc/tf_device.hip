@@ -1012,12 +1012,14 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
                            T.d_supers, T.d_tasks, N, NW, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
-    for (int d = 0; d < ND; ++d) {
-        hipLaunchKernelGGL(jt_reduce_kernel, dim3((unsigned)((npr + 255) / 256), T.nseg), dim3(256), 0, st, ctx->d_ypart + d * S.y, T.d_supers,
-                           T.n_supers, (long long)npr, ctx->d_Jt + (size_t)d * T.nseg * npr);
-        hipLaunchKernelGGL(kd_reduce_kernel, dim3(N, (N + 63) / 64), dim3(256), 0, st, DIc + d * S.DIc, DIr + d * S.DIr, DJc + d * S.DJc,
-                           DJr + d * S.DJr, NW, T.d_gfirst, ctx->d_rowmap, N, dDout[d]);
-    }
+    JKReduce R{};
+    R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.n_supers = T.n_supers; R.nseg = T.nseg; R.NP = (long long)npr;
+    R.Jt = ctx->d_Jt; R.sJt = (size_t)T.nseg * npr;
+    R.DIc = DIc; R.sDIc = S.DIc; R.DIr = DIr; R.sDIr = S.DIr; R.DJc = DJc; R.sDJc = S.DJc; R.DJr = DJr; R.sDJr = S.DJr;
+    R.gfirst = T.d_gfirst; R.rowmap = ctx->d_rowmap; R.N = N; R.NW = NW;
+    for (int d = 0; d < ND; ++d) R.D[d] = dDout[d];
+    const unsigned nblk = (unsigned)ND * ((unsigned)N * ((N + 63) / 64) + (unsigned)((npr + 255) / 256) * T.nseg);
+    hipLaunchKernelGGL(jk_reduce_kernel, dim3(nblk), dim3(256), 0, st, R);
     return TF_OK;
 }
 }  // extern "C++"
@@ -1450,6 +1452,30 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
         xc = [&](const double *dP, double *dV, double *o3) { return tfdft::vxc(ctx->scf.blas, ctx->grid, dP, dV, o3, msg); };
     }
     int rc = tfscf::run_rhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0, E0, n_occ, V_NN, jk, ctx->world, *out, msg, xc);
+    if (rc) ctx->err = msg;
+    return rc;
+}
+
+int tf_scf_uhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const double *T, const double *V, const double *Fext,
+               const double *X, const double *P0_alpha, const double *P0_beta, double E0, int n_alpha, int n_beta, double V_NN,
+               tf_scf_uhf_result *out)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_scf_uhf: call tf_build_eri first");
+    if (!opts || !S || !T || !V || !P0_alpha || !P0_beta || !out || n_alpha < 1 || n_alpha > ctx->N || n_beta < 0 || n_beta > n_alpha)
+        TF_FAIL(ctx, TF_EINVAL, "tf_scf_uhf: bad arguments");
+    if (ctx->grid.G > 0) TF_FAIL(ctx, TF_EINVAL, "tf_scf_uhf: unrestricted Kohn-Sham is not implemented (call tf_dft_clear)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string msg;
+    auto jk2 = [&](const double *dPa, const double *dPb, double *dJa, double *dJb, double *dKa, double *dKb, hipStream_t st) {
+        const double *p[2] = {dPa, dPb};
+        double *j[2] = {dJa, dJb}, *k[2] = {dKa, dKb};
+        return launch_jk(ctx, 2, p, j, k, st);
+    };
+    tfscf::UhfOut uo;
+    for (int sp = 0; sp < 2; ++sp) { uo.P[sp] = out->P_spin[sp]; uo.C[sp] = out->C_spin[sp]; uo.eps[sp] = out->eps_spin[sp]; uo.F[sp] = out->F_spin[sp]; }
+    int rc = tfscf::run_uhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0_alpha, P0_beta, E0, n_alpha, n_beta, V_NN, jk2, ctx->world,
+                            out->common, uo, msg);
     if (rc) ctx->err = msg;
     return rc;
 }

@@ -21,7 +21,7 @@
 // lane owns two adjacent columns (one 16-byte load per row and triangle row k) and walks k up to i.  Tasks are dispatched longest
 // first, so the triangle balances itself.  Lane-local accumulators: the "column" sums (outputs indexed by l); the "row" sums
 // (outputs indexed by k) are reduced across the wave with a transposing butterfly on permlane swaps / DPP (no LDS) and written
-// per task.  Jt partials are written once per group and column (1/JBB of the tensor's bytes) and summed by jt_reduce_kernel.
+// per task.  Jt partials are written once per group and column (1/JBB of the tensor's bytes) and summed by jk_reduce_kernel.
 // No atomics anywhere: results are bitwise reproducible.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -403,7 +403,7 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lan
         for (int d = 0; d < ND; ++d) slots[(w * ND + d) * 64 + lane] = jt[d];
         __syncthreads();
         if (w == 0) {                                  // wave 0 holds the first group: its last column bounds the row; the partial is
-                                                       // written (with zeros) up to its padded length, which jt_reduce_kernel sums over
+                                                       // written (with zeros) up to its padded length, which jk_reduce_kernel sums over
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 double2 t = slots[d * 64 + lane];
@@ -478,34 +478,31 @@ __global__ __launch_bounds__(64 * TF_JKP_W) void jk_packed_kernel(const double *
 }
 
 // Jt partial sums over the padded pair index q: super-groups are sorted by descending partial length, so those that cover q are
-// a prefix of the list.  grid (ceil(NP/256), SEG): segment s sums its slice of that prefix; out[s][q].
-__global__ __launch_bounds__(256) void jt_reduce_kernel(const double *__restrict__ ypart, const JKSuper *__restrict__ groups, int n_groups,
-                                                        long long NP, double *__restrict__ out)
+// a prefix of the list.  Block (bx, by) of a (ceil(NP/256), nseg) grid: segment by sums its slice of that prefix; out[by][q].
+__device__ __forceinline__ void jt_reduce_block(int bx, int by, int nseg, const double *__restrict__ ypart, const JKSuper *__restrict__ groups,
+                                                int n_groups, long long NP, double *__restrict__ out)
 {
-    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long q = (long long)bx * 256 + threadIdx.x;
     if (q >= NP) return;
-    const int per = (n_groups + gridDim.y - 1) / gridDim.y;
-    const int g0 = blockIdx.y * per, g1 = min(n_groups, g0 + per);
+    const int per = (n_groups + nseg - 1) / nseg;
+    const int g0 = by * per, g1 = min(n_groups, g0 + per);
     double s = 0.0;
 #pragma unroll 4
     for (int g = g0; g < g1; ++g) {
         if (groups[g].ylen <= q) break;
         s += ypart[groups[g].yoff + q];
     }
-    out[(size_t)blockIdx.y * NP + q] = s;
+    out[(size_t)by * NP + q] = s;
 }
 
 // D[a][x] = sum over groups with i == a of (column part + row parts of the chunks)[x] + the same over owned rows (i > a, j == a).
-// grid (N, ceil(N/64)), 256 threads = 4 slices x 64 columns; gfirst[a]..gfirst[N+a] are the groups with i == a.
-__global__ __launch_bounds__(256) void kd_reduce_kernel(const double *__restrict__ DIc, const double *__restrict__ DIr,
-                                                        const double *__restrict__ DJc, const double *__restrict__ DJr, int NW,
-                                                        const int *__restrict__ gfirst, const int *__restrict__ rowmap, int N,
-                                                        double *__restrict__ D)
+// Block (a, bx) of an (N, ceil(N/64)) grid, 256 threads = 4 slices x 64 columns; gfirst[a]..gfirst[N+a] are the groups with i == a.
+__device__ __forceinline__ void kd_reduce_block(int a, int bx, double *sPart, const double *__restrict__ DIc, const double *__restrict__ DIr,
+                                                const double *__restrict__ DJc, const double *__restrict__ DJr, int NW,
+                                                const int *__restrict__ gfirst, const int *__restrict__ rowmap, int N, double *__restrict__ D)
 {
-    __shared__ double sPart[256];
-    const int a = blockIdx.x;
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int x = blockIdx.y * 64 + lane;
+    const int x = bx * 64 + lane;
     const int nw = min(NW, x / TF_JKP_CW + 1);            // chunks that start at or before x
     double s = 0.0;
     if (x < N) {
@@ -526,6 +523,35 @@ __global__ __launch_bounds__(256) void kd_reduce_kernel(const double *__restrict
     sPart[threadIdx.x] = s;
     __syncthreads();
     if (sl == 0 && x < N) D[(size_t)a * N + x] = ((sPart[lane] + sPart[64 + lane]) + sPart[128 + lane]) + sPart[192 + lane];
+}
+
+// Both reductions of all densities of a pass in ONE launch (they are independent and each alone leaves most of the chip idle):
+// per density first the N * ceil(N/64) exchange blocks, then the ceil(NP/256) * nseg transposed-Coulomb blocks.  Fixed summation
+// order inside every block: bitwise reproducible.
+struct JKReduce {
+    const double *ypart, *DIc, *DIr, *DJc, *DJr;
+    double *Jt, *D[2];
+    const JKSuper *supers;
+    const int *gfirst, *rowmap;
+    long long NP;
+    size_t sy, sJt, sDIc, sDIr, sDJc, sDJr;              // strides between densities
+    int n_supers, nseg, N, NW;
+};
+__global__ __launch_bounds__(256) void jk_reduce_kernel(JKReduce R)
+{
+    __shared__ double sPart[256];
+    const int gxK = (R.N + 63) / 64, nK = R.N * gxK;
+    const int gxJ = (int)((R.NP + 255) / 256), nJ = gxJ * R.nseg;
+    int b = blockIdx.x;
+    const int d = b / (nK + nJ);
+    b -= d * (nK + nJ);
+    if (b < nK)
+        kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, R.NW, R.gfirst,
+                        R.rowmap, R.N, R.D[d]);
+    else {
+        b -= nK;
+        jt_reduce_block(b % gxJ, b / gxJ, R.nseg, R.ypart + d * R.sy, R.supers, R.n_supers, R.NP, R.Jt + d * R.sJt);
+    }
 }
 
 // K = D + D2^T (D2 = D for a symmetric density; for a general one D = D(P^T), D2 = D(P));

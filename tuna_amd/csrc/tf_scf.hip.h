@@ -44,6 +44,9 @@ struct Workspace {
     size_t ref_cap = 0;
     int ref_n = 0;                   // 0 = no valid start
     long long ref_solves = 0, ref_steps = 0, ref_fallbacks = 0;
+    double *ref_alt_buf = nullptr;   // the same for the second spin of an unrestricted cycle (swapped in around its solves)
+    size_t ref_alt_cap = 0;
+    int ref_alt_n = 0;
     std::vector<hipEvent_t> tev;     // timing events, read after the cycle (no synchronisation inside it)
 };
 
@@ -58,6 +61,7 @@ inline void release(Workspace &w)
     if (w.jac_scratch) (void)hipFree(w.jac_scratch);
     if (w.jac_prev) (void)hipFree(w.jac_prev);
     if (w.ref_buf) (void)hipFree(w.ref_buf);
+    if (w.ref_alt_buf) (void)hipFree(w.ref_alt_buf);
     for (hipEvent_t e : w.tev) (void)hipEventDestroy(e);
     w = Workspace();
 }
@@ -77,7 +81,7 @@ inline int ensure(Workspace &w, int n, int n_mats, std::string &msg)
 {
     if (!w.blas) {
         TFS_BLAS(rocblas_create_handle(&w.blas));
-        TFS_HIP(hipMalloc((void **)&w.d_scal, 64 * sizeof(double)));
+        TFS_HIP(hipMalloc((void **)&w.d_scal, 128 * sizeof(double)));
         TFS_HIP(hipMalloc((void **)&w.d_info, sizeof(rocblas_int)));
         TFS_HIP(hipEventCreate(&w.ev0));
         TFS_HIP(hipEventCreate(&w.ev1));
@@ -861,6 +865,302 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     std::memcpy(out.components, comps, sizeof(comps));
     if (out.P) TFS_HIP(hipMemcpy(out.P, dP, nn * sizeof(double), hipMemcpyDeviceToHost));
     if (out.F) TFS_HIP(hipMemcpy(out.F, dF, nn * sizeof(double), hipMemcpyDeviceToHost));
+    out.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall).count();
+    if (!out.converged) { msg = "Self-consistent field not converged in " + std::to_string(o.max_iter) + " iterations! Increase maximum iterations or give up."; return TF_ENOTCONV; }
+    return TF_OK;
+}
+
+// ---- unrestricted cycle: run_unrestricted_SCF_cycle (scf:1165-1281) inside the outer loop (scf:1292-1435) ---------------------
+// Both spin densities go through the tensor in one fused pass (jk2); every O(N^3) step on the device; per iteration the host reads
+// back a handful of scalars (DIIS scalar products, energy terms, populations, density changes).  Reference behaviour kept: the error
+// vector of an iteration is the concatenation of the alpha and beta commutators (scf:1213), the commutator reported is the larger
+// of the two (scf:1211), each spin is damped with its own factor (scf:1259-1260) in which "P_very_old" and "P_old_before_damping" are
+// zero matrices in every iteration (scf:1281 against scf:1394), and the table shows the larger factor.
+using JK2Fn = std::function<int(const double *, const double *, double *, double *, double *, double *, hipStream_t)>;
+
+struct UhfOut {
+    double *P[2], *C[2], *eps[2], *F[2];                        // host buffers, each may be nullptr
+};
+
+inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, const double *T, const double *V, const double *Fext,
+                   const double *X, const double *Pa0, const double *Pb0, double E0, int n_alpha, int n_beta, double V_NN, const JK2Fn &jk2,
+                   int world, tf_scf_result &out, const UhfOut &uo, std::string &msg)
+{
+    if (world != 1) { msg = "tf_scf_uhf runs on one GPU; use tuna_amd.scf (torch.distributed all-reduce) for sharded tensors"; return TF_EINVAL; }
+    const int max_diis = std::max(1, std::min(8, (int)o.max_diis));
+    const int n_fixed = 30;
+    const int n_mats = n_fixed + 4 * max_diis;
+    int rc = ensure(w, n, n_mats, msg);
+    if (rc) return rc;
+    const size_t nn = (size_t)n * n;
+    const int g = (int)((nn + 255) / 256);
+    auto t_wall = std::chrono::steady_clock::now();
+    double *base = w.pool;
+    auto mat = [&](int k) { return base + (size_t)k * nn; };
+    double *dS = mat(0), *dH = mat(1), *dX = mat(2), *dT = mat(3), *dV = mat(4), *dFx = mat(5), *t1 = mat(6), *t2 = mat(7), *dW = mat(8);
+    double *dC = mat(9), *scr = mat(10), *dPt = mat(11), *dPtold = mat(12);
+    double *dP[2] = {mat(13), mat(14)}, *dPold[2] = {mat(15), mat(16)}, *dPn[2] = {mat(17), mat(18)}, *dF[2] = {mat(19), mat(20)};
+    double *dJ[2] = {mat(21), mat(22)}, *dK[2] = {mat(23), mat(24)}, *dCsave[2] = {mat(25), mat(26)};
+    double *dJt = mat(27);                                       // J_alpha + J_beta; mat(28), mat(29): orthogonaliser scratch
+    double *hist = mat(n_fixed);
+    double *vals = base + (size_t)n_mats * nn, *ework = vals + n, *vals_save[2] = {ework + n, ework + 2 * (size_t)n};
+    auto histF = [&](int k, int s) { return hist + (size_t)(4 * k + s) * nn; };
+    auto histE = [&](int k, int s) { return hist + (size_t)(4 * k + 2 + s) * nn; };
+    const int n_occ[2] = {n_alpha, n_beta};
+
+    TFS_HIP(hipMemcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(hipMemcpy(dT, T, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(hipMemcpy(dV, V, nn * sizeof(double), hipMemcpyHostToDevice));
+    if (Fext) TFS_HIP(hipMemcpy(dFx, Fext, nn * sizeof(double), hipMemcpyHostToDevice));
+    else TFS_HIP(hipMemset(dFx, 0, nn * sizeof(double)));
+    TFS_HIP(hipMemcpy(dP[0], Pa0, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(hipMemcpy(dP[1], Pb0, nn * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dT, 1.0, dV, dH, (int)nn);
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dH, 1.0, dFx, dH, (int)nn);
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dP[0], 1.0, dP[1], dPt, (int)nn);
+    if (X) TFS_HIP(hipMemcpy(dX, X, nn * sizeof(double), hipMemcpyHostToDevice));
+    else {
+        double sm = 0;
+        rc = orthogonaliser_device(w, n, dS, dX, nullptr, &sm, mat(28), msg);
+        if (rc) return rc;
+    }
+    TFS_BLAS(rocblas_set_pointer_mode(w.blas, rocblas_pointer_mode_host));
+    size_t tev_used = 0;
+    std::vector<std::pair<size_t, int>> spans;
+    auto span_begin = [&](int kind) -> int {
+        while (w.tev.size() < tev_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            w.tev.push_back(e);
+        }
+        spans.emplace_back(tev_used, kind);
+        (void)hipEventRecord(w.tev[tev_used], 0);
+        tev_used += 2;
+        return (int)tev_used - 1;
+    };
+    auto span_end = [&](int idx) { if (idx >= 0) (void)hipEventRecord(w.tev[idx], 0); };
+
+    static const bool no_refine = getenv("TF_EIGH") != nullptr;
+    // the refinement state of the beta spin lives in the alternate slot and is swapped in around its solves
+    struct SpinSlot {
+        Workspace &w; bool on;
+        SpinSlot(Workspace &ws, bool o_) : w(ws), on(o_) { swap(); }
+        ~SpinSlot() { swap(); }
+        void swap() { if (on) { std::swap(w.ref_buf, w.ref_alt_buf); std::swap(w.ref_cap, w.ref_alt_cap); std::swap(w.ref_n, w.ref_alt_n); } }
+    };
+    w.ref_n = 0; w.ref_alt_n = 0;
+    w.warm_ok = false; w.jac_prev_n = 0;          // two alternating spins: no warm start for the (rare) Jacobi solves
+    bool orbitals_current[2] = {false, false}, orbitals_final[2] = {false, false};
+    // diagonalise F_s (AO) -> P_s = C_occ C_occ^T symmetrised (one electron per orbital, scf:1227-1228)
+    auto diag_density = [&](int sp, const double *Fao, double *Pout) -> int {
+        orbitals_current[sp] = false;
+        const int no = n_occ[sp];
+        if (no <= 0) { TFS_HIP(hipMemsetAsync(Pout, 0, nn * sizeof(double), 0)); return TF_OK; }
+        SpinSlot slot(w, sp == 1);
+        const bool refining = !no_refine && n >= 2 && no < n;
+        TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, Fao, 0.0, t1));
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+        const int te = span_begin(1);
+        const double one = 1.0, zero = 0.0;
+        if (refining && w.ref_n == n) {
+            double *Xocc = nullptr;
+            std::string rmsg;
+            const int rr = (n <= TFR_NMAX) ? ref_refine_lds(w, n, no, dW, &Xocc, rmsg) : ref_refine(w, n, no, dW, &Xocc, rmsg);
+            if (rr == TF_OK) {
+                TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Xocc, dX, 0.0, t1));
+                TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, t1, n, t1, n, &zero, t2, n));
+                hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, Pout, n);
+                span_end(te);
+                return TF_OK;
+            }
+            if (rr != TF_ELINALG) { msg = rmsg; return rr; }
+        }
+        int r = eigh(w, n, dW, vals, ework, msg);
+        if (r) return r;
+        if (refining) { r = ref_store(w, n, dW, msg); if (r) return r; }
+        span_end(te);
+        TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
+        TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, no, &one, dC, n, dC, n, &zero, t1, n));
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, Pout, n);
+        orbitals_current[sp] = true;
+        return TF_OK;
+    };
+
+    std::vector<double> B((size_t)max_diis * max_diis, 0.0);
+    int n_hist = 0;
+    double E = E0, E_old = E0, commutator = 1.0;
+    double comps[7] = {0, 0, 0, 0, 0, 0, 0};
+    out.fock_seconds = 0; out.eig_seconds = 0; out.n_iter = 0; out.converged = 0;
+    const int nA = (o.n_atoms >= 2) ? o.n_atom_ao[0] : n;
+
+    for (int step = 1; step <= o.max_iter; ++step) {
+        E_old = E;
+        TFS_HIP(hipMemcpyAsync(dPtold, dPt, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        for (int sp = 0; sp < 2; ++sp) TFS_HIP(hipMemcpyAsync(dPold[sp], dP[sp], nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        // Fock matrices (scf:542-589): F_s = H + J_alpha + J_beta - HFX K_s, symmetrised
+        const int tf = span_begin(0);
+        rc = jk2(dP[0], dP[1], dJ[0], dJ[1], dK[0], dK[1], 0);
+        if (rc) { msg = "J/K launch failed"; return rc; }
+        span_end(tf);
+        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dJ[0], 1.0, dJ[1], dJt, (int)nn);
+        if (n_hist == max_diis) {                                   // trim the history to max_diis entries (scf:1216-1219)
+            for (int k = 0; k + 1 < n_hist; ++k)
+                TFS_HIP(hipMemcpyAsync(histF(k, 0), histF(k + 1, 0), 4 * nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            for (int r = 0; r + 1 < n_hist; ++r)
+                for (int c = 0; c + 1 < n_hist; ++c) B[r * max_diis + c] = B[(r + 1) * max_diis + c + 1];
+            --n_hist;
+        }
+        for (int sp = 0; sp < 2; ++sp) {
+            hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, 0, dH, dJt, dK[sp], 2.0 * o.hfx, t1, (int)nn);   // k_fock: H + J - hfx/2 K
+            hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, dF[sp], n);
+            // e_s = X^T (F_s P_s S - S P_s F_s) X   (scf:906-920)
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dF[sp], dP[sp], 0.0, t1));
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dS, 0.0, t2));
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dS, dP[sp], 0.0, t1));
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, -1.0, t1, dF[sp], 1.0, t2));
+            TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, t2, 0.0, t1));
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, histE(n_hist, sp)));
+            TFS_HIP(hipMemcpyAsync(histF(n_hist, sp), dF[sp], nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        }
+        ++n_hist;
+        double ee[2] = {0.0, 0.0};
+        {
+            double hd[16];
+            for (int sp = 0; sp < 2; ++sp) {
+                Ptr8 a;
+                for (int k = 0; k < 8; ++k) { a.p[k] = histE(0, sp); a.c[k] = 0.0; }
+                for (int k = 0; k < n_hist; ++k) a.p[k] = histE(k, sp);
+                hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, histE(n_hist - 1, sp), a, n_hist, (int)nn, w.d_scal + 64 + 8 * sp);
+            }
+            TFS_HIP(hipMemcpy(hd, w.d_scal + 64, 16 * sizeof(double), hipMemcpyDeviceToHost));
+            for (int k = 0; k < n_hist; ++k) B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = hd[k] + hd[8 + k];
+            ee[0] = hd[n_hist - 1]; ee[1] = hd[8 + n_hist - 1];
+        }
+        const double comm_s[2] = {std::sqrt(ee[0] / (double)nn), std::sqrt(ee[1] / (double)nn)};
+        commutator = std::max(comm_s[0], comm_s[1]);                  // scf:1211
+        // new densities from F_alpha, F_beta; energy with the NEW densities and the OLD J, K (scf:1224-1232)
+        for (int sp = 0; sp < 2; ++sp) {
+            rc = diag_density(sp, dF[sp], dPn[sp]);
+            if (rc) return rc;
+            orbitals_final[sp] = orbitals_current[sp];
+            if (orbitals_final[sp]) {
+                TFS_HIP(hipMemcpyAsync(vals_save[sp], vals, n * sizeof(double), hipMemcpyDeviceToDevice, 0));
+                TFS_HIP(hipMemcpyAsync(dCsave[sp], dC, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            }
+        }
+        {
+            double hd[12];
+            for (int sp = 0; sp < 2; ++sp) {
+                Ptr8 a;
+                for (int k = 0; k < 8; ++k) { a.p[k] = dT; a.c[k] = 0.0; }
+                a.p[0] = dT; a.p[1] = dV; a.p[2] = dFx; a.p[3] = dJt; a.p[4] = dK[sp];
+                hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, dPn[sp], a, 5, (int)nn, w.d_scal + 80 + 6 * sp);
+            }
+            TFS_HIP(hipMemcpy(hd, w.d_scal + 80, 12 * sizeof(double), hipMemcpyDeviceToHost));
+            comps[0] = hd[0] + hd[6]; comps[1] = hd[1] + hd[7]; comps[5] = hd[2] + hd[8];
+            comps[2] = (1.0 / 2.0) * (hd[3] + hd[9]);                                        // scf:462
+            comps[3] = -(1.0 / 2.0) * hd[4] * o.hfx + -(1.0 / 2.0) * hd[10] * o.hfx;         // scf:465-466
+            comps[4] = 0.0; comps[6] = 0.0;
+        }
+        E = comps[0] + comps[1] + comps[2] + comps[3] + comps[4] + comps[5] + comps[6];
+        // DIIS (scf:1236-1256): one set of coefficients for both spins
+        if (step > 2 && o.use_diis && commutator < 0.3) {
+            const int m = n_hist + 1;
+            std::vector<double> A((size_t)m * m, 0.0), rhs(m, 0.0), x;
+            for (int r = 0; r < n_hist; ++r) {
+                for (int c = 0; c < n_hist; ++c) A[r * m + c] = B[r * max_diis + c];
+                A[r * m + n_hist] = -1.0; A[n_hist * m + r] = -1.0;
+            }
+            rhs[n_hist] = -1.0;
+            if (small_solve(m, A, rhs, x)) {
+                for (int sp = 0; sp < 2; ++sp) {
+                    Ptr8 a;
+                    for (int k = 0; k < 8; ++k) { a.p[k] = histF(0, sp); a.c[k] = 0.0; }
+                    for (int k = 0; k < n_hist; ++k) { a.p[k] = histF(k, sp); a.c[k] = x[k]; }
+                    hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, 0, a, n_hist, scr, (int)nn);
+                    rc = diag_density(sp, scr, dPn[sp]);
+                    if (rc) return rc;
+                }
+            } else
+                n_hist = 0;
+        }
+        // damping, each spin with its own commutator (scf:1259-1260; calculate_damping_factor scf:763-868 with zero
+        // "P_very_old" / "P_old_before_damping")
+        double damp[2] = {0.0, 0.0};
+        if (o.damping == 2) damp[0] = damp[1] = o.damping_factor;
+        else if (o.damping == 1 && step > 1 && (comm_s[0] > 0.01 || comm_s[1] > 0.01)) {
+            double pop[4][2];
+            const double *dens[4] = {dPn[0], dPold[0], dPn[1], dPold[1]};
+            for (int q = 0; q < 4; ++q) hipLaunchKernelGGL(k_mulliken, dim3(1), dim3(256), 0, 0, dens[q], dS, n, nA, w.d_scal + 2 * q);
+            TFS_HIP(hipMemcpy(&pop[0][0], w.d_scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
+            if (o.n_atoms < 2) { for (int q = 0; q < 4; ++q) pop[q][1] = 0.0; }
+            for (int sp = 0; sp < 2; ++sp) {
+                if (!(comm_s[sp] > 0.01)) continue;
+                const double *out_p = pop[2 * sp], *in_p = pop[2 * sp + 1];
+                double den[2], alpha[2] = {0.0, 0.0};
+                for (int a = 0; a < 2; ++a) den[a] = out_p[a] - in_p[a];
+                if (den[0] != 0.0 && den[1] != 0.0)
+                    for (int a = 0; a < 2; ++a) alpha[a] = out_p[a] / den[a];
+                double f;
+                if (o.n_atoms >= 2) {
+                    const double r0 = o.n_atom_ao[0], r1 = o.n_atom_ao[1];
+                    f = (alpha[0] * r0 + alpha[1] * r1) / (r0 + r1);
+                } else f = alpha[0] * o.n_atom_ao[0];
+                f = std::max(f, 0.0);
+                damp[sp] = (f < std::min(o.max_damping, 1.0)) ? f : o.max_damping;
+            }
+        }
+        for (int sp = 0; sp < 2; ++sp)
+            hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, damp[sp], dPold[sp], 1.0 - damp[sp], dPn[sp], dP[sp], (int)nn);
+        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dP[0], 1.0, dP[1], dPt, (int)nn);
+        hipLaunchKernelGGL(k_delta_norms, dim3(1), dim3(256), 0, 0, dPt, dPtold, (int)nn, w.d_scal + 16);
+        double res[2];
+        TFS_HIP(hipMemcpy(res, w.d_scal + 16, 2 * sizeof(double), hipMemcpyDeviceToHost));
+        const double dE = E - E_old, maxDP = res[0], rmsDP = std::sqrt(res[1] / (double)nn);
+        out.n_iter = step;
+        if (out.table) {
+            double *row = out.table + (size_t)(step - 1) * 7;
+            row[0] = step; row[1] = E + V_NN; row[2] = dE; row[3] = rmsDP; row[4] = maxDP; row[5] = commutator; row[6] = std::max(damp[0], damp[1]);
+        }
+        if (std::fabs(dE) < o.conv_delta_E && std::fabs(maxDP) < o.conv_max_DP && std::fabs(rmsDP) < o.conv_rms_DP &&
+            std::fabs(commutator) < o.conv_commutator) {
+            out.converged = 1;
+            break;
+        }
+    }
+    // orbitals and orbital energies of the last Fock matrices (what the reference's last diagonalisations leave, scf:1224-1225)
+    for (int sp = 0; sp < 2 && out.n_iter > 0; ++sp) {
+        if (!uo.eps[sp] && !uo.C[sp]) continue;
+        if (orbitals_final[sp]) {
+            if (uo.eps[sp]) TFS_HIP(hipMemcpy(uo.eps[sp], vals_save[sp], n * sizeof(double), hipMemcpyDeviceToHost));
+            if (uo.C[sp]) TFS_HIP(hipMemcpy(uo.C[sp], dCsave[sp], nn * sizeof(double), hipMemcpyDeviceToHost));
+            continue;
+        }
+        TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, dF[sp], 0.0, t1));
+        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+        const int te = span_begin(1);
+        rc = eigh(w, n, dW, vals, ework, msg);
+        if (rc) return rc;
+        TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
+        span_end(te);
+        if (uo.eps[sp]) TFS_HIP(hipMemcpy(uo.eps[sp], vals, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (uo.C[sp]) TFS_HIP(hipMemcpy(uo.C[sp], dC, nn * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    w.ref_n = 0; w.ref_alt_n = 0;
+    TFS_HIP(hipDeviceSynchronize());
+    for (const auto &sp : spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, w.tev[sp.first], w.tev[sp.first + 1]) == hipSuccess) (sp.second == 0 ? out.fock_seconds : out.eig_seconds) += ms * 1e-3;
+    }
+    out.energy = E + V_NN;
+    std::memcpy(out.components, comps, sizeof(comps));
+    for (int sp = 0; sp < 2; ++sp) {
+        if (uo.P[sp]) TFS_HIP(hipMemcpy(uo.P[sp], dP[sp], nn * sizeof(double), hipMemcpyDeviceToHost));
+        if (uo.F[sp]) TFS_HIP(hipMemcpy(uo.F[sp], dF[sp], nn * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (out.P) TFS_HIP(hipMemcpy(out.P, dPt, nn * sizeof(double), hipMemcpyDeviceToHost));
     out.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall).count();
     if (!out.converged) { msg = "Self-consistent field not converged in " + std::to_string(o.max_iter) + " iterations! Increase maximum iterations or give up."; return TF_ENOTCONV; }
     return TF_OK;

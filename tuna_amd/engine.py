@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ScfOpts, ScfResult, TunaError, f64, i32, ptr
+from ._lib import ScfOpts, ScfResult, ScfUhfResult, TunaError, f64, i32, ptr
 from .molecule import AOList
 
 # SCF convergence thresholds (tuna_util.py:109-116)
@@ -227,8 +227,8 @@ class Engine:
         self._check(self._L.tf_diagonalise(self._ctx, n, ptr(F), ptr(X), ptr(eps), ptr(Cm)))
         return eps, Cm
 
-    def scf_rhf(self, S, T, V, P0, E0, n_occ, V_NN, *, X=None, Fext=None, conv="medium", max_iter=100, diis=True,
-                max_diis=6, damping="dynamic", damping_factor=0.0, max_damping=0.7, hfx=1.0, n_atom_ao=None):
+    def _scf_opts(self, *, conv="medium", max_iter=100, diis=True, max_diis=6, damping="dynamic", damping_factor=0.0, max_damping=0.7,
+                  hfx=1.0, n_atom_ao=None):
         N = self.N
         conv_d = SCF_CONVERGENCE[conv] if isinstance(conv, str) else conv
         o = ScfOpts()
@@ -242,6 +242,11 @@ class Engine:
         o.n_atoms = len(n_atom_ao)
         o.n_atom_ao[0] = n_atom_ao[0]
         o.n_atom_ao[1] = n_atom_ao[1] if len(n_atom_ao) > 1 else 0
+        return o
+
+    def scf_rhf(self, S, T, V, P0, E0, n_occ, V_NN, *, X=None, Fext=None, max_iter=100, **opts):
+        N = self.N
+        o = self._scf_opts(max_iter=max_iter, **opts)
         r = ScfResult()
         P, Cm, F, eps = np.zeros((N, N)), np.zeros((N, N)), np.zeros((N, N)), np.zeros(N)
         table = np.zeros((max_iter, 7))
@@ -252,6 +257,28 @@ class Engine:
         res = {"energy": r.energy, "components": np.array(r.components[:]), "n_iter": r.n_iter, "converged": bool(r.converged),
                "P": P, "C": Cm, "F": F, "epsilons": eps, "table": table[:r.n_iter].copy(), "fock_seconds": r.fock_seconds,
                "eig_seconds": r.eig_seconds, "wall_seconds": r.wall_seconds}
+        if rc != 0:
+            err = TunaError(self._L.tf_last_error(self._ctx).decode(), rc)
+            err.partial = res
+            raise err
+        return res
+
+    def scf_uhf(self, S, T, V, P0_alpha, P0_beta, E0, n_alpha, n_beta, V_NN, *, X=None, Fext=None, max_iter=100, **opts):
+        """tf_scf_uhf: the unrestricted cycle (scf:1165-1281) on the device; spin quantities come back as pairs (alpha, beta)."""
+        N = self.N
+        o = self._scf_opts(max_iter=max_iter, **opts)
+        r = ScfUhfResult()
+        Pt, table = np.zeros((N, N)), np.zeros((max_iter, 7))
+        P, Cm, F, eps = np.zeros((2, N, N)), np.zeros((2, N, N)), np.zeros((2, N, N)), np.zeros((2, N))
+        r.common.P, r.common.table = Pt.ctypes.data, table.ctypes.data
+        for sp in range(2):
+            r.P_spin[sp], r.C_spin[sp], r.F_spin[sp], r.eps_spin[sp] = (a[sp].ctypes.data for a in (P, Cm, F, eps))
+        arrs = [f64(S), f64(T), f64(V), None if Fext is None else f64(Fext), None if X is None else f64(X), f64(P0_alpha), f64(P0_beta)]
+        rc = self._L.tf_scf_uhf(self._ctx, C.byref(o), *[ptr(a) for a in arrs], float(E0), int(n_alpha), int(n_beta), float(V_NN), C.byref(r))
+        c = r.common
+        res = {"energy": c.energy, "components": np.array(c.components[:]), "n_iter": c.n_iter, "converged": bool(c.converged),
+               "P": Pt, "P_spin": P, "C_spin": Cm, "F_spin": F, "epsilons_spin": eps, "table": table[:c.n_iter].copy(),
+               "fock_seconds": c.fock_seconds, "eig_seconds": c.eig_seconds, "wall_seconds": c.wall_seconds}
         if rc != 0:
             err = TunaError(self._L.tf_last_error(self._ctx).decode(), rc)
             err.partial = res

@@ -330,9 +330,43 @@ def _python_level_cycle(molecule, calculation, integrals, V_NN, X, P, E, o):
 
 
 def _run_unrestricted(molecule, calculation, integrals, V_NN, X, guess_objects, silent, log) -> Output:
-    """run_unrestricted_SCF_cycle (scf:1165-1281) inside the outer loop (scf:1292-1435): fused two-density device Fock
-    builds and rocSOLVER diagonalisations; O(N^2) bookkeeping on the host as in the reference.  Reference quirks kept:
-    "P_very_old" and "P_old_before_damping" of each spin are zero matrices in every iteration (scf:1281 vs scf:1394)."""
+    """run_unrestricted_SCF_cycle (scf:1165-1281) inside the outer loop (scf:1292-1435).  One GPU: the whole cycle in the library
+    (tf_scf_uhf); a sharded tensor (world > 1) or TUNA_AMD_HOST_UHF=1: the host-orchestrated loop below."""
+    import os
+    eng = _device(integrals.ERI_AO).engine
+    if eng.world != 1 or os.environ.get("TUNA_AMD_HOST_UHF"):
+        return _python_level_unrestricted(molecule, calculation, integrals, V_NN, X, guess_objects, silent, log)
+    _, Pa, Pb, E = guess_objects
+    o = _opts(calculation)
+    if not silent:
+        log(SCF_TABLE_HEADER)
+    Fext = integrals.F + integrals.G
+    try:
+        r = eng.scf_uhf(integrals.S, integrals.T, integrals.V_NE, Pa, Pb, E, molecule.n_alpha, molecule.n_beta, V_NN, X=X,
+                        Fext=Fext if np.any(Fext) else None, n_atom_ao=molecule.partition_ranges, **o)
+    except TunaError as e:
+        if not silent and getattr(e, "partial", None) is not None:
+            for row in e.partial["table"]:
+                log(format_output_line(row[1], row[2], row[4], row[3], row[6], row[0], row[5]))
+        raise
+    if not silent:
+        for row in r["table"]:
+            log(format_output_line(row[1], row[2], row[4], row[3], row[6], row[0], row[5]))
+        log(f"\n Self-consistent field converged in {r['n_iter']} cycles!\n")
+    c = r["components"]
+    (Pa, Pb), (Ca, Cb), (Fa, Fb), (eps_a, eps_b) = r["P_spin"], r["C_spin"], r["F_spin"], r["epsilons_spin"]
+    eps = np.concatenate((eps_a, eps_b))
+    order = np.argsort(eps)
+    C_all = np.concatenate((Ca, Cb), axis=1)[:, order]
+    return Output(r["energy"], c[0], c[1], c[2], c[3], c[4], c[5], c[6], r["P"], Pa, Pb, integrals.S, X, C_all, Ca, Cb, eps[order], eps_a, eps_b,
+                  None, None, None, Fa, Fb, integrals.T, integrals.V_NE, integrals, 0, r["n_iter"], r["table"],
+                  {k: r[k] for k in ("fock_seconds", "eig_seconds", "wall_seconds")})
+
+
+def _python_level_unrestricted(molecule, calculation, integrals, V_NN, X, guess_objects, silent, log) -> Output:
+    """The same cycle with fused two-density device Fock builds (all-reduced over ranks when the tensor is sharded) and device
+    diagonalisations; O(N^2) bookkeeping on the host as in the reference.  Reference quirks kept: "P_very_old" and
+    "P_old_before_damping" of each spin are zero matrices in every iteration (scf:1281 vs scf:1394)."""
     import time
     _, Pa, Pb, E = guess_objects
     S = integrals.S
