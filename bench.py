@@ -53,11 +53,14 @@ def cpu_baseline_fock(N_workload: int, budget_s: float = 12.0):
     """The reference's CPU Fock build -- np.einsum("ijkl,kl->ij") + np.einsum("ilkj,kl->ij"), optimize=True
     (scf:70, scf:42, restated in oracle/scf_oracle.py) -- timed on a BOUNDED dense sample tensor and scaled by N^4."""
     from oracle import scf_oracle as so
+    import tuna_amd
+    # BLAS threads = the CPUs this process may use (cgroup quota): more threads than that only spin and get the process throttled
+    threads = tuna_amd.cpu_quota()
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_limits
+        pool = threadpool_limits(limits=threads)
     except Exception:
-        threads = os.cpu_count()
+        pool = None
     Ns = min(N_workload, 96)
     rng = np.random.default_rng(0)
     T = rng.standard_normal((Ns, Ns, Ns, Ns))
@@ -73,6 +76,9 @@ def cpu_baseline_fock(N_workload: int, budget_s: float = 12.0):
         if time.perf_counter() - t0 > budget_s or n >= 200:
             break
     per_build = (time.perf_counter() - t0) / n
+    if pool is not None:
+        pool.restore_original_limits()
+        tuna_amd.limit_host_threads()
     scaled = per_build * (N_workload / Ns) ** 4
     return {"value": 1.0 / scaled, "unit": "Fock builds/s", "cores": int(threads), "kind": "port",
             "sample": f"{n} J+K builds with the reference einsum strings on a dense random {Ns}^4 f64 tensor "
@@ -87,8 +93,10 @@ def cpu_baseline_eri(aos, limit_s: float = 20.0):
         return None
     kind = "reference" if orc.ref_engine() is not None else "port"
     t0 = time.perf_counter()
-    (orc.ref_eri if kind == "reference" else orc.eri)(aos, os.cpu_count())
-    return {"seconds": time.perf_counter() - t0, "kind": kind, "cores": os.cpu_count()}
+    import tuna_amd
+    cores = tuna_amd.cpu_quota()
+    (orc.ref_eri if kind == "reference" else orc.eri)(aos, cores)
+    return {"seconds": time.perf_counter() - t0, "kind": kind, "cores": cores}
 
 
 JK_KERNEL = {"packed": "jk_packed_kernel", "rows": "tfk::jk_rows_kernel"}

@@ -8,3 +8,42 @@ Every numerical step runs in tuna_amd/libtunafock.so (HIP, gfx950) behind the C 
 CPU fallback.
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+
+def cpu_quota() -> int:
+    """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        return max(1, len(_os.sched_getaffinity(0)))
+    except AttributeError:
+        return _os.cpu_count() or 1
+
+
+def limit_host_threads(n: int | None = None):
+    """Caps the thread pool of NumPy's BLAS.  The host side of this package only multiplies matrices of a few hundred rows
+    (guess projection, Mulliken populations, the host-orchestrated SCF loops), but OpenBLAS starts one thread per visible core --
+    256 on an MI355X host -- and its idle workers spin after every call.  In a container with a CPU quota (16 CPUs on the GPU
+    boxes) that spinning exhausts the quota and the kernel throttles the whole process, HIP runtime threads included: measured
+    50-70 ms stalls inside hipDeviceSynchronize / hipMemcpy, an Ar2/cc-pVQZ single point 100-160 ms instead of 54 ms.
+    Default: min(4, CPU quota); TUNA_AMD_HOST_BLAS_THREADS=<n> overrides, 0 leaves the pool alone."""
+    if n is None:
+        env = _os.environ.get("TUNA_AMD_HOST_BLAS_THREADS")
+        n = int(env) if env is not None else min(4, cpu_quota())
+    if n <= 0:
+        return None
+    try:
+        import numpy  # noqa: F401  (the BLAS library has to be loaded before threadpoolctl can find it)
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=n)
+    except Exception:
+        return None
+
+
+_host_threads = limit_host_threads()

@@ -82,6 +82,7 @@ struct tf_ctx {
     hipStream_t streams[NSTREAM_MAX] = {};
     hipEvent_t sev[NSTREAM_MAX] = {};
     bool have_streams = false;
+    size_t cfact_lds_set = 0;                // dynamic LDS limit requested for eri_cfact_kernel
     double *scr[3] = {nullptr, nullptr, nullptr};
     size_t scr_bytes[3] = {0, 0, 0};
 };
@@ -602,15 +603,27 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     auto pair_cost = [&](int p) {                                  // primitive pairs x components: what a quartet with this pair costs
         return (long long)bs.pairs[p].npp * bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
     };
+    constexpr int NGRP = 4;
+    auto pair_group = [&](int p) { const int lp = bs.pairs[p].La + bs.pairs[p].Lb; return lp <= 1 ? 0 : (lp <= 3 ? 1 : (lp <= 5 ? 2 : 3)); };
+    int kets_goff[NGRP + 1] = {0, 0, 0, 0, 0};
     int *d_kets = nullptr, *d_kets_all = nullptr;
+    std::vector<int> kets_all_host;                              // same order as d_kets_all
     if ((rc = upload(ctx, ket_sorted, &d_kets, false))) return rc;
     {
         // generic (single-launch) mode: heaviest ket pairs first -- workgroups are dispatched in index order, and a deeply contracted
         // (pp|pp) quartet of Ar2/cc-pVQZ runs for 12 ms: it has to start early, not at the tail of the launch
+        // the launches are made per (bra group, ket group) of shell pairs -- groups by La + Lb -- so that the LDS carve-out of each
+        // launch fits its own angular momenta (the (gg|gg) tables need 100 KB, the (ss|ss) ones nothing)
         std::vector<int> all(npairs);
         std::iota(all.begin(), all.end(), 0);
-        std::stable_sort(all.begin(), all.end(), [&](int x, int y) { return pair_cost(x) > pair_cost(y); });
+        std::stable_sort(all.begin(), all.end(), [&](int x, int y) {
+            const int gx = pair_group(x), gy = pair_group(y);
+            return gx != gy ? gx < gy : pair_cost(x) > pair_cost(y);
+        });
+        for (int p : all) ++kets_goff[pair_group(p) + 1];
+        for (int g = 0; g < NGRP; ++g) kets_goff[g + 1] += kets_goff[g];
         if ((rc = upload(ctx, all, &d_kets_all, false))) return rc;
+        kets_all_host = all;
     }
     // my bra pairs ordered by class: a slab is a run of that list, launches go per (bra class run, ket class)
     std::vector<int> mine_sorted;
@@ -733,8 +746,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
     };
 
-    // Small problems: one launch per slab mixing every class (LDS carved by launch-wide capacities).
-    auto generic_launch = [&](unsigned n_bra, const int *d_bra, const long long *d_braoff) {
+    // Small problems: per slab one launch per (bra group, ket group), each mixing the classes of its groups (LDS carved by the
+    // capacities the groups need).  bra_host: the slab's bra pairs (sorted by group).
+    static const bool old_generic = getenv("TF_ERI_GENERIC_OLD") != nullptr;
+    auto generic_launch_old = [&](unsigned n_bra, const int *d_bra, const long long *d_braoff, unsigned n_ket, const int *d_ket, hipStream_t st) {
         QClass q{};
         const int RB = 2048, EBa = 1024, EBc = 1024;       // (doubling the E capacities halves the occupancy: Ar2 build 0.084 -> 0.18 s)
         int o = 0;
@@ -748,14 +763,88 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         q.offLmn = o; o += 42;
         q.lds_doubles = o;
         q.offBlk = o;                                            // unused (unfused)
-        q.G = 1; q.n_ket = npairs; q.fused = 0;
+        q.G = 1; q.n_ket = (int)n_ket; q.fused = 0;
         q.tri = packed ? 1 : 0;
-        hipLaunchKernelGGL((eri_class_kernel<true, true>), dim3(npairs, n_bra), dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), streams[0],
-                           ctx->db, q, d_bra, d_braoff, d_kets_all, Nc, d_C);
+        hipLaunchKernelGGL((eri_class_kernel<true, true>), dim3(n_ket, n_bra), dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st,
+                           ctx->db, q, d_bra, d_braoff, d_ket, Nc, d_C);
+    };
+    struct GroupStat { int maxLp = 0, maxT = 1, maxLp1 = 1, maxE = 0, maxcomp = 1, maxnpp = 1; };
+    auto group_stat = [&](const int *pairs_host, size_t n) {
+        GroupStat g;
+        for (size_t k = 0; k < n; ++k) {
+            const tf::Pair &pr = bs.pairs[pairs_host[k]];
+            g.maxLp = std::max(g.maxLp, pr.La + pr.Lb);
+            g.maxT = std::max(g.maxT, (pr.La + 1) * (pr.Lb + 1));
+            g.maxE = std::max(g.maxE, pr.npp * 2 * pr.nE);
+            g.maxcomp = std::max(g.maxcomp, bs.shells[pr.A].ncomp * bs.shells[pr.B].ncomp);
+            g.maxnpp = std::max(g.maxnpp, pr.npp);
+        }
+        g.maxLp1 = g.maxLp + 1;
+        return g;
+    };
+    auto generic_launch = [&](const std::vector<int> &bra_host, const int *d_bra, const long long *d_braoff) -> int {
+        size_t b0 = 0;
+        int si = 0;
+        while (b0 < bra_host.size()) {
+            const int gb = pair_group(bra_host[b0]);
+            size_t b1 = b0;
+            while (b1 < bra_host.size() && pair_group(bra_host[b1]) == gb) ++b1;
+            const GroupStat sb = group_stat(bra_host.data() + b0, b1 - b0);
+            for (int gk = 0; gk < NGRP; ++gk) {
+                const int nk = kets_goff[gk + 1] - kets_goff[gk];
+                if (nk == 0) continue;
+                const GroupStat sk = group_stat(kets_all_host.data() + kets_goff[gk], (size_t)nk);
+                hipStream_t st = streams[si++ % NSTREAM];
+                const int Lmax = sb.maxLp + sk.maxLp, nM = Lmax / 2 + 1, tsize = (Lmax + 1) * (Lmax + 2) / 2;
+                const int xz = sb.maxT * sk.maxT * nM, gsz = sk.maxT * sb.maxLp1 * nM;
+                const bool deep = sb.maxnpp > 1 || sk.maxnpp > 1;
+                const int nbt = deep ? std::min(TF_ERI_THREADS / (Lmax + 1), 48) : 1;       // primitive quartets per batch aimed at
+                CFCaps c{};
+                int o = 0;
+                c.offR = o; c.capR = std::max(2 * tsize, std::min((nbt + 1) * tsize, 2048)); o += c.capR;
+                c.offPref = o; o += TF_ERI_THREADS;
+                c.offPQ = o; o += TF_ERI_THREADS;
+                c.offPP = o; o += TF_ERI_THREADS;
+                c.offG = o; c.capG = std::max(gsz, std::min(nbt * gsz, 1024)); o += c.capG;
+                c.capXZ = std::max(xz, std::min(nbt * xz, 1536));
+                c.offX = o; o += c.capXZ;
+                c.offZ = o; o += c.capXZ;
+                c.offTupG = o; o += (gsz + 3) / 4;
+                c.offTupXZ = o; o += (xz + 3) / 4;
+                c.offEab = o; c.capEab = std::min(sb.maxE, 512); o += c.capEab;
+                c.offEcd = o; c.capEcd = std::min(sk.maxE, 1536); o += c.capEcd;
+                c.offScale = o; o += 84;
+                c.offLmn = o; o += 42;
+                c.offTab = o; o += 2 * (sb.maxcomp + sk.maxcomp) + 2;      // scales (doubles) + index words + class order (ints)
+                c.offRed = o; o += TF_ERI_THREADS;
+                c.lds_doubles = o;
+                c.tri = packed ? 1 : 0;
+                c.dbg_npq_lo = 0; c.dbg_npq_hi = 0x7fffffff;
+                if (const char *e = getenv("TF_ERI_DBG_NPQ")) (void)sscanf(e, "%d:%d", &c.dbg_npq_lo, &c.dbg_npq_hi);
+                const size_t bytes = (size_t)o * sizeof(double);
+                if (old_generic || bytes > 160 * 1024 - 256) {            // (hh|hh)-sized tables do not fit LDS: the component-per-lane kernel
+                    generic_launch_old((unsigned)(b1 - b0), d_bra + b0, d_braoff + b0, (unsigned)nk, d_kets_all + kets_goff[gk], st);
+                    continue;
+                }
+                if (bytes > ctx->cfact_lds_set) {
+                    HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    ctx->cfact_lds_set = 160 * 1024;
+                }
+                hipLaunchKernelGGL(eri_cfact_kernel, dim3((unsigned)nk, (unsigned)(b1 - b0)), dim3(TF_ERI_THREADS), bytes, st, ctx->db, c,
+                                   d_bra + b0, d_braoff + b0, d_kets_all + kets_goff[gk], Nc, d_C);
+                ++launch_count;
+            }
+            b0 = b1;
+        }
+        return TF_OK;
     };
     bool per_class = (long long)mine_sorted.size() * npairs >= 2000000LL;
     if (const char *m = getenv("TF_ERI_MODE")) per_class = (m[0] == 'c');
-    if (!per_class) std::stable_sort(mine_sorted.begin(), mine_sorted.end(), [&](int x, int y) { return pair_cost(x) > pair_cost(y); });
+    if (!per_class)
+        std::stable_sort(mine_sorted.begin(), mine_sorted.end(), [&](int x, int y) {
+            const int gx = pair_group(x), gy = pair_group(y);
+            return gx != gy ? gx < gy : pair_cost(x) > pair_cost(y);
+        });
 
     // device index buffers sized for the largest possible slab, reused by every slab
     size_t max_out = 0;
@@ -803,11 +892,13 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         hipEvent_t e4[4];
         for (auto &e : e4) { HIPCHK(ctx, hipEventCreate(&e)); tev.push_back(e); }
         if (per_class && ld != N) HIPCHK(ctx, hipMemsetAsync(d_T2, 0, (size_t)rows_c * N * ld * sizeof(double), 0));   // pad columns
+        // generic mode: eri_cfact_kernel stores only the components that are not zero by x/y parity
+        if (!per_class) HIPCHK(ctx, hipMemsetAsync(d_C, 0, (size_t)rows_c * Nc * Nc * sizeof(double), 0));
         HIPCHK(ctx, hipEventRecord(e4[0], 0));
         for (int k = 0; k < NSTREAM; ++k) HIPCHK(ctx, hipStreamWaitEvent(streams[k], e4[0], 0));
         // runs of equal bra class inside the slab
         size_t r0 = 0;
-        if (!per_class) { generic_launch((unsigned)bra.size(), d_bra, d_braoff); r0 = bra.size(); }
+        if (!per_class) { if ((rc = generic_launch(bra, d_bra, d_braoff))) return rc; r0 = bra.size(); }
         while (r0 < bra.size()) {
             const int bcls = ctx->pair_class[bra[r0]];
             size_t r1 = r0;

@@ -647,4 +647,263 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Factorised kernel for CONTRACTED shell quartets, class-agnostic (one launch mixes every class of a group of shell pairs).
+// eri_class_kernel gives every lane one Cartesian component and lets it run the reference's 6-deep Hermite sum per primitive
+// quartet: the loop bounds differ from lane to lane, so a wave executes the worst-case nest for every component (measured on
+// Ar2/cc-pVQZ: ~2 400 vector instructions per component and primitive quartet, a (pp|pp) quartet of two 8-primitive shells runs
+// for 12 ms).  Here the per-axis tables of eri_fact_kernel are built for a BATCH of primitive quartets at a time:
+//     X_q[ax,bx,cx,dx][m], Z_q[az,bz,cz,dz][n]   (q = primitive quartet of the batch; definitions above eri_fact_kernel)
+//     (ab|cd) = sum_q pref_q * sum_{m,m'} X_q[x-tuple][m] X_q[y-tuple][m'] Z_q[z-tuple][m+m']
+// Table entries are spread over the workgroup by (primitive, entry) with precomputed index words (no integer divisions in the
+// batch loop); a component costs one unrolled triple-table sum per primitive quartet.  Components < 256: lane groups split the
+// primitive quartets of a batch and are combined in fixed order at the end; more: up to TF_CF_KMAX components per thread in
+// registers.  Uncontracted quartets (one primitive quartet) take the same path with direct stores.  Cartesian output (unfused).
+#define TF_CF_KMAX 4
+struct CFCaps {
+    int offR, capR, offPref, offPQ, offPP, offG, capG, offX, offZ, capXZ, offTupG, offTupXZ, offEab, capEab, offEcd, capEcd;
+    int offScale, offLmn, offTab, offRed, lds_doubles, tri;
+    int dbg_npq_lo, dbg_npq_hi;      // profiling aid (TF_ERI_DBG_NPQ=lo:hi): only quartets with lo <= primitive quartets <= hi are computed
+};
+
+__global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, CFCaps cap, const int *__restrict__ bra_pairs,
+                                                                   const long long *__restrict__ bra_rowoff,
+                                                                   const int *__restrict__ ket_pairs, int Nc, double *__restrict__ Cslab)
+{
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x;
+    const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
+    const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
+    if (cap.tri && cd.A > ab.A) return;
+    if (ab.npp * cd.npp < cap.dbg_npq_lo || ab.npp * cd.npp > cap.dbg_npq_hi) return;
+    const int La1 = ab.La + 1, Lb1 = ab.Lb + 1, Lc1 = cd.La + 1, Ld1 = cd.Lb + 1;
+    const int Lab1 = ab.La + ab.Lb + 1, Lcd1 = cd.La + cd.Lb + 1;
+    const int L = ab.La + ab.Lb + cd.La + cd.Lb, nM = L / 2 + 1, tsize = (L + 1) * (L + 2) / 2;
+    const int nT = La1 * Lb1 * Lc1 * Ld1, xz = nT * nM, gsz = Lc1 * Ld1 * Lab1 * nM;
+    const int nab = ab.nca * ab.ncb, nsubc = cd.nca * cd.ncb, ncomp = nab * nsubc;
+    const int npp_cd = cd.npp, npq = ab.npp * cd.npp;
+    const int nEab = ab.nE, nEcd = cd.nE;
+    double *sR = smem + cap.offR, *sPref = smem + cap.offPref, *sPQ = smem + cap.offPQ, *sG = smem + cap.offG;
+    double *sX = smem + cap.offX, *sZ = smem + cap.offZ, *sScale = smem + cap.offScale, *sRed = smem + cap.offRed;
+    int *sPP = reinterpret_cast<int *>(smem + cap.offPP);            // [2][256]: primitive pair indices (within the pairs) of the batch
+    unsigned short *sTupG = reinterpret_cast<unsigned short *>(smem + cap.offTupG), *sTupXZ = reinterpret_cast<unsigned short *>(smem + cap.offTupXZ);
+    int *sLmn = reinterpret_cast<int *>(smem + cap.offLmn);
+    const long long row0 = bra_rowoff[blockIdx.y];
+    const size_t NcNc = (size_t)Nc * Nc;
+
+    // primitive quartets per batch: what the cooperative R build and the table capacities allow (host: every capacity >= one)
+    int NB = min(npq, TF_ERI_THREADS / (L + 1));
+    NB = min(NB, cap.capR / tsize - 1);
+    NB = min(NB, min(cap.capG / gsz, cap.capXZ / xz));
+    NB = max(NB, 1);
+    const int stride = NB | 1;
+
+    stage_components(B, ab.compoff_a, ab.nca, sLmn, sScale, tid, TF_ERI_THREADS);
+    stage_components(B, ab.compoff_b, ab.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
+    stage_components(B, cd.compoff_a, cd.nca, sLmn + 42, sScale + 42, tid, TF_ERI_THREADS);
+    stage_components(B, cd.compoff_b, cd.ncb, sLmn + 63, sScale + 63, tid, TF_ERI_THREADS);
+    const double *__restrict__ gEab = B.epool + ab.e_off;
+    const double *__restrict__ gEcd = B.epool + cd.e_off;
+    const bool stAB = ab.npp * 2 * nEab <= cap.capEab, stCD = cd.npp * 2 * nEcd <= cap.capEcd;
+    if (stAB) for (int k = tid; k < ab.npp * 2 * nEab; k += TF_ERI_THREADS) smem[cap.offEab + k] = gEab[k];
+    if (stCD) for (int k = tid; k < cd.npp * 2 * nEcd; k += TF_ERI_THREADS) smem[cap.offEcd + k] = gEcd[k];
+    const double *Eab0 = stAB ? smem + cap.offEab : gEab;
+    const double *Ecd0 = stCD ? smem + cap.offEcd : gEcd;
+    // index words of the table entries: G entry r -> (c, d, v, n); X/Z entry r -> (a, b, c, d, m)
+    for (int r = tid; r < gsz; r += TF_ERI_THREADS) {
+        const int n = r % nM;
+        int q = r / nM;
+        const int v = q % Lab1; q /= Lab1;
+        const int d = q % Ld1, c = q / Ld1;
+        sTupG[r] = (unsigned short)(n | (v << 4) | (d << 8) | (c << 11));
+    }
+    for (int r = tid; r < xz; r += TF_ERI_THREADS) {
+        const int m = r % nM;
+        int q = r / nM;
+        const int d = q % Ld1; q /= Ld1;
+        const int c = q % Lc1; q /= Lc1;
+        const int b = q % Lb1, a = q / Lb1;
+        sTupXZ[r] = (unsigned short)(m | (a << 4) | (b << 7) | (c << 10) | (d << 13));
+    }
+    __syncthreads();
+    // per bra / ket component pair: its part of the three table indices, x / y parities, normalisation ratio (as eri_fact_kernel)
+    double *sScAB = smem + cap.offTab, *sScCD = sScAB + nab;
+    int *sIxAB = reinterpret_cast<int *>(sScCD + nsubc), *sIxCD = sIxAB + nab;
+    for (int e = tid; e < nab + nsubc; e += TF_ERI_THREADS) {
+        const bool bra = e < nab;
+        const int f = bra ? e : e - nab;
+        const int n2 = bra ? ab.ncb : cd.ncb, L2 = bra ? Lb1 : Ld1;
+        const int i1 = f / n2, i2 = f - i1 * n2;
+        const int u = bra ? sLmn[i1] : sLmn[42 + i1], w = bra ? sLmn[21 + i2] : sLmn[63 + i2];
+        const int ux = u & 255, uy = (u >> 8) & 255, uz = (u >> 16) & 255, wx = w & 255, wy = (w >> 8) & 255, wz = (w >> 16) & 255;
+        const int packed = (ux * L2 + wx) | ((uy * L2 + wy) << 8) | ((uz * L2 + wz) << 16) | (((ux + wx) & 1) << 24) | (((uy + wy) & 1) << 25);
+        if (bra) { sIxAB[f] = packed; sScAB[f] = sScale[i1] * sScale[21 + i2]; }
+        else { sIxCD[f] = packed; sScCD[f] = sScale[42 + i1] * sScale[63 + i2]; }
+    }
+    __syncthreads();
+    // Only components whose bra and ket pairs have the same (x, y) parity class are non-zero (pyx:1324-1327; the slab is zeroed by
+    // the host): order both pair lists by class, so that non-zero component j <-> (class, i-th bra pair, k-th ket pair of the class).
+    int *sOrdAB = sIxCD + nsubc, *sOrdCD = sOrdAB + nab;
+    __shared__ int sOff[2][5];
+    for (int e = tid; e < nab + nsubc; e += TF_ERI_THREADS) {
+        const bool bra = e < nab;
+        const int f = bra ? e : e - nab, n = bra ? nab : nsubc;
+        const int *tab = bra ? sIxAB : sIxCD;
+        const int cls = (tab[f] >> 24) & 3;
+        int rank = 0;
+        for (int h = 0; h < n; ++h) { const int ch = (tab[h] >> 24) & 3; rank += (ch < cls || (ch == cls && h < f)) ? 1 : 0; }
+        (bra ? sOrdAB : sOrdCD)[rank] = f;
+    }
+    if (tid < 10) {
+        const bool bra = tid < 5;
+        const int c = bra ? tid : tid - 5, n = bra ? nab : nsubc;
+        const int *tab = bra ? sIxAB : sIxCD;
+        int below = 0;
+        for (int h = 0; h < n; ++h) below += (((tab[h] >> 24) & 3) < c) ? 1 : 0;
+        sOff[bra ? 0 : 1][c] = below;
+    }
+    __syncthreads();
+    int pre[5];
+    pre[0] = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pre[c + 1] = pre[c] + (sOff[0][c + 1] - sOff[0][c]) * (sOff[1][c + 1] - sOff[1][c]);
+    const int nnz = pre[4];
+    const int LcLd = Lc1 * Ld1;
+    // non-zero component j: the two pair indices and the table offsets (X row of the x tuple, X row of the y tuple, Z row)
+    auto comp_rows = [&](int j, int &xo, int &yo, int &zo, int &iab, int &icd) {
+        const int c = (j >= pre[1] ? 1 : 0) + (j >= pre[2] ? 1 : 0) + (j >= pre[3] ? 1 : 0);
+        const int r = j - pre[c], ncd_c = sOff[1][c + 1] - sOff[1][c];
+        const int i = r / ncd_c, k = r - i * ncd_c;
+        iab = sOrdAB[sOff[0][c] + i]; icd = sOrdCD[sOff[1][c] + k];
+        const int pa = sIxAB[iab], pc = sIxCD[icd];
+        xo = ((pa & 255) * LcLd + (pc & 255)) * nM;
+        yo = (((pa >> 8) & 255) * LcLd + ((pc >> 8) & 255)) * nM;
+        zo = (((pa >> 16) & 255) * LcLd + ((pc >> 16) & 255)) * nM;
+    };
+    auto store = [&](int iab, int icd, double val) {
+        const int ic = icd / cd.ncb, id = icd - ic * cd.ncb;
+        const size_t row = (size_t)(row0 + iab);
+        const int k = cd.cartoff_a + ic, l = cd.cartoff_b + id;
+        Cslab[row * NcNc + (size_t)k * Nc + l] = val;
+        if (cd.A != cd.B && !cap.tri) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+    };
+
+    // tables of the primitive quartets b0 .. b0 + nb - 1
+    int rstepG = 1, rstepX = 1;
+    while (rstepG < gsz && rstepG < TF_ERI_THREADS) rstepG <<= 1;
+    while (rstepX < xz && rstepX < TF_ERI_THREADS) rstepX <<= 1;
+    auto build_tables = [&](int b0, int nb) {
+        coop_tables(B, L, nb, stride, sR, sPref, sPQ,
+                    [&](int e, int &ppab, int &ppcd) {
+                        const int pq = b0 + e;
+                        const int pab = pq / npp_cd, pcd = pq - pab * npp_cd;
+                        sPP[e] = pab; sPP[TF_ERI_THREADS + e] = pcd;
+                        ppab = ab.pp_off + pab; ppcd = cd.pp_off + pcd;
+                    }, tid);
+        __syncthreads();
+        // ket half of the z tables: G_q[c,d][v][n] = sum_phi (-1)^phi Ez34[phi] R_q[v + phi][n]
+        for (int p0 = 0; p0 < nb; p0 += TF_ERI_THREADS / rstepG) {
+            const int q = p0 + tid / rstepG;
+            if (q >= nb) continue;
+            const double *Ez34q = Ecd0 + (size_t)sPP[TF_ERI_THREADS + q] * 2 * nEcd + nEcd;
+            for (int r = tid & (rstepG - 1); r < gsz; r += rstepG) {
+                const int w = sTupG[r];
+                const int n = w & 15, v = (w >> 4) & 15, d = (w >> 8) & 7, c = (w >> 11) & 7;
+                const int l34 = c + d;
+                double gsum = 0.0;
+                if (n <= L - v - l34) {
+                    const double *Ez34 = Ez34q + (c * Ld1 + d) * Lcd1;
+                    for (int phi = 0; phi <= l34; ++phi) {
+                        const double term = Ez34[phi] * sR[tri_index(v + phi, n, L) * stride + q];
+                        gsum += (phi & 1) ? -term : term;
+                    }
+                }
+                sG[q * gsz + r] = gsum;
+            }
+        }
+        __syncthreads();
+        for (int p0 = 0; p0 < nb; p0 += TF_ERI_THREADS / rstepX) {
+            const int q = p0 + tid / rstepX;
+            if (q >= nb) continue;
+            const double *E12q = Eab0 + (size_t)sPP[q] * 2 * nEab, *E34q = Ecd0 + (size_t)sPP[TF_ERI_THREADS + q] * 2 * nEcd;
+            for (int r = tid & (rstepX - 1); r < xz; r += rstepX) {
+                const int w = sTupXZ[r];
+                const int m = w & 15, a = (w >> 4) & 7, b = (w >> 7) & 7, c = (w >> 10) & 7, d = (w >> 13) & 7;
+                const int l12 = a + b, l34 = c + d;
+                const double *E12 = E12q + (a * Lb1 + b) * Lab1, *E34 = E34q + (c * Ld1 + d) * Lcd1;
+                double x = 0.0;
+                if (((l12 + l34) & 1) == 0 && 2 * m <= l12 + l34) {
+                    for (int t = l12 & 1; t <= l12; t += 2) {
+                        const int tau = 2 * m - t;
+                        if (tau < 0 || tau > l34) continue;
+                        const double term = E12[t] * E34[tau];
+                        x += (tau & 1) ? -term : term;
+                    }
+                    x *= c_dfact[m];
+                }
+                sX[q * xz + r] = x;
+                double z = 0.0;
+                if (m <= L - l12 - l34) {
+                    const double *Ez12 = E12 + nEab;
+                    const double *G = sG + q * gsz + ((c * Ld1 + d) * Lab1) * nM + m;
+                    for (int v = 0; v <= l12; ++v) z += Ez12[v] * G[v * nM];
+                }
+                sZ[q * xz + r] = z;
+            }
+        }
+        __syncthreads();
+    };
+
+    if (npq == 1) {                                                   // uncontracted: one batch, direct stores
+        build_tables(0, 1);
+        const double pref = sPref[0];
+        for (int j = tid; j < nnz; j += TF_ERI_THREADS) {
+            int xo, yo, zo, iab, icd;
+            comp_rows(j, xo, yo, zo, iab, icd);
+            store(iab, icd, pref * fact_sum_any(nM, sX + xo, sX + yo, sZ + zo) * (sScAB[iab] * sScCD[icd]));
+        }
+        return;
+    }
+    // fewer than 256 non-zero components: NG lane groups split the primitive quartets of a batch
+    const int NG = nnz < TF_ERI_THREADS ? TF_ERI_THREADS / nnz : 1, ncp = NG > 1 ? nnz : TF_ERI_THREADS;
+    const int g = tid / ncp, c0 = tid - g * ncp;
+    const bool lane_on = g < NG;
+    for (int cbase = 0; cbase < nnz; cbase += TF_ERI_THREADS * TF_CF_KMAX) {
+        int xo[TF_CF_KMAX], yo[TF_CF_KMAX], zo[TF_CF_KMAX], iab[TF_CF_KMAX], icd[TF_CF_KMAX];
+        double acc[TF_CF_KMAX];
+        const int nk = min(TF_CF_KMAX, (nnz - cbase + TF_ERI_THREADS - 1) / TF_ERI_THREADS);
+#pragma unroll
+        for (int k = 0; k < TF_CF_KMAX; ++k) {
+            acc[k] = 0.0; xo[k] = -1; yo[k] = zo[k] = iab[k] = icd[k] = 0;
+            const int j = cbase + k * TF_ERI_THREADS + c0;
+            if (k < nk && j < nnz && lane_on) comp_rows(j, xo[k], yo[k], zo[k], iab[k], icd[k]);
+        }
+        for (int b0 = 0; b0 < npq; b0 += NB) {
+            const int nb = min(NB, npq - b0);
+            build_tables(b0, nb);
+#pragma unroll
+            for (int k = 0; k < TF_CF_KMAX; ++k) {
+                if (k >= nk || xo[k] < 0) continue;
+                double a = 0.0;
+                for (int q = g; q < nb; q += NG) a += sPref[q] * fact_sum_any(nM, sX + q * xz + xo[k], sX + q * xz + yo[k], sZ + q * xz + zo[k]);
+                acc[k] += a;
+            }
+            __syncthreads();                                          // the tables are rebuilt by the next batch
+        }
+        if (NG > 1) {                                                 // combine the lane groups in fixed order (reproducible)
+            sRed[tid] = acc[0];
+            __syncthreads();
+            if (g == 0) {
+                double t = 0.0;
+                for (int gg = 0; gg < NG; ++gg) t += sRed[gg * ncp + c0];
+                acc[0] = t;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < TF_CF_KMAX; ++k)
+            if (k < nk && xo[k] >= 0 && g == 0) store(iab[k], icd[k], acc[k] * (sScAB[iab[k]] * sScCD[icd[k]]));
+    }
+}
+
 }  // namespace tfk
