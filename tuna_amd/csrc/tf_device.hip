@@ -83,6 +83,8 @@ struct tf_ctx {
     hipEvent_t sev[NSTREAM_MAX] = {};
     bool have_streams = false;
     size_t cfact_lds_set = 0;                // dynamic LDS limit requested for eri_cfact_kernel
+    tfk::LRec *d_lrec = nullptr;             // per-(La,Lb|Lc,Ld) records and entry index words of eri_cfact_kernel (per build)
+    unsigned short *d_tup = nullptr;
     double *scr[3] = {nullptr, nullptr, nullptr};
     size_t scr_bytes[3] = {0, 0, 0};
 };
@@ -268,6 +270,8 @@ void tf_destroy(tf_ctx *ctx)
         for (int k = 0; k < tf_ctx::NSTREAM_MAX; ++k) { (void)hipStreamDestroy(ctx->streams[k]); (void)hipEventDestroy(ctx->sev[k]); }
     for (int k = 0; k < 3; ++k)
         if (ctx->scr[k]) (void)hipFree(ctx->scr[k]);
+    if (ctx->d_lrec) (void)hipFree(ctx->d_lrec);
+    if (ctx->d_tup) (void)hipFree(ctx->d_tup);
     delete ctx;
 }
 
@@ -334,6 +338,35 @@ int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t
             }
         }
     }
+    // component-pair tables of every shell pair (eri_cfact_kernel): index word, normalisation ratio, position, parity-class order
+    std::vector<int> ct_ix, ct_pos, ct_ord;
+    std::vector<double> ct_sc;
+    for (size_t i = 0; i < hp.size(); ++i) {
+        DPair &pr = hp[i];
+        const int nab = pr.nca * pr.ncb, L2 = pr.Lb + 1;
+        pr.tab_off = (int)ct_ix.size();
+        std::vector<int> cls(nab);
+        for (int ca = 0; ca < pr.nca; ++ca)
+            for (int cb = 0; cb < pr.ncb; ++cb) {
+                const int a = pr.compoff_a + ca, b = pr.compoff_b + cb;
+                const int ux = bs.c_lx[a], uy = bs.c_ly[a], uz = bs.c_lz[a], wx = bs.c_lx[b], wy = bs.c_ly[b], wz = bs.c_lz[b];
+                const int c = ((ux + wx) & 1) | (((uy + wy) & 1) << 1);
+                cls[ca * pr.ncb + cb] = c;
+                ct_ix.push_back((ux * L2 + wx) | ((uy * L2 + wy) << 8) | ((uz * L2 + wz) << 16) | (c << 24));
+                ct_pos.push_back((ca << 8) | cb);
+                ct_sc.push_back(bs.c_scale[a] * bs.c_scale[b]);
+            }
+        pr.pcls[0] = 0;
+        for (int c = 0; c < 4; ++c) {
+            int n = 0;
+            for (int f = 0; f < nab; ++f)
+                if (cls[f] == c) { ct_ord.push_back(f); ++n; }
+            pr.pcls[c + 1] = pr.pcls[c] + n;
+        }
+    }
+    int *d_cti, *d_ctp, *d_cto; double *d_cts;
+    if ((rc = upload(ctx, ct_ix, &d_cti)) || (rc = upload(ctx, ct_pos, &d_ctp)) || (rc = upload(ctx, ct_ord, &d_cto)) || (rc = upload(ctx, ct_sc, &d_cts)))
+        return rc;
     int *d_sb, *d_sp, *d_si; double *d_sv;
     if ((rc = upload(ctx, hs, &d_sh)) || (rc = upload(ctx, hp, &d_pr)) || (rc = upload(ctx, bs.c_lx, &d_lx)) ||
         (rc = upload(ctx, bs.c_ly, &d_ly)) || (rc = upload(ctx, bs.c_lz, &d_lz)) || (rc = upload(ctx, bs.c_scale, &d_sc)) ||
@@ -341,7 +374,7 @@ int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t
         (rc = upload(ctx, bs.epool, &d_E)) || (rc = upload(ctx, boys, &d_boys)) || (rc = upload(ctx, sph_base, &d_sb)) ||
         (rc = upload(ctx, sph_ptr, &d_sp)) || (rc = upload(ctx, sph_idx, &d_si)) || (rc = upload(ctx, sph_val, &d_sv)))
         return rc;
-    ctx->db = DBasis{d_sh, d_pr, d_lx, d_ly, d_lz, d_sc, d_p, d_Pz, d_K, d_E, d_boys, d_sb, d_sp, d_si, d_sv};
+    ctx->db = DBasis{d_sh, d_pr, d_lx, d_ly, d_lz, d_sc, d_p, d_Pz, d_K, d_E, d_boys, d_sb, d_sp, d_si, d_sv, d_cti, d_ctp, d_cto, d_cts, nullptr, nullptr};
     ctx->host_pairs = hp;
     ctx->d_pairs = d_pr;
     ctx->have_basis = true;
@@ -603,9 +636,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     auto pair_cost = [&](int p) {                                  // primitive pairs x components: what a quartet with this pair costs
         return (long long)bs.pairs[p].npp * bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
     };
-    constexpr int NGRP = 4;
-    auto pair_group = [&](int p) { const int lp = bs.pairs[p].La + bs.pairs[p].Lb; return lp <= 1 ? 0 : (lp <= 3 ? 1 : (lp <= 5 ? 2 : 3)); };
-    int kets_goff[NGRP + 1] = {0, 0, 0, 0, 0};
+    // groups of shell pairs: by La + Lb (0-1, 2-3, 4-5, 6+) and by contracted / uncontracted
+    constexpr int NGRP = 8;
+    auto lp_group = [](int lp) { return lp <= 1 ? 0 : (lp <= 3 ? 1 : (lp <= 5 ? 2 : 3)); };
+    auto pair_group = [&](int p) { return 2 * lp_group(bs.pairs[p].La + bs.pairs[p].Lb) + (bs.pairs[p].npp > 1 ? 1 : 0); };
+    int kets_goff[NGRP + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int *d_kets = nullptr, *d_kets_all = nullptr;
     std::vector<int> kets_all_host;                              // same order as d_kets_all
     if ((rc = upload(ctx, ket_sorted, &d_kets, false))) return rc;
@@ -782,19 +817,15 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         g.maxLp1 = g.maxLp + 1;
         return g;
     };
-    auto generic_launch = [&](const std::vector<int> &bra_host, const int *d_bra, const long long *d_braoff) -> int {
-        size_t b0 = 0;
-        int si = 0;
-        while (b0 < bra_host.size()) {
-            const int gb = pair_group(bra_host[b0]);
-            size_t b1 = b0;
-            while (b1 < bra_host.size() && pair_group(bra_host[b1]) == gb) ++b1;
-            const GroupStat sb = group_stat(bra_host.data() + b0, b1 - b0);
+    // LDS carve-out of the launch (bra group gb, ket group gk), from the largest angular momenta / contraction depths of the groups
+    CFCaps gcaps[NGRP][NGRP];
+    bool gcaps_fit[NGRP][NGRP];
+    auto make_caps = [&]() {
+        GroupStat gs[NGRP];
+        for (int g = 0; g < NGRP; ++g) gs[g] = group_stat(kets_all_host.data() + kets_goff[g], (size_t)(kets_goff[g + 1] - kets_goff[g]));
+        for (int gb = 0; gb < NGRP; ++gb)
             for (int gk = 0; gk < NGRP; ++gk) {
-                const int nk = kets_goff[gk + 1] - kets_goff[gk];
-                if (nk == 0) continue;
-                const GroupStat sk = group_stat(kets_all_host.data() + kets_goff[gk], (size_t)nk);
-                hipStream_t st = streams[si++ % NSTREAM];
+                const GroupStat &sb = gs[gb], &sk = gs[gk];
                 const int Lmax = sb.maxLp + sk.maxLp, nM = Lmax / 2 + 1, tsize = (Lmax + 1) * (Lmax + 2) / 2;
                 const int xz = sb.maxT * sk.maxT * nM, gsz = sk.maxT * sb.maxLp1 * nM;
                 const bool deep = sb.maxnpp > 1 || sk.maxnpp > 1;
@@ -813,33 +844,127 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 c.offTupXZ = o; o += (xz + 3) / 4;
                 c.offEab = o; c.capEab = std::min(sb.maxE, 512); o += c.capEab;
                 c.offEcd = o; c.capEcd = std::min(sk.maxE, 1536); o += c.capEcd;
-                c.offScale = o; o += 84;
-                c.offLmn = o; o += 42;
-                c.offTab = o; o += 2 * (sb.maxcomp + sk.maxcomp) + 2;      // scales (doubles) + index words + class order (ints)
                 c.offRed = o; o += TF_ERI_THREADS;
                 c.lds_doubles = o;
                 c.tri = packed ? 1 : 0;
                 c.dbg_npq_lo = 0; c.dbg_npq_hi = 0x7fffffff;
                 if (const char *e = getenv("TF_ERI_DBG_NPQ")) (void)sscanf(e, "%d:%d", &c.dbg_npq_lo, &c.dbg_npq_hi);
-                const size_t bytes = (size_t)o * sizeof(double);
-                if (old_generic || bytes > 160 * 1024 - 256) {            // (hh|hh)-sized tables do not fit LDS: the component-per-lane kernel
-                    generic_launch_old((unsigned)(b1 - b0), d_bra + b0, d_braoff + b0, (unsigned)nk, d_kets_all + kets_goff[gk], st);
-                    continue;
-                }
-                if (bytes > ctx->cfact_lds_set) {
-                    HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-                    ctx->cfact_lds_set = 160 * 1024;
-                }
-                hipLaunchKernelGGL(eri_cfact_kernel, dim3((unsigned)nk, (unsigned)(b1 - b0)), dim3(TF_ERI_THREADS), bytes, st, ctx->db, c,
-                                   d_bra + b0, d_braoff + b0, d_kets_all + kets_goff[gk], Nc, d_C);
-                ++launch_count;
+                gcaps[gb][gk] = c;
+                gcaps_fit[gb][gk] = (size_t)o * sizeof(double) <= 160 * 1024 - 256;     // (hh|hh)-sized tables do not fit LDS
             }
+    };
+    // per (La, Lb | Lc, Ld): table sizes, index words of the table entries, batch capacity under the caps of its launch
+    auto make_lrecs = [&]() -> int {
+        std::vector<LRec> recs(6 * 6 * 6 * 6, LRec{});
+        std::vector<unsigned short> tup;
+        std::vector<char> seen_pair(36, 0);
+        for (const tf::Pair &pr : bs.pairs) seen_pair[pr.La * 6 + pr.Lb] = 1;
+        auto grp_of = [&](int lp) { return lp_group(lp); };
+        for (int ab = 0; ab < 36; ++ab)
+            for (int cd = 0; cd < 36; ++cd) {
+                if (!seen_pair[ab] || !seen_pair[cd]) continue;
+                const int La = ab / 6, Lb = ab % 6, Lc = cd / 6, Ld = cd % 6;
+                const int gb = grp_of(La + Lb), gk = grp_of(Lc + Ld);
+                LRec r{};
+                r.L = La + Lb + Lc + Ld; r.nM = r.L / 2 + 1; r.tsize = (r.L + 1) * (r.L + 2) / 2;
+                r.nT = (La + 1) * (Lb + 1) * (Lc + 1) * (Ld + 1); r.xz = r.nT * r.nM;
+                const int Lab1 = La + Lb + 1;
+                r.gsz = (Lc + 1) * (Ld + 1) * Lab1 * r.nM;
+                r.lgG = 0; while ((1 << r.lgG) < r.gsz && (1 << r.lgG) < TF_ERI_THREADS) ++r.lgG;
+                r.lgX = 0; while ((1 << r.lgX) < r.xz && (1 << r.lgX) < TF_ERI_THREADS) ++r.lgX;
+                // batch capacity: the smallest over the launches (contracted bra and / or ket group) this tuple can occur in
+                int nb = TF_ERI_THREADS / (r.L + 1);
+                for (int fb = 0; fb < 2; ++fb)
+                    for (int fk = 0; fk < 2; ++fk) {
+                        if (fb + fk == 0) continue;
+                        const CFCaps &c = gcaps[2 * gb + fb][2 * gk + fk];
+                        if (c.capR < 2 * r.tsize || c.capG < r.gsz || c.capXZ < r.xz) continue;   // (no such quartet in that launch)
+                        nb = std::min(nb, c.capR / r.tsize - 1);
+                        nb = std::min(nb, std::min(c.capG / r.gsz, c.capXZ / r.xz));
+                    }
+                r.nb_cap = std::max(nb, 1);
+                r.tupG_off = (int)tup.size();
+                for (int e = 0; e < r.gsz; ++e) {
+                    const int n = e % r.nM;
+                    int q = e / r.nM;
+                    const int v = q % Lab1; q /= Lab1;
+                    const int d = q % (Ld + 1), cc = q / (Ld + 1);
+                    tup.push_back((unsigned short)(n | (v << 4) | (d << 8) | (cc << 11)));
+                }
+                r.tupXZ_off = (int)tup.size();
+                for (int e = 0; e < r.xz; ++e) {
+                    const int m = e % r.nM;
+                    int q = e / r.nM;
+                    const int d = q % (Ld + 1); q /= (Ld + 1);
+                    const int cc = q % (Lc + 1); q /= (Lc + 1);
+                    const int b2 = q % (Lb + 1), a2 = q / (Lb + 1);
+                    tup.push_back((unsigned short)(m | (a2 << 4) | (b2 << 7) | (cc << 10) | (d << 13)));
+                }
+                recs[ab * 36 + cd] = r;
+            }
+        if (ctx->d_lrec) { (void)hipFree(ctx->d_lrec); ctx->d_lrec = nullptr; }
+        if (ctx->d_tup) { (void)hipFree(ctx->d_tup); ctx->d_tup = nullptr; }
+        int rc2;
+        if ((rc2 = upload(ctx, recs, &ctx->d_lrec, false)) || (rc2 = upload(ctx, tup, &ctx->d_tup, false))) return rc2;
+        ctx->db.lrec = ctx->d_lrec; ctx->db.tup = ctx->d_tup;
+        return TF_OK;
+    };
+    // One launch per (bra group, ket group) with work.  A process has few hardware queues (4 by default) and the launches of one
+    // queue run one after the other, each as long as its slowest workgroup: the launches are spread over NQ streams by estimated
+    // cost (heaviest first, always onto the least loaded stream) instead of round-robin over all of them.
+    auto generic_launch = [&](const std::vector<int> &bra_host, const int *d_bra, const long long *d_braoff) -> int {
+        struct Launch { size_t b0, b1; int gb, gk; double cost; };
+        std::vector<Launch> launches;
+        double ket_cost[NGRP];
+        for (int g = 0; g < NGRP; ++g) {
+            ket_cost[g] = 0.0;
+            for (int k = kets_goff[g]; k < kets_goff[g + 1]; ++k) ket_cost[g] += (double)pair_cost(kets_all_host[k]);
+        }
+        for (size_t b0 = 0; b0 < bra_host.size();) {
+            const int gb = pair_group(bra_host[b0]);
+            size_t b1 = b0;
+            double bc = 0.0;
+            while (b1 < bra_host.size() && pair_group(bra_host[b1]) == gb) { bc += (double)pair_cost(bra_host[b1]); ++b1; }
+            for (int gk = 0; gk < NGRP; ++gk)
+                if (kets_goff[gk + 1] > kets_goff[gk]) launches.push_back(Launch{b0, b1, gb, gk, bc * ket_cost[gk]});
             b0 = b1;
+        }
+        std::stable_sort(launches.begin(), launches.end(), [](const Launch &x, const Launch &y) { return x.cost > y.cost; });
+        const int NQ = std::min(NSTREAM, getenv("TF_ERI_NQ") ? std::max(1, atoi(getenv("TF_ERI_NQ"))) : 4);
+        std::vector<double> load(NQ, 0.0);
+        for (const Launch &l : launches) {
+            const int qi = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            load[qi] += l.cost;
+            hipStream_t st = streams[qi];
+            const int gb = l.gb, gk = l.gk, nk = kets_goff[gk + 1] - kets_goff[gk];
+            const size_t b0 = l.b0, b1 = l.b1;
+            const CFCaps &c = gcaps[gb][gk];
+            const size_t bytes = (size_t)c.lds_doubles * sizeof(double);
+            if (old_generic || !gcaps_fit[gb][gk]) {             // the component-per-lane kernel
+                generic_launch_old((unsigned)(b1 - b0), d_bra + b0, d_braoff + b0, (unsigned)nk, d_kets_all + kets_goff[gk], st);
+                continue;
+            }
+            if (bytes > 64 * 1024 && !ctx->cfact_lds_set) {
+                HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                ctx->cfact_lds_set = 160 * 1024;
+            }
+            if (((gb | gk) & 1) == 0)                            // both groups uncontracted: one primitive quartet per shell quartet
+                hipLaunchKernelGGL(eri_cfact_kernel<true>, dim3((unsigned)nk, (unsigned)(b1 - b0)), dim3(TF_ERI_THREADS), bytes, st, ctx->db, c,
+                                   d_bra + b0, d_braoff + b0, d_kets_all + kets_goff[gk], Nc, d_C);
+            else
+                hipLaunchKernelGGL(eri_cfact_kernel<false>, dim3((unsigned)nk, (unsigned)(b1 - b0)), dim3(TF_ERI_THREADS), bytes, st, ctx->db, c,
+                                   d_bra + b0, d_braoff + b0, d_kets_all + kets_goff[gk], Nc, d_C);
+            ++launch_count;
         }
         return TF_OK;
     };
     bool per_class = (long long)mine_sorted.size() * npairs >= 2000000LL;
     if (const char *m = getenv("TF_ERI_MODE")) per_class = (m[0] == 'c');
+    if (!per_class) {
+        make_caps();
+        if ((rc = make_lrecs())) return rc;
+    }
     if (!per_class)
         std::stable_sort(mine_sorted.begin(), mine_sorted.end(), [&](int x, int y) {
             const int gx = pair_group(x), gy = pair_group(y);

@@ -173,23 +173,35 @@ __device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, 
 
 // Cooperative Boys/R tables: entry e of the batch (column e of sR) belongs to primitive quartet (pab[e], pcd[e]) of the
 // pairs (ab[e], cd[e]).  Lanes e*(L+1)+n, n = 0..L; one barrier per table row.  All threads of the block must call.
+template <bool DENSE, class PairOf>
+__device__ __forceinline__ void coop_tables_en(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
+                                               PairOf pair_of, int e, int n, int tid);
 template <class PairOf>
 __device__ __forceinline__ void coop_tables(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
                                             PairOf pair_of, int tid)
 {
     const int L1 = L + 1;
-    const int e = tid / L1, n = tid - e * L1;
+    coop_tables_en<false>(B, L, n_entries, stride, sR, sPref, sPQ, pair_of, tid / L1, tid % L1, tid);
+}
+// the same with the lane's (entry, row position) = (tid / (L + 1), tid % (L + 1)) given (callers in a loop divide once).
+// DENSE: the Boys values of entry e are computed by thread e (the first waves, all lanes busy) instead of the lane (e, 0) of the
+// row layout -- one wave instead of L + 1 runs the expensive part of the build.
+template <bool DENSE, class PairOf>
+__device__ __forceinline__ void coop_tables_en(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
+                                               PairOf pair_of, int e, int n, int tid)
+{
     const bool mine = e < n_entries;
-    if (mine && n == 0) {
+    if (DENSE ? tid < n_entries : (mine && n == 0)) {
+        const int le = DENSE ? tid : e;
         int ppab, ppcd;            // absolute primitive-pair indices
-        pair_of(e, ppab, ppcd);
+        pair_of(le, ppab, ppcd);
         const double p = B.pp_p[ppab], q = B.pp_p[ppcd];
         const double s = p + q, alpha = p * q / s;
         const double PQ = B.pp_Pz[ppab] - B.pp_Pz[ppcd];
-        build_R_row0(sR, stride, e, L, alpha, PQ, B.boys);
-        sPQ[e] = PQ;
+        build_R_row0(sR, stride, le, L, alpha, PQ, B.boys);
+        sPQ[le] = PQ;
         // 2 pi^(5/2) / (p q sqrt(p+q)) * coefficient product, pyx:1219-1221
-        sPref[e] = B.pp_K[ppab] * B.pp_K[ppcd] * (34.986836655249725 / (p * q * sqrt(s)));
+        sPref[le] = B.pp_K[ppab] * B.pp_K[ppcd] * (34.986836655249725 / (p * q * sqrt(s)));
     }
     for (int v = 1; v <= L; ++v) {
         __syncthreads();
@@ -502,6 +514,28 @@ __device__ __forceinline__ double fact_sum_any(int nM, const double *__restrict_
     }
 }
 
+// the same for the contracted kernel, whose accumulators leave fewer registers: unrolled up to 6 rows, a plain loop beyond
+__device__ __forceinline__ double fact_sum_small(int nM, const double *__restrict__ X, const double *__restrict__ Y, const double *__restrict__ Z)
+{
+    switch (nM) {
+    case 1: return fact_sum<1>(X, Y, Z);
+    case 2: return fact_sum<2>(X, Y, Z);
+    case 3: return fact_sum<3>(X, Y, Z);
+    case 4: return fact_sum<4>(X, Y, Z);
+    case 5: return fact_sum<5>(X, Y, Z);
+    case 6: return fact_sum<6>(X, Y, Z);
+    default: {
+        double sum = 0.0;
+        for (int m = 0; m < nM; ++m) {
+            double t = 0.0;
+            for (int mp = 0; mp + m < nM; ++mp) t += Y[mp] * Z[m + mp];
+            sum += X[m] * t;
+        }
+        return sum;
+    }
+    }
+}
+
 __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QClass qc, const int *__restrict__ bra_pairs,
                                                                   const long long *__restrict__ bra_rowoff,
                                                                   const int *__restrict__ ket_pairs, int Nc,
@@ -659,13 +693,14 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
 // batch loop); a component costs one unrolled triple-table sum per primitive quartet.  Components < 256: lane groups split the
 // primitive quartets of a batch and are combined in fixed order at the end; more: up to TF_CF_KMAX components per thread in
 // registers.  Uncontracted quartets (one primitive quartet) take the same path with direct stores.  Cartesian output (unfused).
-#define TF_CF_KMAX 4
+#define TF_CF_KMAX 2
 struct CFCaps {
     int offR, capR, offPref, offPQ, offPP, offG, capG, offX, offZ, capXZ, offTupG, offTupXZ, offEab, capEab, offEcd, capEcd;
-    int offScale, offLmn, offTab, offRed, lds_doubles, tri;
+    int offRed, lds_doubles, tri;
     int dbg_npq_lo, dbg_npq_hi;      // profiling aid (TF_ERI_DBG_NPQ=lo:hi): only quartets with lo <= primitive quartets <= hi are computed
 };
 
+template <bool UNC>
 __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, CFCaps cap, const int *__restrict__ bra_pairs,
                                                                    const long long *__restrict__ bra_rowoff,
                                                                    const int *__restrict__ ket_pairs, int Nc, double *__restrict__ Cslab)
@@ -676,32 +711,23 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
     const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
     if (cap.tri && cd.A > ab.A) return;
     if (ab.npp * cd.npp < cap.dbg_npq_lo || ab.npp * cd.npp > cap.dbg_npq_hi) return;
-    const int La1 = ab.La + 1, Lb1 = ab.Lb + 1, Lc1 = cd.La + 1, Ld1 = cd.Lb + 1;
+    const LRec lr = B.lrec[((ab.La * 6 + ab.Lb) * 6 + cd.La) * 6 + cd.Lb];
+    const int Lb1 = ab.Lb + 1, Lc1 = cd.La + 1, Ld1 = cd.Lb + 1;
     const int Lab1 = ab.La + ab.Lb + 1, Lcd1 = cd.La + cd.Lb + 1;
-    const int L = ab.La + ab.Lb + cd.La + cd.Lb, nM = L / 2 + 1, tsize = (L + 1) * (L + 2) / 2;
-    const int nT = La1 * Lb1 * Lc1 * Ld1, xz = nT * nM, gsz = Lc1 * Ld1 * Lab1 * nM;
-    const int nab = ab.nca * ab.ncb, nsubc = cd.nca * cd.ncb, ncomp = nab * nsubc;
+    const int L = lr.L, nM = lr.nM, xz = lr.xz, gsz = lr.gsz;
+    const int nsubc = cd.nca * cd.ncb;
     const int npp_cd = cd.npp, npq = ab.npp * cd.npp;
     const int nEab = ab.nE, nEcd = cd.nE;
     double *sR = smem + cap.offR, *sPref = smem + cap.offPref, *sPQ = smem + cap.offPQ, *sG = smem + cap.offG;
-    double *sX = smem + cap.offX, *sZ = smem + cap.offZ, *sScale = smem + cap.offScale, *sRed = smem + cap.offRed;
+    double *sX = smem + cap.offX, *sZ = smem + cap.offZ, *sRed = smem + cap.offRed;
     int *sPP = reinterpret_cast<int *>(smem + cap.offPP);            // [2][256]: primitive pair indices (within the pairs) of the batch
     unsigned short *sTupG = reinterpret_cast<unsigned short *>(smem + cap.offTupG), *sTupXZ = reinterpret_cast<unsigned short *>(smem + cap.offTupXZ);
-    int *sLmn = reinterpret_cast<int *>(smem + cap.offLmn);
     const long long row0 = bra_rowoff[blockIdx.y];
     const size_t NcNc = (size_t)Nc * Nc;
-
-    // primitive quartets per batch: what the cooperative R build and the table capacities allow (host: every capacity >= one)
-    int NB = min(npq, TF_ERI_THREADS / (L + 1));
-    NB = min(NB, cap.capR / tsize - 1);
-    NB = min(NB, min(cap.capG / gsz, cap.capXZ / xz));
-    NB = max(NB, 1);
+    // primitive quartets per batch: what the cooperative R build and the table capacities of this launch allow (LRec::nb_cap)
+    const int NB = min(npq, lr.nb_cap);
     const int stride = NB | 1;
 
-    stage_components(B, ab.compoff_a, ab.nca, sLmn, sScale, tid, TF_ERI_THREADS);
-    stage_components(B, ab.compoff_b, ab.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
-    stage_components(B, cd.compoff_a, cd.nca, sLmn + 42, sScale + 42, tid, TF_ERI_THREADS);
-    stage_components(B, cd.compoff_b, cd.ncb, sLmn + 63, sScale + 63, tid, TF_ERI_THREADS);
     const double *__restrict__ gEab = B.epool + ab.e_off;
     const double *__restrict__ gEcd = B.epool + cd.e_off;
     const bool stAB = ab.npp * 2 * nEab <= cap.capEab, stCD = cd.npp * 2 * nEcd <= cap.capEcd;
@@ -709,101 +735,60 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
     if (stCD) for (int k = tid; k < cd.npp * 2 * nEcd; k += TF_ERI_THREADS) smem[cap.offEcd + k] = gEcd[k];
     const double *Eab0 = stAB ? smem + cap.offEab : gEab;
     const double *Ecd0 = stCD ? smem + cap.offEcd : gEcd;
-    // index words of the table entries: G entry r -> (c, d, v, n); X/Z entry r -> (a, b, c, d, m)
-    for (int r = tid; r < gsz; r += TF_ERI_THREADS) {
-        const int n = r % nM;
-        int q = r / nM;
-        const int v = q % Lab1; q /= Lab1;
-        const int d = q % Ld1, c = q / Ld1;
-        sTupG[r] = (unsigned short)(n | (v << 4) | (d << 8) | (c << 11));
-    }
-    for (int r = tid; r < xz; r += TF_ERI_THREADS) {
-        const int m = r % nM;
-        int q = r / nM;
-        const int d = q % Ld1; q /= Ld1;
-        const int c = q % Lc1; q /= Lc1;
-        const int b = q % Lb1, a = q / Lb1;
-        sTupXZ[r] = (unsigned short)(m | (a << 4) | (b << 7) | (c << 10) | (d << 13));
-    }
-    __syncthreads();
-    // per bra / ket component pair: its part of the three table indices, x / y parities, normalisation ratio (as eri_fact_kernel)
-    double *sScAB = smem + cap.offTab, *sScCD = sScAB + nab;
-    int *sIxAB = reinterpret_cast<int *>(sScCD + nsubc), *sIxCD = sIxAB + nab;
-    for (int e = tid; e < nab + nsubc; e += TF_ERI_THREADS) {
-        const bool bra = e < nab;
-        const int f = bra ? e : e - nab;
-        const int n2 = bra ? ab.ncb : cd.ncb, L2 = bra ? Lb1 : Ld1;
-        const int i1 = f / n2, i2 = f - i1 * n2;
-        const int u = bra ? sLmn[i1] : sLmn[42 + i1], w = bra ? sLmn[21 + i2] : sLmn[63 + i2];
-        const int ux = u & 255, uy = (u >> 8) & 255, uz = (u >> 16) & 255, wx = w & 255, wy = (w >> 8) & 255, wz = (w >> 16) & 255;
-        const int packed = (ux * L2 + wx) | ((uy * L2 + wy) << 8) | ((uz * L2 + wz) << 16) | (((ux + wx) & 1) << 24) | (((uy + wy) & 1) << 25);
-        if (bra) { sIxAB[f] = packed; sScAB[f] = sScale[i1] * sScale[21 + i2]; }
-        else { sIxCD[f] = packed; sScCD[f] = sScale[42 + i1] * sScale[63 + i2]; }
-    }
-    __syncthreads();
-    // Only components whose bra and ket pairs have the same (x, y) parity class are non-zero (pyx:1324-1327; the slab is zeroed by
-    // the host): order both pair lists by class, so that non-zero component j <-> (class, i-th bra pair, k-th ket pair of the class).
-    int *sOrdAB = sIxCD + nsubc, *sOrdCD = sOrdAB + nab;
-    __shared__ int sOff[2][5];
-    for (int e = tid; e < nab + nsubc; e += TF_ERI_THREADS) {
-        const bool bra = e < nab;
-        const int f = bra ? e : e - nab, n = bra ? nab : nsubc;
-        const int *tab = bra ? sIxAB : sIxCD;
-        const int cls = (tab[f] >> 24) & 3;
-        int rank = 0;
-        for (int h = 0; h < n; ++h) { const int ch = (tab[h] >> 24) & 3; rank += (ch < cls || (ch == cls && h < f)) ? 1 : 0; }
-        (bra ? sOrdAB : sOrdCD)[rank] = f;
-    }
-    if (tid < 10) {
-        const bool bra = tid < 5;
-        const int c = bra ? tid : tid - 5, n = bra ? nab : nsubc;
-        const int *tab = bra ? sIxAB : sIxCD;
-        int below = 0;
-        for (int h = 0; h < n; ++h) below += (((tab[h] >> 24) & 3) < c) ? 1 : 0;
-        sOff[bra ? 0 : 1][c] = below;
-    }
-    __syncthreads();
-    int pre[5];
-    pre[0] = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) pre[c + 1] = pre[c] + (sOff[0][c + 1] - sOff[0][c]) * (sOff[1][c + 1] - sOff[1][c]);
-    const int nnz = pre[4];
+    // index words of the table entries (tabulated by the host per (La, Lb | Lc, Ld)): G entry r -> (c, d, v, n); X/Z entry r -> (a, b, c, d, m)
+    for (int r = tid; r < gsz; r += TF_ERI_THREADS) sTupG[r] = B.tup[lr.tupG_off + r];
+    for (int r = tid; r < xz; r += TF_ERI_THREADS) sTupXZ[r] = B.tup[lr.tupXZ_off + r];
+    // Component pairs of the two shell pairs (tabulated by the host, DBasis::ct_*): index words, normalisation ratios, positions,
+    // and their order by (x, y) parity class.  Only components whose bra and ket classes agree are non-zero (pyx:1324-1327; the
+    // slab is zeroed by the host): non-zero component j <-> (class, i-th bra pair, k-th ket pair of the class).
+    const int *__restrict__ ixAB = B.ct_ix + ab.tab_off, *__restrict__ ixCD = B.ct_ix + cd.tab_off;
+    const int *__restrict__ ordAB = B.ct_ord + ab.tab_off, *__restrict__ ordCD = B.ct_ord + cd.tab_off;
+    const double *__restrict__ scAB = B.ct_sc + ab.tab_off, *__restrict__ scCD = B.ct_sc + cd.tab_off;
+    const int *__restrict__ posCD = B.ct_pos + cd.tab_off;
+    // (scalars, not arrays: a dynamically indexed local array would live in scratch memory)
+    const int oa0 = ab.pcls[0], oa1 = ab.pcls[1], oa2 = ab.pcls[2], oa3 = ab.pcls[3], oa4 = ab.pcls[4];
+    const int oc0 = cd.pcls[0], oc1 = cd.pcls[1], oc2 = cd.pcls[2], oc3 = cd.pcls[3], oc4 = cd.pcls[4];
+    const int pre1 = (oa1 - oa0) * (oc1 - oc0), pre2 = pre1 + (oa2 - oa1) * (oc2 - oc1), pre3 = pre2 + (oa3 - oa2) * (oc3 - oc2);
+    const int nnz = pre3 + (oa4 - oa3) * (oc4 - oc3);
     const int LcLd = Lc1 * Ld1;
+    __syncthreads();
     // non-zero component j: the two pair indices and the table offsets (X row of the x tuple, X row of the y tuple, Z row)
     auto comp_rows = [&](int j, int &xo, int &yo, int &zo, int &iab, int &icd) {
-        const int c = (j >= pre[1] ? 1 : 0) + (j >= pre[2] ? 1 : 0) + (j >= pre[3] ? 1 : 0);
-        const int r = j - pre[c], ncd_c = sOff[1][c + 1] - sOff[1][c];
+        const bool g1 = j >= pre1, g2 = j >= pre2, g3 = j >= pre3;
+        const int base = g3 ? pre3 : (g2 ? pre2 : (g1 ? pre1 : 0));
+        const int offa = g3 ? oa3 : (g2 ? oa2 : (g1 ? oa1 : oa0)), offc = g3 ? oc3 : (g2 ? oc2 : (g1 ? oc1 : oc0));
+        const int ncd_c = (g3 ? oc4 : (g2 ? oc3 : (g1 ? oc2 : oc1))) - offc;
+        const int r = j - base;
         const int i = r / ncd_c, k = r - i * ncd_c;
-        iab = sOrdAB[sOff[0][c] + i]; icd = sOrdCD[sOff[1][c] + k];
-        const int pa = sIxAB[iab], pc = sIxCD[icd];
+        iab = ordAB[offa + i]; icd = ordCD[offc + k];
+        const int pa = ixAB[iab], pc = ixCD[icd];
         xo = ((pa & 255) * LcLd + (pc & 255)) * nM;
         yo = (((pa >> 8) & 255) * LcLd + ((pc >> 8) & 255)) * nM;
         zo = (((pa >> 16) & 255) * LcLd + ((pc >> 16) & 255)) * nM;
     };
     auto store = [&](int iab, int icd, double val) {
-        const int ic = icd / cd.ncb, id = icd - ic * cd.ncb;
+        const int pos = posCD[icd];
         const size_t row = (size_t)(row0 + iab);
-        const int k = cd.cartoff_a + ic, l = cd.cartoff_b + id;
+        const int k = cd.cartoff_a + (pos >> 8), l = cd.cartoff_b + (pos & 255);
         Cslab[row * NcNc + (size_t)k * Nc + l] = val;
         if (cd.A != cd.B && !cap.tri) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
     };
 
     // tables of the primitive quartets b0 .. b0 + nb - 1
-    int rstepG = 1, rstepX = 1;
-    while (rstepG < gsz && rstepG < TF_ERI_THREADS) rstepG <<= 1;
-    while (rstepX < xz && rstepX < TF_ERI_THREADS) rstepX <<= 1;
+    const int lgG = lr.lgG, lgX = lr.lgX, rstepG = 1 << lgG, rstepX = 1 << lgX;
+    const int ce = tid / (L + 1), cn = tid - ce * (L + 1);            // lane (entry, row position) of the cooperative R build
     auto build_tables = [&](int b0, int nb) {
-        coop_tables(B, L, nb, stride, sR, sPref, sPQ,
-                    [&](int e, int &ppab, int &ppcd) {
-                        const int pq = b0 + e;
-                        const int pab = pq / npp_cd, pcd = pq - pab * npp_cd;
-                        sPP[e] = pab; sPP[TF_ERI_THREADS + e] = pcd;
-                        ppab = ab.pp_off + pab; ppcd = cd.pp_off + pcd;
-                    }, tid);
+        coop_tables_en<true>(B, L, nb, stride, sR, sPref, sPQ,
+                       [&](int e, int &ppab, int &ppcd) {
+                           const int pq = b0 + e;
+                           const int pab = pq / npp_cd, pcd = pq - pab * npp_cd;
+                           sPP[e] = pab; sPP[TF_ERI_THREADS + e] = pcd;
+                           ppab = ab.pp_off + pab; ppcd = cd.pp_off + pcd;
+                       }, ce, cn, tid);
         __syncthreads();
         // ket half of the z tables: G_q[c,d][v][n] = sum_phi (-1)^phi Ez34[phi] R_q[v + phi][n]
-        for (int p0 = 0; p0 < nb; p0 += TF_ERI_THREADS / rstepG) {
-            const int q = p0 + tid / rstepG;
+        for (int p0 = 0; p0 < nb; p0 += TF_ERI_THREADS >> lgG) {
+            const int q = p0 + (tid >> lgG);
             if (q >= nb) continue;
             const double *Ez34q = Ecd0 + (size_t)sPP[TF_ERI_THREADS + q] * 2 * nEcd + nEcd;
             for (int r = tid & (rstepG - 1); r < gsz; r += rstepG) {
@@ -822,8 +807,8 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
             }
         }
         __syncthreads();
-        for (int p0 = 0; p0 < nb; p0 += TF_ERI_THREADS / rstepX) {
-            const int q = p0 + tid / rstepX;
+        for (int p0 = 0; p0 < nb; p0 += TF_ERI_THREADS >> lgX) {
+            const int q = p0 + (tid >> lgX);
             if (q >= nb) continue;
             const double *E12q = Eab0 + (size_t)sPP[q] * 2 * nEab, *E34q = Ecd0 + (size_t)sPP[TF_ERI_THREADS + q] * 2 * nEcd;
             for (int r = tid & (rstepX - 1); r < xz; r += rstepX) {
@@ -854,13 +839,13 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
         __syncthreads();
     };
 
-    if (npq == 1) {                                                   // uncontracted: one batch, direct stores
+    if (UNC) {                                                        // uncontracted (npq == 1 for every quartet of the launch): one batch, direct stores
         build_tables(0, 1);
         const double pref = sPref[0];
         for (int j = tid; j < nnz; j += TF_ERI_THREADS) {
             int xo, yo, zo, iab, icd;
             comp_rows(j, xo, yo, zo, iab, icd);
-            store(iab, icd, pref * fact_sum_any(nM, sX + xo, sX + yo, sZ + zo) * (sScAB[iab] * sScCD[icd]));
+            store(iab, icd, pref * fact_sum_any(nM, sX + xo, sX + yo, sZ + zo) * (scAB[iab] * scCD[icd]));
         }
         return;
     }
@@ -885,7 +870,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
             for (int k = 0; k < TF_CF_KMAX; ++k) {
                 if (k >= nk || xo[k] < 0) continue;
                 double a = 0.0;
-                for (int q = g; q < nb; q += NG) a += sPref[q] * fact_sum_any(nM, sX + q * xz + xo[k], sX + q * xz + yo[k], sZ + q * xz + zo[k]);
+                for (int q = g; q < nb; q += NG) a += sPref[q] * fact_sum_small(nM, sX + q * xz + xo[k], sX + q * xz + yo[k], sZ + q * xz + zo[k]);
                 acc[k] += a;
             }
             __syncthreads();                                          // the tables are rebuilt by the next batch
@@ -902,7 +887,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
         }
 #pragma unroll
         for (int k = 0; k < TF_CF_KMAX; ++k)
-            if (k < nk && xo[k] >= 0 && g == 0) store(iab[k], icd[k], acc[k] * (sScAB[iab[k]] * sScCD[icd[k]]));
+            if (k < nk && xo[k] >= 0 && g == 0) store(iab[k], icd[k], acc[k] * (scAB[iab[k]] * scCD[icd[k]]));
     }
 }
 

@@ -12,7 +12,14 @@ struct DPair {
     long long e_off;
     int nca, ncb, compoff_a, compoff_b, cartoff_a, cartoff_b;
     int outoff_a, outoff_b;      // first OUTPUT AO (spherical, or Cartesian for CARTHARM) of the two shells; set by tf_build_eri
+    int tab_off;                 // component-pair tables of this pair in DBasis::ct_* (nca * ncb entries)
+    int pcls[5];                 // ct_ord: component pairs ordered by (x, y) parity class; class c is [pcls[c], pcls[c + 1])
 };
+
+// What a shell quartet with the angular momenta (La, Lb | Lc, Ld) needs to know, tabulated once per tf_build_eri (index
+// ((La * 6 + Lb) * 6 + Lc) * 6 + Ld): sizes of the per-axis factor tables of eri_cfact_kernel, the index words of their entries
+// (DBasis::tup) and the primitive quartets per batch the launch of its shell-pair groups has LDS for.
+struct LRec { int L, nM, tsize, nT, xz, gsz, lgG, lgX, nb_cap, tupG_off, tupXZ_off, pad; };
 
 struct DBasis {
     const DShell *shells;
@@ -25,6 +32,12 @@ struct DBasis {
     // per-L Cartesian->spherical rows (CSR over the components of one shell): row base sphL_base[L], then ptr/idx/val
     const int *sphL_base, *sphL_ptr, *sphL_idx;
     const double *sphL_val;
+    // per shell pair, entry f = ca * ncb + cb (DPair::tab_off): index word ((ax (Lb+1) + bx) | (ay (Lb+1) + by) << 8 | (az (Lb+1) + bz)
+    // << 16 | x parity << 24 | y parity << 25), normalisation ratio, position word (ca << 8 | cb), parity-class order
+    const int *ct_ix, *ct_pos, *ct_ord;
+    const double *ct_sc;
+    const LRec *lrec;
+    const unsigned short *tup;
 };
 
 #define TF_ERI_THREADS 256
