@@ -680,6 +680,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     int launch_count = 0;
     DBG("streams created");
 
+    std::vector<LRec> lrecs_host;                              // per (La, Lb | Lc, Ld), filled by make_lrecs below
     // bra_Amax: largest first shell among the bra pairs of the run -- in the packed layout only kets with first shell <= it are needed
     // (the class ket lists ascend in the first shell, so that is a prefix: workgroups beyond it are not even launched)
     auto class_launch = [&](int bcls, int kcls, int max_npp_bra, unsigned n_bra, const int *d_bra, const long long *d_braoff, int bra_Amax) {
@@ -733,6 +734,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             // uncontracted, many components: per-axis factor tables in LDS
             const int nT = (q.La + 1) * (q.Lb + 1) * (q.Lc + 1) * (q.Ld + 1), nM = q.L / 2 + 1;
             q.PB = 1; q.stride = 1; q.G = 1; q.ncp = 0;
+            const LRec &lr = lrecs_host[((q.La * 6 + q.Lb) * 6 + q.Lc) * 6 + q.Ld];
+            q.tupG_off = lr.tupG_off; q.tupXZ_off = lr.tupXZ_off;
             int o = 0;
             q.offR = o; o += q.tsize;
             q.offPref = o; o += 2;
@@ -854,7 +857,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             }
     };
     // per (La, Lb | Lc, Ld): table sizes, index words of the table entries, batch capacity under the caps of its launch
-    auto make_lrecs = [&]() -> int {
+    auto make_lrecs = [&](bool with_caps) -> int {
         std::vector<LRec> recs(6 * 6 * 6 * 6, LRec{});
         std::vector<unsigned short> tup;
         std::vector<char> seen_pair(36, 0);
@@ -874,7 +877,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 r.lgX = 0; while ((1 << r.lgX) < r.xz && (1 << r.lgX) < TF_ERI_THREADS) ++r.lgX;
                 // batch capacity: the smallest over the launches (contracted bra and / or ket group) this tuple can occur in
                 int nb = TF_ERI_THREADS / (r.L + 1);
-                for (int fb = 0; fb < 2; ++fb)
+                for (int fb = 0; fb < 2 && with_caps; ++fb)
                     for (int fk = 0; fk < 2; ++fk) {
                         if (fb + fk == 0) continue;
                         const CFCaps &c = gcaps[2 * gb + fb][2 * gk + fk];
@@ -907,6 +910,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         int rc2;
         if ((rc2 = upload(ctx, recs, &ctx->d_lrec, false)) || (rc2 = upload(ctx, tup, &ctx->d_tup, false))) return rc2;
         ctx->db.lrec = ctx->d_lrec; ctx->db.tup = ctx->d_tup;
+        lrecs_host = recs;
         return TF_OK;
     };
     // One launch per (bra group, ket group) with work.  A process has few hardware queues (4 by default) and the launches of one
@@ -961,10 +965,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     };
     bool per_class = (long long)mine_sorted.size() * npairs >= 2000000LL;
     if (const char *m = getenv("TF_ERI_MODE")) per_class = (m[0] == 'c');
-    if (!per_class) {
-        make_caps();
-        if ((rc = make_lrecs())) return rc;
-    }
+    if (!per_class) make_caps();
+    if ((rc = make_lrecs(!per_class))) return rc;
     if (!per_class)
         std::stable_sort(mine_sorted.begin(), mine_sorted.end(), [&](int x, int y) {
             const int gx = pair_group(x), gy = pair_group(y);

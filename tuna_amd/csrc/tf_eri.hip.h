@@ -28,6 +28,7 @@ struct QClass {
     int offTab;            // factorised kernel: per-pair component tables, (nab + ncc*ncd) * 3/2 doubles
     int offCsr;            // fused spherical ket transform: LDS copy of the two shells' Cartesian->spherical CSR rows (TF_CSR_DOUBLES)
     int tri;               // packed layout: only kets with first shell <= the bra's first shell are needed ((kl) <= (ij))
+    int tupG_off, tupXZ_off;   // factorised kernel: index words of its table entries in DBasis::tup (LRec of the class)
     // LDS carve-out, offsets in doubles
     int offR, offPref, offPQ, offRed, offEab, offEcd, offScale, offLmn, lds_doubles;
 };
@@ -558,10 +559,6 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     const long long row0 = bra_rowoff[blockIdx.y];
     const size_t NcNc = (size_t)Nc * Nc;
 
-    stage_components(B, ab.compoff_a, qc.nca, sLmn, sScale, tid, TF_ERI_THREADS);
-    stage_components(B, ab.compoff_b, qc.ncb, sLmn + 21, sScale + 21, tid, TF_ERI_THREADS);
-    stage_components(B, cd.compoff_a, qc.ncc, sLmn + 42, sScale + 42, tid, TF_ERI_THREADS);
-    stage_components(B, cd.compoff_b, qc.ncd, sLmn + 63, sScale + 63, tid, TF_ERI_THREADS);
     {
         const double *__restrict__ gEab = B.epool + ab.e_off;
         const double *__restrict__ gEcd = B.epool + cd.e_off;
@@ -572,11 +569,10 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     __syncthreads();
     // ---- ket half of the z tables: G[c,d][v][n], v <= La + Lb, n <= L - v - (c + d) (zero beyond) ----
     double *sG = smem + qc.offG;
+    const unsigned short *__restrict__ tupG = B.tup + qc.tupG_off, *__restrict__ tupXZ = B.tup + qc.tupXZ_off;   // entry index words (host)
     for (int e = tid; e < Lc1 * Ld1 * Lab1 * nM; e += TF_ERI_THREADS) {
-        const int n = e % nM;
-        int r = e / nM;
-        const int v = r % Lab1; r /= Lab1;
-        const int d = r % Ld1, c = r / Ld1;
+        const int w = tupG[e];
+        const int n = w & 15, v = (w >> 4) & 15, d = (w >> 8) & 7, c = (w >> 11) & 7;
         const int l34 = c + d;
         double gsum = 0.0;
         if (n <= L - v - l34) {
@@ -591,11 +587,8 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     __syncthreads();
     // ---- per-axis tables ----
     for (int e = tid; e < nT * nM; e += TF_ERI_THREADS) {
-        const int T = e / nM, m = e - T * nM;
-        int r = T;
-        const int d = r % Ld1; r /= Ld1;
-        const int c = r % Lc1; r /= Lc1;
-        const int b = r % Lb1; const int a = r / Lb1;
+        const int w = tupXZ[e];
+        const int m = w & 15, a = (w >> 4) & 7, b = (w >> 7) & 7, c = (w >> 10) & 7, d = (w >> 13) & 7;
         const int l12 = a + b, l34 = c + d;
         const double *E12 = sEab + (a * Lb1 + b) * Lab1, *E34 = sEcd + (c * Ld1 + d) * Lcd1;
         // X: t + tau = 2m, with t = l12 (mod 2) and tau = l34 (mod 2) -- other parities have zero coefficients
@@ -628,21 +621,15 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     // table indices, the parities of its x and y exponent sums, and its normalisation ratio.  A component is then two table lookups,
     // one parity test and one unrolled triple-table sum -- no integer division by runtime shell sizes, no per-component lmn decode.
     const double pref = sPref[0];
-    const int *lmnA = sLmn, *lmnB = sLmn + 21, *lmnC = sLmn + 42, *lmnD = sLmn + 63;
     double *sBlk = smem + qc.offBlk;
     const int nsubc = qc.ncc * qc.ncd, nab = qc.nca * qc.ncb;
     double *sScAB = smem + qc.offTab, *sScCD = sScAB + nab;
     int *sIxAB = reinterpret_cast<int *>(sScCD + nsubc), *sIxCD = sIxAB + nab;
-    for (int e = tid; e < nab + nsubc; e += TF_ERI_THREADS) {
+    for (int e = tid; e < nab + nsubc; e += TF_ERI_THREADS) {         // host-tabulated per shell pair (DBasis::ct_*)
         const bool bra = e < nab;
-        const int f = bra ? e : e - nab;
-        const int n2 = bra ? qc.ncb : qc.ncd, L2 = bra ? Lb1 : Ld1;
-        const int i1 = f / n2, i2 = f - i1 * n2;
-        const int u = bra ? lmnA[i1] : lmnC[i1], w = bra ? lmnB[i2] : lmnD[i2];
-        const int ux = u & 255, uy = (u >> 8) & 255, uz = (u >> 16) & 255, wx = w & 255, wy = (w >> 8) & 255, wz = (w >> 16) & 255;
-        const int packed = (ux * L2 + wx) | ((uy * L2 + wy) << 8) | ((uz * L2 + wz) << 16) | (((ux + wx) & 1) << 24) | (((uy + wy) & 1) << 25);
-        if (bra) { sIxAB[f] = packed; sScAB[f] = sScale[i1] * sScale[21 + i2]; }
-        else { sIxCD[f] = packed; sScCD[f] = sScale[42 + i1] * sScale[63 + i2]; }
+        const int f = bra ? e : e - nab, g = (bra ? ab.tab_off : cd.tab_off) + f;
+        if (bra) { sIxAB[f] = B.ct_ix[g]; sScAB[f] = B.ct_sc[g]; }
+        else { sIxCD[f] = B.ct_ix[g]; sScCD[f] = B.ct_sc[g]; }
     }
     __syncthreads();
     const int LcLd = Lc1 * Ld1;
