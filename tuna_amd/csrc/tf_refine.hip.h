@@ -28,17 +28,17 @@ inline size_t lds_bytes(int n)
 // One 16 x 16 output tile per wave on the FP64 matrix core: V_MFMA_F64_16X16X4_F64 takes A[i = lane % 16][k = lane / 16] and
 // B[k = lane / 16][j = lane % 16] and leaves D[i = 4 v + lane / 16][j = lane % 16] in accumulator v (checked on gfx950).
 // C = beta D + alpha A B^T (NT) or alpha A B (NN); tile (I, J) of this wave, or nothing if the wave has none.
-template <bool NT>
+template <bool NT, bool TA = false>
 __device__ __forceinline__ void mm_tile(double *C, const double *A, const double *B, double alpha, double beta, const double *D, int np, int ns,
                                         int I, int J, int lane, bool on)
 {
     if (!on) return;
     const int r = lane & 15, q = lane >> 4;
-    const double *ap = A + (16 * I + r) * ns + q;
+    const double *ap = TA ? A + q * ns + 16 * I + r : A + (16 * I + r) * ns + q;         // TA: C = alpha A^T B
     const double *bp = NT ? B + (16 * J + r) * ns + q : B + q * ns + 16 * J + r;
-    const int bstep = NT ? 4 : 4 * ns;
+    const int astep = TA ? 4 * ns : 4, bstep = NT ? 4 : 4 * ns;
     tfr_v4d acc = {0.0, 0.0, 0.0, 0.0};
-    for (int kk = 0; kk < np / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kk], bp[kk * bstep], acc, 0, 0, 0);
+    for (int kk = 0; kk < np / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[kk * astep], bp[kk * bstep], acc, 0, 0, 0);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int idx = (16 * I + 4 * v + q) * ns + 16 * J + r;
@@ -48,9 +48,13 @@ __device__ __forceinline__ void mm_tile(double *C, const double *A, const double
 
 // A: symmetric n x n (global, row-major); X: rows = orthonormal approximate eigenvectors (global, in/out).
 // status[0] = 1: converged (X, lam, wocc written; wocc[i] = 1 for the n_occ lowest), 0: not (X untouched); status[1] = steps taken.
+// Fused form (Fao != nullptr): A = sym(Xo Fao Xo) with the symmetric orthogonaliser Xo = S^-1/2 is formed in LDS first, and after
+// convergence the density P = occ * sym(C_occ C_occ^T), C_occ = Xo x_occ (scf:183-250), is written to Pout -- a whole
+// "diagonalise the Fock matrix and rebuild the density" step of the SCF cycle in one launch.
 __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_occ, const double *__restrict__ A, double *__restrict__ X,
                                                                  double *__restrict__ lam_out, double *__restrict__ wocc_out, int max_steps,
-                                                                 int *__restrict__ status)
+                                                                 int *__restrict__ status, const double *__restrict__ Fao,
+                                                                 const double *__restrict__ Xo, double *__restrict__ Pout, double occ)
 {
     extern __shared__ double sm[];
     const int np = tfr_np(n), ns = tfr_stride(np);
@@ -67,9 +71,24 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
         const int i = e / np, j = e - i * np;
         const bool in = i < n && j < n;
         sX[i * ns + j] = in ? X[(size_t)i * n + j] : ((i == j) ? 1.0 : 0.0);
-        sA[i * ns + j] = in ? 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]) : ((i == j) ? 1.0e6 : 0.0);
+        if (Fao) {
+            sT1[i * ns + j] = in ? Fao[(size_t)i * n + j] : 0.0;
+            sT2[i * ns + j] = in ? Xo[(size_t)i * n + j] : 0.0;
+        } else
+            sA[i * ns + j] = in ? 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]) : ((i == j) ? 1.0e6 : 0.0);
     }
     __syncthreads();
+    if (Fao) {                                                 // A = sym(Xo^T F Xo); the padding stays decoupled
+        mm_tile<false>(sA, sT1, sT2, 1.0, 0.0, sX, np, ns, I, J, lane, on);          // F Xo
+        __syncthreads();
+        mm_tile<false, true>(sT1, sT2, sA, 1.0, 0.0, sX, np, ns, I, J, lane, on);    // Xo^T (F Xo)
+        __syncthreads();
+        for (int e = tid; e < np * np; e += TFR_THREADS) {
+            const int i = e / np, j = e - i * np;
+            sA[i * ns + j] = (i < n && j < n) ? 0.5 * (sT1[i * ns + j] + sT1[j * ns + i]) : ((i == j) ? 1.0e6 : 0.0);
+        }
+        __syncthreads();
+    }
     int steps = 0;
     bool ok = false;
     for (int step = 0; step < max_steps; ++step) {
@@ -130,11 +149,26 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
     if (sFlag) {
         for (int e = tid; e < n * n; e += TFR_THREADS) { const int i = e / n, j = e - i * n; X[e] = sX[i * ns + j]; }
         if (tid < n) { lam_out[tid] = sLam[tid]; wocc_out[tid] = sOcc[tid]; }
+        if (Pout) {                                            // (uniform branch: sFlag and Pout are the same for every thread)
+            // rows of the occupied eigenvectors (others zeroed) -> AO basis: T = Xocc Xo^T; P = occ * sym(T^T T)
+            for (int e = tid; e < np * np; e += TFR_THREADS) {
+                const int i = e / np, j = e - i * np;
+                sT1[i * ns + j] = (i < n && j < n) ? sOcc[i] * sX[i * ns + j] : 0.0;
+                sA[i * ns + j] = (i < n && j < n) ? Xo[(size_t)i * n + j] : 0.0;
+            }
+            __syncthreads();
+            mm_tile<true>(sT2, sT1, sA, 1.0, 0.0, sX, np, ns, I, J, lane, on);
+            __syncthreads();
+            mm_tile<false, true>(sT1, sT2, sT2, occ, 0.0, sX, np, ns, I, J, lane, on);
+            __syncthreads();
+            for (int e = tid; e < n * n; e += TFR_THREADS) { const int i = e / n, j = e - i * n; Pout[e] = 0.5 * (sT1[i * ns + j] + sT1[j * ns + i]); }
+        }
     }
     if (tid == 0) { status[0] = sFlag; status[1] = steps; }
 }
 
-inline bool launch(int n, int n_occ, const double *A, double *X, double *lam, double *wocc, int *status, hipStream_t st, hipError_t *err)
+inline bool launch(int n, int n_occ, const double *A, double *X, double *lam, double *wocc, int *status, hipStream_t st, hipError_t *err,
+                   const double *Fao = nullptr, const double *Xo = nullptr, double *Pout = nullptr, double occ = 2.0)
 {
     static bool attr_set = false;
     if (n < 2 || n > TFR_NMAX) return false;
@@ -142,7 +176,7 @@ inline bool launch(int n, int n_occ, const double *A, double *X, double *lam, do
         (void)hipFuncSetAttribute((const void *)refine_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         attr_set = true;
     }
-    hipLaunchKernelGGL(refine_lds_kernel, dim3(1), dim3(TFR_THREADS), lds_bytes(n), st, n, n_occ, A, X, lam, wocc, 12, status);
+    hipLaunchKernelGGL(refine_lds_kernel, dim3(1), dim3(TFR_THREADS), lds_bytes(n), st, n, n_occ, A, X, lam, wocc, 12, status, Fao, Xo, Pout, occ);
     *err = hipGetLastError();
     return *err == hipSuccess;
 }

@@ -20,6 +20,7 @@
 #include "../../include/tunafock.h"
 #include "tf_jacobi.hip.h"
 #include "tf_refine.hip.h"
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 
@@ -415,6 +416,29 @@ inline int ref_refine_lds(Workspace &w, int n, int n_occ, const double *A, doubl
     return TF_OK;
 }
 
+// n <= 64, fused: A = sym(Xo^T Fao Xo), the refinement and the density P = occ * sym(C_occ C_occ^T) in the same launch
+// (tf_refine.hip.h); nothing else of the "diagonalise and rebuild the density" step is left to launch.
+inline int ref_density_lds(Workspace &w, int n, int n_occ, const double *Fao, const double *Xo, double *Pout, double occ, std::string &msg)
+{
+    if (w.ref_n != n || !w.ref_buf || n > TFR_NMAX) return TF_ELINALG;
+    const size_t nn = (size_t)n * n;
+    double *X = w.ref_buf, *lam = X + 6 * nn, *wocc = lam + n;
+    int *status = reinterpret_cast<int *>(w.d_scal + 62);
+    hipError_t e = hipSuccess;
+    ++w.ref_solves;
+    if (!tfref::launch(n, n_occ, nullptr, X, lam, wocc, status, 0, &e, Fao, Xo, Pout, occ)) {
+        if (e != hipSuccess) { msg = std::string("refinement kernel launch failed: ") + hipGetErrorString(e); return TF_ENODEVICE; }
+        return TF_ELINALG;
+    }
+    int h[2] = {0, 0};
+    TFS_HIP(hipMemcpy(h, status, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    static const bool dbg = getenv("TF_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[tf refine/lds fused] n %d: %s after %d steps\n", n, h[0] ? "converged" : "NOT converged", h[1]);
+    if (!h[0]) { ++w.ref_fallbacks; w.ref_n = 0; return TF_ELINALG; }
+    w.ref_steps += h[1];
+    return TF_OK;
+}
+
 // after a real eigensolve: rows of V (row-major, as eigh() leaves them) become the refinement start
 inline int ref_store(Workspace &w, int n, const double *V, std::string &msg)
 {
@@ -596,8 +620,11 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     double *dC = mat(16), *dW = mat(17), *dPn = mat(18), *scr = mat(19), *dVxc = mat(20), *dCsave = mat(21);
     double *hist = mat(22);
     double *vals = base + (size_t)n_mats * nn, *ework = vals + n, *vals_save = ework + n;
-    auto histF = [&](int k) { return hist + (size_t)(2 * k) * nn; };
-    auto histE = [&](int k) { return hist + (size_t)(2 * k + 1) * nn; };
+    // logical history entry k lives in physical slot slot[k]: trimming the oldest entry renumbers, nothing is copied
+    std::vector<int> slot(max_diis);
+    for (int k = 0; k < max_diis; ++k) slot[k] = k;
+    auto histF = [&](int k) { return hist + (size_t)(2 * slot[k]) * nn; };
+    auto histE = [&](int k) { return hist + (size_t)(2 * slot[k] + 1) * nn; };
 
     TFS_HIP(hipMemcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
     TFS_HIP(hipMemcpy(dT, T, nn * sizeof(double), hipMemcpyHostToDevice));
@@ -642,7 +669,16 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     const bool refining = !no_refine && n >= 2 && n_occ > 0 && n_occ < n;
     bool orbitals_current = false, orbitals_final = false;
     w.ref_n = 0;
+    static const bool no_fused = getenv("TF_REFINE_UNFUSED") != nullptr;
     auto diag_density = [&](const double *Fao, double *Pout) -> int {
+        if (refining && !no_fused && n <= TFR_NMAX && w.ref_n == n && !getenv("TF_REFINE_CHECK")) {
+            const int te = span_begin(1);
+            std::string rmsg;
+            const int rr = ref_density_lds(w, n, n_occ, Fao, dX, Pout, 2.0, rmsg);
+            span_end(te);
+            if (rr == TF_OK) { orbitals_current = false; return TF_OK; }
+            if (rr != TF_ELINALG) { msg = rmsg; return rr; }
+        }
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, Fao, 0.0, t1));     // X^T F
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));     // (X^T F) X
         hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
@@ -727,13 +763,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, t2, 0.0, t1));         // X^T e
         // push into the history (trim to max_diis, scf:943-946)
         if (n_hist == max_diis) {
-            double *f0 = histF(0), *e0 = histE(0);
-            (void)f0; (void)e0;
-            // rotate: slot k <- slot k+1 by pointer arithmetic is not possible in one pool; copy down
-            for (int k = 0; k + 1 < n_hist; ++k) {
-                TFS_HIP(hipMemcpyAsync(histF(k), histF(k + 1), nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
-                TFS_HIP(hipMemcpyAsync(histE(k), histE(k + 1), nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
-            }
+            std::rotate(slot.begin(), slot.begin() + 1, slot.end());     // the oldest entry's slot becomes the newest
             for (int r = 0; r + 1 < n_hist; ++r)
                 for (int c = 0; c + 1 < n_hist; ++c) B[r * max_diis + c] = B[(r + 1) * max_diis + c + 1];
             --n_hist;
@@ -904,8 +934,10 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     double *dJt = mat(27);                                       // J_alpha + J_beta; mat(28), mat(29): orthogonaliser scratch
     double *hist = mat(n_fixed);
     double *vals = base + (size_t)n_mats * nn, *ework = vals + n, *vals_save[2] = {ework + n, ework + 2 * (size_t)n};
-    auto histF = [&](int k, int s) { return hist + (size_t)(4 * k + s) * nn; };
-    auto histE = [&](int k, int s) { return hist + (size_t)(4 * k + 2 + s) * nn; };
+    std::vector<int> slot(max_diis);                             // logical history entry -> physical slot (see run_rhf)
+    for (int k = 0; k < max_diis; ++k) slot[k] = k;
+    auto histF = [&](int k, int s) { return hist + (size_t)(4 * slot[k] + s) * nn; };
+    auto histE = [&](int k, int s) { return hist + (size_t)(4 * slot[k] + 2 + s) * nn; };
     const int n_occ[2] = {n_alpha, n_beta};
 
     TFS_HIP(hipMemcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
@@ -958,6 +990,15 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         if (no <= 0) { TFS_HIP(hipMemsetAsync(Pout, 0, nn * sizeof(double), 0)); return TF_OK; }
         SpinSlot slot(w, sp == 1);
         const bool refining = !no_refine && n >= 2 && no < n;
+        static const bool no_fused = getenv("TF_REFINE_UNFUSED") != nullptr;
+        if (refining && !no_fused && n <= TFR_NMAX && w.ref_n == n) {
+            const int te0 = span_begin(1);
+            std::string rmsg;
+            const int rr = ref_density_lds(w, n, no, Fao, dX, Pout, 1.0, rmsg);
+            span_end(te0);
+            if (rr == TF_OK) return TF_OK;
+            if (rr != TF_ELINALG) { msg = rmsg; return rr; }
+        }
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, Fao, 0.0, t1));
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
         hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
@@ -1005,8 +1046,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         span_end(tf);
         hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dJ[0], 1.0, dJ[1], dJt, (int)nn);
         if (n_hist == max_diis) {                                   // trim the history to max_diis entries (scf:1216-1219)
-            for (int k = 0; k + 1 < n_hist; ++k)
-                TFS_HIP(hipMemcpyAsync(histF(k, 0), histF(k + 1, 0), 4 * nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            std::rotate(slot.begin(), slot.begin() + 1, slot.end());
             for (int r = 0; r + 1 < n_hist; ++r)
                 for (int c = 0; c + 1 < n_hist; ++c) B[r * max_diis + c] = B[(r + 1) * max_diis + c + 1];
             --n_hist;
