@@ -45,6 +45,7 @@ struct tf_ctx {
     int spherical = 1, N = 0, ld = 0;
     long long n_rows = 0;
     double *d_eri = nullptr;
+    size_t eri_cap = 0;                  // bytes allocated behind d_eri: kept across builds (freeing and reallocating 27 GB costs ~1.4 s)
     int2 *d_row_ij = nullptr;
     int *d_rowmap = nullptr;
     std::vector<int> my_pairs;          // bra shell pairs owned by this rank
@@ -127,7 +128,7 @@ static int upload(tf_ctx *ctx, const std::vector<T> &h, T **d, bool track = true
 
 static void free_eri(tf_ctx *ctx)
 {
-    for (void *p : {(void *)ctx->d_eri, (void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
+    for (void *p : {(void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
                     (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_Psym,
                     (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ, (void *)ctx->d_Jt, (void *)ctx->d_D})
         if (p) (void)hipFree(p);
@@ -136,7 +137,7 @@ static void free_eri(tf_ctx *ctx)
             if (p) (void)hipFree(p);
         t = tf_ctx::JKTables();
     }
-    ctx->d_eri = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
+    ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
     ctx->d_Ppad = nullptr; ctx->d_J = nullptr; ctx->d_K = nullptr; ctx->d_P = nullptr;
     ctx->d_rowoff = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
     ctx->d_ypart = nullptr; ctx->d_DI = nullptr; ctx->d_DJ = nullptr; ctx->d_Jt = nullptr; ctx->d_D = nullptr;
@@ -262,6 +263,7 @@ void tf_destroy(tf_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     free_eri(ctx);
+    if (ctx->d_eri) { (void)hipFree(ctx->d_eri); ctx->d_eri = nullptr; ctx->eri_cap = 0; }
     free_basis(ctx);
     tfscf::release(ctx->scf);
     tfdft::release(ctx->grid);
@@ -581,7 +583,19 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     const long long row_len = (long long)N * ld;
     if (!packed) ctx->n_elems = ctx->n_rows * row_len;
     if (ctx->n_rows > 0x7fffffffLL) TF_FAIL(ctx, TF_EINVAL, "too many tensor rows for this build");
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_eri, std::max<size_t>(1, (size_t)ctx->n_elems * sizeof(double))));
+    {
+        // the tensor buffer is kept across builds (geometry scans rebuild a tensor of the same size); it is replaced when it is
+        // too small or more than twice too large
+        const size_t need = std::max<size_t>(1, (size_t)ctx->n_elems * sizeof(double));
+        if (ctx->d_eri && (ctx->eri_cap < need || ctx->eri_cap > 2 * need + (64u << 20))) {
+            (void)hipFree(ctx->d_eri);
+            ctx->d_eri = nullptr; ctx->eri_cap = 0;
+        }
+        if (!ctx->d_eri) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_eri, need));
+            ctx->eri_cap = need;
+        }
+    }
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
     if (packed) {
         if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = build_jk_tables(TF_JKP_JBB, ctx->jkt[0])) ||

@@ -32,6 +32,7 @@ struct Workspace {
     double *pool = nullptr;      // all N x N device matrices live in one allocation
     size_t pool_doubles = 0;
     double *d_scal = nullptr;    // small device scalar array
+    double *d_part = nullptr;    // [256][8] block partials of the two-stage reductions
     rocblas_int *d_info = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double *jac_scratch = nullptr;   // eigenvector scratch of the Jacobi solver when it does not fit LDS
@@ -55,6 +56,7 @@ inline void release(Workspace &w)
 {
     if (w.pool) (void)hipFree(w.pool);
     if (w.d_scal) (void)hipFree(w.d_scal);
+    if (w.d_part) (void)hipFree(w.d_part);
     if (w.d_info) (void)hipFree(w.d_info);
     if (w.blas) (void)rocblas_destroy_handle(w.blas);
     if (w.ev0) (void)hipEventDestroy(w.ev0);
@@ -83,6 +85,7 @@ inline int ensure(Workspace &w, int n, int n_mats, std::string &msg)
     if (!w.blas) {
         TFS_BLAS(rocblas_create_handle(&w.blas));
         TFS_HIP(hipMalloc((void **)&w.d_scal, 128 * sizeof(double)));
+        TFS_HIP(hipMalloc((void **)&w.d_part, 256 * 8 * sizeof(double)));
         TFS_HIP(hipMalloc((void **)&w.d_info, sizeof(rocblas_int)));
         TFS_HIP(hipEventCreate(&w.ev0));
         TFS_HIP(hipEventCreate(&w.ev1));
@@ -167,6 +170,68 @@ __global__ void k_multi_dot(const double *__restrict__ x, Ptr8 a, int m, int nn,
     if (threadIdx.x < m) out[threadIdx.x] = sm[threadIdx.x][0];
 }
 
+// The same in two stages for long vectors (one block over 160 000 elements took 1.1 ms at N = 400, twice per SCF iteration):
+// block b leaves its partial sums in part[b][0..7]; k_multi_dot_fin adds the blocks in index order (fixed: reproducible).
+__global__ __launch_bounds__(256) void k_multi_dot_part(const double *__restrict__ x, Ptr8 a, int m, int nn, double *__restrict__ part)
+{
+    __shared__ double sm[8][256];
+    double acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+    const int per = (nn + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * per, e1 = min(nn, e0 + per);
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+        const double xv = x[e];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < m) acc[k] += xv * a.p[k][e];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sm[k][threadIdx.x] += sm[k][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) part[blockIdx.x * 8 + threadIdx.x] = sm[threadIdx.x][0];
+}
+__global__ void k_multi_dot_fin(const double *__restrict__ part, int nblk, int m, double *__restrict__ out)
+{
+    const int k = threadIdx.x;
+    if (k >= m) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[b * 8 + k];
+    out[k] = s;
+}
+
+// res[0] = max |a-b|, res[1] = sum (a-b)^2 in two stages (as above)
+__global__ __launch_bounds__(256) void k_delta_norms_part(const double *__restrict__ a, const double *__restrict__ b, int nn, double *__restrict__ part)
+{
+    __shared__ double smax[256], ssum[256];
+    double mx = 0.0, sm = 0.0;
+    const int per = (nn + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * per, e1 = min(nn, e0 + per);
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+        const double d = a[e] - b[e];
+        mx = fmax(mx, fabs(d));
+        sm += d * d;
+    }
+    smax[threadIdx.x] = mx; ssum[threadIdx.x] = sm;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]); ssum[threadIdx.x] += ssum[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x * 8] = smax[0]; part[blockIdx.x * 8 + 1] = ssum[0]; }
+}
+__global__ void k_delta_norms_fin(const double *__restrict__ part, int nblk, double *__restrict__ res)
+{
+    if (threadIdx.x != 0) return;
+    double mx = 0.0, sm = 0.0;
+    for (int b = 0; b < nblk; ++b) { mx = fmax(mx, part[b * 8]); sm += part[b * 8 + 1]; }
+    res[0] = mx; res[1] = sm;
+}
+
 // res[0] = max |a-b|, res[1] = sum (a-b)^2       (scf:285-286), single block
 __global__ void k_delta_norms(const double *__restrict__ a, const double *__restrict__ b, int nn, double *__restrict__ res)
 {
@@ -206,6 +271,21 @@ __global__ void k_mulliken(const double *__restrict__ P, const double *__restric
 }
 
 // row-major C = alpha * op(A) * op(B) + beta * C, all n x n (k = inner dimension, default n)
+inline void launch_multi_dot(Workspace &w, const double *x, const Ptr8 &a, int m, int nn, double *out)
+{
+    if (nn <= 8192) { hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, x, a, m, nn, out); return; }
+    const int nblk = std::min(256, (nn + 2047) / 2048);
+    hipLaunchKernelGGL(k_multi_dot_part, dim3(nblk), dim3(256), 0, 0, x, a, m, nn, w.d_part);
+    hipLaunchKernelGGL(k_multi_dot_fin, dim3(1), dim3(64), 0, 0, w.d_part, nblk, m, out);
+}
+inline void launch_delta_norms(Workspace &w, const double *a, const double *b, int nn, double *res)
+{
+    if (nn <= 8192) { hipLaunchKernelGGL(k_delta_norms, dim3(1), dim3(256), 0, 0, a, b, nn, res); return; }
+    const int nblk = std::min(256, (nn + 2047) / 2048);
+    hipLaunchKernelGGL(k_delta_norms_part, dim3(nblk), dim3(256), 0, 0, a, b, nn, w.d_part);
+    hipLaunchKernelGGL(k_delta_norms_fin, dim3(1), dim3(64), 0, 0, w.d_part, nblk, res);
+}
+
 inline rocblas_status gemm_rm(rocblas_handle h, bool tA, bool tB, int n, double alpha, const double *A, const double *B, double beta,
                               double *C)
 {
@@ -777,7 +857,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             for (int k = 0; k < 8; ++k) { a.p[k] = histE(0); a.c[k] = 0.0; }
             for (int k = 0; k < n_hist; ++k) a.p[k] = histE(k);
             double hd[8];
-            hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, histE(n_hist - 1), a, n_hist, (int)nn, w.d_scal + 48);
+            launch_multi_dot(w, histE(n_hist - 1), a, n_hist, (int)nn, w.d_scal + 48);
             TFS_HIP(hipMemcpy(hd, w.d_scal + 48, n_hist * sizeof(double), hipMemcpyDeviceToHost));
             for (int k = 0; k < n_hist; ++k) {
                 // the reference stores the error twice (alpha and beta copies, scf:934), hence the factor 2
@@ -795,7 +875,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             for (int k = 0; k < 8; ++k) { a.p[k] = dT; a.c[k] = 0.0; }
             a.p[0] = dT; a.p[1] = dV; a.p[2] = dFx; a.p[3] = dJ; a.p[4] = dK;
             double hd[5];
-            hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, dPn, a, 5, (int)nn, w.d_scal + 56);
+            launch_multi_dot(w, dPn, a, 5, (int)nn, w.d_scal + 56);
             TFS_HIP(hipMemcpy(hd, w.d_scal + 56, 5 * sizeof(double), hipMemcpyDeviceToHost));
             eT = hd[0]; eV = hd[1]; eF = hd[2]; eJ = hd[3]; eK = hd[4];
         }
@@ -853,7 +933,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         }
         hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, damp, dPold, 1.0 - damp, dPbd, dP, (int)nn);
         // changes and convergence (scf:261-333)
-        hipLaunchKernelGGL(k_delta_norms, dim3(1), dim3(256), 0, 0, dP, dPold, (int)nn, w.d_scal + 16);
+        launch_delta_norms(w, dP, dPold, (int)nn, w.d_scal + 16);
         double res[2];
         TFS_HIP(hipMemcpy(res, w.d_scal + 16, 2 * sizeof(double), hipMemcpyDeviceToHost));
         const double dE = E - E_old, maxDP = res[0], rmsDP = std::sqrt(res[1] / (double)nn);
@@ -1071,7 +1151,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                 Ptr8 a;
                 for (int k = 0; k < 8; ++k) { a.p[k] = histE(0, sp); a.c[k] = 0.0; }
                 for (int k = 0; k < n_hist; ++k) a.p[k] = histE(k, sp);
-                hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, histE(n_hist - 1, sp), a, n_hist, (int)nn, w.d_scal + 64 + 8 * sp);
+                launch_multi_dot(w, histE(n_hist - 1, sp), a, n_hist, (int)nn, w.d_scal + 64 + 8 * sp);
             }
             TFS_HIP(hipMemcpy(hd, w.d_scal + 64, 16 * sizeof(double), hipMemcpyDeviceToHost));
             for (int k = 0; k < n_hist; ++k) B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = hd[k] + hd[8 + k];
@@ -1095,7 +1175,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                 Ptr8 a;
                 for (int k = 0; k < 8; ++k) { a.p[k] = dT; a.c[k] = 0.0; }
                 a.p[0] = dT; a.p[1] = dV; a.p[2] = dFx; a.p[3] = dJt; a.p[4] = dK[sp];
-                hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, dPn[sp], a, 5, (int)nn, w.d_scal + 80 + 6 * sp);
+                launch_multi_dot(w, dPn[sp], a, 5, (int)nn, w.d_scal + 80 + 6 * sp);
             }
             TFS_HIP(hipMemcpy(hd, w.d_scal + 80, 12 * sizeof(double), hipMemcpyDeviceToHost));
             comps[0] = hd[0] + hd[6]; comps[1] = hd[1] + hd[7]; comps[5] = hd[2] + hd[8];
@@ -1154,7 +1234,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         for (int sp = 0; sp < 2; ++sp)
             hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, damp[sp], dPold[sp], 1.0 - damp[sp], dPn[sp], dP[sp], (int)nn);
         hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dP[0], 1.0, dP[1], dPt, (int)nn);
-        hipLaunchKernelGGL(k_delta_norms, dim3(1), dim3(256), 0, 0, dPt, dPtold, (int)nn, w.d_scal + 16);
+        launch_delta_norms(w, dPt, dPtold, (int)nn, w.d_scal + 16);
         double res[2];
         TFS_HIP(hipMemcpy(res, w.d_scal + 16, 2 * sizeof(double), hipMemcpyDeviceToHost));
         const double dE = E - E_old, maxDP = res[0], rmsDP = std::sqrt(res[1] / (double)nn);
