@@ -142,7 +142,7 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
         __syncthreads();
         { double *t = sX; sX = sT2; sT2 = t; }
         ++steps;
-        ok = eov < 1e-9 && emax < 1e-3;
+        ok = eov < 1e-9 && emax < 0.1;       // rotations inside the occupied or the virtual space leave the projector alone
     }
     if (tid == 0) sFlag = ok ? 1 : 0;
     __syncthreads();

@@ -453,7 +453,7 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, E, X, 1.0, Xn));         // X + E^T X   (rows)
         std::swap(X, Xn);
         w.ref_steps += 1;
-        ok = eov < 1e-9 && emax < 1e-3;
+        ok = eov < 1e-9 && emax < 0.1;       // rotations inside the occupied or the virtual space leave the projector alone
     }
     if (ok) {
         if ((rc = orthonormalise())) return rc;
