@@ -92,12 +92,14 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
     int steps = 0;
     bool ok = false;
     for (int step = 0; step < max_steps; ++step) {
-        // X <- (3/2 I - 1/2 X X^T) X
-        mm_tile<true>(sT1, sX, sX, 1.0, 0.0, sX, np, ns, I, J, lane, on);
-        __syncthreads();
-        mm_tile<false>(sT2, sT1, sX, -0.5, 1.5, sX, np, ns, I, J, lane, on);
-        __syncthreads();
-        { double *t = sX; sX = sT2; sT2 = t; }
+        // X <- (3/2 I - 1/2 X X^T) X   (not before the first step: the stored vectors are orthonormal, every solve closes with this)
+        if (step > 0) {
+            mm_tile<true>(sT1, sX, sX, 1.0, 0.0, sX, np, ns, I, J, lane, on);
+            __syncthreads();
+            mm_tile<false>(sT2, sT1, sX, -0.5, 1.5, sX, np, ns, I, J, lane, on);
+            __syncthreads();
+            { double *t = sX; sX = sT2; sT2 = t; }
+        }
         if (ok) break;                                         // that was the closing orthonormalisation
         // S = X A X^T
         mm_tile<false>(sT1, sX, sA, 1.0, 0.0, sX, np, ns, I, J, lane, on);

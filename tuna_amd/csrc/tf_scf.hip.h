@@ -437,7 +437,7 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
     int rc = TF_OK;
     bool ok = false;
     for (int step = 0; step < 16 && !ok; ++step) {
-        if ((rc = orthonormalise())) return rc;
+        if (step > 0 && (rc = orthonormalise())) return rc;                    // (the stored vectors are orthonormal: every solve closes with this step)
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, X, A, 0.0, Y));         // rows A x_i
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Y, X, 0.0, S));          // S = X^T A X
         hipLaunchKernelGGL(k_ref_diag, dim3(1), dim3(1024), 0, 0, S, n, n_occ, lam, wocc, w.d_scal + 40);
