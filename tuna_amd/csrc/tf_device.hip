@@ -1074,7 +1074,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             for (size_t o0 = 0; o0 < outs.size(); o0 += 65535) {
                 const unsigned ny = (unsigned)std::min<size_t>(65535, outs.size() - o0);
                 if (packed)
-                    hipLaunchKernelGGL(xform_bra_store_packed, dim3(std::max(1u, gx / 2), ny), dim3(256), 0, 0, d_T2, ctx->d_eri,
+                    hipLaunchKernelGGL(xform_bra_store_packed, dim3((unsigned)((N + TF_XBP_KR - 1) / TF_XBP_KR), ny), dim3(64 * TF_XBP_KR), 0, 0, d_T2, ctx->d_eri,
                                        reinterpret_cast<const OutRowP *>(d_out + o0), row_len, ld, ctx->d_csr_ptr, ctx->d_csr_idx,
                                        ctx->d_csr_val);
                 else

@@ -574,18 +574,6 @@ __global__ void jk_packed_final_kernel(const double *__restrict__ D, const doubl
     J[e] = s;
 }
 
-// padded index -> (k, l); l > k marks a pad slot
-__device__ __forceinline__ void unpair_padded(long long x, int &k, int &l)
-{
-    const double c = 0.5 * (TF_TRI_PAD + 1);                 // tri_off(k) ~ k^2/2 + c k
-    long long kk = (long long)(sqrt(2.0 * (double)x + c * c) - c);
-    if (kk < 0) kk = 0;
-    while (tri_off(kk) > x) --kk;
-    while (tri_off(kk + 1) <= x) ++kk;
-    k = (int)kk;
-    l = (int)(x - tri_off(kk));
-}
-
 struct OutRowP {
     int i, j;              // output AO indices (i >= j)
     int cartA, cartB;      // first Cartesian AO of the two bra shells
@@ -594,29 +582,46 @@ struct OutRowP {
     long long dst_off;     // offset of the packed row in the stored tensor
 };
 
-// packed tensor row (i,j) = bra transform of the ket-transformed slab, keeping only pairs (k >= l) up to (i,j); pad slots <- 0
-__global__ void xform_bra_store_packed(const double *__restrict__ in, double *__restrict__ eri, const OutRowP *__restrict__ rows,
-                                       long long row_len, int ld, const int *__restrict__ ptr, const int *__restrict__ idx,
-                                       const double *__restrict__ val)
+// packed tensor row (i,j) = bra transform of the ket-transformed slab, keeping only pairs (k >= l) up to (i,j); pad slots <- 0.
+// grid (ceil(N / 4), rows): a block takes four triangle rows k (one per wave), lanes run over l -- the padded index is
+// tri_off(k) + l, no index inversion per element; the (<= 6 x 6) Cartesian -> spherical terms of the two bra AOs are staged in LDS
+// once per block (nested sums in the order of xform_bra_store: the same rounding).
+#define TF_XBP_KR 4
+__global__ __launch_bounds__(64 * TF_XBP_KR) void xform_bra_store_packed(const double *__restrict__ in, double *__restrict__ eri,
+                                                                       const OutRowP *__restrict__ rows, long long row_len, int ld,
+                                                                       const int *__restrict__ ptr, const int *__restrict__ idx,
+                                                                       const double *__restrict__ val)
 {
+    __shared__ double sValA[32], sValB[32];
+    __shared__ long long sOffA[32], sOffB[32];
     const OutRowP R = rows[blockIdx.y];
-    const double *__restrict__ src = in + R.slab_off * row_len;
-    double *__restrict__ dst = eri + R.dst_off;
-    const long long len = packed_row_len(R.i, R.j);
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < len; q += (long long)gridDim.x * blockDim.x) {
-        int k, l;
-        unpair_padded(q, k, l);
+    const int k0 = TF_XBP_KR * blockIdx.x;
+    if (k0 > R.i) return;
+    const int pa = ptr[R.i], na = min(32, ptr[R.i + 1] - pa), pb = ptr[R.j], nb = min(32, ptr[R.j + 1] - pb);
+    if (threadIdx.x < na) { sValA[threadIdx.x] = val[pa + threadIdx.x]; sOffA[threadIdx.x] = (long long)(idx[pa + threadIdx.x] - R.cartA) * R.ncb * row_len; }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + nb) {
+        const int t = threadIdx.x - 64;
+        sValB[t] = val[pb + t]; sOffB[t] = (long long)(idx[pb + t] - R.cartB) * row_len;
+    }
+    __syncthreads();
+    const int k = k0 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k > R.i) return;
+    const long long tk = tri_off(k);
+    // stored slots of triangle row k in this tensor row: the whole padded row for k < i, up to the row's padded end for k == i
+    const int lenk = (k < R.i) ? (int)(tri_off(k + 1) - tk) : (int)(packed_row_len(R.i, R.j) - tk);
+    const int lmax = (k < R.i) ? k : R.j;                           // pairs (k, l <= lmax) exist; beyond: pad slots
+    const double *__restrict__ src = in + R.slab_off * row_len + (long long)k * ld;
+    double *__restrict__ dst = eri + R.dst_off + tk;
+    for (int l = lane; l < lenk; l += 64) {
         double s = 0.0;
-        if (l <= k && (k < R.i || l <= R.j)) {
-            const long long x = (long long)k * ld + l;
-            for (int qa = ptr[R.i]; qa < ptr[R.i + 1]; ++qa) {
-                const long long ra = (long long)(idx[qa] - R.cartA) * R.ncb;
+        if (l <= lmax) {
+            for (int qa = 0; qa < na; ++qa) {
                 double t = 0.0;
-                for (int qb = ptr[R.j]; qb < ptr[R.j + 1]; ++qb) t += val[qb] * src[(ra + (idx[qb] - R.cartB)) * row_len + x];
-                s += val[qa] * t;
+                for (int qb = 0; qb < nb; ++qb) t += sValB[qb] * src[sOffA[qa] + sOffB[qb] + l];
+                s += sValA[qa] * t;
             }
         }
-        dst[q] = s;
+        dst[l] = s;
     }
 }
 
