@@ -223,3 +223,20 @@ def test_packed_and_rows_layouts_agree(engine):
         assert np.abs(a[q] - b[q]).max() < 1e-11 * scale
     assert np.abs(b[3][0] - b[1]).max() < 1e-11 * scale and np.abs(b[4][0] - b[2]).max() < 1e-11 * scale   # fused pass = single pass
     assert b[5] < 0.30 * a[5]                                         # ~N^4 bytes (+ cache-line padding: 11 % at N = 200) against 4 N^4
+
+
+def test_rebuilding_reuses_the_tensor_buffer(engine, small):
+    """The tensor buffer is kept across builds (tf_build_eri): a larger basis, then a smaller one in the same buffer, then the
+    larger one again -- every build is complete (no stale values), rebuilds are bitwise identical."""
+    aos_big, aos_small = make_system("n2_ccpvdz")[2], make_system("n2_sto3g")[2]
+    rng = np.random.default_rng(5)
+    nb = engine.set_basis(aos_big).build_eri(True).N
+    idx = rng.integers(0, nb, size=(4000, 4)).astype(np.int32)
+    first = engine.sample_eri(idx)
+    bytes_big = engine.eri_storage()["bytes"]
+    engine.set_basis(aos_small).build_eri(True)
+    assert engine.eri_storage()["bytes"] < bytes_big
+    engine.build_eri(spherical=False)                                 # (the golden tensor of this system is Cartesian)
+    assert np.abs(engine.copy_eri() - small["n2_sto3g"]["ERI"]).max() < TOL_INT
+    engine.set_basis(aos_big).build_eri(True)
+    assert np.array_equal(engine.sample_eri(idx), first)

@@ -153,3 +153,34 @@ def test_integration_grid_matches_reference(dft_golden, tag):
     np.testing.assert_allclose(wts.reshape(-1)[pick], g["w_pick"], rtol=1e-12, atol=1e-300)
     if tag.startswith("c4"):
         assert info["n_points"] == 88536
+
+
+def test_packed_index_mirror_matches_the_library():
+    """tuna_amd.distributed.packed_tri_offset / packed_row_length against the layout constants of the library (tf_packed_pad):
+    triangle rows and tensor rows start at multiples of the alignment unit, one 128-byte cache line."""
+    from tuna_amd import distributed as tdist
+    pad = tdist.packed_pad()
+    assert pad == 16
+    k = np.arange(0, 300)
+    off = tdist.packed_tri_offset(k)
+    assert off[0] == 0 and np.all(off % pad == 0)
+    assert np.all(np.diff(off) == ((k[:-1] + 1 + pad - 1) // pad) * pad)          # row k holds k + 1 pairs, rounded up to the unit
+    i, j = 37, 11
+    assert tdist.packed_row_length(i, j) == ((off[i] + j + 1 + pad - 1) // pad) * pad
+    assert np.array_equal(tdist.packed_tri_offset(k, 2), 2 * (k >> 1) * ((k >> 1) + 1) + np.where(k & 1, k + 1, 0))
+
+
+def test_host_blas_pool_is_capped():
+    """The package caps NumPy's BLAS pool on import (a 256-thread OpenBLAS pool spinning inside a 16-CPU quota gets the whole
+    process throttled, HIP runtime threads included: tuna_amd/__init__.py)."""
+    import tuna_amd
+    from threadpoolctl import threadpool_info
+    assert tuna_amd.cpu_quota() >= 1
+    tuna_amd.limit_host_threads()
+    import scipy.linalg  # noqa: F401  (SciPy's own OpenBLAS: covered whether it was loaded before or after the cap)
+    tuna_amd.limit_host_threads()
+    if os.environ.get("TUNA_AMD_HOST_BLAS_THREADS") is None:
+        assert all(p["num_threads"] <= 4 for p in threadpool_info() if p.get("user_api") == "blas")
+    tuna_amd.limit_host_threads(2)
+    assert all(p["num_threads"] <= 2 for p in threadpool_info() if p.get("user_api") == "blas")
+    tuna_amd.limit_host_threads()

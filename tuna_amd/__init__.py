@@ -38,6 +38,8 @@ def limit_host_threads(n: int | None = None):
         n = int(env) if env is not None else min(4, cpu_quota())
     if n <= 0:
         return None
+    # BLAS libraries loaded later (SciPy ships its own OpenBLAS) read their pool size from the environment when they start
+    _os.environ.setdefault("OPENBLAS_NUM_THREADS", str(n))
     try:
         import numpy  # noqa: F401  (the BLAS library has to be loaded before threadpoolctl can find it)
         from threadpoolctl import threadpool_limits
