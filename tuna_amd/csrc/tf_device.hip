@@ -86,6 +86,8 @@ struct tf_ctx {
     size_t cfact_lds_set = 0;                // dynamic LDS limit requested for eri_cfact_kernel
     tfk::LRec *d_lrec = nullptr;             // per-(La,Lb|Lc,Ld) records and entry index words of eri_cfact_kernel (per build)
     unsigned short *d_tup = nullptr;
+    double *d_gtab = nullptr;                // global-memory tables of the top angular momenta (eri_cfact_kernel<true, true>)
+    size_t gtab_bytes = 0;
     double *scr[3] = {nullptr, nullptr, nullptr};
     size_t scr_bytes[3] = {0, 0, 0};
 };
@@ -274,6 +276,7 @@ void tf_destroy(tf_ctx *ctx)
         if (ctx->scr[k]) (void)hipFree(ctx->scr[k]);
     if (ctx->d_lrec) (void)hipFree(ctx->d_lrec);
     if (ctx->d_tup) (void)hipFree(ctx->d_tup);
+    if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
     delete ctx;
 }
 
@@ -650,11 +653,12 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     auto pair_cost = [&](int p) {                                  // primitive pairs x components: what a quartet with this pair costs
         return (long long)bs.pairs[p].npp * bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
     };
-    // groups of shell pairs: by La + Lb (0-1, 2-3, 4-5, 6+) and by contracted / uncontracted
-    constexpr int NGRP = 8;
-    auto lp_group = [](int lp) { return lp <= 1 ? 0 : (lp <= 3 ? 1 : (lp <= 5 ? 2 : 3)); };
+    // groups of shell pairs: by La + Lb (0-1, 2-3, 4-5, 6-7, 8, 9, 10: the table sizes grow with the fourth power of L, and only the
+    // very top -- (hh|hh), (hh|gh), ... -- exceeds LDS and falls back to the component-per-lane kernel) and by contracted / uncontracted
+    constexpr int NLPG = 7, NGRP = 2 * NLPG;
+    auto lp_group = [](int lp) { return lp <= 1 ? 0 : (lp <= 3 ? 1 : (lp <= 5 ? 2 : (lp <= 7 ? 3 : std::min(lp - 4, 6)))); };
     auto pair_group = [&](int p) { return 2 * lp_group(bs.pairs[p].La + bs.pairs[p].Lb) + (bs.pairs[p].npp > 1 ? 1 : 0); };
-    int kets_goff[NGRP + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int kets_goff[NGRP + 1] = {};
     int *d_kets = nullptr, *d_kets_all = nullptr;
     std::vector<int> kets_all_host;                              // same order as d_kets_all
     if ((rc = upload(ctx, ket_sorted, &d_kets, false))) return rc;
@@ -836,7 +840,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     };
     // LDS carve-out of the launch (bra group gb, ket group gk), from the largest angular momenta / contraction depths of the groups
     CFCaps gcaps[NGRP][NGRP];
-    bool gcaps_fit[NGRP][NGRP];
+    bool gcaps_fit[NGRP][NGRP], gcaps_gtab[NGRP][NGRP];
     auto make_caps = [&]() {
         GroupStat gs[NGRP];
         for (int g = 0; g < NGRP; ++g) gs[g] = group_stat(kets_all_host.data() + kets_goff[g], (size_t)(kets_goff[g + 1] - kets_goff[g]));
@@ -867,7 +871,27 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 c.dbg_npq_lo = 0; c.dbg_npq_hi = 0x7fffffff;
                 if (const char *e = getenv("TF_ERI_DBG_NPQ")) (void)sscanf(e, "%d:%d", &c.dbg_npq_lo, &c.dbg_npq_hi);
                 gcaps[gb][gk] = c;
-                gcaps_fit[gb][gk] = (size_t)o * sizeof(double) <= 160 * 1024 - 256;     // (hh|hh)-sized tables do not fit LDS
+                gcaps_fit[gb][gk] = (size_t)o * sizeof(double) <= 160 * 1024 - 256;
+                gcaps_gtab[gb][gk] = false;
+                if (!gcaps_fit[gb][gk] && !deep) {
+                    // (hh|hh)-sized tables: G, X and Z of a workgroup go to global memory, everything else stays in LDS
+                    CFCaps d = c;
+                    int q = 0;
+                    d.offR = q; q += d.capR;
+                    d.offPref = q; q += TF_ERI_THREADS;
+                    d.offPQ = q; q += TF_ERI_THREADS;
+                    d.offPP = q; q += TF_ERI_THREADS;
+                    d.offTupG = q; q += (gsz + 3) / 4;
+                    d.offTupXZ = q; q += (xz + 3) / 4;
+                    d.offEab = q; q += d.capEab;
+                    d.offEcd = q; q += d.capEcd;
+                    d.offRed = q; q += TF_ERI_THREADS;
+                    d.lds_doubles = q;
+                    d.capG = gsz; d.capXZ = xz;
+                    d.offG = 0; d.offX = gsz; d.offZ = gsz + xz;
+                    d.gtab_doubles = gsz + 2 * xz;
+                    if ((size_t)q * sizeof(double) <= 160 * 1024 - 256) { gcaps[gb][gk] = d; gcaps_fit[gb][gk] = true; gcaps_gtab[gb][gk] = true; }
+                }
             }
     };
     // per (La, Lb | Lc, Ld): table sizes, index words of the table entries, batch capacity under the caps of its launch
@@ -965,9 +989,23 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             if (bytes > 64 * 1024 && !ctx->cfact_lds_set) {
                 HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
                 HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
                 ctx->cfact_lds_set = 160 * 1024;
             }
-            if (((gb | gk) & 1) == 0)                            // both groups uncontracted: one primitive quartet per shell quartet
+            if (gcaps_gtab[gb][gk]) {
+                const size_t need = (size_t)nk * (b1 - b0) * (size_t)c.gtab_doubles * sizeof(double);
+                if (need > ctx->gtab_bytes) {
+                    HIPCHK(ctx, hipDeviceSynchronize());           // (earlier launches of this build may still use the old block)
+                    if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
+                    ctx->d_gtab = nullptr; ctx->gtab_bytes = 0;
+                    HIPCHK(ctx, hipMalloc((void **)&ctx->d_gtab, need));
+                    ctx->gtab_bytes = need;
+                }
+                // launches that share the block must not overlap: they all go to one stream
+                hipLaunchKernelGGL((eri_cfact_kernel<true, true>), dim3((unsigned)nk, (unsigned)(b1 - b0)), dim3(TF_ERI_THREADS), bytes, streams[0], ctx->db, c,
+                                   d_bra + b0, d_braoff + b0, d_kets_all + kets_goff[gk], Nc, d_C, ctx->d_gtab);
+                load[qi] -= l.cost; load[0] += l.cost;
+            } else if (((gb | gk) & 1) == 0)                     // both groups uncontracted: one primitive quartet per shell quartet
                 hipLaunchKernelGGL(eri_cfact_kernel<true>, dim3((unsigned)nk, (unsigned)(b1 - b0)), dim3(TF_ERI_THREADS), bytes, st, ctx->db, c,
                                    d_bra + b0, d_braoff + b0, d_kets_all + kets_goff[gk], Nc, d_C);
             else

@@ -684,13 +684,17 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
 struct CFCaps {
     int offR, capR, offPref, offPQ, offPP, offG, capG, offX, offZ, capXZ, offTupG, offTupXZ, offEab, capEab, offEcd, capEcd;
     int offRed, lds_doubles, tri;
+    int gtab_doubles;                // GTAB launches: offG / offX / offZ are relative to the workgroup's block of this many doubles in global memory
     int dbg_npq_lo, dbg_npq_hi;      // profiling aid (TF_ERI_DBG_NPQ=lo:hi): only quartets with lo <= primitive quartets <= hi are computed
 };
 
-template <bool UNC>
+// GTAB: the G / X / Z tables of the workgroup live in global memory (gtab, one block of cap.gtab_doubles per workgroup, L2-resident)
+// instead of LDS -- the very top of the angular momenta ((hh|hh): 2 x 14 256 + 4 356 doubles) does not fit the 160 KB.
+template <bool UNC, bool GTAB = false>
 __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, CFCaps cap, const int *__restrict__ bra_pairs,
                                                                    const long long *__restrict__ bra_rowoff,
-                                                                   const int *__restrict__ ket_pairs, int Nc, double *__restrict__ Cslab)
+                                                                   const int *__restrict__ ket_pairs, int Nc, double *__restrict__ Cslab,
+                                                                   double *__restrict__ gtab = nullptr)
 {
     extern __shared__ double smem[];
     const int tid = threadIdx.x;
@@ -705,8 +709,9 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
     const int nsubc = cd.nca * cd.ncb;
     const int npp_cd = cd.npp, npq = ab.npp * cd.npp;
     const int nEab = ab.nE, nEcd = cd.nE;
-    double *sR = smem + cap.offR, *sPref = smem + cap.offPref, *sPQ = smem + cap.offPQ, *sG = smem + cap.offG;
-    double *sX = smem + cap.offX, *sZ = smem + cap.offZ, *sRed = smem + cap.offRed;
+    double *sR = smem + cap.offR, *sPref = smem + cap.offPref, *sPQ = smem + cap.offPQ, *sRed = smem + cap.offRed;
+    double *tab = GTAB ? gtab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)cap.gtab_doubles : smem;
+    double *sG = tab + cap.offG, *sX = tab + cap.offX, *sZ = tab + cap.offZ;
     int *sPP = reinterpret_cast<int *>(smem + cap.offPP);            // [2][256]: primitive pair indices (within the pairs) of the batch
     unsigned short *sTupG = reinterpret_cast<unsigned short *>(smem + cap.offTupG), *sTupXZ = reinterpret_cast<unsigned short *>(smem + cap.offTupXZ);
     const long long row0 = bra_rowoff[blockIdx.y];
