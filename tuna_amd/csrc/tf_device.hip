@@ -863,7 +863,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 c.offZ = o; o += c.capXZ;
                 c.offTupG = o; o += (gsz + 3) / 4;
                 c.offTupXZ = o; o += (xz + 3) / 4;
-                c.offEab = o; c.capEab = std::min(sb.maxE, 512); o += c.capEab;
+                c.offEab = o; c.capEab = std::min(sb.maxE, 1536); o += c.capEab;
                 c.offEcd = o; c.capEcd = std::min(sk.maxE, 1536); o += c.capEcd;
                 c.offRed = o; o += TF_ERI_THREADS;
                 c.lds_doubles = o;
