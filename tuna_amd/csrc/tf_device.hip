@@ -86,6 +86,7 @@ struct tf_ctx {
     size_t cfact_lds_set = 0;                // dynamic LDS limit requested for eri_cfact_kernel
     tfk::LRec *d_lrec = nullptr;             // per-(La,Lb|Lc,Ld) records and entry index words of eri_cfact_kernel (per build)
     unsigned short *d_tup = nullptr;
+    tfone::Arena arena1e;                    // device block for the short-lived buffers of the one-electron integrals
     double *d_gtab = nullptr;                // global-memory tables of the top angular momenta (eri_cfact_kernel<true, true>)
     size_t gtab_bytes = 0;
     double *scr[3] = {nullptr, nullptr, nullptr};
@@ -277,6 +278,7 @@ void tf_destroy(tf_ctx *ctx)
     if (ctx->d_lrec) (void)hipFree(ctx->d_lrec);
     if (ctx->d_tup) (void)hipFree(ctx->d_tup);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
+    ctx->arena1e.release();
     delete ctx;
 }
 
@@ -1481,7 +1483,7 @@ int tf_one_electron(tf_ctx *ctx, int n_atoms, const double *atom_xyz, const doub
             TF_FAIL(ctx, TF_EGEOM, "Molecule is incorrectly aligned! Unable to calculate molecular integrals.");
     if (spherical && !ctx->bs.all_full) TF_FAIL(ctx, TF_EINVAL, "spherical output needs complete shells");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::string msg = tfone::one_electron(ctx->bs, n_atoms, atom_xyz, atom_charge, dipole_origin, spherical, S, T, V, D, Q);
+    std::string msg = tfone::one_electron(ctx->bs, n_atoms, atom_xyz, atom_charge, dipole_origin, spherical, S, T, V, D, Q, ctx->db.boys, &ctx->arena1e);
     if (!msg.empty()) TF_FAIL(ctx, TF_ENODEVICE, "%s", msg.c_str());
     return TF_OK;
 }
@@ -1497,7 +1499,7 @@ int tf_cross_overlap(tf_ctx *ctx, int n2, const double *origin2, const int32_t *
     tf::Basis other;
     std::string msg = tf::build_basis(other, n2, origin2, lmn2, prim_off2, exps2, coefs_raw2);
     if (!msg.empty()) TF_FAIL(ctx, TF_EINVAL, "%s", msg.c_str());
-    msg = tfone::cross_overlap(ctx->bs, other, S_cross);
+    msg = tfone::cross_overlap(ctx->bs, other, S_cross, &ctx->arena1e);
     if (!msg.empty()) TF_FAIL(ctx, TF_ENODEVICE, "%s", msg.c_str());
     return TF_OK;
 }

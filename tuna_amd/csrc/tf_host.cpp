@@ -120,7 +120,7 @@ void sph_block(int L, std::vector<double> &U)
 // ---- Boys Taylor grid ------------------------------------------------------------------------------
 // F_m(T0) for T0 = i/8, m < NORD, by the all-positive series at the top order and downward recursion,
 // in long double, so the tabulated values are good to ~1e-19.
-void boys_table(std::vector<double> &tab)
+static void boys_table_compute(std::vector<double> &tab)
 {
     tab.assign((size_t)TF_BOYS_NGRID * TF_BOYS_NORD, 0.0);
     const int top = TF_BOYS_NORD - 1;
@@ -138,6 +138,13 @@ void boys_table(std::vector<double> &tab)
         for (int m = top; m > 0; --m) F[m - 1] = (2.0L * T * F[m] + e) / (2.0L * m - 1.0L);
         for (int m = 0; m < TF_BOYS_NORD; ++m) tab[(size_t)i * TF_BOYS_NORD + m] = (double)F[m];
     }
+}
+
+// the table is a constant of the library: computed once per process (~1 ms of long double arithmetic)
+void boys_table(std::vector<double> &tab)
+{
+    static const std::vector<double> cached = [] { std::vector<double> t; boys_table_compute(t); return t; }();
+    tab = cached;
 }
 
 // ---- basis ---------------------------------------------------------------------------------------

@@ -89,7 +89,10 @@ __global__ void oneel_kernel(DAO A, int n, int n_atoms, double zc0, double zc1, 
                              const double *__restrict__ boys, double *__restrict__ S, double *__restrict__ T,
                              double *__restrict__ V, double *__restrict__ D, double *__restrict__ Q)
 {
-    const long long pidx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per AO pair: the lanes share the primitive pairs (a deeply contracted pair -- 13 x 13 primitives of two Ar s shells --
+    // kept one thread busy for milliseconds) and are summed in a fixed butterfly at the end
+    const long long pidx = blockIdx.x;
+    const int lane = threadIdx.x;
     const long long npair = (long long)n * (n + 1) / 2;
     if (pidx >= npair) return;
     int i = (int)((sqrt(8.0 * (double)pidx + 1.0) - 1.0) * 0.5);
@@ -106,9 +109,11 @@ __global__ void oneel_kernel(DAO A, int n, int n_atoms, double zc0, double zc1, 
     double s = 0, t = 0, dx = 0, dy = 0, dzz = 0, qx = 0, qy = 0, qz = 0, v0 = 0, v1 = 0;
     const double PI = 3.141592653589793238462643383279, PI32 = 5.5683279968317078452848179821188357;
     const int Vmax = n1 + n2, Nmax = L1 + L2, stride = Nmax + 1;
-    for (int a = A.prim_off[i]; a < A.prim_off[i + 1]; ++a) {
-        const double ea = A.exps[a], wa = A.w[a];
-        for (int b = A.prim_off[j]; b < A.prim_off[j + 1]; ++b) {
+    const int pa0 = A.prim_off[i], npa = A.prim_off[i + 1] - pa0, pb0 = A.prim_off[j], npb = A.prim_off[j + 1] - pb0;
+    for (int pq = lane; pq < npa * npb; pq += 64) {
+        {
+            const int a = pa0 + pq / npb, b = pb0 + pq % npb;
+            const double ea = A.exps[a], wa = A.w[a];
             const double eb = A.exps[b], wb = A.w[b];
             const double p = ea + eb;
             const double pref = wa * wb * PI32 / (p * sqrt(p));
@@ -157,6 +162,12 @@ __global__ void oneel_kernel(DAO A, int n, int n_atoms, double zc0, double zc1, 
             }
         }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off); t += __shfl_xor(t, off); dx += __shfl_xor(dx, off); dy += __shfl_xor(dy, off); dzz += __shfl_xor(dzz, off);
+        qx += __shfl_xor(qx, off); qy += __shfl_xor(qy, off); qz += __shfl_xor(qz, off); v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off);
+    }
+    if (lane != 0) return;
     double v = 0.0;                         // pyx:391-395: v = v - integral * charge, atom by atom
     v = v - v0 * q0;
     if (n_atoms > 1) v = v - v1 * q1;
@@ -204,24 +215,49 @@ __global__ void sph_matrix_kernel(const double *__restrict__ M, int Nc, int Ns, 
     out[e] = s;
 }
 
+// A block of device memory kept by the context for these short-lived buffers: a dozen hipMalloc / hipFree pairs per call cost more
+// (~0.2 ms each) than the kernels of a small molecule.  Bump allocation; what does not fit is allocated separately and the block
+// grows on the next call.
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, used = 0, wanted = 0;
+    void release() { if (base) (void)hipFree(base); base = nullptr; cap = used = wanted = 0; }
+};
+
 struct DevBuf {
     std::vector<void *> ptrs;
-    ~DevBuf() { for (void *p : ptrs) (void)hipFree(p); }
+    Arena *arena = nullptr;
+    explicit DevBuf(Arena *a = nullptr) : arena(a)
+    {
+        if (!arena) return;
+        if (arena->wanted > arena->cap) {
+            if (arena->base) (void)hipFree(arena->base);
+            arena->base = nullptr; arena->cap = 0;
+            const size_t want = arena->wanted + arena->wanted / 4 + 4096;
+            if (hipMalloc((void **)&arena->base, want) == hipSuccess) arena->cap = want;
+        }
+        arena->used = 0; arena->wanted = 0;
+    }
+    ~DevBuf() { for (void *p : ptrs) (void)hipFree(p); if (arena) arena->used = 0; }
+    void *raw(size_t bytes, std::string &err)
+    {
+        bytes = (std::max<size_t>(1, bytes) + 255) & ~(size_t)255;
+        if (arena) {
+            arena->wanted += bytes;
+            if (arena->used + bytes <= arena->cap) { void *p = arena->base + arena->used; arena->used += bytes; return p; }
+        }
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) { err = "hipMalloc failed (one-electron)"; return nullptr; }
+        ptrs.push_back(d);
+        return d;
+    }
     template <class T> T *put(const std::vector<T> &h, std::string &err)
     {
-        T *d = nullptr;
-        if (hipMalloc((void **)&d, std::max<size_t>(1, h.size()) * sizeof(T)) != hipSuccess) { err = "hipMalloc failed (one-electron)"; return nullptr; }
-        ptrs.push_back(d);
-        if (!h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy failed (one-electron)"; return nullptr; }
+        T *d = static_cast<T *>(raw(h.size() * sizeof(T), err));
+        if (d && !h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy failed (one-electron)"; return nullptr; }
         return d;
     }
-    template <class T> T *alloc(size_t n, std::string &err)
-    {
-        T *d = nullptr;
-        if (hipMalloc((void **)&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) { err = "hipMalloc failed (one-electron)"; return nullptr; }
-        ptrs.push_back(d);
-        return d;
-    }
+    template <class T> T *alloc(size_t n, std::string &err) { return static_cast<T *>(raw(n * sizeof(T), err)); }
 };
 
 inline DAO upload_aos(const tf::Basis &bs, DevBuf &buf, std::string &err)
@@ -251,21 +287,25 @@ inline void sph_csr(const tf::Basis &bs, std::vector<int> &ptr, std::vector<int>
 }
 
 inline std::string one_electron(const tf::Basis &bs, int n_atoms, const double *xyz, const double *charge, const double *origin,
-                                int spherical, double *S, double *T, double *V, double *D, double *Q)
+                                int spherical, double *S, double *T, double *V, double *D, double *Q, const double *d_boys_cached = nullptr,
+                                Arena *arena = nullptr)
 {
     std::string err;
-    DevBuf buf;
+    DevBuf buf(arena);
     const int n = bs.n_cart;
     const size_t nn = (size_t)n * n;
     DAO A = upload_aos(bs, buf, err);
-    std::vector<double> boys;
-    tf::boys_table(boys);
-    double *d_boys = buf.put(boys, err);
+    const double *d_boys = d_boys_cached;                       // the context's copy (tf_set_basis) when there is one
+    if (!d_boys) {
+        std::vector<double> boys;
+        tf::boys_table(boys);
+        d_boys = buf.put(boys, err);
+    }
     double *d_all = buf.alloc<double>(9 * nn, err);
     if (!err.empty()) return err;
     double *dS = d_all, *dT = d_all + nn, *dV = d_all + 2 * nn, *dD = d_all + 3 * nn, *dQ = d_all + 6 * nn;
     const long long npair = (long long)n * (n + 1) / 2;
-    hipLaunchKernelGGL(oneel_kernel, dim3((unsigned)((npair + 63) / 64)), dim3(64), 0, 0, A, n, n_atoms, xyz[2],
+    hipLaunchKernelGGL(oneel_kernel, dim3((unsigned)npair), dim3(64), 0, 0, A, n, n_atoms, xyz[2],
                        n_atoms > 1 ? xyz[5] : 0.0, charge[0], n_atoms > 1 ? charge[1] : 0.0, origin[2], d_boys, dS, dT, dV, dD, dQ);
     double *src = d_all;
     int m = n;
@@ -293,10 +333,10 @@ inline std::string one_electron(const tf::Basis &bs, int n_atoms, const double *
     return "";
 }
 
-inline std::string cross_overlap(const tf::Basis &b1, const tf::Basis &b2, double *S)
+inline std::string cross_overlap(const tf::Basis &b1, const tf::Basis &b2, double *S, Arena *arena = nullptr)
 {
     std::string err;
-    DevBuf buf;
+    DevBuf buf(arena);
     DAO A = upload_aos(b1, buf, err), B = upload_aos(b2, buf, err);
     const size_t tot = (size_t)b1.n_cart * b2.n_cart;
     double *dS = buf.alloc<double>(tot, err);
