@@ -206,3 +206,30 @@ with Engine(0) as eng:
     assert np.abs(ta[big, 6] - tb[big, 6]).max() < 1e-6                    # same damping factors
     assert np.abs(np.asarray(a["eps"]) - np.asarray(b["eps"])).max() < 1e-8   # final orbital energies come from a real eigensolve
     assert a["orth"] < 1e-10 and abs(a["P_sum"] - b["P_sum"]) < 1e-6 * b["P_sum"]
+
+
+@pytest.mark.parametrize("reference", ["RHF", "UHF"])
+def test_electric_field_term_of_the_fock_matrix(engine, reference):
+    """The field term of the Fock matrix (F_fld in scf:525, `integrals.F`) through the native cycles: the field energy component is
+    tr(P F), and the energy responds to a small field with the dipole expectation value, dE/d(eps) = tr(P D_z) (Hellmann-Feynman for
+    the variational SCF energy): central difference against the analytic value."""
+    from tuna_amd.energy import Calculation, build_molecule_and_integrals
+    from tuna_amd.engine import SCF_CONVERGENCE
+    from tuna_amd import scf
+    mult = 1 if reference == "RHF" else 3
+    sym = ["H", "F"] if reference == "RHF" else ["N", "H"]
+    calc = Calculation(basis="6-31G", SCF_conv=SCF_CONVERGENCE["extreme"], multiplicity=mult, damping=False, core_guess=True)
+    molecule, integrals, X, guess, _ = build_molecule_and_integrals(sym, mol.angstrom_to_bohr(0.95), calc, engine)
+    assert calc.reference == reference
+    Dz = np.asarray(integrals.D)[2]
+    eps = 2e-4
+    res = {}
+    for f in (-eps, 0.0, eps):
+        integrals.F = f * Dz
+        out = scf.run_self_consistent_field_cycle(molecule, calc, integrals, 0.0, X, guess)
+        assert abs(out.electric_field_energy - np.sum(out.P * integrals.F)) < 1e-11
+        res[f] = out
+    slope = (res[eps].energy - res[-eps].energy) / (2 * eps)
+    mu = float(np.sum(res[0.0].P * Dz))
+    assert abs(mu) > 1e-2                                           # (electronic dipole about the centre of mass: not zero by symmetry)
+    assert abs(slope - mu) < 2e-6
