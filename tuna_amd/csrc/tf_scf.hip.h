@@ -424,7 +424,7 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
     double *X = w.ref_buf, *Xn = X + nn, *G = Xn + nn, *Y = G + nn, *S = Y + nn, *E = S + nn;
     double *lam = E + nn, *wocc = lam + n, *bmax = wocc + n;
     const int g = (int)((nn + 255) / 256);
-    std::vector<double> hb(2 * (size_t)g);
+    std::vector<double> hb(2 * (size_t)g + 2);                 // block maxima of the rotations + (homo, lumo): one read-back per step
     // X <- (3/2 I - 1/2 G) X with G = X X^T (rows are the vectors)
     auto orthonormalise = [&]() -> int {
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, X, X, 0.0, G));
@@ -440,11 +440,10 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
         if (step > 0 && (rc = orthonormalise())) return rc;                    // (the stored vectors are orthonormal: every solve closes with this step)
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, X, A, 0.0, Y));         // rows A x_i
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Y, X, 0.0, S));          // S = X^T A X
-        hipLaunchKernelGGL(k_ref_diag, dim3(1), dim3(1024), 0, 0, S, n, n_occ, lam, wocc, w.d_scal + 40);
+        hipLaunchKernelGGL(k_ref_diag, dim3(1), dim3(1024), 0, 0, S, n, n_occ, lam, wocc, bmax + 2 * (size_t)g);
         hipLaunchKernelGGL(k_ref_E, dim3(g), dim3(256), 0, 0, S, lam, wocc, n, E, bmax);
-        double h[2];
-        TFS_HIP(hipMemcpy(h, w.d_scal + 40, 2 * sizeof(double), hipMemcpyDeviceToHost));
-        TFS_HIP(hipMemcpy(hb.data(), bmax, 2 * (size_t)g * sizeof(double), hipMemcpyDeviceToHost));
+        TFS_HIP(hipMemcpy(hb.data(), bmax, (2 * (size_t)g + 2) * sizeof(double), hipMemcpyDeviceToHost));
+        const double h[2] = {hb[2 * (size_t)g], hb[2 * (size_t)g + 1]};
         double emax = 0.0, eov = 0.0;
         for (int b = 0; b < g; ++b) { emax = std::max(emax, hb[2 * b]); eov = std::max(eov, hb[2 * b + 1]); }
         if (dbg) fprintf(stderr, "[tf refine] step %d: homo %.6f lumo %.6f max|E| %.3e max|E_ov| %.3e\n", step, h[0], h[1], emax, eov);
