@@ -46,6 +46,9 @@ struct Workspace {
     size_t ref_cap = 0;
     int ref_n = 0;                   // 0 = no valid start
     long long ref_solves = 0, ref_steps = 0, ref_fallbacks = 0;
+    double *h_pin = nullptr;         // pinned host buffer + event: the per-step read-back of the refinement overlaps the next GEMMs
+    size_t h_pin_cap = 0;
+    hipEvent_t ev_pin = nullptr;
     double *ref_alt_buf = nullptr;   // the same for the second spin of an unrestricted cycle (swapped in around its solves)
     size_t ref_alt_cap = 0;
     int ref_alt_n = 0;
@@ -65,6 +68,8 @@ inline void release(Workspace &w)
     if (w.jac_prev) (void)hipFree(w.jac_prev);
     if (w.ref_buf) (void)hipFree(w.ref_buf);
     if (w.ref_alt_buf) (void)hipFree(w.ref_alt_buf);
+    if (w.h_pin) (void)hipHostFree(w.h_pin);
+    if (w.ev_pin) (void)hipEventDestroy(w.ev_pin);
     for (hipEvent_t e : w.tev) (void)hipEventDestroy(e);
     w = Workspace();
 }
@@ -411,6 +416,14 @@ inline int ref_ensure(Workspace &w, int n, std::string &msg)
         TFS_HIP(hipMalloc((void **)&w.ref_buf, need * sizeof(double)));
         w.ref_cap = need;
     }
+    const size_t npin = 2 * (((size_t)n * n + 255) / 256) + 2;
+    if (npin > w.h_pin_cap) {
+        if (w.h_pin) (void)hipHostFree(w.h_pin);
+        w.h_pin = nullptr; w.h_pin_cap = 0;
+        TFS_HIP(hipHostMalloc((void **)&w.h_pin, npin * sizeof(double), hipHostMallocDefault));
+        w.h_pin_cap = npin;
+    }
+    if (!w.ev_pin) TFS_HIP(hipEventCreateWithFlags(&w.ev_pin, hipEventDisableTiming));
     return TF_OK;
 }
 
@@ -424,7 +437,6 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
     double *X = w.ref_buf, *Xn = X + nn, *G = Xn + nn, *Y = G + nn, *S = Y + nn, *E = S + nn;
     double *lam = E + nn, *wocc = lam + n, *bmax = wocc + n;
     const int g = (int)((nn + 255) / 256);
-    std::vector<double> hb(2 * (size_t)g + 2);                 // block maxima of the rotations + (homo, lumo): one read-back per step
     // X <- (3/2 I - 1/2 G) X with G = X X^T (rows are the vectors)
     auto orthonormalise = [&]() -> int {
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, X, X, 0.0, G));
@@ -436,26 +448,33 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
     ++w.ref_solves;
     int rc = TF_OK;
     bool ok = false;
+    // Every step ends with the update X <- X + E^T X and the orthonormalisation that either the next step or the end of the solve
+    // needs; they are queued BEFORE the host looks at the step's convergence numbers (asynchronous copy to pinned memory + event), so
+    // the read-back costs no idle time on the device.  (The stored vectors are orthonormal: no orthonormalisation before step 0.)
+    const size_t npin = 2 * (size_t)g + 2;
+    if (!w.h_pin || w.h_pin_cap < npin || !w.ev_pin) return TF_ELINALG;
     for (int step = 0; step < 16 && !ok; ++step) {
-        if (step > 0 && (rc = orthonormalise())) return rc;                    // (the stored vectors are orthonormal: every solve closes with this step)
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, X, A, 0.0, Y));         // rows A x_i
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Y, X, 0.0, S));          // S = X^T A X
         hipLaunchKernelGGL(k_ref_diag, dim3(1), dim3(1024), 0, 0, S, n, n_occ, lam, wocc, bmax + 2 * (size_t)g);
         hipLaunchKernelGGL(k_ref_E, dim3(g), dim3(256), 0, 0, S, lam, wocc, n, E, bmax);
-        TFS_HIP(hipMemcpy(hb.data(), bmax, (2 * (size_t)g + 2) * sizeof(double), hipMemcpyDeviceToHost));
+        TFS_HIP(hipMemcpyAsync(w.h_pin, bmax, npin * sizeof(double), hipMemcpyDeviceToHost, 0));
+        TFS_HIP(hipEventRecord(w.ev_pin, 0));
+        TFS_HIP(hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, E, X, 1.0, Xn));         // X + E^T X   (rows)
+        std::swap(X, Xn);
+        if ((rc = orthonormalise())) return rc;
+        TFS_HIP(hipEventSynchronize(w.ev_pin));
+        const double *hb = w.h_pin;
         const double h[2] = {hb[2 * (size_t)g], hb[2 * (size_t)g + 1]};
         double emax = 0.0, eov = 0.0;
         for (int b = 0; b < g; ++b) { emax = std::max(emax, hb[2 * b]); eov = std::max(eov, hb[2 * b + 1]); }
         if (dbg) fprintf(stderr, "[tf refine] step %d: homo %.6f lumo %.6f max|E| %.3e max|E_ov| %.3e\n", step, h[0], h[1], emax, eov);
-        if (!std::isfinite(emax) || !(h[1] > h[0]) || emax > 0.3) break;
-        TFS_HIP(hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
-        TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, E, X, 1.0, Xn));         // X + E^T X   (rows)
-        std::swap(X, Xn);
+        if (!std::isfinite(emax) || !(h[1] > h[0]) || emax > 0.3) break;       // (the queued update is discarded with the vectors)
         w.ref_steps += 1;
         ok = eov < 1e-9 && emax < 0.1;       // rotations inside the occupied or the virtual space leave the projector alone
     }
     if (ok) {
-        if ((rc = orthonormalise())) return rc;
         if (X != w.ref_buf) {                                                  // keep the vectors in the first slot for the next solve
             TFS_HIP(hipMemcpyAsync(w.ref_buf, X, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
             X = w.ref_buf;
