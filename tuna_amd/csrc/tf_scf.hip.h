@@ -887,19 +887,12 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         // diagonalise, new density, energy with the NEW P and the OLD J,K   (scf:1133-1141)
         rc = diag_density(dF, dPn);
         if (rc) return rc;
-        double eT, eV, eF, eJ, eK;
-        {
+        {   // the five energy terms are read back at the end of the iteration, together with the density changes
             Ptr8 a;
             for (int k = 0; k < 8; ++k) { a.p[k] = dT; a.c[k] = 0.0; }
             a.p[0] = dT; a.p[1] = dV; a.p[2] = dFx; a.p[3] = dJ; a.p[4] = dK;
-            double hd[5];
-            launch_multi_dot(w, dPn, a, 5, (int)nn, w.d_scal + 56);
-            TFS_HIP(hipMemcpy(hd, w.d_scal + 56, 5 * sizeof(double), hipMemcpyDeviceToHost));
-            eT = hd[0]; eV = hd[1]; eF = hd[2]; eJ = hd[3]; eK = hd[4];
+            launch_multi_dot(w, dPn, a, 5, (int)nn, w.d_scal + 18);
         }
-        comps[0] = eT; comps[1] = eV; comps[2] = (1.0 / 2.0) * eJ; comps[3] = -(1.0 / 4.0) * eK * o.hfx + xc3[1]; comps[4] = xc3[2];   // scf:380-394
-        comps[5] = eF; comps[6] = 0.0;
-        E = comps[0] + comps[1] + comps[2] + comps[3] + comps[4] + comps[5] + comps[6];
         orbitals_final = orbitals_current;                            // of THIS iteration's Fock matrix (the DIIS solve below reuses dC)
         if (orbitals_final && (out.eps || out.C)) {                  // kept on the device; copied out after the cycle
             TFS_HIP(hipMemcpyAsync(vals_save, vals, n * sizeof(double), hipMemcpyDeviceToDevice, 0));
@@ -952,8 +945,14 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, damp, dPold, 1.0 - damp, dPbd, dP, (int)nn);
         // changes and convergence (scf:261-333)
         launch_delta_norms(w, dP, dPold, (int)nn, w.d_scal + 16);
-        double res[2];
-        TFS_HIP(hipMemcpy(res, w.d_scal + 16, 2 * sizeof(double), hipMemcpyDeviceToHost));
+        double res[7];
+        TFS_HIP(hipMemcpy(res, w.d_scal + 16, 7 * sizeof(double), hipMemcpyDeviceToHost));
+        {
+            const double eT = res[2], eV = res[3], eF = res[4], eJ = res[5], eK = res[6];
+            comps[0] = eT; comps[1] = eV; comps[2] = (1.0 / 2.0) * eJ; comps[3] = -(1.0 / 4.0) * eK * o.hfx + xc3[1]; comps[4] = xc3[2];   // scf:380-394
+            comps[5] = eF; comps[6] = 0.0;
+            E = comps[0] + comps[1] + comps[2] + comps[3] + comps[4] + comps[5] + comps[6];
+        }
         const double dE = E - E_old, maxDP = res[0], rmsDP = std::sqrt(res[1] / (double)nn);
         out.n_iter = step;
         if (out.table) {
@@ -1187,21 +1186,12 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                 TFS_HIP(hipMemcpyAsync(dCsave[sp], dC, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
             }
         }
-        {
-            double hd[12];
-            for (int sp = 0; sp < 2; ++sp) {
-                Ptr8 a;
-                for (int k = 0; k < 8; ++k) { a.p[k] = dT; a.c[k] = 0.0; }
-                a.p[0] = dT; a.p[1] = dV; a.p[2] = dFx; a.p[3] = dJt; a.p[4] = dK[sp];
-                launch_multi_dot(w, dPn[sp], a, 5, (int)nn, w.d_scal + 80 + 6 * sp);
-            }
-            TFS_HIP(hipMemcpy(hd, w.d_scal + 80, 12 * sizeof(double), hipMemcpyDeviceToHost));
-            comps[0] = hd[0] + hd[6]; comps[1] = hd[1] + hd[7]; comps[5] = hd[2] + hd[8];
-            comps[2] = (1.0 / 2.0) * (hd[3] + hd[9]);                                        // scf:462
-            comps[3] = -(1.0 / 2.0) * hd[4] * o.hfx + -(1.0 / 2.0) * hd[10] * o.hfx;         // scf:465-466
-            comps[4] = 0.0; comps[6] = 0.0;
+        for (int sp = 0; sp < 2; ++sp) {     // the energy terms are read back at the end of the iteration, together with the density changes
+            Ptr8 a;
+            for (int k = 0; k < 8; ++k) { a.p[k] = dT; a.c[k] = 0.0; }
+            a.p[0] = dT; a.p[1] = dV; a.p[2] = dFx; a.p[3] = dJt; a.p[4] = dK[sp];
+            launch_multi_dot(w, dPn[sp], a, 5, (int)nn, w.d_scal + 18 + 6 * sp);
         }
-        E = comps[0] + comps[1] + comps[2] + comps[3] + comps[4] + comps[5] + comps[6];
         // DIIS (scf:1236-1256): one set of coefficients for both spins
         if (step > 2 && o.use_diis && commutator < 0.3) {
             const int m = n_hist + 1;
@@ -1253,8 +1243,16 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, damp[sp], dPold[sp], 1.0 - damp[sp], dPn[sp], dP[sp], (int)nn);
         hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dP[0], 1.0, dP[1], dPt, (int)nn);
         launch_delta_norms(w, dPt, dPtold, (int)nn, w.d_scal + 16);
-        double res[2];
-        TFS_HIP(hipMemcpy(res, w.d_scal + 16, 2 * sizeof(double), hipMemcpyDeviceToHost));
+        double res[14];
+        TFS_HIP(hipMemcpy(res, w.d_scal + 16, 14 * sizeof(double), hipMemcpyDeviceToHost));
+        {
+            const double *hd = res + 2;
+            comps[0] = hd[0] + hd[6]; comps[1] = hd[1] + hd[7]; comps[5] = hd[2] + hd[8];
+            comps[2] = (1.0 / 2.0) * (hd[3] + hd[9]);                                        // scf:462
+            comps[3] = -(1.0 / 2.0) * hd[4] * o.hfx + -(1.0 / 2.0) * hd[10] * o.hfx;         // scf:465-466
+            comps[4] = 0.0; comps[6] = 0.0;
+            E = comps[0] + comps[1] + comps[2] + comps[3] + comps[4] + comps[5] + comps[6];
+        }
         const double dE = E - E_old, maxDP = res[0], rmsDP = std::sqrt(res[1] / (double)nn);
         out.n_iter = step;
         if (out.table) {
