@@ -12,6 +12,13 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (the .so is git-ignored): compile it once, as __graft_entry__.build() does
+    try:
+        from tuna_amd import _lib
+        if not os.path.exists(_lib.LIB_PATH):
+            _lib.build_library()
+    except Exception as e:            # (hipcc missing: the ABI test reports it)
+        print(f"conftest: libtunafock.so not built: {e}", file=sys.stderr)
 
 
 @pytest.fixture(scope="session")
