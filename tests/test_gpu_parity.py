@@ -240,3 +240,41 @@ def test_rebuilding_reuses_the_tensor_buffer(engine, small):
     assert np.abs(engine.copy_eri() - small["n2_sto3g"]["ERI"]).max() < TOL_INT
     engine.set_basis(aos_big).build_eri(True)
     assert np.array_equal(engine.sample_eri(idx), first)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_contracted_bases_against_oracle(engine, seed):
+    """Seeded random basis sets -- shells s..g with 1-5 primitives each, different on the two atoms, also a single atom -- through
+    the small-problem path (contracted and uncontracted quartets of every angular-momentum group in one build): every element of
+    the spherical tensor against the C oracle, and a Fock build against the reference's einsums."""
+    rng = np.random.default_rng(seed)
+
+    def random_atom_basis(n_shells, l_max):
+        out = []
+        for _ in range(n_shells):
+            L = int(rng.integers(0, l_max + 1))
+            nprim = int(rng.integers(1, 6)) if L <= 2 else int(rng.integers(1, 3))
+            exps = np.sort(10.0 ** rng.uniform(-1.0, 1.6, nprim))[::-1]
+            coefs = rng.uniform(0.2, 1.0, nprim) * rng.choice([-1.0, 1.0], nprim)
+            out.append(("SPDFG"[L], [(float(e), float(c)) for e, c in zip(exps, coefs)]))
+        return out
+
+    symbols, R = ((["N", "O"], 2.0 + 0.5 * rng.random()) if seed != 13 else (["N"], None))
+    basis = {7: random_atom_basis(5, 4), 8: random_atom_basis(4, 3)}
+    atoms = mol.make_atoms(symbols, R)
+    aos = mol.expand_cartesian_aos(mol.build_shells(atoms, basis))
+    engine.set_basis(aos)
+    Eo = orc.eri(aos)
+    scale = np.abs(Eo).max()
+    engine.build_eri(spherical=False)
+    assert np.abs(engine.copy_eri() - Eo).max() < 1e-12 * max(1.0, scale)
+    U = engine.sph_matrix()
+    engine.build_eri(spherical=True)
+    Es = engine.copy_eri()
+    Eos = so.eri_to_spherical(U, Eo)
+    assert np.abs(Es - Eos).max() < 1e-12 * max(1.0, scale)
+    A = rng.standard_normal((engine.N, engine.N))
+    P = A + A.T
+    J, K = engine.fock_jk(P)
+    tol = 1e-10 * max(1.0, scale) * engine.N
+    assert np.abs(J - so.coulomb(P, Eos)).max() < tol and np.abs(K - so.exchange(P, Eos)).max() < tol
