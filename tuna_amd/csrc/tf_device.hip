@@ -625,10 +625,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         max_rows_c = std::max<long long>(biggest, std::min(max_rows_c, need));
     }
     if ((rc = ensure_scratch(ctx, 0, (size_t)max_rows_c * Nc * Nc * sizeof(double))) ||
-        (rc = ensure_scratch(ctx, 1, (size_t)max_rows_c * Nc * N * sizeof(double))) ||
         (rc = ensure_scratch(ctx, 2, (size_t)max_rows_c * N * ld * sizeof(double))))
         return rc;
-    double *d_C = ctx->scr[0], *d_T1 = ctx->scr[1], *d_T2 = ctx->scr[2];
+    double *d_C = ctx->scr[0], *d_T2 = ctx->scr[2];
     double t_stage[4] = {0, 0, 0, 0};
     long long n_quart = 0, n_primq = 0, n_compq = 0;
     // work counters: ket pairs / primitive pairs / component pairs with first shell <= A (the pair list is A-major).  The packed
@@ -1099,14 +1098,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
         HIPCHK(ctx, hipEventRecord(e4[1], 0));
         if (!per_class) {
-            const long long tot1 = rows_c * Nc * (long long)N;
-            const unsigned g1 = (unsigned)std::min<long long>((tot1 + 255) / 256, 1 << 20);
-            hipLaunchKernelGGL(xform_last_axis, dim3(g1), dim3(256), 0, 0, d_C, d_T1, rows_c * Nc, Nc, N, ctx->d_csr_ptr,
-                               ctx->d_csr_idx, ctx->d_csr_val);
-            const long long tot2 = rows_c * (long long)N * ld;
-            const unsigned g2 = (unsigned)std::min<long long>((tot2 + 255) / 256, 1 << 20);
-            hipLaunchKernelGGL(xform_mid_axis, dim3(g2), dim3(256), 0, 0, d_T1, d_T2, rows_c, Nc, N, ld, ctx->d_csr_ptr,
-                               ctx->d_csr_idx, ctx->d_csr_val);
+            for (long long r0s = 0; r0s < rows_c; r0s += 65535) {      // both ket axes in one pass over the slab
+                const unsigned ny = (unsigned)std::min<long long>(65535, rows_c - r0s);
+                hipLaunchKernelGGL(xform_ket_both, dim3((unsigned)((N + 3) / 4), ny), dim3(256), 0, 0, d_C + (size_t)r0s * Nc * Nc,
+                                   d_T2 + (size_t)r0s * N * ld, Nc, N, ld, ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val, packed ? 1 : 0);
+            }
         }
         HIPCHK(ctx, hipEventRecord(e4[2], 0));
         if (!outs.empty()) {
