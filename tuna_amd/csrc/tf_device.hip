@@ -611,9 +611,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
     // ---- slabs of bra pairs: Cartesian block -> ket transform -> bra transform -> tensor rows
     // Cartesian slab: 1 GiB, more (up to 4 GiB) for big tensors -- fewer, larger class launches (N = 500: 0.52 -> 0.44 s)
-    size_t slab_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>((size_t)1 << 30, (size_t)ctx->n_elems));
-    if (const char *e = getenv("TF_SLAB_MB")) slab_bytes = (size_t)std::max(1, atoi(e)) << 20;
     const size_t cart_row_bytes = (size_t)Nc * Nc * sizeof(double);
+    size_t cart_total = 0;                                       // this rank's Cartesian bra rows x Nc^2: one slab if that is <= 4 GiB
+    for (int p : ctx->my_pairs) cart_total += (size_t)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp * cart_row_bytes;
+    size_t slab_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>((size_t)1 << 30, std::max((size_t)ctx->n_elems, cart_total)));
+    if (const char *e = getenv("TF_SLAB_MB")) slab_bytes = (size_t)std::max(1, atoi(e)) << 20;
     long long max_rows_c = std::max<long long>(1, (long long)(slab_bytes / cart_row_bytes));
     long long biggest = 1;
     for (int p : ctx->my_pairs)
