@@ -853,21 +853,25 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 const int Lmax = sb.maxLp + sk.maxLp, nM = Lmax / 2 + 1, tsize = (Lmax + 1) * (Lmax + 2) / 2;
                 const int xz = sb.maxT * sk.maxT * nM, gsz = sk.maxT * sb.maxLp1 * nM;
                 const bool deep = sb.maxnpp > 1 || sk.maxnpp > 1;
-                const int nbt = deep ? std::min(TF_ERI_THREADS / (Lmax + 1), 48) : 1;       // primitive quartets per batch aimed at
+                // batch size aimed at and LDS doubles for the X / Z tables and the staged Hermite tables (tuning knobs; smaller carve-outs
+                // mean more workgroups per CU: Ar2/cc-pVQZ ERI kernels 21.1 ms with 48 / 1536 / 1536, 18.3 ms with 24 / 768 / 1024)
+                static const int k_nbt = getenv("TF_CF_NBT") ? atoi(getenv("TF_CF_NBT")) : 24, k_xz = getenv("TF_CF_XZ") ? atoi(getenv("TF_CF_XZ")) : 768;
+                static const int k_e = getenv("TF_CF_E") ? atoi(getenv("TF_CF_E")) : 1024;
+                const int nbt = deep ? std::min(TF_ERI_THREADS / (Lmax + 1), k_nbt) : 1;       // primitive quartets per batch aimed at
                 CFCaps c{};
                 int o = 0;
-                c.offR = o; c.capR = std::max(2 * tsize, std::min((nbt + 1) * tsize, 2048)); o += c.capR;
+                c.offR = o; c.capR = std::max(2 * tsize, std::min((nbt + 1) * tsize, 2 * k_xz * 2 / 3)); o += c.capR;
                 c.offPref = o; o += TF_ERI_THREADS;
                 c.offPQ = o; o += TF_ERI_THREADS;
                 c.offPP = o; o += TF_ERI_THREADS;
-                c.offG = o; c.capG = std::max(gsz, std::min(nbt * gsz, 1024)); o += c.capG;
-                c.capXZ = std::max(xz, std::min(nbt * xz, 1536));
+                c.offG = o; c.capG = std::max(gsz, std::min(nbt * gsz, k_xz * 2 / 3)); o += c.capG;
+                c.capXZ = std::max(xz, std::min(nbt * xz, k_xz));
                 c.offX = o; o += c.capXZ;
                 c.offZ = o; o += c.capXZ;
                 c.offTupG = o; o += (gsz + 3) / 4;
                 c.offTupXZ = o; o += (xz + 3) / 4;
-                c.offEab = o; c.capEab = std::min(sb.maxE, 1536); o += c.capEab;
-                c.offEcd = o; c.capEcd = std::min(sk.maxE, 1536); o += c.capEcd;
+                c.offEab = o; c.capEab = std::min(sb.maxE, k_e); o += c.capEab;
+                c.offEcd = o; c.capEcd = std::min(sk.maxE, k_e); o += c.capEcd;
                 c.offRed = o; o += TF_ERI_THREADS;
                 c.lds_doubles = o;
                 c.tri = packed ? 1 : 0;
