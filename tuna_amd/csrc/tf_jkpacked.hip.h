@@ -486,9 +486,18 @@ __device__ __forceinline__ void jt_reduce_block(int bx, int by, int nseg, const 
     if (q >= NP) return;
     const int per = (n_groups + nseg - 1) / nseg;
     const int g0 = by * per, g1 = min(n_groups, g0 + per);
+    // the partials that cover every column of this block (a prefix: found by a wave-uniform bisection) are summed without the
+    // per-element test, so their loads can be issued ahead; the few that end inside the block follow with the test
+    const long long qmax = min(NP - 1, (long long)bx * 256 + 255);
+    int lo = g0, hi = g1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (groups[mid].ylen > qmax) lo = mid + 1; else hi = mid;
+    }
     double s = 0.0;
-#pragma unroll 4
-    for (int g = g0; g < g1; ++g) {
+#pragma unroll 8
+    for (int g = g0; g < lo; ++g) s += ypart[groups[g].yoff + q];
+    for (int g = lo; g < g1; ++g) {
         if (groups[g].ylen <= q) break;
         s += ypart[groups[g].yoff + q];
     }
@@ -507,17 +516,36 @@ __device__ __forceinline__ void kd_reduce_block(int a, int bx, double *sPart, co
     double s = 0.0;
     if (x < N) {
         if (x <= a)
-            for (int g = gfirst[a] + sl; g < gfirst[N + a]; g += 4) {
-                double t = DIc[(size_t)g * N + x];
-                for (int w = 0; w < nw; ++w) t += DIr[((size_t)g * NW + w) * N + x];
-                s += t;
+            for (int g0 = gfirst[a] + sl, ge = gfirst[N + a]; g0 < ge; g0 += 16) {
+                double t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = (g0 + 4 * u < ge) ? DIc[(size_t)(g0 + 4 * u) * N + x] : 0.0;
+                for (int w = 0; w < nw; ++w) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (g0 + 4 * u < ge) t[u] += DIr[((size_t)(g0 + 4 * u) * NW + w) * N + x];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (g0 + 4 * u < ge) s += t[u];
             }
-        for (int i = max(a + 1, x) + sl; i < N; i += 4) {
-            const int r = rowmap[(size_t)i * (i + 1) / 2 + a];
-            if (r < 0) continue;
-            double t = DJc[(size_t)r * N + x];
-            for (int w = 0; w < nw; ++w) t += DJr[((size_t)r * NW + w) * N + x];
-            s += t;
+        // four rows of the slice at a time: their row lookups, then all their loads, are issued together (the loads depend on the
+        // lookups; one row at a time left a single dependent chain per lane); summed in row order as before
+        for (int i0 = max(a + 1, x) + sl; i0 < N; i0 += 16) {
+            int r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + 4 * u; r[u] = (i < N) ? rowmap[(size_t)i * (i + 1) / 2 + a] : -1; }
+            double t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = (r[u] >= 0) ? DJc[(size_t)r[u] * N + x] : 0.0;
+            for (int w = 0; w < nw; ++w) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (r[u] >= 0) t[u] += DJr[((size_t)r[u] * NW + w) * N + x];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r[u] >= 0) s += t[u];
         }
     }
     sPart[threadIdx.x] = s;
