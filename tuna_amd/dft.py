@@ -3,9 +3,9 @@ it, and the table of functionals the GPU kernels implement.  Everything per-iter
 libtunafock (csrc/tf_dft.hip.h).
 
 Reference: set_up_integration_grid tuna_dft.py:94-208 (extent = mult * max(real_vdw_radius) / 6, n_radial = int(extent * acc),
-Lebedev order nearest to 9 * acc), build_atomic_radial_and_angular_grid :210-258 (Gauss-Legendre in t, r = R t^3, Lebedev angular
-rule from SciPy), calculate_Becke_diatomic_weights :268-322 (steepness 4, size adjustment by the vdW-radius ratio),
-build_molecular_grid :332-394; grid presets tuna_util.py:129-137; functional table tuna_util.py:1440-1500.
+Lebedev order nearest to 9 * acc), the atomic product grid :210-258 (Gauss-Legendre in u, r = R u^3, Lebedev angular rule from
+SciPy) -> atomic_grid, the Becke diatomic weights :268-322 (four smoothing steps, size adjustment by the vdW-radius ratio) ->
+becke_cell_functions, the molecular grid :332-394 -> molecular_grid; grid presets tuna_util.py:129-137; functional table tuna_util.py:1440-1500.
 """
 from __future__ import annotations
 
@@ -41,46 +41,50 @@ def real_vdw_radius(symbol: str) -> float:
     return float(atomic_data()[s]["real_vdw_radius"])
 
 
-def build_atomic_radial_and_angular_grid(radial_grid_cutoff, n_radial, lebedev_order, radial_power=3):     # tuna_dft.py:210-258
+def atomic_grid(r_max, n_radial, lebedev_order, power=3):
+    """One atom-centred product grid: points [3, n_radial, n_ang] and weights [n_radial, n_ang].
+
+    Radial part: Gauss-Legendre nodes x on [-1, 1] mapped to u = (x + 1) / 2 in [0, 1] and then to r = r_max * u**power, so the
+    volume element r^2 dr carries the Jacobian r_max * power * u**(power - 1) / 2 per Legendre weight.  Angular part: SciPy's
+    Lebedev rule (its weights already sum to 4 pi).  Same quadrature as the reference builds (tuna_dft.py:210-258).
+    """
     from scipy.integrate import lebedev_rule
-    t_nodes, t_weights = np.polynomial.legendre.leggauss(n_radial)
-    t = (t_nodes + 1) / 2
-    w_t = t_weights / 2
-    r = radial_grid_cutoff * t ** radial_power
-    dr_dt = radial_grid_cutoff * radial_power * t ** (radial_power - 1)
-    weights_radial = w_t * dr_dt
-    unit_sphere_directions, weights_angular = lebedev_rule(lebedev_order)
-    atomic_points = np.einsum("m,in->imn", r, unit_sphere_directions, optimize=True)
-    atomic_weights = np.einsum("m,m,n->mn", weights_radial, r ** 2, weights_angular, optimize=True)
-    return atomic_points, atomic_weights
+    x, wx = np.polynomial.legendre.leggauss(n_radial)
+    u = 0.5 * (x + 1.0)
+    radius = r_max * u ** power
+    shell_weight = (0.5 * wx) * (r_max * power * u ** (power - 1)) * radius * radius          # w_r * r^2 * dr/du
+    directions, w_ang = lebedev_rule(lebedev_order)                                          # [3, n_ang], [n_ang]
+    return directions[:, None, :] * radius[None, :, None], shell_weight[:, None] * w_ang[None, :]
 
 
-def calculate_Becke_diatomic_weights(X, Y, Z, bond_length, radii, steepness=4):                            # tuna_dft.py:268-322
-    R_A = (X * X + Y * Y + Z * Z) ** (1 / 2)
-    R_B = (X * X + Y * Y + (Z - bond_length) * (Z - bond_length)) ** (1 / 2)
-    s = (R_A - R_B) / bond_length
+def becke_cell_functions(points, bond_length, radii, n_smooth=4):
+    """Becke's fuzzy-cell weights (w_A, w_B) of a diatomic A at the origin, B at (0, 0, bond_length); tuna_dft.py:268-322.
+
+    mu = (|r - A| - |r - B|) / R is shifted by the atomic-size correction nu = mu + a (1 - mu^2) with a = u / (u^2 - 1),
+    u = (chi - 1) / (chi + 1), chi = radius_A / radius_B, and then smoothed n_smooth times with p(t) = (3 t - t^3) / 2.
+    """
+    x, y, z = points
+    rho2 = x * x + y * y
+    mu = (np.sqrt(rho2 + z * z) - np.sqrt(rho2 + (z - bond_length) ** 2)) / bond_length
     chi = radii[0] / radii[1]
-    u = (chi - 1) / (chi + 1)
-    a = u / (u * u - 1)
-    s = s + a * (1 - s * s)
-    for _ in range(steepness):
-        s = (3 * s - s * s * s) / 2
-    return (1 - s) / 2, (1 + s) / 2
+    u = (chi - 1.0) / (chi + 1.0)
+    nu = mu + (u / (u * u - 1.0)) * (1.0 - mu * mu)
+    for _ in range(n_smooth):
+        nu = (3.0 * nu - nu * nu * nu) / 2.0         # Becke's p(t); this association keeps the near-zero cell weights bit-identical
+    return 0.5 * (1.0 - nu), 0.5 * (1.0 + nu)
 
 
-def build_molecular_grid(radial_grid_cutoff, n_radial, lebedev_order, bond_length, atoms):                 # tuna_dft.py:332-394
-    points_A, atomic_weights_A = build_atomic_radial_and_angular_grid(radial_grid_cutoff, n_radial, lebedev_order)
-    X_A, Y_A, Z_A = points_A
+def molecular_grid(r_max, n_radial, lebedev_order, bond_length, atoms):
+    """Atom A's grid followed by the same grid shifted to atom B, each weighted by its Becke cell function (tuna_dft.py:332-394);
+    a single atom (or an atom next to a ghost centre) keeps the bare atomic grid."""
+    pts, w = atomic_grid(r_max, n_radial, lebedev_order)
     if len(atoms) == 1 or any(a.charge == 0 for a in atoms):
-        return points_A, atomic_weights_A
-    X = np.concatenate([X_A, X_A], axis=0)
-    Y = np.concatenate([Y_A, Y_A], axis=0)
-    Z = np.concatenate([Z_A, Z_A + bond_length], axis=0)
-    points = np.stack((X, Y, Z), axis=0)
-    wA, wB = calculate_Becke_diatomic_weights(X, Y, Z, bond_length, [real_vdw_radius(a.symbol) for a in atoms])
-    n_A = X_A.shape[0]
-    weights = np.concatenate([atomic_weights_A * wA[:n_A], atomic_weights_A * wB[n_A:]], axis=0)
-    return points, weights
+        return pts, w
+    shifted = pts + np.array([0.0, 0.0, bond_length])[:, None, None]
+    both = np.concatenate([pts, shifted], axis=1)
+    cell_A, cell_B = becke_cell_functions(both, bond_length, [real_vdw_radius(a.symbol) for a in atoms])
+    n = w.shape[0]
+    return both, np.concatenate([w * cell_A[:n], w * cell_B[n:]], axis=0)
 
 
 def integration_grid(atoms, grid_conv="medium"):
@@ -92,6 +96,6 @@ def integration_grid(atoms, grid_conv="medium"):
     lebedev_order = int(LEBEDEV_ORDERS[np.abs(LEBEDEV_ORDERS - n).argmin()])
     n_radial = int(extent * acc)
     bond_length = float(atoms[-1].origin[2] - atoms[0].origin[2]) if len(atoms) == 2 else 0.0
-    points, weights = build_molecular_grid(extent, n_radial, lebedev_order, bond_length, atoms)
+    points, weights = molecular_grid(extent, n_radial, lebedev_order, bond_length, atoms)
     return points, weights, {"n_radial": n_radial, "lebedev_order": lebedev_order, "n_angular": weights.shape[1], "extent": float(extent),
                              "n_points": int(weights.size)}

@@ -86,19 +86,23 @@ def check_convergence(SCF_conv, step, delta_E, max_DP, RMS_DP, commutator, calcu
                 and abs(commutator) < SCF_conv["commutator"])
 
 
+def _one_electron_traces(integrals, P):
+    """tr(P T), tr(P V_NE), tr(P F_field), tr(P G_field) -- all four matrices are symmetric, so tr(P M) = sum(P * M)."""
+    return tuple(float(np.sum(P * M)) for M in (integrals.T, integrals.V_NE, integrals.F, integrals.G))
+
+
+def _energy_tuple(e_kin, e_ne, e_coul, e_exch, e_field, e_fgrad):
+    # the reference's component order (scf:400-404): T, V_NE, J, K, correlation (0 here: Hartree-Fock part), field, field gradient
+    parts = (e_kin, e_ne, e_coul, e_exch, 0, e_field, e_fgrad)
+    return sum(parts), parts
+
+
 def calculate_restricted_electronic_energy(integrals, P, J, K, calculation, density=None, weights=None, e_X=None, e_C=None):
-    """scf:344-404 (Hartree-Fock part; the grid terms belong to the DFT row, out of scope here)."""
-    kinetic_energy = np.einsum("ij,ij->", P, integrals.T, optimize=True)
-    nuclear_electron_energy = np.einsum("ij,ij->", P, integrals.V_NE, optimize=True)
-    electric_field_energy = np.einsum("ij,ij->", P, integrals.F, optimize=True)
-    electric_field_gradient_energy = np.einsum("ij,ij->", P, integrals.G, optimize=True)
-    coulomb_energy = (1 / 2) * np.einsum("ij,ij->", P, J, optimize=True)
-    exchange_energy = -(1 / 4) * np.einsum("ij,ij->", P, K, optimize=True) * calculation.HFX_prop
-    correlation_energy = 0
-    electronic_energy = (kinetic_energy + nuclear_electron_energy + coulomb_energy + exchange_energy + correlation_energy
-                         + electric_field_energy + electric_field_gradient_energy)
-    return electronic_energy, (kinetic_energy, nuclear_electron_energy, coulomb_energy, exchange_energy, correlation_energy,
-                               electric_field_energy, electric_field_gradient_energy)
+    """scf:344-404, Hartree-Fock part (the grid terms are added by the Kohn-Sham path): E = tr(P h) + tr(P J)/2 - HFX tr(P K)/4."""
+    e_kin, e_ne, e_field, e_fgrad = _one_electron_traces(integrals, P)
+    e_coul = 0.5 * float(np.sum(P * J))
+    e_exch = -0.25 * calculation.HFX_prop * float(np.sum(P * K))
+    return _energy_tuple(e_kin, e_ne, e_coul, e_exch, e_field, e_fgrad)
 
 
 def construct_restricted_Fock_matrix(integrals, P, HFX_prop, V_XC=None):             # scf:497-531
@@ -121,19 +125,12 @@ def construct_unrestricted_Fock_matrices(integrals, P_alpha, P_beta, HFX_prop, V
 
 
 def calculate_unrestricted_electronic_energy(integrals, P_alpha, P_beta, J_alpha, J_beta, K_alpha, K_beta, calculation):   # scf:415-486
-    P = P_alpha + P_beta
-    kinetic_energy = np.einsum("ij,ij->", P, integrals.T, optimize=True)
-    nuclear_electron_energy = np.einsum("ij,ij->", P, integrals.V_NE, optimize=True)
-    electric_field_energy = np.einsum("ij,ij->", P, integrals.F, optimize=True)
-    electric_field_gradient_energy = np.einsum("ij,ij->", P, integrals.G, optimize=True)
-    coulomb_energy = (1 / 2) * np.einsum("ij,ij->", P, J_alpha + J_beta, optimize=True)
-    exchange_energy = (-(1 / 2) * np.einsum("ij,ij->", P_alpha, K_alpha, optimize=True) * calculation.HFX_prop
-                       + -(1 / 2) * np.einsum("ij,ij->", P_beta, K_beta, optimize=True) * calculation.HFX_prop)
-    correlation_energy = 0
-    electronic_energy = (kinetic_energy + nuclear_electron_energy + coulomb_energy + exchange_energy + correlation_energy
-                         + electric_field_energy + electric_field_gradient_energy)
-    return electronic_energy, (kinetic_energy, nuclear_electron_energy, coulomb_energy, exchange_energy, correlation_energy,
-                               electric_field_energy, electric_field_gradient_energy)
+    """One-electron and Coulomb terms on the total density, exchange per spin: -HFX (tr(Pa Ka) + tr(Pb Kb)) / 2."""
+    P_total = P_alpha + P_beta
+    e_kin, e_ne, e_field, e_fgrad = _one_electron_traces(integrals, P_total)
+    e_coul = 0.5 * float(np.sum(P_total * (J_alpha + J_beta)))
+    e_exch = -0.5 * calculation.HFX_prop * (float(np.sum(P_alpha * K_alpha)) + float(np.sum(P_beta * K_beta)))
+    return _energy_tuple(e_kin, e_ne, e_coul, e_exch, e_field, e_fgrad)
 
 
 def format_output_line(E_total, delta_E, max_DP, RMS_DP, damping_factor, step, commutator):   # scf:83-107
