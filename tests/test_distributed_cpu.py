@@ -37,32 +37,22 @@ def _partial_jk(Es, P, owner, rank):
     return J, K
 
 
-def _partial_jk_packed(Es, P, owner, rank):
-    """The packed layout's pass (same algebra as jk_packed_kernel and its reductions): a rank holds, for each row (i,j) it
-    owns, the unique values (ij|kl) with pair(k,l) <= pair(i,j); every value feeds J twice and D four times, K = D + D^T."""
+def ao_parity_classes(U, lmn):
+    """x/y reflection parity class of every output AO: (lx & 1) | (ly & 1) << 1 of the first Cartesian component of its row of U."""
+    first = np.argmax(np.abs(U) > 0, axis=1)
+    return (lmn[first, 0] & 1) | ((lmn[first, 1] & 1) << 1)
+
+
+def _partial_jk_packed(Es, P, owner, rank, cls):
+    """The packed layout's pass through tests/layout_model.py -- the NumPy model of the parity-blocked layout, of the task
+    structure of jk_packed_kernel and of the validity rules of its reductions: a rank holds, for each row (i,j) it owns, the unique
+    values (ij|kl) with pair(k,l) <= pair(i,j) and class(k) ^ class(l) == class(i) ^ class(j)."""
+    import layout_model as lm
     N = P.shape[0]
-    J = np.zeros((N, N)); D = np.zeros((N, N))
-    tri = np.tril(np.ones((N, N), dtype=bool))
-    for i in range(N):
-        for j in range(i + 1):
-            if owner[i, j] != rank:
-                continue
-            M = np.where(tri, Es[i, j], 0.0)                       # k >= l
-            M[i + 1:, :] = 0.0; M[i, j + 1:] = 0.0                 # pair(k,l) <= pair(i,j)
-            Mk = M.copy(); Mk[i, j] *= 0.5                          # the diagonal element (ij|ij) counts once in K
-            Pp = np.where(np.eye(N, dtype=bool), P, 2.0 * P)
-            jd = np.sum(M * Pp)
-            J[i, j] += jd
-            if i != j:
-                J[j, i] += jd
-            Mt = M.copy(); Mt[i, j] = 0.0                           # transposed image, not for (kl) == (ij)
-            Jt = Mt * (P[i, j] if i == j else 2.0 * P[i, j])
-            J += Jt + np.tril(Jt, -1).T
-            off = np.tril(Mk, -1)
-            D[i, :] += Mk @ P[j, :] + off.T @ P[j, :]
-            if i != j:
-                D[j, :] += Mk @ P[i, :] + off.T @ P[i, :]
-    return J, D + D.T
+    L = lm.Layout(cls, pad=8, cw=16)                                   # (narrow chunks: several chunks per class at these sizes)
+    rows = [(i, j) for i in range(N) for j in range(i + 1) if owner[i, j] == rank]
+    J, K, _ = lm.fock_partial(L, Es, P, rows)
+    return J, K
 
 
 def _worker(rank, world, port, tag, layout, ret):
@@ -77,7 +67,10 @@ def _worker(rank, world, port, tag, layout, ret):
         N = Es.shape[0]
         P = np.random.default_rng(0).standard_normal((N, N)); P = P + P.T
         owner = tdist.row_owner_matrix(shells, world, layout=layout)
-        J, K = (_partial_jk_packed if layout == "packed" else _partial_jk)(Es, P, owner, rank)
+        if layout == "packed":
+            J, K = _partial_jk_packed(Es, P, owner, rank, ao_parity_classes(U, aos.lmn))
+        else:
+            J, K = _partial_jk(Es, P, owner, rank)
         jk = torch.from_numpy(np.stack([J, K]))
         tdist.all_reduce_jk_(jk)
         Jf, Kf = jk.numpy()

@@ -60,6 +60,26 @@ struct tf_ctx {
     int layout = 0;
     long long n_elems = 0;              // stored doubles
     long long *d_rowoff = nullptr;
+    int *d_rowsec = nullptr;            // [n_rows][4]: start of section a inside local row r
+    // parity-blocked layout tables (tf_layout.hip.h), host mirror and device view
+    struct HostLayout {
+        int N = 0, NW = 0, RS = 0;
+        int cstart[4] = {}, csize[4] = {}, corder[4] = {}, wfirst[5] = {}, fullsec[4][4] = {}, gbase[4] = {};
+        long long cbase[4] = {}, NP[4] = {}, NPtot = 0, RLS = 0;
+        std::vector<int> cls, loc, sigma, ao, origI, clsI, cntA, kap0, kapF, rpoff, chunk_c0, chunk_width, chunk_cls, chunk_of, gk;
+        std::vector<KInfo> kinfo;                                   // [4][N]
+        std::vector<int> offE;                                      // [4][N]: offA + padded segment length
+        int ke(int a, int xI) const { return cntA[(size_t)a * N + xI]; }
+        int seclen(int c, int a, int iI) const { const int k = ke(a, iI); return k == 0 ? 0 : offE[(size_t)c * N + cstart[a] + k - 1]; }
+        int row_shape(int c, int iI, int *secoff) const {           // section starts and the length of a class-c row with first index iI
+            int tot = 0;
+            for (int t = 0; t < 4; ++t) { const int a = corder[t]; secoff[a] = tot; tot += seclen(c, a, iI); }
+            return tot;
+        }
+        bool task_exists(int c, int w, int iI) const { return kap0[(size_t)c * NW + w] < ke(chunk_cls[w] ^ c, iI); }
+    } hl;
+    BLayout bl{};
+    std::vector<void *> layout_allocs;
     // work tables of jk_packed_kernel: set 0 for one density per pass (groups of 8 rows), set 1 for two (groups of 4 rows)
     struct JKTables {
         JKGroup *d_groups = nullptr;
@@ -68,6 +88,7 @@ struct tf_ctx {
         int *d_gfirst = nullptr;        // [2][N]: first / one-past-last group with i == a
         int n_groups = 0, n_tasks = 0, n_supers = 0, nseg = 1;
         long long ypart_len = 0;
+        JKJtPlan jp{};
     } jkt[2];
     double *d_Psym = nullptr, *d_Pp = nullptr, *d_ypart = nullptr, *d_DI = nullptr, *d_DJ = nullptr, *d_Jt = nullptr, *d_D = nullptr;
     // instrumentation
@@ -140,6 +161,10 @@ static void free_eri(tf_ctx *ctx)
             if (p) (void)hipFree(p);
         t = tf_ctx::JKTables();
     }
+    for (void *p : ctx->layout_allocs) (void)hipFree(p);
+    ctx->layout_allocs.clear();
+    if (ctx->d_rowsec) { (void)hipFree(ctx->d_rowsec); ctx->d_rowsec = nullptr; }
+    ctx->bl = BLayout{};
     ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
     ctx->d_Ppad = nullptr; ctx->d_J = nullptr; ctx->d_K = nullptr; ctx->d_P = nullptr;
     ctx->d_rowoff = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
@@ -156,6 +181,138 @@ static void free_basis(tf_ctx *ctx)
         if (p) (void)hipFree(p);
     ctx->d_csr_ptr = ctx->d_csr_idx = nullptr; ctx->d_csr_val = nullptr;
     ctx->have_basis = false;
+}
+
+// Tables of the parity-blocked layout for the output AOs of this build (tf_layout.hip.h; the NumPy model tests/layout_model.py
+// builds the same tables).  cls[k]: x/y parity class of output AO k (original order).
+static int build_blocked_layout(tf_ctx *ctx, const std::vector<int> &cls)
+{
+    tf_ctx::HostLayout &H = ctx->hl;
+    H = tf_ctx::HostLayout();
+    const int N = (int)cls.size(), PAD = TF_SEG_PAD;
+    H.N = N; H.cls = cls;
+    for (int k = 0; k < N; ++k) ++H.csize[cls[k]];
+    int order[4] = {0, 1, 2, 3};
+    std::stable_sort(order, order + 4, [&](int x, int y) { return H.csize[x] > H.csize[y]; });   // larger classes first (ties: class id)
+    for (int t = 0, s0 = 0; t < 4; ++t) { H.corder[t] = order[t]; H.cstart[order[t]] = s0; s0 += H.csize[order[t]]; }
+    H.loc.assign(N, 0); H.sigma.assign(N, 0); H.ao.assign(N, 0); H.origI.assign(N, 0); H.clsI.assign(N, 0);
+    std::vector<int> cnt((size_t)4 * N, 0);                          // cnt[b][k]: class-b AOs with original index <= k
+    {
+        int seen[4] = {0, 0, 0, 0};
+        for (int k = 0; k < N; ++k) {
+            H.loc[k] = seen[cls[k]]++;
+            H.sigma[k] = H.cstart[cls[k]] + H.loc[k];
+            H.ao[k] = cls[k] | (H.loc[k] << 2);
+            H.origI[H.sigma[k]] = k;
+            H.clsI[H.sigma[k]] = cls[k];
+            for (int b = 0; b < 4; ++b) cnt[(size_t)b * N + k] = seen[b];
+        }
+    }
+    H.cntA.assign((size_t)4 * N, 0);
+    for (int a = 0; a < 4; ++a)
+        for (int x = 0; x < N; ++x) H.cntA[(size_t)a * N + x] = cnt[(size_t)a * N + H.origI[x]];
+    H.kinfo.assign((size_t)4 * N, KInfo{0, 0});
+    H.offE.assign((size_t)4 * N, 0);
+    for (int c = 0; c < 4; ++c) {
+        long long tot = 0;
+        for (int t = 0; t < 4; ++t) {
+            const int a = H.corder[t];
+            H.fullsec[c][a] = (int)tot;
+            long long off = 0;
+            for (int kk = 0; kk < H.csize[a]; ++kk) {
+                const int kI = H.cstart[a] + kk;
+                const int n = cnt[(size_t)(a ^ c) * N + H.origI[kI]];
+                H.kinfo[(size_t)c * N + kI] = KInfo{(int)off, n};
+                off += (n + PAD - 1) / PAD * PAD;
+                H.offE[(size_t)c * N + kI] = (int)off;
+            }
+            tot += off;
+        }
+        if (tot > 0x7fffffffLL / 8) TF_FAIL(ctx, TF_EINVAL, "basis too large for the packed layout's 32-bit row offsets");
+        H.NP[c] = tot;
+    }
+    H.NPtot = 0; H.RLS = 0;
+    for (int c = 0; c < 4; ++c) { H.cbase[c] = H.NPtot; H.NPtot += H.NP[c]; H.RLS = std::max(H.RLS, H.NP[c]); }
+    // granule table: AO k of the segment that holds granule g of class c's pair index space
+    {
+        int gb = 0;
+        for (int c = 0; c < 4; ++c) { H.gbase[c] = gb; gb += (int)(H.NP[c] / PAD); }
+        H.gk.assign((size_t)std::max(gb, 1), 0);
+        for (int c = 0; c < 4; ++c)
+            for (int kI = 0; kI < N; ++kI) {
+                const int a = H.clsI[kI];
+                const int g0 = (H.fullsec[c][a] + H.kinfo[(size_t)c * N + kI].offA) / PAD, g1 = (H.fullsec[c][a] + H.offE[(size_t)c * N + kI]) / PAD;
+                for (int g = g0; g < g1; ++g) H.gk[(size_t)H.gbase[c] + g] = kI;
+            }
+    }
+    // column chunks: the internal columns cut at class boundaries and every TF_JKP_CW columns
+    H.chunk_of.assign(N, 0);
+    for (int b = 0; b < 4; ++b) {
+        H.wfirst[b] = (int)H.chunk_cls.size();
+        for (int lam0 = 0; lam0 < H.csize[b]; lam0 += TF_JKP_CW) {
+            const int wd = std::min(TF_JKP_CW, H.csize[b] - lam0);
+            for (int u = 0; u < wd; ++u) H.chunk_of[H.cstart[b] + lam0 + u] = (int)H.chunk_cls.size();
+            H.chunk_cls.push_back(b); H.chunk_c0.push_back(H.cstart[b] + lam0); H.chunk_width.push_back(wd);
+        }
+    }
+    H.wfirst[4] = (int)H.chunk_cls.size();
+    H.NW = (int)H.chunk_cls.size();
+    const int NW = H.NW;
+    H.kap0.assign((size_t)4 * std::max(NW, 1), 0); H.kapF.assign((size_t)4 * std::max(NW, 1), 0); H.rpoff.assign((size_t)4 * std::max(NW, 1), 0);
+    H.RS = 1;
+    for (int c = 0; c < 4; ++c) {
+        int o = 0;
+        for (int w = 0; w < NW; ++w) {
+            const int b = H.chunk_cls[w], a = b ^ c, lam0 = H.chunk_c0[w] - H.cstart[b];
+            const int cm = (c == 0) ? 1 : 0;
+            int k0 = H.csize[a], kF = H.csize[a];
+            for (int kk = H.csize[a] - 1; kk >= 0; --kk) {           // the counts are non-decreasing along a class
+                const int n = H.kinfo[(size_t)c * N + H.cstart[a] + kk].cnt;
+                if (n > lam0) k0 = kk;
+                if (H.chunk_width[w] == TF_JKP_CW && n - cm >= lam0 + TF_JKP_CW) kF = kk;
+            }
+            H.kap0[(size_t)c * NW + w] = k0; H.kapF[(size_t)c * NW + w] = kF; H.rpoff[(size_t)c * NW + w] = o;
+            o += H.csize[a];
+        }
+        H.RS = std::max(H.RS, o);
+    }
+    // device copy
+    BLayout L{};
+    L.N = N; L.NW = NW; L.RS = H.RS; L.NPtot = H.NPtot;
+    std::vector<int> itab(BL_ITAB, 0);
+    std::vector<long long> ltab(BL_LTAB, 0);
+    for (int c = 0; c < 4; ++c) {
+        itab[BL_CSTART + c] = H.cstart[c]; itab[BL_CSIZE + c] = H.csize[c]; itab[BL_GBASE + c] = H.gbase[c];
+        ltab[BL_CBASE + c] = H.cbase[c]; ltab[BL_NP + c] = H.NP[c];
+        for (int a = 0; a < 4; ++a) itab[BL_FULLSEC + 4 * c + a] = H.fullsec[c][a];
+    }
+    for (int b = 0; b < 5; ++b) itab[BL_WFIRST + b] = H.wfirst[b];
+    auto up_i = [&](const std::vector<int> &h, const int **d) -> int {
+        int *p = nullptr;
+        int rc = upload(ctx, h, &p, false);
+        if (rc) return rc;
+        ctx->layout_allocs.push_back(p);
+        *d = p;
+        return TF_OK;
+    };
+    int rc;
+    {
+        long long *dl = nullptr;
+        if ((rc = upload(ctx, ltab, &dl, false))) return rc;
+        ctx->layout_allocs.push_back(dl);
+        L.ltab = dl;
+    }
+    if ((rc = up_i(itab, &L.itab)) || (rc = up_i(H.ao, &L.ao)) || (rc = up_i(H.origI, &L.origI)) || (rc = up_i(H.clsI, &L.clsI)) || (rc = up_i(H.cntA, &L.cntA)) ||
+        (rc = up_i(H.kap0, &L.kap0)) || (rc = up_i(H.kapF, &L.kapF)) || (rc = up_i(H.rpoff, &L.rpoff)) || (rc = up_i(H.chunk_c0, &L.chunk_c0)) ||
+        (rc = up_i(H.chunk_width, &L.chunk_width)) || (rc = up_i(H.chunk_cls, &L.chunk_cls)) || (rc = up_i(H.chunk_of, &L.chunk_of)) ||
+        (rc = up_i(H.gk, &L.gk)))
+        return rc;
+    KInfo *dk = nullptr;
+    if ((rc = upload(ctx, H.kinfo, &dk, false))) return rc;
+    ctx->layout_allocs.push_back(dk);
+    L.kinfo = dk;
+    ctx->bl = L;
+    return TF_OK;
 }
 
 // Longest-processing-time assignment of row blocks (bra shell pairs) to ranks: heaviest block first, always to
@@ -506,8 +663,32 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     for (int p = 0; p < npairs; ++p)
         if (owner[p] == ctx->rank) ctx->my_pairs.push_back(p);
 
+    // ---- parity classes of the output AOs and the layout tables (packed layout)
+    if (packed) {
+        std::vector<int> cls(N);
+        // every Cartesian component of a real spherical AO has the AO's x/y parity: the first one decides
+        {
+            std::vector<double> blk;
+            int o = 0;
+            for (const auto &sh : bs.shells) {
+                const int nout = out_dim(sh);
+                if (spherical) tf::sph_block(sh.L, blk);
+                for (int r = 0; r < nout; ++r) {
+                    int cc = r;
+                    if (spherical) {
+                        cc = 0;
+                        while (cc < sh.ncomp && blk[(size_t)r * sh.ncomp + cc] == 0.0) ++cc;
+                    }
+                    const int ca = sh.cart_off + cc;
+                    cls[o++] = (bs.ao_lmn[3 * ca] & 1) | ((bs.ao_lmn[3 * ca + 1] & 1) << 1);
+                }
+            }
+        }
+        if ((rc = build_blocked_layout(ctx, cls))) return rc;
+    }
+    const tf_ctx::HostLayout &H = ctx->hl;
     // ---- row tables
-    std::vector<int2> row_ij;
+    std::vector<int2> row_ij;                                       // original (i >= j) of every local row
     std::vector<int> rowmap((size_t)N * (N + 1) / 2, -1);
     std::vector<long long> pair_first_row(npairs, -1);
     for (int p : ctx->my_pairs) {
@@ -522,15 +703,25 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             }
     }
     std::vector<long long> rowoff;
+    std::vector<int> rowsec, rowlen;
+    auto ikey = [](int x, int y) { const int hi = std::max(x, y), lo = std::min(x, y); return (size_t)hi * (hi + 1) / 2 + lo; };
     if (packed) {
-        // owned rows in ascending (i,j); row (i,j) holds the pairs (k,l) <= (i,j) at their padded indices (tf_jkpacked.hip.h)
-        std::sort(row_ij.begin(), row_ij.end(), [](const int2 &u, const int2 &v) { return u.x != v.x ? u.x < v.x : u.y < v.y; });
+        // owned rows in ascending internal (sigma(i), sigma(j)): rows that share i and the class of j are adjacent (the row groups of the
+        // J/K kernel); rowmap is keyed by the unordered pair of internal indices
+        std::sort(row_ij.begin(), row_ij.end(), [&](const int2 &u, const int2 &v) {
+            return H.sigma[u.x] != H.sigma[v.x] ? H.sigma[u.x] < H.sigma[v.x] : H.sigma[u.y] < H.sigma[v.y];
+        });
+        std::fill(rowmap.begin(), rowmap.end(), -1);
         rowoff.resize(row_ij.size() + 1);
+        rowsec.resize(4 * row_ij.size() + 4);
+        rowlen.resize(row_ij.size() + 1);
         long long off = 0;
         for (size_t r = 0; r < row_ij.size(); ++r) {
-            rowmap[(size_t)row_ij[r].x * (row_ij[r].x + 1) / 2 + row_ij[r].y] = (int)r;
+            const int i = row_ij[r].x, j = row_ij[r].y;
+            rowmap[ikey(H.sigma[i], H.sigma[j])] = (int)r;
             rowoff[r] = off;
-            off += packed_row_len(row_ij[r].x, row_ij[r].y);
+            rowlen[r] = H.row_shape(H.cls[i] ^ H.cls[j], H.sigma[i], &rowsec[4 * r]);
+            off += rowlen[r];
         }
         rowoff[row_ij.size()] = off;
         ctx->n_elems = off;
@@ -542,46 +733,75 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         std::vector<JKSuper> supers;
         std::vector<int> gfirst(2 * (size_t)N, 0);
         long long ypart_len = 0;
-        // groups: runs of consecutive j with the same i, longest rows first
+        auto sI = [&](long long r) { return H.sigma[row_ij[r].x]; };
+        auto sJ = [&](long long r) { return H.sigma[row_ij[r].y]; };
+        // groups: runs of consecutive internal j of one class with the same i, largest j first
         for (long long r = (long long)row_ij.size() - 1; r >= 0;) {
             long long r0 = r;
-            while (r0 > 0 && row_ij[r0 - 1].x == row_ij[r].x && row_ij[r0 - 1].y == row_ij[r0].y - 1 && r - r0 + 1 < RB) --r0;
+            while (r0 > 0 && sI(r0 - 1) == sI(r) && sJ(r0 - 1) == sJ(r0) - 1 && H.clsI[sJ(r0 - 1)] == H.clsI[sJ(r)] && r - r0 + 1 < RB) --r0;
             JKGroup g{};
-            g.i = row_ij[r].x; g.j0 = row_ij[r0].y; g.nr = (int)(r - r0 + 1); g.r0 = (int)r0;
+            g.i = sI(r); g.j0 = sJ(r0); g.nr = (int)(r - r0 + 1); g.r0 = (int)r0;
+            g.c = H.clsI[g.i] ^ H.clsI[g.j0]; g.lamj0 = g.j0 - H.cstart[H.clsI[g.j0]];
             for (int q = 0; q < TF_JKP_JBB; ++q) g.roff[q] = (int)(rowoff[r0 + std::min<long long>(q, r - r0)] - rowoff[r0]);
+            for (int a = 0; a < 4; ++a) g.secoff[a] = rowsec[4 * (size_t)r0 + a];
             groups.push_back(g);
             r = r0 - 1;
         }
+        // (the reductions want the groups of one i contiguous: they are, the rows being sorted by i)
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const int a = groups[gi].i;
             if (gfirst[N + a] == gfirst[a]) gfirst[a] = (int)gi;
             gfirst[N + a] = (int)gi + 1;
         }
-        // super-groups: up to TF_JKP_W adjacent groups with the same i share a workgroup and one Jt partial
+        // super-groups: up to TF_JKP_W adjacent groups with the same i and class share a workgroup and one Jt partial.  The kernel's
+        // groups index into `groups`, so the super list may be reordered freely: by class, then by descending original i (the Jt
+        // reduction needs those that reach an AO k to be a prefix of their class's list)
         for (size_t gi = 0; gi < groups.size();) {
             size_t ge = gi + 1;
-            while (ge < groups.size() && groups[ge].i == groups[gi].i && ge - gi < TF_JKP_W) ++ge;
+            while (ge < groups.size() && groups[ge].i == groups[gi].i && groups[ge].c == groups[gi].c && ge - gi < TF_JKP_W) ++ge;
             JKSuper sg{};
-            sg.g0 = (int)gi; sg.ng = (int)(ge - gi);
-            sg.yoff = ypart_len;
-            sg.ylen = packed_row_len(groups[gi].i, groups[gi].j0 + groups[gi].nr - 1);   // the first group ends last
-            ypart_len += sg.ylen;
+            sg.g0 = (int)gi; sg.ng = (int)(ge - gi); sg.c = groups[gi].c; sg.i = groups[gi].i;
+            for (int a = 0; a < 4; ++a) sg.ke[a] = H.ke(a, sg.i);
             supers.push_back(sg);
             gi = ge;
         }
-        // tasks (super-group, 128-column chunk), longest first: the hardware dispatches workgroups in this order
-        for (size_t si = 0; si < supers.size(); ++si)
-            for (int c = 0; c * TF_JKP_CW <= groups[supers[si].g0].i; ++c) tasks.push_back(JKTask{(int)si, c});
-        std::stable_sort(tasks.begin(), tasks.end(), [&](const JKTask &u, const JKTask &v) {
-            return groups[supers[u.super].g0].i - u.chunk * TF_JKP_CW > groups[supers[v.super].g0].i - v.chunk * TF_JKP_CW;
+        std::stable_sort(supers.begin(), supers.end(), [&](const JKSuper &u, const JKSuper &v) {
+            return u.c != v.c ? u.c < v.c : H.origI[u.i] > H.origI[v.i];
         });
+        JKJtPlan jp{};
+        for (size_t si = 0; si < supers.size(); ++si) {
+            supers[si].yoff = ypart_len;
+            ypart_len += H.NP[supers[si].c];
+            ++jp.sfirst[supers[si].c + 1];
+        }
+        for (int c = 0; c < 4; ++c) {
+            jp.sfirst[c + 1] += jp.sfirst[c];
+            jp.bfirst[c + 1] = jp.bfirst[c] + (int)((H.NP[c] + 255) / 256);
+        }
+        // tasks (super-group, chunk) that have at least one step, longest first: the hardware dispatches workgroups in this order
+        std::vector<int> steps;
+        for (size_t si = 0; si < supers.size(); ++si)
+            for (int w = 0; w < H.NW; ++w)
+                if (H.task_exists(supers[si].c, w, supers[si].i)) {
+                    tasks.push_back(JKTask{(int)si, w});
+                    steps.push_back(H.ke(H.chunk_cls[w] ^ supers[si].c, supers[si].i) - H.kap0[(size_t)supers[si].c * H.NW + w]);
+                }
+        {
+            std::vector<int> ord(tasks.size());
+            std::iota(ord.begin(), ord.end(), 0);
+            std::stable_sort(ord.begin(), ord.end(), [&](int u, int v) { return steps[u] > steps[v]; });
+            std::vector<JKTask> sorted(tasks.size());
+            for (size_t t = 0; t < ord.size(); ++t) sorted[t] = tasks[ord[t]];
+            tasks.swap(sorted);
+        }
         int rc2;
         if ((rc2 = upload(ctx, groups, &T.d_groups, false)) || (rc2 = upload(ctx, gfirst, &T.d_gfirst, false)) ||
             (rc2 = upload(ctx, tasks, &T.d_tasks, false)) || (rc2 = upload(ctx, supers, &T.d_supers, false)))
             return rc2;
         T.n_groups = (int)groups.size(); T.n_tasks = (int)tasks.size(); T.n_supers = (int)supers.size();
-        T.nseg = std::max(1, std::min(TF_JKP_SEG, T.n_supers / 32));
+        T.nseg = std::max(1, std::min(TF_JKP_SEG, T.n_supers / 128));
         T.ypart_len = ypart_len;
+        T.jp = jp;
         return TF_OK;
     };
     ctx->n_rows = (long long)row_ij.size();
@@ -603,20 +823,29 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     }
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
     if (packed) {
-        if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = build_jk_tables(TF_JKP_JBB, ctx->jkt[0])) ||
-            (rc = build_jk_tables(TF_JKP_JBB / 2, ctx->jkt[1])))
+        if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, rowsec, &ctx->d_rowsec, false)) ||
+            (rc = build_jk_tables(TF_JKP_JBB, ctx->jkt[0])) || (rc = build_jk_tables(TF_JKP_JBB / 2, ctx->jkt[1])))
             return rc;
+        ctx->db.bl = ctx->bl;
+        ctx->db.RLS = H.RLS;
     }
 
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
     // ---- slabs of bra pairs: Cartesian block -> ket transform -> bra transform -> tensor rows
-    // Cartesian slab: 1 GiB, more (up to 4 GiB) for big tensors -- fewer, larger class launches (N = 500: 0.52 -> 0.44 s)
+    // Large problems launch per (bra class, ket class) with the ket transform fused into the ERI kernels: no Cartesian slab at all.
+    bool per_class = (long long)ctx->my_pairs.size() * npairs >= 2000000LL;
+    if (const char *m = getenv("TF_ERI_MODE")) per_class = (m[0] == 'c');
+    // A slab row is one Cartesian bra component pair: Nc^2 Cartesian ket values (small-problem mode only) and the ket-transformed
+    // row -- N x ld (rows layout) or the complete-row shape of the packed layout (RLS doubles, ~ N^2 / 8).  1 GiB of slab, more (up
+    // to 4 GiB) for big tensors: fewer, larger class launches.
     const size_t cart_row_bytes = (size_t)Nc * Nc * sizeof(double);
-    size_t cart_total = 0;                                       // this rank's Cartesian bra rows x Nc^2: one slab if that is <= 4 GiB
-    for (int p : ctx->my_pairs) cart_total += (size_t)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp * cart_row_bytes;
-    size_t slab_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>((size_t)1 << 30, std::max((size_t)ctx->n_elems, cart_total)));
+    const size_t t2_row_bytes = (packed ? (size_t)H.RLS : (size_t)N * ld) * sizeof(double);
+    const size_t slab_row_bytes = std::max<size_t>(8, std::max(t2_row_bytes, per_class ? (size_t)0 : cart_row_bytes));
+    size_t slab_total = 0;                                       // this rank's bra rows: one slab if that is <= 4 GiB
+    for (int p : ctx->my_pairs) slab_total += (size_t)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp * slab_row_bytes;
+    size_t slab_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>((size_t)1 << 30, std::max((size_t)ctx->n_elems, slab_total)));
     if (const char *e = getenv("TF_SLAB_MB")) slab_bytes = (size_t)std::max(1, atoi(e)) << 20;
-    long long max_rows_c = std::max<long long>(1, (long long)(slab_bytes / cart_row_bytes));
+    long long max_rows_c = std::max<long long>(1, (long long)(slab_bytes / slab_row_bytes));
     long long biggest = 1;
     for (int p : ctx->my_pairs)
         biggest = std::max<long long>(biggest, (long long)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp);
@@ -626,8 +855,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         for (int p : ctx->my_pairs) need += (long long)bs.shells[bs.pairs[p].A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
         max_rows_c = std::max<long long>(biggest, std::min(max_rows_c, need));
     }
-    if ((rc = ensure_scratch(ctx, 0, (size_t)max_rows_c * Nc * Nc * sizeof(double))) ||
-        (rc = ensure_scratch(ctx, 2, (size_t)max_rows_c * N * ld * sizeof(double))))
+    if ((rc = ensure_scratch(ctx, 0, per_class ? 8 : (size_t)max_rows_c * cart_row_bytes)) ||
+        (rc = ensure_scratch(ctx, 2, (size_t)max_rows_c * t2_row_bytes)))
         return rc;
     double *d_C = ctx->scr[0], *d_T2 = ctx->scr[2];
     double t_stage[4] = {0, 0, 0, 0};
@@ -1022,8 +1251,6 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
         return TF_OK;
     };
-    bool per_class = (long long)mine_sorted.size() * npairs >= 2000000LL;
-    if (const char *m = getenv("TF_ERI_MODE")) per_class = (m[0] == 'c');
     if (!per_class) make_caps();
     if ((rc = make_lrecs(!per_class))) return rc;
     if (!per_class)
@@ -1037,31 +1264,45 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     for (int p : mine_sorted) max_out = std::max<size_t>(max_out, (size_t)pair_rows[p]);
     const size_t cap_bra = std::min<size_t>(mine_sorted.size(), 65535) + 1;
     const size_t cap_out = (size_t)std::min<long long>(ctx->n_rows, max_rows_c * 2 + (long long)max_out) + 1;
-    int *d_bra = nullptr; long long *d_braoff = nullptr; OutRow *d_out = nullptr;
-    static_assert(sizeof(OutRow) == sizeof(OutRowP), "the two row descriptors share one device buffer");
+    int *d_bra = nullptr; long long *d_braoff = nullptr; void *d_out = nullptr;
+    signed char *d_rowcls = nullptr;                               // parity class of every slab row (small-problem mode, packed layout)
     HIPCHK(ctx, hipMalloc((void **)&d_bra, cap_bra * sizeof(int)));
     HIPCHK(ctx, hipMalloc((void **)&d_braoff, cap_bra * sizeof(long long)));
-    HIPCHK(ctx, hipMalloc((void **)&d_out, cap_out * sizeof(OutRow)));
+    HIPCHK(ctx, hipMalloc((void **)&d_out, cap_out * std::max(sizeof(OutRow), sizeof(OutRowP))));
+    if (packed && !per_class) HIPCHK(ctx, hipMalloc((void **)&d_rowcls, (size_t)max_rows_c + 1));
     std::vector<hipEvent_t> tev;                                   // 4 timing events per slab, read at the end
     size_t cursor = 0;
     while (cursor < mine_sorted.size()) {
         std::vector<int> bra; std::vector<long long> braoff; std::vector<OutRow> outs;
+        std::vector<OutRowP> outsP;
+        std::vector<signed char> rowcls;
         long long rows_c = 0;
         while (cursor < mine_sorted.size()) {
             const int p = mine_sorted[cursor];
             const tf::Shell &a = bs.shells[bs.pairs[p].A], &b = bs.shells[bs.pairs[p].B];
             const long long nr = (long long)a.ncomp * b.ncomp;
-            if (!bra.empty() && (rows_c + nr > max_rows_c || bra.size() >= 65535 || outs.size() + (size_t)pair_rows[p] >= cap_out)) break;
+            if (!bra.empty() && (rows_c + nr > max_rows_c || bra.size() >= 65535 || outs.size() + outsP.size() + (size_t)pair_rows[p] >= cap_out)) break;
             bra.push_back(p); braoff.push_back(rows_c);
             long long r = pair_first_row[p];
             for (int x = 0; x < out_dim(a); ++x)
                 for (int y = 0; y < out_dim(b); ++y) {
                     const int i = out_off(a) + x, j = out_off(b) + y;
                     if (i < j) continue;
-                    // packed: dst_row carries the element offset of the row (OutRowP::dst_off)
-                    const long long dst = packed ? rowoff[rowmap[(size_t)i * (i + 1) / 2 + j]] : r++;
-                    outs.push_back(OutRow{i, j, a.cart_off, b.cart_off, b.ncomp, 0, rows_c, dst});
+                    if (!packed) { outs.push_back(OutRow{i, j, a.cart_off, b.cart_off, b.ncomp, 0, rows_c, r++}); continue; }
+                    const int lr = rowmap[ikey(H.sigma[i], H.sigma[j])];
+                    OutRowP o{};
+                    o.i = i; o.j = j; o.iI = H.sigma[i]; o.lamj = H.loc[j]; o.c = H.cls[i] ^ H.cls[j]; o.ncb = b.ncomp;
+                    o.cartA = a.cart_off; o.cartB = b.cart_off;
+                    for (int t = 0; t < 4; ++t) o.secoff[t] = rowsec[4 * (size_t)lr + t];
+                    o.len = rowlen[lr]; o.slab_off = rows_c; o.dst_off = rowoff[lr];
+                    outsP.push_back(o);
                 }
+            if (packed && !per_class)
+                for (int ca = 0; ca < a.ncomp; ++ca)
+                    for (int cb = 0; cb < b.ncomp; ++cb) {
+                        const int u = a.comp_off + ca, v = b.comp_off + cb;
+                        rowcls.push_back((signed char)(((bs.c_lx[u] + bs.c_lx[v]) & 1) | (((bs.c_ly[u] + bs.c_ly[v]) & 1) << 1)));
+                    }
             rows_c += nr;
             const int Alim = packed ? bs.pairs[p].A + 1 : nsh;
             n_quart += cum_pairs[Alim];
@@ -1074,10 +1315,12 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         HIPCHK(ctx, hipMemcpy(d_bra, bra.data(), bra.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(d_braoff, braoff.data(), braoff.size() * sizeof(long long), hipMemcpyHostToDevice));
         if (!outs.empty()) HIPCHK(ctx, hipMemcpy(d_out, outs.data(), outs.size() * sizeof(OutRow), hipMemcpyHostToDevice));
-        DBG("slab: %zu bra pairs, %lld cart rows, %zu out rows", bra.size(), rows_c, outs.size());
+        if (!outsP.empty()) HIPCHK(ctx, hipMemcpy(d_out, outsP.data(), outsP.size() * sizeof(OutRowP), hipMemcpyHostToDevice));
+        if (!rowcls.empty()) HIPCHK(ctx, hipMemcpy(d_rowcls, rowcls.data(), rowcls.size(), hipMemcpyHostToDevice));
+        DBG("slab: %zu bra pairs, %lld cart rows, %zu out rows", bra.size(), rows_c, outs.size() + outsP.size());
         hipEvent_t e4[4];
         for (auto &e : e4) { HIPCHK(ctx, hipEventCreate(&e)); tev.push_back(e); }
-        if (per_class && ld != N) HIPCHK(ctx, hipMemsetAsync(d_T2, 0, (size_t)rows_c * N * ld * sizeof(double), 0));   // pad columns
+        if (per_class && !packed && ld != N) HIPCHK(ctx, hipMemsetAsync(d_T2, 0, (size_t)rows_c * N * ld * sizeof(double), 0));   // pad columns
         // generic mode: eri_cfact_kernel stores only the components that are not zero by x/y parity
         if (!per_class) HIPCHK(ctx, hipMemsetAsync(d_C, 0, (size_t)rows_c * Nc * Nc * sizeof(double), 0));
         HIPCHK(ctx, hipEventRecord(e4[0], 0));
@@ -1106,8 +1349,13 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         if (!per_class) {
             for (long long r0s = 0; r0s < rows_c; r0s += 65535) {      // both ket axes in one pass over the slab
                 const unsigned ny = (unsigned)std::min<long long>(65535, rows_c - r0s);
-                hipLaunchKernelGGL(xform_ket_both, dim3((unsigned)((N + 3) / 4), ny), dim3(256), 0, 0, d_C + (size_t)r0s * Nc * Nc,
-                                   d_T2 + (size_t)r0s * N * ld, Nc, N, ld, ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val, packed ? 1 : 0);
+                if (packed)
+                    hipLaunchKernelGGL(xform_ket_packed, dim3((unsigned)((N + 3) / 4), ny), dim3(256), 0, 0, d_C + (size_t)r0s * Nc * Nc,
+                                       d_T2 + (size_t)r0s * H.RLS, Nc, ctx->bl, (long long)H.RLS, d_rowcls + r0s, ctx->d_csr_ptr, ctx->d_csr_idx,
+                                       ctx->d_csr_val);
+                else
+                    hipLaunchKernelGGL(xform_ket_both, dim3((unsigned)((N + 3) / 4), ny), dim3(256), 0, 0, d_C + (size_t)r0s * Nc * Nc,
+                                       d_T2 + (size_t)r0s * N * ld, Nc, N, ld, ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val, 0);
             }
         }
         HIPCHK(ctx, hipEventRecord(e4[2], 0));
@@ -1115,13 +1363,18 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             const unsigned gx = (unsigned)std::min<long long>((row_len + 255) / 256, 4096);
             for (size_t o0 = 0; o0 < outs.size(); o0 += 65535) {
                 const unsigned ny = (unsigned)std::min<size_t>(65535, outs.size() - o0);
-                if (packed)
-                    hipLaunchKernelGGL(xform_bra_store_packed, dim3((unsigned)((N + TF_XBP_KR - 1) / TF_XBP_KR), ny), dim3(64 * TF_XBP_KR), 0, 0, d_T2, ctx->d_eri,
-                                       reinterpret_cast<const OutRowP *>(d_out + o0), row_len, ld, ctx->d_csr_ptr, ctx->d_csr_idx,
-                                       ctx->d_csr_val);
-                else
-                    hipLaunchKernelGGL(xform_bra_store, dim3(gx, ny), dim3(256), 0, 0, d_T2, ctx->d_eri, d_out + o0, row_len,
-                                       ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val);
+                hipLaunchKernelGGL(xform_bra_store, dim3(gx, ny), dim3(256), 0, 0, d_T2, ctx->d_eri, reinterpret_cast<const OutRow *>(d_out) + o0,
+                                   row_len, ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val);
+            }
+        }
+        if (!outsP.empty()) {
+            int maxlen = 1;
+            for (const OutRowP &o : outsP) maxlen = std::max(maxlen, o.len);
+            for (size_t o0 = 0; o0 < outsP.size(); o0 += 65535) {
+                const unsigned ny = (unsigned)std::min<size_t>(65535, outsP.size() - o0);
+                hipLaunchKernelGGL(xform_bra_store_packed, dim3((unsigned)((maxlen + 255) / 256), ny), dim3(256), 0, 0, d_T2, ctx->d_eri,
+                                   reinterpret_cast<const OutRowP *>(d_out) + o0, (long long)H.RLS, ctx->bl, ctx->d_csr_ptr, ctx->d_csr_idx,
+                                   ctx->d_csr_val);
             }
         }
         HIPCHK(ctx, hipEventRecord(e4[3], 0));
@@ -1137,6 +1390,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     }
     for (hipEvent_t e : tev) (void)hipEventDestroy(e);
     (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out);
+    if (d_rowcls) (void)hipFree(d_rowcls);
     (void)hipFree(d_kets); (void)hipFree(d_kets_all);
     t_stage[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall0).count();
     std::copy(t_stage, t_stage + 4, ctx->eri_seconds);
@@ -1146,11 +1400,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // ---- J/K scratch
     const size_t nn = (size_t)N * N;
     // (sized for two densities per pass)
-    const int NWjk = (N + TF_JKP_CW - 1) / TF_JKP_CW;               // column chunks of jk_packed_kernel
+    const int NWjk = packed ? std::max(1, H.NW) : 1;                // column chunks of jk_packed_kernel
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     if (packed) {
         // everything sized for a two-density pass (second density behind the first)
-        const size_t npr = (size_t)tri_off(N);                      // padded pair index space
+        const size_t npr = (size_t)std::max<long long>(1, H.NPtot);    // padded pair index space
         const size_t ny = (size_t)std::max(ctx->jkt[0].ypart_len, 2 * ctx->jkt[1].ypart_len);
         const size_t ng = (size_t)std::max(ctx->jkt[0].n_groups, 2 * ctx->jkt[1].n_groups);
         const int nsegmax = std::max(ctx->jkt[0].nseg, ctx->jkt[1].nseg);
@@ -1158,9 +1412,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Pp, 2 * npr * sizeof(double)));
         HIPCHK(ctx, hipMemset(ctx->d_Pp, 0, 2 * npr * sizeof(double)));   // pad slots stay zero
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_ypart, std::max<size_t>(1, ny) * sizeof(double)));
-        // column parts [.][N] followed by the per-chunk row parts [.][NW][N]
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, std::max<size_t>(1, ng) * (1 + NWjk) * N * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * (1 + NWjk) * N * sizeof(double)));
+        // column parts [.][N] followed by the row parts [.][RS]
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, std::max<size_t>(1, ng) * (size_t)(N + H.RS) * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * (size_t)(N + H.RS) * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jt, 2 * (size_t)nsegmax * npr * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_D, 2 * nn * sizeof(double)));
     } else
@@ -1218,7 +1472,7 @@ int tf_copy_eri(tf_ctx *ctx, double *host_out)
     HIPCHK(ctx, hipMalloc((void **)&d_dense, total * sizeof(double)));
     const unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 1 << 20);
     if (ctx->layout == 1)
-        hipLaunchKernelGGL(expand_dense_packed_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->d_rowoff, ctx->N, d_dense);
+        hipLaunchKernelGGL(expand_dense_packed_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->d_rowoff, ctx->d_rowsec, ctx->bl, d_dense);
     else
         hipLaunchKernelGGL(expand_dense_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N, ctx->ld, d_dense);
     hipError_t e = hipMemcpy(host_out, d_dense, total * sizeof(double), hipMemcpyDeviceToHost);
@@ -1241,7 +1495,7 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
     HIPCHK(ctx, hipMemcpy(d_idx, idx, (size_t)n_idx * 4 * sizeof(int), hipMemcpyHostToDevice));
     if (ctx->layout == 1)
         hipLaunchKernelGGL(sample_packed_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap,
-                           ctx->d_rowoff, (long long)n_idx, d_idx, d_val);
+                           ctx->d_rowoff, ctx->d_rowsec, ctx->bl, (long long)n_idx, d_idx, d_val);
     else
         hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N,
                            ctx->ld, (long long)n_idx, d_idx, d_val);
@@ -1260,14 +1514,15 @@ extern "C++" {
 template <int ND>
 static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
 {
-    const int N = ctx->N, NW = (N + TF_JKP_CW - 1) / TF_JKP_CW;
-    const size_t nn = (size_t)N * N, npr = (size_t)tri_off(N), nrows = (size_t)std::max<long long>(1, ctx->n_rows);
+    const BLayout &L = ctx->bl;
+    const int N = ctx->N, NW = L.NW;
+    const size_t nn = (size_t)N * N, npr = (size_t)L.NPtot, nrows = (size_t)std::max<long long>(1, ctx->n_rows);
     const tf_ctx::JKTables &T = ctx->jkt[ND - 1];
     const size_t ng = (size_t)std::max(1, T.n_groups);
     // layout of the partial arrays: [column parts of density 0 | .. density 1 | row parts of density 0 | .. density 1]
     JKStrides S{};
     S.P = nn; S.Pp = npr; S.y = (size_t)T.ypart_len; S.Jd = nrows * NW;
-    S.DIc = ng * N; S.DIr = ng * NW * N; S.DJc = nrows * N; S.DJr = nrows * NW * N;
+    S.DIc = ng * N; S.DIr = ng * (size_t)L.RS; S.DJc = nrows * N; S.DJr = nrows * (size_t)L.RS;
     double *DIc = ctx->d_DI, *DIr = ctx->d_DI + ND * S.DIc, *DJc = ctx->d_DJ, *DJr = ctx->d_DJ + ND * S.DJc;
     if (T.n_tasks > 0) {
         hipEvent_t ev_after = nullptr;
@@ -1283,17 +1538,17 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
             }
         }
         hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)T.n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, ctx->d_rowoff, T.d_groups,
-                           T.d_supers, T.d_tasks, N, NW, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+                           T.d_supers, T.d_tasks, L, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
     JKReduce R{};
-    R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.n_supers = T.n_supers; R.nseg = T.nseg; R.NP = (long long)npr;
+    R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.groups = T.d_groups; R.nseg = T.nseg; R.jp = T.jp;
     R.Jt = ctx->d_Jt; R.sJt = (size_t)T.nseg * npr;
     R.DIc = DIc; R.sDIc = S.DIc; R.DIr = DIr; R.sDIr = S.DIr; R.DJc = DJc; R.sDJc = S.DJc; R.DJr = DJr; R.sDJr = S.DJr;
-    R.gfirst = T.d_gfirst; R.rowmap = ctx->d_rowmap; R.N = N; R.NW = NW;
+    R.gfirst = T.d_gfirst; R.rowmap = ctx->d_rowmap;
     for (int d = 0; d < ND; ++d) R.D[d] = dDout[d];
-    const unsigned nblk = (unsigned)ND * ((unsigned)N * ((N + 63) / 64) + (unsigned)((npr + 255) / 256) * T.nseg);
-    hipLaunchKernelGGL(jk_reduce_kernel, dim3(nblk), dim3(256), 0, st, R);
+    const unsigned nblk = (unsigned)ND * ((unsigned)N * ((N + 63) / 64) + (unsigned)T.jp.bfirst[4] * T.nseg);
+    hipLaunchKernelGGL(jk_reduce_kernel, dim3(nblk), dim3(256), 0, st, R, L);
     return TF_OK;
 }
 }  // extern "C++"
@@ -1302,33 +1557,34 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
 static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st,
                             const int *nonsym)
 {
-    const int N = ctx->N, NW = (N + TF_JKP_CW - 1) / TF_JKP_CW;
-    const size_t nn = (size_t)N * N, npr = (size_t)tri_off(N), nrows = (size_t)std::max<long long>(1, ctx->n_rows);
+    const BLayout &L = ctx->bl;
+    const int N = ctx->N, NW = L.NW;
+    const size_t nn = (size_t)N * N, npr = (size_t)L.NPtot, nrows = (size_t)std::max<long long>(1, ctx->n_rows);
     const dim3 gN((N * N + 255) / 256), b256(256);
     static const bool no_fuse = getenv("TF_JK_NOFUSE") != nullptr;
     if (nd == 2 && !no_fuse && !(nonsym && (nonsym[0] || nonsym[1]))) {
         // two symmetric densities (UHF alpha / beta): one pass over the tensor, groups of 4 rows x 2 densities
         for (int d = 0; d < 2; ++d)
-            hipLaunchKernelGGL(pack_density_kernel, gN, b256, 0, st, dP[d], N, 0, ctx->d_Psym + d * nn, ctx->d_Pp + d * npr);
+            hipLaunchKernelGGL(pack_density_kernel, gN, b256, 0, st, dP[d], L, 0, ctx->d_Psym + d * nn, ctx->d_Pp + d * npr);
         double *dD[2] = {ctx->d_D, ctx->d_D + nn};
         int rc = jk_packed_pass<2>(ctx, st, dD);
         if (rc) return rc;
         const int nseg = ctx->jkt[1].nseg;
         for (int d = 0; d < 2; ++d)
-            hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, dD[d], dD[d], ctx->d_Jrow + d * nrows * NW, NW,
-                               ctx->d_Jt + (size_t)d * nseg * npr, nseg, ctx->d_rowmap, N, dJ[d], dK[d]);
+            hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, dD[d], dD[d], ctx->d_Jrow + d * nrows * NW,
+                               ctx->d_Jt + (size_t)d * nseg * npr, nseg, ctx->d_rowmap, L, dJ[d], dK[d]);
         return TF_OK;
     }
     for (int d = 0; d < nd; ++d)                                 // one density per pass over the packed tensor
       for (int pass = 0; pass < ((nonsym && nonsym[d]) ? 2 : 1); ++pass) {
         const bool general = nonsym && nonsym[d];
         double *dD = (pass == 0) ? ctx->d_D : ctx->d_D + nn;
-        hipLaunchKernelGGL(pack_density_kernel, gN, b256, 0, st, dP[d], N, (general && pass == 0) ? 1 : 0, ctx->d_Psym, ctx->d_Pp);
+        hipLaunchKernelGGL(pack_density_kernel, gN, b256, 0, st, dP[d], L, (general && pass == 0) ? 1 : 0, ctx->d_Psym, ctx->d_Pp);
         double *dDp[1] = {dD};
         int rc = jk_packed_pass<1>(ctx, st, dDp);
         if (rc) return rc;
         if (general && pass == 0) continue;
-        hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, ctx->d_D, dD, ctx->d_Jrow, NW, ctx->d_Jt, ctx->jkt[0].nseg, ctx->d_rowmap, N,
+        hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, ctx->d_D, dD, ctx->d_Jrow, ctx->d_Jt, ctx->jkt[0].nseg, ctx->d_rowmap, L,
                            dJ[d], dK[d]);
       }
     return TF_OK;
@@ -1637,8 +1893,8 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
         HIPCHK(ctx, hipMemcpy(dC[k], hC[k], (size_t)N * nk[k] * sizeof(double), hipMemcpyHostToDevice));
     }
     HIPCHK(ctx, hipMalloc((void **)d_out, (size_t)n1 * n2 * n3 * n4 * sizeof(double)));
-    rc = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, ctx->layout == 1 ? ctx->d_rowoff : nullptr, ctx->d_row_ij, ctx->n_rows, N,
-                          ctx->ld, dC[0], n1, dC[1], n2, dC[2], n3, dC[3], n4,
+    rc = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, ctx->layout == 1 ? ctx->d_rowoff : nullptr, ctx->d_rowsec, ctx->bl,
+                          ctx->d_row_ij, ctx->n_rows, N, ctx->ld, dC[0], n1, dC[1], n2, dC[2], n3, dC[3], n4,
                           *d_out, seconds, msg);
     for (int k = 0; k < 4; ++k) (void)hipFree(dC[k]);
     if (rc) { ctx->err = msg; (void)hipFree(*d_out); *d_out = nullptr; }

@@ -139,7 +139,8 @@ __device__ __forceinline__ KetCsr stage_ket_csr(const DBasis &B, const QClass &q
 // products and writes them straight into the half-transformed slab T2[row(ca,cb)][k_out][l_out] (and, for the rows layout, the
 // mirror image).
 __device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, const KetCsr &K, const double *sBlk, int nblk,
-                                             long long row_first, const DPair &cd, double *__restrict__ T2, int tid, int nthreads)
+                                             long long row_first, const DPair &ab, int iab0, const DPair &cd, double *__restrict__ T2,
+                                             int tid, int nthreads)
 {
     const int per = qc.nsc * qc.nsd;
     const size_t row_len = (size_t)qc.Nout * qc.ld;
@@ -147,6 +148,19 @@ __device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, 
     for (int e = tid; e < nblk * per; e += nthreads) {
         const int b = e / per, r = e - b * per;
         const int sc = r / qc.nsd, sd = r - sc * qc.nsd;
+        const int k = cd.outoff_a + sc, l = cd.outoff_b + sd;
+        size_t dst_index;
+        if (qc.tri) {
+            // packed layout: slab row (ca, cb) keeps the pairs (k >= l) of its own x/y parity class, at their pair index in the
+            // complete-row shape (tf_jkpacked.hip.h); everything else is an exact zero (pyx:1324-1327) or a mirror image
+            if (l > k) continue;
+            const int wk = B.bl.ao[k], wl = B.bl.ao[l];
+            const int cb = (B.ct_ix[ab.tab_off + iab0 + b] >> 24) & 3;
+            if ((ao_cls(wk) ^ ao_cls(wl)) != cb) continue;
+            dst_index = (size_t)(row_first + b) * (size_t)B.RLS + bl_fullsec(B.bl, cb, ao_cls(wk)) + B.bl.kinfo[(size_t)cb * B.bl.N + ao_sigma(B.bl, wk)].offA +
+                        ao_loc(wl);
+        } else
+            dst_index = (size_t)(row_first + b) * row_len + (size_t)k * qc.ld + l;
         const double *blk = sBlk + (size_t)b * qc.ncc * qc.ncd;
         double s = 0.0;
         if (qc.spherical && K.ok) {
@@ -165,10 +179,8 @@ __device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, 
             }
         } else
             s = blk[sc * qc.ncd + sd];
-        const int k = cd.outoff_a + sc, l = cd.outoff_b + sd;
-        double *dst = T2 + (size_t)(row_first + b) * row_len;
-        dst[(size_t)k * qc.ld + l] = s;
-        if (cd.A != cd.B && !qc.tri) dst[(size_t)l * qc.ld + k] = s;   // the packed layout keeps k >= l only: no mirror image
+        T2[dst_index] = s;
+        if (!qc.tri && cd.A != cd.B) T2[(size_t)(row_first + b) * row_len + (size_t)l * qc.ld + k] = s;   // rows layout: the mirror image
     }
 }
 
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_class_kernel(DBasis B, QCl
         }
         if (qc.fused) {
             __syncthreads();
-            ket_epilogue(B, qc, kcsr, sBlk, nblk, row0 + blk0, cd, Cslab, tid, TF_ERI_THREADS);
+            ket_epilogue(B, qc, kcsr, sBlk, nblk, row0 + blk0, ab, blk0, cd, Cslab, tid, TF_ERI_THREADS);
             __syncthreads();
         }
     }
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_multi_kernel(DBasis B, QCl
         if (lanes > 0 && sq < nsub) {
             const DPair cd = B.pairs[sKet[sq]];
             (void)per;
-            ket_epilogue(B, qc, kcsr, smem + qc.offBlk + (size_t)sq * qc.ncomp, nab, row0, cd, Cslab, lt, lanes);
+            ket_epilogue(B, qc, kcsr, smem + qc.offBlk + (size_t)sq * qc.ncomp, nab, row0, ab, 0, cd, Cslab, lt, lanes);
         }
     }
 }
@@ -662,7 +674,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
         }
         if (qc.fused) {
             __syncthreads();
-            ket_epilogue(B, qc, kcsr, sBlk, nblk, row0 + blk0, cd, Cslab, tid, TF_ERI_THREADS);
+            ket_epilogue(B, qc, kcsr, sBlk, nblk, row0 + blk0, ab, blk0, cd, Cslab, tid, TF_ERI_THREADS);
             __syncthreads();
         }
     }

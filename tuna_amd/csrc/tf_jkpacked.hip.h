@@ -1,14 +1,21 @@
-// tf_jkpacked.hip.h -- Fock build from the 8-fold symmetry-unique tensor ("packed" layout).
+// tf_jkpacked.hip.h -- Fock build from the symmetry-unique, parity-blocked tensor ("packed" layout).
 // Reference: calculate_coulomb_matrix tuna_scf.py:55-72 ("ijkl,kl->ij"), calculate_exchange_matrix tuna_scf.py:27-44
-// ("ilkj,kl->ij"); the reference keeps all 8 images of every (ij|kl) (pyx:1335-1342), here each unique value is stored once.
+// ("ilkj,kl->ij"); the reference keeps all 8 images of every (ij|kl) (pyx:1335-1342) and the exact zeros of the x/y reflection
+// parity rule (pyx:1324-1327).  Here each unique value is stored once and the parity zeros are not stored at all.
 //
-// Layout: a pair (k >= l) has the padded index tri_off(k) + l, where every row k of the triangle starts at a multiple of
-// TF_TRI_PAD = 16 doubles = one 128-byte cache line (tri_off(k) = sum of the row lengths 1, 2, 3, ... each rounded up to 16); pad
-// slots hold 0.  Row (i >= j) of the tensor holds (ij|kl) for every pair (k,l) <= (i,j) at [tri_off(k) + l], its length rounded up
-// to 16; a rank stores the rows it owns in ascending (i,j) with a row-offset table.  ~1.05 N^4 bytes at N = 400 instead of the
-// reference's 8 N^4.  Why whole cache lines: a wave reads 128 columns (1 KB) of a triangle row per load; with rows packed to even
-// indices only, that KB straddled 9 lines and the line shared with the neighbouring 128-column chunk -- another workgroup, usually
-// on another XCD with its own L2 -- came from HBM twice.  Aligned: 4.7 % more stored bytes, 9 % fewer fetched, kernel 6 % faster.
+// Parity classes.  On a z-axis diatomic every AO (Cartesian or real spherical) is even or odd under x -> -x and under y -> -y:
+// class(AO) = (x parity) | (y parity) << 1.  (ij|kl) vanishes unless class(i) ^ class(j) == class(k) ^ class(l).
+//
+// Layout (tests/layout_model.py is a NumPy model of everything below and is checked against the reference einsums on a CPU):
+//   * internal AO index sigma(k) = cstart[class(k)] + loc(k): the AOs sorted by class (larger classes first), original order
+//     inside a class; loc(k) = rank of k in its class.  Densities and the exchange partial sums live in internal indices.
+//   * tensor row (i >= j) (original order), class c = class(i) ^ class(j), stores for every AO k <= i ONE segment: the values
+//     (ij|kl) for the AOs l <= k of class class(k) ^ c in ascending l -- cnt[c][k] of them, padded to TF_SEG_PAD doubles with
+//     zeros (in the segment of k == i the slots beyond l == j hold zeros too).  The segments of a row are ordered by
+//     (class of k, k): four sections, so that a task -- one class of k against one class of l -- streams contiguous memory.
+//     All rows with the same (i, c) have the same shape.  ~N^4 / 4 bytes (+ padding) instead of the reference's 8 N^4.
+//   * pair index of (k >= l), class c: cbase[c] + fullsec[c][class(k)] + offA[c][sigma(k)] + loc(l) -- the shape of a complete
+//     row; the packed density Pp and the transposed-Coulomb partials use it.
 //
 // One pass over row (i,j) has to feed six outputs per element m = (ij|kl):
 //     Jd[ij] += m Pp[kl]                      (Pp[kl] = P[k][l] + P[l][k], or P[k][k])
@@ -17,22 +24,25 @@
 // (the four D terms at half weight when kl == ij), and K = D + D^T covers the transposed images when P is symmetric, as every SCF
 // density is.  A general P takes two passes: K = D(P^T) + D(P)^T (the einsum of scf:42 exactly).
 //
-// Kernel shape: a task = (group of up to JBB rows (i; j0..j0+nr-1) sharing i) x (one chunk of 128 columns); one wave per task, a
-// lane owns two adjacent columns (one 16-byte load per row and triangle row k) and walks k up to i.  Tasks are dispatched longest
-// first, so the triangle balances itself.  Lane-local accumulators: the "column" sums (outputs indexed by l); the "row" sums
-// (outputs indexed by k) are reduced across the wave with a transposing butterfly on permlane swaps / DPP (no LDS) and written
-// per task.  Jt partials are written once per group and column (1/JBB of the tensor's bytes) and summed by jk_reduce_kernel.
-// No atomics anywhere: results are bitwise reproducible.
+// Kernel shape: a task = (up to TF_JKP_W groups of up to JBB rows (i; j0..j0+nr-1) sharing i and the class of j) x (one chunk of
+// <= 128 columns l of one class b); one wave per group, a lane owns two adjacent columns (one 16-byte load per row and k) and walks
+// the AOs k <= i of class a = b ^ c whose segment reaches the chunk.  Lane-local accumulators: the "column" sums (outputs indexed
+// by l); the "row" sums (outputs indexed by k) are reduced across the wave with a transposing butterfly on permlane swaps / DPP
+// (no LDS) and written per task.  Jt partials are merged over the waves of a workgroup in LDS, written once per super-group and
+// summed by jk_reduce_kernel.  No atomics anywhere: results are bitwise reproducible.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "tf_layout.hip.h"
 
 #define TF_JKP_JBB 8
 #define TF_JKP_CW 128            // columns per chunk (2 per lane)
-#define TF_JKP_SEG 16            // segments of the group list in the Jt reduction
+#define TF_JKP_SEG 16            // segments of the super-group lists in the Jt reduction
 
-// padded triangle: first index of row k, and the stored length of tensor row (i,j)
+
+// Weight proxy of the shard plan (tf_shard_plan_pairs works from shell dimensions alone): the row lengths of the unblocked
+// triangle, every triangle row rounded up to TF_TRI_PAD.  The blocked rows are ~1/4 of that, uniformly enough for balancing.
 #ifndef TF_TRI_PAD
-#define TF_TRI_PAD 16            // triangle rows and tensor rows start at multiples of this many doubles (a power of two >= 2)
+#define TF_TRI_PAD 16
 #endif
 __host__ __device__ inline long long tri_off(long long k)
 {
@@ -42,15 +52,17 @@ __host__ __device__ inline long long tri_off(long long k)
 __host__ __device__ inline long long packed_row_len(long long i, long long j) { return (tri_off(i) + j + TF_TRI_PAD) & ~(long long)(TF_TRI_PAD - 1); }
 
 struct JKGroup {
-    int i, j0, nr, r0;           // rows r0..r0+nr-1 (local numbering) = pairs (i, j0..j0+nr-1)
+    int i, j0, nr, r0;           // rows r0..r0+nr-1 (local numbering) = pairs (i, j0..j0+nr-1), internal indices
+    int c, lamj0;                // class of the rows; loc of j0
     int roff[TF_JKP_JBB];        // start of row r relative to row 0, in doubles
+    int secoff[4];               // start of section a inside the rows of this group
 };
 #define TF_JKP_W 4                // groups (waves) per workgroup: their Jt partials are merged in LDS before they are written
-#define TF_JKP_KB 4               // triangle rows per merge block
+#define TF_JKP_KB 4               // k steps per merge block
 static_assert(TF_JKP_KB <= TF_JKP_W, "one wave per merged row");
-// up to TF_JKP_W adjacent groups with the same i share one Jt partial (length = stored length of the first, longest group)
-struct JKSuper { int g0, ng; long long yoff, ylen; };
-struct JKTask { int super, chunk; };
+// up to TF_JKP_W adjacent groups with the same i and class share one Jt partial (complete-row shape: NP[c] doubles at yoff)
+struct JKSuper { int g0, ng, c, i; long long yoff; int ke[4]; };   // ke[a] = cntA[a][i]: the rows reach the members kappa < ke[a] of class a
+struct JKTask { int super, w; };
 
 __device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
 
@@ -138,16 +150,22 @@ __device__ __forceinline__ double wave_sum1(double t)                   // every
     return sum8(t);
 }
 
-// X = P or P^T (dense [N][N], what the exchange terms contract with); Pp[tri_off(k)+l] = P[k][l] + P[l][k] (k != l), P[k][k];
-// the pad slots of Pp stay zero (set once at allocation).
-__global__ void pack_density_kernel(const double *__restrict__ P, int N, int transpose, double *__restrict__ X, double *__restrict__ Pp)
+// X[sigma(r)][sigma(c)] = P[r][c] (or P[c][r]): what the exchange terms contract with, in internal indices;
+// Pp[pair index of (k >= l)] = P[k][l] + P[l][k] (k != l), P[k][k]; the pad slots of Pp stay zero (set once at allocation).
+__global__ void pack_density_kernel(const double *__restrict__ P, BLayout L, int transpose, double *__restrict__ X, double *__restrict__ Pp)
 {
+    const int N = L.N;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N * N) return;
     const int k = e / N, l = e - k * N;
     const double a = P[e], b = P[(size_t)l * N + k];
-    X[e] = transpose ? b : a;
-    if (l <= k) Pp[tri_off(k) + l] = (k == l) ? a : a + b;
+    const int wk = L.ao[k], wl = L.ao[l];
+    const int sk = ao_sigma(L, wk), sl = ao_sigma(L, wl);
+    X[(size_t)sk * N + sl] = transpose ? b : a;
+    if (l <= k) {
+        const int c = ao_cls(wk) ^ ao_cls(wl);
+        Pp[bl_cbase(L, c) + bl_fullsec(L, c, ao_cls(wk)) + L.kinfo[c * N + sk].offA + ao_loc(wl)] = (k == l) ? a : a + b;
+    }
 }
 
 // The kernel handles ND = 1 or 2 densities per pass.  Its eight "virtual rows" v = d * RB + r are RB = 8 / ND tensor rows times
@@ -156,43 +174,49 @@ __global__ void pack_density_kernel(const double *__restrict__ P, int N, int tra
 
 // Wave-uniform description of a task (lives in SGPRs).
 struct JKWave {
-    const double *T0, *P, *Pp;           // first row of the group; density matrices [ND][N][N]; packed densities [ND][NP]
-    long long NP;
-    int N, i, j0, nr, c0;                // c0 = first column of the chunk
+    const double *T0, *X, *Pp;           // section a of the group's first row; densities [ND][N][N] (internal); packed densities (class
+                                         // base + section a) [ND][NPtot]
+    const KInfo *kinfo;                  // kinfo[c] + cstart[a]: indexed by kappa
+    long long NPtot;
+    int N, i, j0, nr, lamj0;             // internal indices of the rows; loc of j0
+    int kI0, c0, lam0, width, cm;        // first internal AO of the k class; first internal column, its loc, columns of the chunk;
+                                         // cm = 1 when k and l are of the same class (the pair (k,k) exists)
     unsigned roff8[TF_JKP_JBB];          // byte offset of row r from row 0
     double *yg, *DIr_w, *DJr_w;          // density d: + d * ystride / dstrideI / dstrideJ
-    size_t rowW, ystride, dstrideI, dstrideJ;
+    size_t RS, ystride, dstrideI, dstrideJ;
     double ppij[TF_JKP_JBB];             // Pp_d[(i, j_r)] by virtual row
 };
 
-// Per-lane state: the two columns l0, l0 + 1 of the lane
+// Per-lane state: the two columns of the lane (loc lam, lam + 1 of class b; internal index lI, lI + 1)
 template <int ND>
 struct JKLane {
-    int l0;
+    int lam, lI;
     double2 pil[ND], pjl[TF_JKP_JBB];    // P_d[i][l];  P_d[j_r][l] by virtual row
     double2 colI[ND], colJ[TF_JKP_JBB];  // D_d[i][l], D_d[j_r][l] accumulators
 };
 
 enum { JKP_DIAG = 1, JKP_FULL = 2 };
 
-// The values a lane needs from triangle row k < i: the tensor elements of its two columns and Pp_d[kl].
+// The values a lane needs from the segment of AO k: the tensor elements of its two columns and Pp_d[kl]; cnt = stored values.
 template <int ND>
-struct JKLoad { double2 m[TF_JKP_JBB / ND], pp[ND]; };
+struct JKLoad { double2 m[TF_JKP_JBB / ND], pp[ND]; int cnt; };
 
-// MODE FULL: every lane has l < k (no masks); DIAG: the 128-column tile on the diagonal (a pair is present iff l0 <= k; the pad
-// slot after an odd-length row reads 0).  ALLR: the group has all RB rows.
+// MODE FULL: every lane has l < k (no masks); DIAG: a pair is present iff lam < cnt (the slot after an odd count reads 0).
+// ALLR: the group has all RB rows.
 template <int ND, bool ALLR, int MODE>
-__device__ __forceinline__ void jkp_load(JKLoad<ND> &L, int l0, int lane, const JKWave &U, int k)
+__device__ __forceinline__ void jkp_load(JKLoad<ND> &L, int lam, int lane, const JKWave &U, int kap)
 {
     constexpr int RB = TF_JKP_JBB / ND;
-    const long long bk = tri_off(k) + U.c0;
-    const bool v = (MODE == JKP_FULL) || l0 <= k;
+    const KInfo ki = U.kinfo[kap];
+    const long long bk = (long long)ki.offA + U.lam0;
+    L.cnt = ki.cnt;
+    const bool v = (MODE == JKP_FULL) || lam < ki.cnt;
     const __amdgpu_buffer_rsrc_t rt = buf_rsrc(U.T0 + bk);
     const double2 zero = make_double2(0.0, 0.0);
 #pragma unroll
     for (int r = 0; r < RB; ++r) L.m[r] = (v && (ALLR || r < U.nr)) ? buf_load2<2>(rt, 16u * (unsigned)lane, U.roff8[r]) : zero;
 #pragma unroll
-    for (int d = 0; d < ND; ++d) L.pp[d] = v ? buf_load2<0>(buf_rsrc(U.Pp + d * U.NP + bk), 16u * (unsigned)lane, 0u) : zero;
+    for (int d = 0; d < ND; ++d) L.pp[d] = v ? buf_load2<0>(buf_rsrc(U.Pp + d * U.NPtot + bk), 16u * (unsigned)lane, 0u) : zero;
 }
 
 // part 1: everything that needs only the lane's own P values (Jd, Jt, the row sums); part 2: the column sums, which need the
@@ -220,10 +244,11 @@ __device__ __forceinline__ void jkp_row1(const JKLane<ND> &C, const JKLoad<ND> &
 }
 
 template <int ND, int MODE>
-__device__ __forceinline__ void jkp_row2(JKLane<ND> &C, const JKLoad<ND> &L, int k, const double (&pjk)[TF_JKP_JBB], const double (&pik)[ND])
+__device__ __forceinline__ void jkp_row2(JKLane<ND> &C, const JKLoad<ND> &L, const JKWave &U, const double (&pjk)[TF_JKP_JBB], const double (&pik)[ND])
 {
     constexpr int RB = TF_JKP_JBB / ND;
-    const double o0 = (MODE == JKP_FULL || C.l0 < k) ? 1.0 : 0.0, o1 = (MODE == JKP_FULL || C.l0 + 1 < k) ? 1.0 : 0.0;
+    const int lim = L.cnt - U.cm;                           // columns strictly below k (the pair (k,k) has no column term)
+    const double o0 = (MODE == JKP_FULL || C.lam < lim) ? 1.0 : 0.0, o1 = (MODE == JKP_FULL || C.lam + 1 < lim) ? 1.0 : 0.0;
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const double mx = (MODE == JKP_FULL) ? L.m[r].x : L.m[r].x * o0, my = (MODE == JKP_FULL) ? L.m[r].y : L.m[r].y * o1;
@@ -236,41 +261,42 @@ __device__ __forceinline__ void jkp_row2(JKLane<ND> &C, const JKLoad<ND> &L, int
     }
 }
 
-// The last triangle row k == i: row r ends at l == j_r, where the element (ij|ij) counts half in K and not at all in Jt.
+// The segment of k == i (tasks whose k class is that of i): row r ends at l == j_r, where the element (ij|ij) counts half in K
+// and not at all in Jt.
 template <int ND>
 __device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const double (&pjk)[TF_JKP_JBB], const double (&pik)[ND],
                                          double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double (&rI)[ND], double2 (&jt2)[ND])
 {
     constexpr int RB = TF_JKP_JBB / ND;
-    const int i = U.i, jlast = U.j0 + U.nr - 1;
-    const long long bk = tri_off(i);
+    const int i = U.i, lamlast = U.lamj0 + U.nr - 1;
+    const long long bk = U.kinfo[i - U.kI0].offA;
 #pragma unroll
     for (int d = 0; d < ND; ++d) { rI[d] = 0.0; jt2[d] = make_double2(0.0, 0.0); }
 #pragma unroll
     for (int v = 0; v < TF_JKP_JBB; ++v) rJ[v] = 0.0;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int l = C.l0 + e;
-        const bool valid = l <= jlast;
+        const int lam = C.lam + e;
+        const bool valid = lam <= lamlast;
         double mrow[RB];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) mrow[r] = (r < U.nr && l <= U.j0 + r) ? ld_stream(U.T0 + (U.roff8[r] >> 3) + bk + l) : 0.0;
+        for (int r = 0; r < RB; ++r) mrow[r] = (r < U.nr && lam <= U.lamj0 + r) ? ld_stream(U.T0 + (U.roff8[r] >> 3) + bk + lam) : 0.0;
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const double pp = valid ? U.Pp[d * U.NP + bk + l] : 0.0;
+            const double pp = valid ? U.Pp[d * U.NPtot + bk + lam] : 0.0;
             const double pil = e ? C.pil[d].y : C.pil[d].x;
             double jt = 0.0, cI = 0.0;
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const int v = d * RB + r;
                 const double mr = mrow[r];
-                const bool diag = (l == U.j0 + r);
+                const bool diag = (lam == U.lamj0 + r);
                 jd[v] += mr * pp;
                 jt += diag ? 0.0 : mr * U.ppij[v];
                 const double mk = diag ? 0.5 * mr : mr;
                 rI[d] += mk * (e ? C.pjl[v].y : C.pjl[v].x);
                 rJ[v] += mk * pil;
-                const double mc = (l < i) ? mk : 0.0;
+                const double mc = (C.lI + e != i) ? mk : 0.0;
                 cI += mc * pjk[v];
                 if (e) C.colJ[v].y += mc * pik[d]; else C.colJ[v].x += mc * pik[d];
             }
@@ -280,54 +306,55 @@ __device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const d
 }
 
 template <int ND, bool ALLR>
-__device__ __forceinline__ void jkp_row_sums(const JKWave &U, int k, int lane, double (&rJ)[TF_JKP_JBB], const double (&rI)[ND])
+__device__ __forceinline__ void jkp_row_sums(const JKWave &U, int kap, int lane, double (&rJ)[TF_JKP_JBB], const double (&rI)[ND])
 {
     constexpr int RB = TF_JKP_JBB / ND;
     const double tJ = wave_sum8(rJ);
     const int v = lane >> 3, d = v / RB, r = v - d * RB;
-    if ((lane & 7) == 0 && (ALLR || r < U.nr)) U.DJr_w[d * U.dstrideJ + (size_t)r * U.rowW + k] = tJ;
+    if ((lane & 7) == 0 && (ALLR || r < U.nr)) U.DJr_w[d * U.dstrideJ + (size_t)r * U.RS + kap] = tJ;
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) {
         const double tI = wave_sum1(rI[dd]);
-        if (lane == 0) U.DIr_w[dd * U.dstrideI + k] = tI;
+        if (lane == 0) U.DIr_w[dd * U.dstrideI + kap] = tI;
     }
 }
 
-// Jt of the rows kb..kb+KB-1: the waves of the workgroup have left their partials in slots[kk][wave][d][lane]; wave w adds up
-// row kb + w and writes it (fixed order: bitwise reproducible).  Two barriers per block.
+// Jt of the steps kb..kb+KB-1: the waves of the workgroup have left their partials in slots[kk][wave][d][lane]; wave w adds up
+// step kb + w and writes it (fixed order: bitwise reproducible).  Two barriers per block.
 template <int ND, int MODE>
-__device__ __forceinline__ void jkp_merge_jt(const JKWave &U, double2 *slots, int ng, int w, int lane, int kb, int k1)
+__device__ __forceinline__ void jkp_merge_jt(const JKWave &U, double2 *slots, int ng, int w, int lane, int lam, int kb, int k1)
 {
     __syncthreads();
-    const int k = kb + w;
-    if (w < TF_JKP_KB && k < k1) {
+    const int kap = kb + w;
+    if (w < TF_JKP_KB && kap < k1) {
+        const KInfo ki = U.kinfo[kap];
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             double2 t = slots[((w * TF_JKP_W) * ND + d) * 64 + lane];
             for (int u = 1; u < ng; ++u) { const double2 x = slots[((w * TF_JKP_W + u) * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
-            if (MODE == JKP_FULL || U.c0 + 2 * lane <= k)
-                buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + tri_off(k) + U.c0), 16u * (unsigned)lane, 0u, t);
+            if (MODE == JKP_FULL || lam < ki.cnt)
+                buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), 16u * (unsigned)lane, 0u, t);
         }
     }
     __syncthreads();
 }
 
 template <int ND, bool ALLR>
-__device__ __forceinline__ void jkp_uniform_p(const JKWave &U, int k, double (&pjk)[TF_JKP_JBB], double (&pik)[ND])
+__device__ __forceinline__ void jkp_uniform_p(const JKWave &U, int kI, double (&pjk)[TF_JKP_JBB], double (&pik)[ND])
 {
     constexpr int RB = TF_JKP_JBB / ND;
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-        const double *Pd = U.P + (size_t)d * U.N * U.N;
+        const double *Pd = U.X + (size_t)d * U.N * U.N;
 #pragma unroll
-        for (int r = 0; r < RB; ++r) pjk[d * RB + r] = (ALLR || r < U.nr) ? Pd[(size_t)(U.j0 + r) * U.N + k] : 0.0;
-        pik[d] = Pd[(size_t)U.i * U.N + k];
+        for (int r = 0; r < RB; ++r) pjk[d * RB + r] = (ALLR || r < U.nr) ? Pd[(size_t)(U.j0 + r) * U.N + kI] : 0.0;
+        pik[d] = Pd[(size_t)U.i * U.N + kI];
     }
 }
 
-// Rows k0 <= k < k1 of a task in one mode.  The loads of row k + 1 are issued before row k is consumed, so a wave always has a
-// full row of requests in flight; the wave-uniform P[j_r][k], P[i][k] come through the scalar unit while part 1 runs.
-// Every wave of the workgroup runs the same k range (idle waves included): the barriers of the Jt merge must match.
+// Steps k0 <= kappa < k1 of a task in one mode.  The loads of step kappa + 1 are issued before step kappa is consumed, so a wave
+// always has a full row of requests in flight; the wave-uniform P[j_r][k], P[i][k] come through the scalar unit while part 1 runs.
+// Every wave of the workgroup runs the same range (idle waves included): the barriers of the Jt merge must match.
 template <int ND, bool ALLR, int MODE>
 __device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane<ND> &C, double (&jd)[TF_JKP_JBB], int k0, int k1, int lane, bool active,
                                             double2 *slots, int ng, int w)
@@ -335,49 +362,51 @@ __device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane<ND> &C, doub
     constexpr int JBB = TF_JKP_JBB;
     if (k0 >= k1) return;
     JKLoad<ND> L, Nx;
-    if (active) jkp_load<ND, ALLR, MODE>(L, C.l0, lane, U, k0);
+    if (active) jkp_load<ND, ALLR, MODE>(L, C.lam, lane, U, k0);
     for (int kb = k0; kb < k1; kb += TF_JKP_KB) {
         if (active) {
             const int ke = min(kb + TF_JKP_KB, k1);
             for (int k = kb; k < ke; ++k) {
-                jkp_load<ND, ALLR, MODE>(Nx, C.l0, lane, U, min(k + 1, k1 - 1));
+                jkp_load<ND, ALLR, MODE>(Nx, C.lam, lane, U, min(k + 1, k1 - 1));
                 double pjk[JBB], pik[ND], rJ[JBB], rI[ND];
                 double2 jt[ND];
-                jkp_uniform_p<ND, ALLR>(U, k, pjk, pik);
+                jkp_uniform_p<ND, ALLR>(U, U.kI0 + k, pjk, pik);
                 jkp_row1<ND>(C, L, U, jd, rJ, rI, jt);
 #pragma unroll
                 for (int d = 0; d < ND; ++d) slots[(((k - kb) * TF_JKP_W + w) * ND + d) * 64 + lane] = jt[d];
                 jkp_row_sums<ND, ALLR>(U, k, lane, rJ, rI);
-                jkp_row2<ND, MODE>(C, L, k, pjk, pik);
+                jkp_row2<ND, MODE>(C, L, U, pjk, pik);
                 L = Nx;
             }
         }
-        jkp_merge_jt<ND, MODE>(U, slots, ng, w, lane, kb, k1);
+        jkp_merge_jt<ND, MODE>(U, slots, ng, w, lane, C.lam, kb, k1);
     }
 }
 
+// kap0 <= kappa < kd1: masked steps; kd1 <= kappa < klim: unmasked; then (last) the segment of k == i.
 template <int ND, bool ALLR>
-__device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lane, int group, int r0, bool active, double2 *slots, int ng,
-                                         int w, double *__restrict__ Jd, size_t strideJd, double *__restrict__ DIc, size_t strideDIc,
-                                         double *__restrict__ DJc, size_t strideDJc)
+__device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int wchunk, int lane, int group, int r0, bool active, double2 *slots, int ng,
+                                         int w, int kap0, int kd1, int klim, bool last, double *__restrict__ Jd, size_t strideJd,
+                                         double *__restrict__ DIc, size_t strideDIc, double *__restrict__ DJc, size_t strideDJc)
 {
     constexpr int JBB = TF_JKP_JBB, RB = JBB / ND;
     const int N = U.N, i = U.i;
     JKLane<ND> C;
-    C.l0 = U.c0 + 2 * lane;
+    C.lam = U.lam0 + 2 * lane;
+    C.lI = U.c0 + 2 * lane;
+    const bool in0 = 2 * lane < U.width, in1 = 2 * lane + 1 < U.width;
     {
-        const bool in0 = C.l0 < N, in1 = C.l0 + 1 < N;
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const double *Pd = U.P + (size_t)d * N * N;
+            const double *Pd = U.X + (size_t)d * N * N;
             const double *Pi = Pd + (size_t)i * N;
-            C.pil[d] = make_double2(in0 ? Pi[C.l0] : 0.0, in1 ? Pi[C.l0 + 1] : 0.0);
+            C.pil[d] = make_double2(in0 ? Pi[C.lI] : 0.0, in1 ? Pi[C.lI + 1] : 0.0);
             C.colI[d] = make_double2(0.0, 0.0);
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const bool have = ALLR || r < U.nr;
                 const double *Pj = Pd + (size_t)(U.j0 + r) * N;
-                C.pjl[d * RB + r] = make_double2((in0 && have) ? Pj[C.l0] : 0.0, (in1 && have) ? Pj[C.l0 + 1] : 0.0);
+                C.pjl[d * RB + r] = make_double2((in0 && have) ? Pj[C.lI] : 0.0, (in1 && have) ? Pj[C.lI + 1] : 0.0);
                 C.colJ[d * RB + r] = make_double2(0.0, 0.0);
             }
         }
@@ -386,10 +415,9 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lan
 #pragma unroll
     for (int v = 0; v < JBB; ++v) jd[v] = 0.0;
 
-    const int kd1 = min(U.c0 + TF_JKP_CW, i);                         // end of the diagonal tile (exclusive), rows k < i only
-    jkp_segment<ND, ALLR, JKP_DIAG>(U, C, jd, U.c0, kd1, lane, active, slots, ng, w);
-    jkp_segment<ND, ALLR, JKP_FULL>(U, C, jd, kd1, i, lane, active, slots, ng, w);
-    {   // k == i: the groups end at different columns; the first group of the workgroup is the longest
+    jkp_segment<ND, ALLR, JKP_DIAG>(U, C, jd, kap0, kd1, lane, active, slots, ng, w);
+    jkp_segment<ND, ALLR, JKP_FULL>(U, C, jd, kd1, klim, lane, active, slots, ng, w);
+    if (last) {   // k == i: the rows end at different columns
         double2 jt[ND];
 #pragma unroll
         for (int d = 0; d < ND; ++d) jt[d] = make_double2(0.0, 0.0);
@@ -397,27 +425,27 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lan
             double pjk[JBB], pik[ND], rJ[JBB], rI[ND];
             jkp_uniform_p<ND, ALLR>(U, i, pjk, pik);
             jkp_last<ND>(C, U, pjk, pik, jd, rJ, rI, jt);
-            jkp_row_sums<ND, ALLR>(U, i, lane, rJ, rI);
+            jkp_row_sums<ND, ALLR>(U, i - U.kI0, lane, rJ, rI);
         }
 #pragma unroll
         for (int d = 0; d < ND; ++d) slots[(w * ND + d) * 64 + lane] = jt[d];
         __syncthreads();
-        if (w == 0) {                                  // wave 0 holds the first group: its last column bounds the row; the partial is
-                                                       // written (with zeros) up to its padded length, which jk_reduce_kernel sums over
+        if (w == 0) {                                  // the whole segment is written (zeros beyond the rows' last columns)
+            const KInfo ki = U.kinfo[i - U.kI0];
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 double2 t = slots[d * 64 + lane];
                 for (int u = 1; u < ng; ++u) { const double2 x = slots[(u * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
-                if (C.l0 <= ((U.j0 + U.nr - 1) | (TF_TRI_PAD - 1))) buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + tri_off(i) + U.c0), 16u * (unsigned)lane, 0u, t);
+                if (C.lam < ki.cnt) buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), 16u * (unsigned)lane, 0u, t);
             }
         }
     }
     if (!active) return;
-    // column parts (every column l < N of the group belongs to exactly one task)
+    // column parts (every column of the chunk belongs to this task alone)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int l = C.l0 + e;
-        if (l < N) {
+        if (e ? in1 : in0) {
+            const int l = C.lI + e;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 DIc[d * strideDIc + (size_t)group * N + l] = e ? C.colI[d].y : C.colI[d].x;
@@ -430,22 +458,22 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int c, int lan
     {
         const double t = wave_sum8(jd);
         const int v = lane >> 3, d = v / RB, r = v - d * RB;
-        if ((lane & 7) == 0 && (ALLR || r < U.nr)) Jd[d * strideJd + (size_t)(r0 + r) * NW + c] = t;
+        if ((lane & 7) == 0 && (ALLR || r < U.nr)) Jd[d * strideJd + (size_t)(r0 + r) * NW + wchunk] = t;
     }
 }
 
 // Strides (in doubles) between the arrays of density 0 and density 1 of a two-density pass
 struct JKStrides { size_t P, Pp, y, Jd, DIc, DIr, DJc, DJr; };
 
-// One workgroup per task (super-group, chunk): wave w owns group g0 + w (idle if the super-group has fewer).  NW = ceil(N / 128)
-// chunks; only tasks with 128 chunk <= i exist.  ND densities per pass: groups of 8 / ND rows.
+// One workgroup per task (super-group, chunk): wave w owns group g0 + w (idle if the super-group has fewer).  Only tasks with at
+// least one step exist (kap0[c][w] < cntA[a][i]).  ND densities per pass: groups of 8 / ND rows.
 // Outputs: Jd [n_rows][NW] per-task partials; ypart: Jt partials per super-group; DIc [G][N], DJc [n_rows][N]: column parts
-// (l-indexed); DIr [G][NW][N], DJr [n_rows][NW][N]: row parts per task (k-indexed, written for 128 chunk <= k <= i).
+// (l-indexed); DIr [G][RS], DJr [n_rows][RS]: row parts per task (k-indexed: entry rpoff[c][w] + kappa, written for every step).
 template <int ND>
 __global__ __launch_bounds__(64 * TF_JKP_W) void jk_packed_kernel(const double *__restrict__ T, const long long *__restrict__ rowoff,
                                                                   const JKGroup *__restrict__ groups, const JKSuper *__restrict__ supers,
-                                                                  const JKTask *__restrict__ tasks, int N, int NW,
-                                                                  const double *__restrict__ P, const double *__restrict__ Pp,
+                                                                  const JKTask *__restrict__ tasks, BLayout L,
+                                                                  const double *__restrict__ X, const double *__restrict__ Pp,
                                                                   double *__restrict__ Jd, double *__restrict__ ypart,
                                                                   double *__restrict__ DIc, double *__restrict__ DIr,
                                                                   double *__restrict__ DJc, double *__restrict__ DJr, JKStrides S)
@@ -458,216 +486,254 @@ __global__ __launch_bounds__(64 * TF_JKP_W) void jk_packed_kernel(const double *
     const bool active = w < sg.ng;
     const int gi = sg.g0 + (active ? w : 0);
     const JKGroup g = groups[gi];
+    const int N = L.N, NW = L.NW, c = sg.c;
+    const int b = L.chunk_cls[t.w], a = b ^ c;
     JKWave U;
-    U.T0 = T + rowoff[g.r0]; U.P = P; U.Pp = Pp; U.NP = (long long)S.Pp;
-    U.N = N; U.i = g.i; U.j0 = g.j0; U.nr = g.nr; U.c0 = t.chunk * TF_JKP_CW;
-    U.yg = ypart + sg.yoff; U.ystride = S.y;
-    U.DIr_w = DIr + ((size_t)gi * NW + t.chunk) * N; U.dstrideI = S.DIr;
-    U.rowW = (size_t)NW * N;
-    U.DJr_w = DJr + ((size_t)g.r0 * NW + t.chunk) * N; U.dstrideJ = S.DJr;
+    U.N = N; U.i = g.i; U.j0 = g.j0; U.nr = g.nr; U.lamj0 = g.lamj0;
+    U.kI0 = bl_cstart(L, a); U.c0 = L.chunk_c0[t.w]; U.lam0 = U.c0 - bl_cstart(L, b); U.width = L.chunk_width[t.w]; U.cm = (c == 0) ? 1 : 0;
+    U.T0 = T + rowoff[g.r0] + groups[gi].secoff[a]; U.X = X; U.NPtot = (long long)S.Pp;   // (table reads from memory: a is a run-time index)
+    const long long pbase = bl_cbase(L, c) + bl_fullsec(L, c, a);
+    U.Pp = Pp + pbase;
+    U.kinfo = L.kinfo + (size_t)c * N + U.kI0;
+    U.yg = ypart + sg.yoff + bl_fullsec(L, c, a); U.ystride = S.y;
+    U.RS = (size_t)L.RS;
+    const int rp = L.rpoff[c * NW + t.w];
+    U.DIr_w = DIr + (size_t)gi * L.RS + rp; U.dstrideI = S.DIr;
+    U.DJr_w = DJr + (size_t)g.r0 * L.RS + rp; U.dstrideJ = S.DJr;
 #pragma unroll
     for (int r = 0; r < JBB; ++r) U.roff8[r] = 8u * (unsigned)g.roff[r < RB ? r : 0];
+    {
+        // Pp[(i, j_r)]: pair index of (i, j_r) -- i is the larger original index of the row
+        const int ci = L.clsI[g.i];
+        const long long pij = bl_cbase(L, c) + bl_fullsec(L, c, ci) + L.kinfo[(size_t)c * N + g.i].offA + g.lamj0;
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
+        for (int d = 0; d < ND; ++d)
 #pragma unroll
-        for (int r = 0; r < RB; ++r) U.ppij[d * RB + r] = (r < g.nr) ? Pp[d * S.Pp + tri_off(g.i) + g.j0 + r] : 0.0;
+            for (int r = 0; r < RB; ++r) U.ppij[d * RB + r] = (r < g.nr) ? Pp[d * S.Pp + pij + r] : 0.0;
+    }
+    const int kap0 = L.kap0[c * NW + t.w], ke = supers[t.super].ke[a];
+    const bool last = (a == L.clsI[g.i]);
+    const int klim = ke - (last ? 1 : 0);
+    const int kd1 = min(max(L.kapF[c * NW + t.w], kap0), klim);
     if (g.nr == RB)
-        jkp_task<ND, true>(U, NW, t.chunk, lane, gi, g.r0, active, slots, sg.ng, w, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
+        jkp_task<ND, true>(U, NW, t.w, lane, gi, g.r0, active, slots, sg.ng, w, kap0, kd1, klim, last, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
     else
-        jkp_task<ND, false>(U, NW, t.chunk, lane, gi, g.r0, active, slots, sg.ng, w, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
+        jkp_task<ND, false>(U, NW, t.w, lane, gi, g.r0, active, slots, sg.ng, w, kap0, kd1, klim, last, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
 }
 
-// Jt partial sums over the padded pair index q: super-groups are sorted by descending partial length, so those that cover q are
-// a prefix of the list.  Block (bx, by) of a (ceil(NP/256), nseg) grid: segment by sums its slice of that prefix; out[by][q].
-__device__ __forceinline__ void jt_reduce_block(int bx, int by, int nseg, const double *__restrict__ ypart, const JKSuper *__restrict__ groups,
-                                                int n_groups, long long NP, double *__restrict__ out)
+// Jt partial sums over the pair index q of class c: the super-groups of a class are sorted by descending original i, so those whose
+// rows reach the AO k of q are a prefix of the class's list (ke[a] is non-increasing along it).  Block (bx, by) of a
+// (sum_c ceil(NP[c] / 256), nseg) grid: segment by sums its slice of every class's list; out[by][q].
+struct JKJtPlan { int sfirst[5]; int bfirst[5]; };   // supers of class c: sfirst[c] .. sfirst[c + 1]; blocks of class c: bfirst[c] .. bfirst[c + 1]
+__device__ __forceinline__ void jt_reduce_block(int bx, int by, int nseg, const double *__restrict__ ypart, const JKSuper *__restrict__ supers,
+                                                const JKJtPlan &JP, const BLayout &L, double *__restrict__ out)
 {
-    const long long q = (long long)bx * 256 + threadIdx.x;
-    if (q >= NP) return;
-    const int per = (n_groups + nseg - 1) / nseg;
-    const int g0 = by * per, g1 = min(n_groups, g0 + per);
-    // the partials that cover every column of this block (a prefix: found by a wave-uniform bisection) are summed without the
-    // per-element test, so their loads can be issued ahead; the few that end inside the block follow with the test
-    const long long qmax = min(NP - 1, (long long)bx * 256 + 255);
-    int lo = g0, hi = g1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (groups[mid].ylen > qmax) lo = mid + 1; else hi = mid;
-    }
+    int c = 0;
+    while (c < 3 && bx >= JP.bfirst[c + 1]) ++c;
+    const long long q = (long long)(bx - JP.bfirst[c]) * 256 + threadIdx.x;
+    if (q >= bl_np(L, c)) return;
+    const int kI = L.gk[bl_gbase(L, c) + (int)(q / TF_SEG_PAD)];
+    const int a = L.clsI[kI], kap = kI - bl_cstart(L, a);
+    const KInfo ki = L.kinfo[(size_t)c * L.N + kI];
     double s = 0.0;
-#pragma unroll 8
-    for (int g = g0; g < lo; ++g) s += ypart[groups[g].yoff + q];
-    for (int g = lo; g < g1; ++g) {
-        if (groups[g].ylen <= q) break;
-        s += ypart[groups[g].yoff + q];
+    if ((int)(q - bl_fullsec(L, c, a)) - ki.offA < ki.cnt) {                    // (pad slots: 0)
+        const int n = JP.sfirst[c + 1] - JP.sfirst[c], per = (n + nseg - 1) / nseg;
+        const int s0 = JP.sfirst[c] + by * per, s1 = min(JP.sfirst[c + 1], s0 + per);
+        for (int g = s0; g < s1; ++g) {
+            if (supers[g].ke[a] <= kap) break;
+            s += ypart[supers[g].yoff + q];
+        }
     }
-    out[(size_t)by * NP + q] = s;
+    out[(size_t)by * L.NPtot + bl_cbase(L, c) + q] = s;
 }
 
-// D[a][x] = sum over groups with i == a of (column part + row parts of the chunks)[x] + the same over owned rows (i > a, j == a).
-// Block (a, bx) of an (N, ceil(N/64)) grid, 256 threads = 4 slices x 64 columns; gfirst[a]..gfirst[N+a] are the groups with i == a.
-__device__ __forceinline__ void kd_reduce_block(int a, int bx, double *sPart, const double *__restrict__ DIc, const double *__restrict__ DIr,
-                                                const double *__restrict__ DJc, const double *__restrict__ DJr, int NW,
-                                                const int *__restrict__ gfirst, const int *__restrict__ rowmap, int N, double *__restrict__ D)
+// D[x][y] (internal indices) = sum over the groups whose rows have first index x of (column part + row parts of the chunks)[y]
+//                            + the same over the owned rows (z, x) with second index x.
+// A part exists only where a task wrote it: column part of chunk w for a bra index i of class-c rows iff kap0[c][w] < cntA[a][i]
+// (a = class of the chunk ^ c); row part (w, kappa) iff kap0[c][w] <= kappa < cntA[class of k][i].
+// Block (x, bx) of an (N, ceil(N/64)) grid, 256 threads = 4 slices x 64 columns; gfirst[x]..gfirst[N+x] are the groups with i == x.
+__device__ __forceinline__ double kd_parts(const BLayout &L, int c, int ibra, int y, int cy, int ly, int wy, const double *__restrict__ colp,
+                                           const double *__restrict__ rowp)
 {
+    const int N = L.N, NW = L.NW;
+    double t = 0.0;
+    if (L.kap0[c * NW + wy] < L.cntA[(cy ^ c) * N + ibra]) t = colp[y];
+    if (ly < L.cntA[cy * N + ibra]) {
+        const int bcl = cy ^ c;
+        for (int w = bl_wfirst(L, bcl); w < bl_wfirst(L, bcl + 1); ++w)
+            if (L.kap0[c * NW + w] <= ly) t += rowp[L.rpoff[c * NW + w] + ly];
+    }
+    return t;
+}
+
+__device__ __forceinline__ void kd_reduce_block(int x, int bx, double *sPart, const double *__restrict__ DIc, const double *__restrict__ DIr,
+                                                const double *__restrict__ DJc, const double *__restrict__ DJr, const BLayout &L,
+                                                const JKGroup *__restrict__ groups, const int *__restrict__ gfirst,
+                                                const int *__restrict__ rowmap, double *__restrict__ D)
+{
+    const int N = L.N;
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int x = bx * 64 + lane;
-    const int nw = min(NW, x / TF_JKP_CW + 1);            // chunks that start at or before x
+    const int y = bx * 64 + lane;
     double s = 0.0;
-    if (x < N) {
-        if (x <= a)
-            for (int g0 = gfirst[a] + sl, ge = gfirst[N + a]; g0 < ge; g0 += 16) {
-                double t[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) t[u] = (g0 + 4 * u < ge) ? DIc[(size_t)(g0 + 4 * u) * N + x] : 0.0;
-                for (int w = 0; w < nw; ++w) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (g0 + 4 * u < ge) t[u] += DIr[((size_t)(g0 + 4 * u) * NW + w) * N + x];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (g0 + 4 * u < ge) s += t[u];
-            }
-        // four rows of the slice at a time: their row lookups, then all their loads, are issued together (the loads depend on the
-        // lookups; one row at a time left a single dependent chain per lane); summed in row order as before
-        for (int i0 = max(a + 1, x) + sl; i0 < N; i0 += 16) {
-            int r[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i0 + 4 * u; r[u] = (i < N) ? rowmap[(size_t)i * (i + 1) / 2 + a] : -1; }
-            double t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = (r[u] >= 0) ? DJc[(size_t)r[u] * N + x] : 0.0;
-            for (int w = 0; w < nw; ++w) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (r[u] >= 0) t[u] += DJr[((size_t)r[u] * NW + w) * N + x];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (r[u] >= 0) s += t[u];
+    if (y < N) {
+        const int cy = L.clsI[y], ly = y - bl_cstart(L, cy), wy = L.chunk_of[y];
+        const int xo = L.origI[x], cx = L.clsI[x];
+        for (int g = gfirst[x] + sl, ge = gfirst[N + x]; g < ge; g += 4)
+            s += kd_parts(L, groups[g].c, x, y, cy, ly, wy, DIc + (size_t)g * N, DIr + (size_t)g * L.RS);
+        for (int z = sl; z < N; z += 4) {
+            if (L.origI[z] <= xo) continue;
+            const int hi = max(z, x), lo = min(z, x);
+            const int r = rowmap[(size_t)hi * (hi + 1) / 2 + lo];
+            if (r < 0) continue;
+            s += kd_parts(L, L.clsI[z] ^ cx, z, y, cy, ly, wy, DJc + (size_t)r * N, DJr + (size_t)r * L.RS);
         }
     }
     sPart[threadIdx.x] = s;
     __syncthreads();
-    if (sl == 0 && x < N) D[(size_t)a * N + x] = ((sPart[lane] + sPart[64 + lane]) + sPart[128 + lane]) + sPart[192 + lane];
+    if (sl == 0 && y < N) D[(size_t)x * N + y] = ((sPart[lane] + sPart[64 + lane]) + sPart[128 + lane]) + sPart[192 + lane];
 }
 
 // Both reductions of all densities of a pass in ONE launch (they are independent and each alone leaves most of the chip idle):
-// per density first the N * ceil(N/64) exchange blocks, then the ceil(NP/256) * nseg transposed-Coulomb blocks.  Fixed summation
-// order inside every block: bitwise reproducible.
+// per density first the N * ceil(N/64) exchange blocks, then the Jt blocks.  Fixed summation order inside every block: bitwise
+// reproducible.
 struct JKReduce {
     const double *ypart, *DIc, *DIr, *DJc, *DJr;
     double *Jt, *D[2];
     const JKSuper *supers;
+    const JKGroup *groups;
     const int *gfirst, *rowmap;
-    long long NP;
+    JKJtPlan jp;
     size_t sy, sJt, sDIc, sDIr, sDJc, sDJr;              // strides between densities
-    int n_supers, nseg, N, NW;
+    int nseg;
 };
-__global__ __launch_bounds__(256) void jk_reduce_kernel(JKReduce R)
+__global__ __launch_bounds__(256) void jk_reduce_kernel(JKReduce R, BLayout L)
 {
     __shared__ double sPart[256];
-    const int gxK = (R.N + 63) / 64, nK = R.N * gxK;
-    const int gxJ = (int)((R.NP + 255) / 256), nJ = gxJ * R.nseg;
+    const int gxK = (L.N + 63) / 64, nK = L.N * gxK;
+    const int gxJ = R.jp.bfirst[4], nJ = gxJ * R.nseg;
     int b = blockIdx.x;
     const int d = b / (nK + nJ);
     b -= d * (nK + nJ);
     if (b < nK)
-        kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, R.NW, R.gfirst,
-                        R.rowmap, R.N, R.D[d]);
+        kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, L, R.groups,
+                        R.gfirst, R.rowmap, R.D[d]);
     else {
         b -= nK;
-        jt_reduce_block(b % gxJ, b / gxJ, R.nseg, R.ypart + d * R.sy, R.supers, R.n_supers, R.NP, R.Jt + d * R.sJt);
+        jt_reduce_block(b % gxJ, b / gxJ, R.nseg, R.ypart + d * R.sy, R.supers, R.jp, L, R.Jt + d * R.sJt);
     }
 }
 
-// K = D + D2^T (D2 = D for a symmetric density; for a general one D = D(P^T), D2 = D(P));
-// J[a][b] = sum over the chunks of Jd[row(ab)] (owned rows) + sum_s Jt_s[pair(ab)]
-__global__ void jk_packed_final_kernel(const double *__restrict__ D, const double *__restrict__ D2, const double *__restrict__ Jd, int NW,
-                                       const double *__restrict__ Jt, int nseg, const int *__restrict__ rowmap, int N,
+// Original indices (a, b): K = D + D2^T (D2 = D for a symmetric density; for a general one D = D(P^T), D2 = D(P));
+// J[a][b] = sum over the chunks with a task of Jd[row(ab)] (owned rows) + sum_s Jt_s[pair(ab)]
+__global__ void jk_packed_final_kernel(const double *__restrict__ D, const double *__restrict__ D2, const double *__restrict__ Jd,
+                                       const double *__restrict__ Jt, int nseg, const int *__restrict__ rowmap, BLayout L,
                                        double *__restrict__ J, double *__restrict__ K)
 {
+    const int N = L.N, NW = L.NW;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N * N) return;
     const int a = e / N, b = e - a * N;
-    K[e] = D[e] + D2[(size_t)b * N + a];
-    const int hi = max(a, b), lo = min(a, b);
-    const long long NP = tri_off(N), q = tri_off(hi) + lo;
-    const int r = rowmap[(size_t)hi * (hi + 1) / 2 + lo];
+    const int wa = L.ao[a], wb = L.ao[b];
+    const int sa = ao_sigma(L, wa), sb = ao_sigma(L, wb);
+    K[e] = D[(size_t)sa * N + sb] + D2[(size_t)sb * N + sa];
+    const int whi = a >= b ? wa : wb, wlo = a >= b ? wb : wa;                // the pair (hi >= lo) in original order
+    const int shi = a >= b ? sa : sb;
+    const int c = ao_cls(wa) ^ ao_cls(wb);
+    const long long q = bl_cbase(L, c) + bl_fullsec(L, c, ao_cls(whi)) + L.kinfo[(size_t)c * N + shi].offA + ao_loc(wlo);
+    const int h2 = max(sa, sb), l2 = min(sa, sb);
+    const int r = rowmap[(size_t)h2 * (h2 + 1) / 2 + l2];
     double s = 0.0;
     if (r >= 0)
-        for (int w = 0; w <= hi / TF_JKP_CW; ++w) s += Jd[(size_t)r * NW + w];
-    for (int t = 0; t < nseg; ++t) s += Jt[(size_t)t * NP + q];
+        for (int w = 0; w < NW; ++w)
+            if (L.kap0[c * NW + w] < L.cntA[(L.chunk_cls[w] ^ c) * N + shi]) s += Jd[(size_t)r * NW + w];
+    for (int t = 0; t < nseg; ++t) s += Jt[(size_t)t * L.NPtot + q];
     J[e] = s;
 }
 
+// ---- writing the tensor -------------------------------------------------------------------------------------------------------
+// The generation slab holds, per Cartesian bra component pair (ca, cb) of class c, a row of the COMPLETE-row shape of class c
+// (pair index without cbase; stride RLS = max_c NP[c]): the ket-transformed values (ca cb|kl) for the pairs (k >= l) of class c.
 struct OutRowP {
-    int i, j;              // output AO indices (i >= j)
+    int i, j;              // output AO indices (i >= j), original order: rows of the Cartesian -> spherical CSR
+    int iI, lamj;          // internal index of i; loc of j
+    int c, ncb;            // class of the row; components of the second bra shell
     int cartA, cartB;      // first Cartesian AO of the two bra shells
-    int ncb, pad;
+    int secoff[4];         // start of section a in the stored row
+    int len, pad;          // stored doubles of the row
     long long slab_off;    // first slab row of this bra pair
-    long long dst_off;     // offset of the packed row in the stored tensor
+    long long dst_off;     // offset of the row in the stored tensor
 };
 
-// packed tensor row (i,j) = bra transform of the ket-transformed slab, keeping only pairs (k >= l) up to (i,j); pad slots <- 0.
-// grid (ceil(N / 4), rows): a block takes four triangle rows k (one per wave), lanes run over l -- the padded index is
-// tri_off(k) + l, no index inversion per element; the (<= 6 x 6) Cartesian -> spherical terms of the two bra AOs are staged in LDS
-// once per block (nested sums in the order of xform_bra_store: the same rounding).
-#define TF_XBP_KR 4
-__global__ __launch_bounds__(64 * TF_XBP_KR) void xform_bra_store_packed(const double *__restrict__ in, double *__restrict__ eri,
-                                                                       const OutRowP *__restrict__ rows, long long row_len, int ld,
-                                                                       const int *__restrict__ ptr, const int *__restrict__ idx,
-                                                                       const double *__restrict__ val)
+// tensor row (i,j) = bra transform of the slab rows; pad slots and the slots beyond l == j in the segment of k == i <- 0.
+// grid (ceil(max row length / 256), rows); the (<= 6 x 6) Cartesian -> spherical terms of the two bra AOs are staged in LDS once
+// per block (nested sums, fixed order).
+__global__ __launch_bounds__(256) void xform_bra_store_packed(const double *__restrict__ in, double *__restrict__ eri,
+                                                              const OutRowP *__restrict__ rows, long long RLS, BLayout L,
+                                                              const int *__restrict__ ptr, const int *__restrict__ idx,
+                                                              const double *__restrict__ val)
 {
     __shared__ double sValA[32], sValB[32];
     __shared__ long long sOffA[32], sOffB[32];
     const OutRowP R = rows[blockIdx.y];
-    const int k0 = TF_XBP_KR * blockIdx.x;
-    if (k0 > R.i) return;
+    if ((int)(blockIdx.x * 256) >= R.len) return;
     const int pa = ptr[R.i], na = min(32, ptr[R.i + 1] - pa), pb = ptr[R.j], nb = min(32, ptr[R.j + 1] - pb);
-    if (threadIdx.x < na) { sValA[threadIdx.x] = val[pa + threadIdx.x]; sOffA[threadIdx.x] = (long long)(idx[pa + threadIdx.x] - R.cartA) * R.ncb * row_len; }
+    if (threadIdx.x < na) { sValA[threadIdx.x] = val[pa + threadIdx.x]; sOffA[threadIdx.x] = (long long)(idx[pa + threadIdx.x] - R.cartA) * R.ncb * RLS; }
     if (threadIdx.x >= 64 && threadIdx.x < 64 + nb) {
         const int t = threadIdx.x - 64;
-        sValB[t] = val[pb + t]; sOffB[t] = (long long)(idx[pb + t] - R.cartB) * row_len;
+        sValB[t] = val[pb + t]; sOffB[t] = (long long)(idx[pb + t] - R.cartB) * RLS;
     }
     __syncthreads();
-    const int k = k0 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (k > R.i) return;
-    const long long tk = tri_off(k);
-    // stored slots of triangle row k in this tensor row: the whole padded row for k < i, up to the row's padded end for k == i
-    const int lenk = (k < R.i) ? (int)(tri_off(k + 1) - tk) : (int)(packed_row_len(R.i, R.j) - tk);
-    const int lmax = (k < R.i) ? k : R.j;                           // pairs (k, l <= lmax) exist; beyond: pad slots
-    const double *__restrict__ src = in + R.slab_off * row_len + (long long)k * ld;
-    double *__restrict__ dst = eri + R.dst_off + tk;
-    for (int l = lane; l < lenk; l += 64) {
-        double s = 0.0;
-        if (l <= lmax) {
-            for (int qa = 0; qa < na; ++qa) {
-                double t = 0.0;
-                for (int qb = 0; qb < nb; ++qb) t += sValB[qb] * src[sOffA[qa] + sOffB[qb] + l];
-                s += sValA[qa] * t;
-            }
-        }
-        dst[l] = s;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= R.len) return;
+    // section of x: the sections follow each other in internal class order (ascending cstart)
+    int a = 0, best = -1, besta = -1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int so = R.secoff[t], st = bl_cstart(L, t);
+        if (so <= x && (so > best || (so == best && st > besta))) { best = so; besta = st; a = t; }
     }
+    const int c = R.c;
+    const int srcidx = x - best + bl_fullsec(L, c, a);
+    const int kI = L.gk[bl_gbase(L, c) + srcidx / TF_SEG_PAD];
+    const KInfo ki = L.kinfo[(size_t)c * L.N + kI];
+    const int lam = srcidx - bl_fullsec(L, c, a) - ki.offA;
+    double s = 0.0;
+    if (lam < ki.cnt && !(kI == R.iI && lam > R.lamj)) {
+        const double *__restrict__ src = in + R.slab_off * RLS + srcidx;
+        for (int qa = 0; qa < na; ++qa) {
+            double t = 0.0;
+            for (int qb = 0; qb < nb; ++qb) t += sValB[qb] * src[sOffA[qa] + sOffB[qb]];
+            s += sValA[qa] * t;
+        }
+    }
+    eri[R.dst_off + x] = s;
 }
 
+// (ij|kl) from the stored tensor, original indices; rows owned by another rank read as 0 (sum over ranks = the tensor)
 __device__ __forceinline__ double packed_element(const double *__restrict__ eri, const int *__restrict__ rowmap,
-                                                 const long long *__restrict__ rowoff, int i, int j, int k, int l)
+                                                 const long long *__restrict__ rowoff, const int *__restrict__ rowsec, const BLayout &L,
+                                                 int i, int j, int k, int l)
 {
-    const int ih = max(i, j), il = min(i, j), kh = max(k, l), kl = min(k, l);
+    int ih = max(i, j), il = min(i, j), kh = max(k, l), kl = min(k, l);
+    const int wi = L.ao[ih], wj = L.ao[il], wk = L.ao[kh], wl = L.ao[kl];
+    const int c = ao_cls(wi) ^ ao_cls(wj);
+    if (c != (ao_cls(wk) ^ ao_cls(wl))) return 0.0;                          // x/y parity, pyx:1324-1327
     const long long p = (long long)ih * (ih + 1) / 2 + il, q = (long long)kh * (kh + 1) / 2 + kl;
-    const int r = rowmap[max(p, q)];
+    int wr1 = wi, wr2 = wj, wc1 = wk, wc2 = wl;                              // row pair (the larger one), column pair
+    if (q > p) { wr1 = wk; wr2 = wl; wc1 = wi; wc2 = wj; }
+    const int s1 = ao_sigma(L, wr1), s2 = ao_sigma(L, wr2);
+    const int h2 = max(s1, s2), l2 = min(s1, s2);
+    const int r = rowmap[(size_t)h2 * (h2 + 1) / 2 + l2];
     if (r < 0) return 0.0;
-    return eri[rowoff[r] + (p >= q ? tri_off(kh) + kl : tri_off(ih) + il)];
+    const int a = ao_cls(wc1);
+    return eri[rowoff[r] + rowsec[4 * (size_t)r + a] + L.kinfo[(size_t)c * L.N + ao_sigma(L, wc1)].offA + ao_loc(wc2)];
 }
 
-// packed -> dense N^4 with all images (what the reference leaves in ERI_AO, pyx:1335-1342).  On several ranks an element
-// appears on the rank that owns row max(p,q); the others contribute zero (sum over ranks = dense tensor).
+// packed -> dense N^4 with all images (what the reference leaves in ERI_AO, pyx:1335-1342).
 __global__ void expand_dense_packed_kernel(const double *__restrict__ eri, const int *__restrict__ rowmap, const long long *__restrict__ rowoff,
-                                           int N, double *__restrict__ dense)
+                                           const int *__restrict__ rowsec, BLayout L, double *__restrict__ dense)
 {
+    const int N = L.N;
     const long long total = (long long)N * N * N * N;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int l = (int)(e % N);
@@ -675,28 +741,31 @@ __global__ void expand_dense_packed_kernel(const double *__restrict__ eri, const
         const int k = (int)(r % N); r /= N;
         const int j = (int)(r % N);
         const int i = (int)(r / N);
-        dense[e] = packed_element(eri, rowmap, rowoff, i, j, k, l);
+        dense[e] = packed_element(eri, rowmap, rowoff, rowsec, L, i, j, k, l);
     }
 }
 
 __global__ void sample_packed_kernel(const double *__restrict__ eri, const int *__restrict__ rowmap, const long long *__restrict__ rowoff,
-                                     long long n, const int *__restrict__ idx, double *__restrict__ out)
+                                     const int *__restrict__ rowsec, BLayout L, long long n, const int *__restrict__ idx, double *__restrict__ out)
 {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    out[q] = packed_element(eri, rowmap, rowoff, idx[4 * q], idx[4 * q + 1], idx[4 * q + 2], idx[4 * q + 3]);
+    out[q] = packed_element(eri, rowmap, rowoff, rowsec, L, idx[4 * q], idx[4 * q + 1], idx[4 * q + 2], idx[4 * q + 3]);
 }
 
-// full rows for the GEMM-shaped consumers (AO->MO): out[r - r0][k][l] (leading dimension ld) for local rows r0 <= r < r0 + nb
+// full rows for the GEMM-shaped consumers (AO->MO): out[r - r0][k][l] (leading dimension ld, ORIGINAL indices) for local rows
+// r0 <= r < r0 + nb; row_ij holds the original (i, j) of every local row
 __global__ void unpack_full_rows_kernel(const double *__restrict__ eri, const int *__restrict__ rowmap, const long long *__restrict__ rowoff,
-                                        const int2 *__restrict__ row_ij, long long r0, int nb, int N, int ld, double *__restrict__ out)
+                                        const int *__restrict__ rowsec, BLayout L, const int2 *__restrict__ row_ij, long long r0, int nb, int ld,
+                                        double *__restrict__ out)
 {
+    const int N = L.N;
     const long long per = (long long)N * ld, total = (long long)nb * per;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const long long rr = e / per;
         const int rem = (int)(e - rr * per);
         const int k = rem / ld, l = rem - k * ld;
         const int2 ij = row_ij[r0 + rr];
-        out[e] = (l < N) ? packed_element(eri, rowmap, rowoff, ij.x, ij.y, k, l) : 0.0;
+        out[e] = (l < N) ? packed_element(eri, rowmap, rowoff, rowsec, L, ij.x, ij.y, k, l) : 0.0;
     }
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tf_internal.h"
+#include "tf_layout.hip.h"
 
 namespace tfk {
 
@@ -38,6 +39,9 @@ struct DBasis {
     const double *ct_sc;
     const LRec *lrec;
     const unsigned short *tup;
+    // packed layout (set by tf_build_eri): the layout tables and the stride of a slab row (complete-row shape, max_c NP[c] doubles)
+    BLayout bl;
+    long long RLS;
 };
 
 #define TF_ERI_THREADS 256
@@ -187,6 +191,44 @@ __global__ __launch_bounds__(256) void xform_ket_both(const double *__restrict__
             }
         }
         dst[l] = s;
+    }
+}
+
+// The same for the packed layout: slab row r (a Cartesian bra component pair of parity class rowcls[r]) keeps only the pairs
+// (ks >= ls) of that class, in the complete-row shape (tf_jkpacked.hip.h): out[r][fullsec + offA(ks) + loc(ls)].  A quarter of the
+// outputs of xform_ket_both, no zeros stored.  grid (ceil(Ns / 4), rows): one output AO ks per wave, lanes over the segment.
+__global__ __launch_bounds__(256) void xform_ket_packed(const double *__restrict__ in, double *__restrict__ out, int Nc, BLayout L, long long RLS,
+                                                        const signed char *__restrict__ rowcls, const int *__restrict__ ptr,
+                                                        const int *__restrict__ idx, const double *__restrict__ val)
+{
+    __shared__ double sVal[4][32];
+    __shared__ int sIdx[4][32];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ks = 4 * blockIdx.x + w, Ns = L.N;
+    const long long r = blockIdx.y;
+    int na = 0;
+    if (ks < Ns) {
+        const int p0 = ptr[ks];
+        na = min(32, ptr[ks + 1] - p0);
+        if (lane < na) { sVal[w][lane] = val[p0 + lane]; sIdx[w][lane] = idx[p0 + lane]; }
+    }
+    __syncthreads();
+    if (ks >= Ns) return;
+    const int c = rowcls[r], wk = L.ao[ks], ck = ao_cls(wk), b = ck ^ c;
+    const KInfo ki = L.kinfo[(size_t)c * Ns + ao_sigma(L, wk)];
+    const double *__restrict__ src = in + r * (long long)Nc * Nc;
+    double *__restrict__ dst = out + r * RLS + bl_fullsec(L, c, ck) + ki.offA;
+    for (int lam = lane; lam < ki.cnt; lam += 64) {
+        const int l = L.origI[bl_cstart(L, b) + lam];
+        const int q0 = ptr[l], q1 = ptr[l + 1];
+        double s = 0.0;
+        for (int qa = 0; qa < na; ++qa) {
+            const double *__restrict__ rowp = src + (long long)sIdx[w][qa] * Nc;
+            double t = 0.0;
+            for (int q = q0; q < q1; ++q) t += val[q] * rowp[idx[q]];
+            s += sVal[w][qa] * t;
+        }
+        dst[lam] = s;
     }
 }
 

@@ -30,15 +30,17 @@ namespace tfmp2 {
         if (_s != rocblas_status_success) { msg = std::string(#call) + " failed (rocBLAS status " + std::to_string((int)_s) + ")"; rc = TF_ELINALG; goto done; } \
     } while (0)
 
-// Qfull[mu][nu][x] = Q[row(max,min)][x]
+// Qfull[mu][nu][x] = Q[row(max,min)][x]; the row table of the packed layout is keyed by internal AO indices (ao: class | loc << 2
+// of every original AO, nullptr for the rows layout)
 __global__ void unpack_rows_kernel(const double *__restrict__ Q, const int *__restrict__ rowmap, int N, long long width,
-                                   double *__restrict__ Qfull)
+                                   double *__restrict__ Qfull, BLayout L, int packed)
 {
     const long long total = (long long)N * N * width;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const long long mn = e / width;
         const long long x = e - mn * width;
-        const int mu = (int)(mn / N), nu = (int)(mn - (long long)mu * N);
+        int mu = (int)(mn / N), nu = (int)(mn - (long long)mu * N);
+        if (packed) { mu = ao_sigma(L, L.ao[mu]); nu = ao_sigma(L, L.ao[nu]); }
         const int hi = max(mu, nu), lo = min(mu, nu);
         const int r = rowmap[hi * (hi + 1) / 2 + lo];
         Qfull[e] = (r >= 0) ? Q[(long long)r * width + x] : 0.0;
@@ -76,8 +78,8 @@ __global__ void mp2_energy_kernel(const double *__restrict__ g, const double *__
 // out[p][q][r][s] = sum C1[mu p] C2[nu q] C3[la r] C4[si s] (mu nu|la si); C_k are [N, n_k] row-major DEVICE matrices;
 // d_out [n1,n2,n3,n4] on the device.  Rows of the stored tensor are processed in slabs to bound the scratch.
 // Packed layout (d_rowoff != nullptr): the rows of a slab are first materialised as full [N][ld] matrices (unpack_full_rows_kernel).
-inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowmap, const long long *d_rowoff, const int2 *d_row_ij,
-                     long long n_rows, int N, int ld, const double *dC1, int n1, const double *dC2, int n2, const double *dC3, int n3,
+inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowmap, const long long *d_rowoff, const int *d_rowsec,
+                     const BLayout &BL, const int2 *d_row_ij, long long n_rows, int N, int ld, const double *dC1, int n1, const double *dC2, int n2, const double *dC3, int n3,
                      const double *dC4, int n4, double *d_out, double *gemm_seconds, std::string &msg)
 {
     int rc = TF_OK;
@@ -105,7 +107,7 @@ inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowm
         if (packed) {
             const long long tot = (long long)nb * row_len;
             hipLaunchKernelGGL(unpack_full_rows_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 1 << 20)), dim3(256), 0, 0, d_eri,
-                               d_rowmap, d_rowoff, d_row_ij, r0, nb, N, ld, dM);
+                               d_rowmap, d_rowoff, d_rowsec, BL, d_row_ij, r0, nb, ld, dM);
             Mrows = dM;
         }
         // R[row] (n3 x N, row-major) = C3^T (n3 x N) * M[row] (N x N, ld)
@@ -121,7 +123,7 @@ inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowm
     {
         const long long tot = (long long)N * N * n34;
         hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 1 << 20)), dim3(256), 0, 0, dQ, d_rowmap, N,
-                           n34, dQfull);
+                           n34, dQfull, BL, packed ? 1 : 0);
     }
     TFM_HIP(hipDeviceSynchronize());
     (void)hipFree(dQ); dQ = nullptr;
