@@ -16,9 +16,9 @@ from __future__ import annotations
 import numpy as np
 
 PAD = 8          # segment alignment in doubles (TF_SEG_PAD)
-CW = 128         # columns per chunk (TF_JKP_CW)
+CW = 64          # columns per chunk (TF_JKP_CW)
 JBB = 8          # rows per group (one density per pass)
-W = 4            # groups per workgroup
+W = 8            # groups per workgroup (two per wave)
 
 
 def pad_up(n, pad=PAD):

@@ -39,14 +39,14 @@ def test_model_reproduces_the_reference_einsums(shell_L, pad, cw, jbb, w):
             Js, Ks = Js + Jr, Ks + Kr
         assert np.abs(Js - Jref).max() < 1e-12 and np.abs(Ks - Kref).max() < 1e-12
     finally:
-        lm.JBB, lm.W = 8, 4
+        lm.JBB, lm.W = 8, 8
 
 
 def test_stored_fraction():
     """20s15p13d10f per atom (the 400-AO bench workload): the blocked rows hold ~1/4 of the 8-fold unique tensor."""
     cls = classes_of(([0] * 20 + [1] * 15 + [2] * 13 + [3] * 10) * 2)
-    L = lm.Layout(cls, 8, 128)
-    assert L.N == 400 and L.NW == 5 and sorted(L.csize) == [46, 96, 96, 162]
+    L = lm.Layout(cls, 8, 64)
+    assert L.N == 400 and L.NW == 8 and sorted(L.csize) == [46, 96, 96, 162]
     stored = sum(L.row_len(i, 0) * (i + 1) for i in range(0))         # (row_len depends on the class of j: sum per class below)
     tot = 0
     for i in range(L.N):

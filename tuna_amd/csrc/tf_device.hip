@@ -60,7 +60,7 @@ struct tf_ctx {
     int layout = 0;
     long long n_elems = 0;              // stored doubles
     long long *d_rowoff = nullptr;
-    int *d_rowsec = nullptr;            // [n_rows][4]: start of section a inside local row r
+    int *d_rowsec = nullptr;            // [n_rows][6]: start of section a inside local row r; position in its storage unit, rows of the unit
     // parity-blocked layout tables (tf_layout.hip.h), host mirror and device view
     struct HostLayout {
         int N = 0, NW = 0, RS = 0;
@@ -712,16 +712,26 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             return H.sigma[u.x] != H.sigma[v.x] ? H.sigma[u.x] < H.sigma[v.x] : H.sigma[u.y] < H.sigma[v.y];
         });
         std::fill(rowmap.begin(), rowmap.end(), -1);
-        rowoff.resize(row_ij.size() + 1);
-        rowsec.resize(4 * row_ij.size() + 4);
-        rowlen.resize(row_ij.size() + 1);
-        long long off = 0;
+        rowoff.assign(row_ij.size() + 1, 0);
+        rowsec.assign(6 * row_ij.size() + 6, 0);
+        rowlen.assign(row_ij.size() + 1, 0);
         for (size_t r = 0; r < row_ij.size(); ++r) {
             const int i = row_ij[r].x, j = row_ij[r].y;
             rowmap[ikey(H.sigma[i], H.sigma[j])] = (int)r;
-            rowoff[r] = off;
-            rowlen[r] = H.row_shape(H.cls[i] ^ H.cls[j], H.sigma[i], &rowsec[4 * r]);
-            off += rowlen[r];
+            rowlen[r] = H.row_shape(H.cls[i] ^ H.cls[j], H.sigma[i], &rowsec[6 * r]);
+        }
+        // storage units: runs of up to 8 consecutive j of one class with the same i, cut from the top (the row groups of the kernel; its
+        // groups of 4 for two densities are halves of them); the rows of a unit are interleaved segment by segment
+        long long off = 0;
+        for (long long r = (long long)row_ij.size() - 1; r >= 0;) {
+            long long r0 = r;
+            auto sI = [&](long long q) { return H.sigma[row_ij[q].x]; };
+            auto sJ = [&](long long q) { return H.sigma[row_ij[q].y]; };
+            while (r0 > 0 && sI(r0 - 1) == sI(r) && sJ(r0 - 1) == sJ(r0) - 1 && H.clsI[sJ(r0 - 1)] == H.clsI[sJ(r)] && r - r0 + 1 < TF_JKP_JBB) --r0;
+            const int nr = (int)(r - r0 + 1);
+            for (long long q = r0; q <= r; ++q) { rowoff[q] = off; rowsec[6 * q + 4] = (int)(q - r0); rowsec[6 * q + 5] = nr; }
+            off += (long long)nr * rowlen[r0];
+            r = r0 - 1;
         }
         rowoff[row_ij.size()] = off;
         ctx->n_elems = off;
@@ -742,8 +752,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             JKGroup g{};
             g.i = sI(r); g.j0 = sJ(r0); g.nr = (int)(r - r0 + 1); g.r0 = (int)r0;
             g.c = H.clsI[g.i] ^ H.clsI[g.j0]; g.lamj0 = g.j0 - H.cstart[H.clsI[g.j0]];
-            for (int q = 0; q < TF_JKP_JBB; ++q) g.roff[q] = (int)(rowoff[r0 + std::min<long long>(q, r - r0)] - rowoff[r0]);
-            for (int a = 0; a < 4; ++a) g.secoff[a] = rowsec[4 * (size_t)r0 + a];
+            g.ub = rowoff[r0]; g.p0 = rowsec[6 * (size_t)r0 + 4]; g.unr = rowsec[6 * (size_t)r0 + 5];
+            for (int a = 0; a < 4; ++a) g.secoff[a] = rowsec[6 * (size_t)r0 + a];
             groups.push_back(g);
             r = r0 - 1;
         }
@@ -753,12 +763,12 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             if (gfirst[N + a] == gfirst[a]) gfirst[a] = (int)gi;
             gfirst[N + a] = (int)gi + 1;
         }
-        // super-groups: up to TF_JKP_W adjacent groups with the same i and class share a workgroup and one Jt partial.  The kernel's
+        // super-groups: up to 2 TF_JKP_W adjacent groups (two per wave) with the same i and class share a workgroup and one Jt partial.  The kernel's
         // groups index into `groups`, so the super list may be reordered freely: by class, then by descending original i (the Jt
         // reduction needs those that reach an AO k to be a prefix of their class's list)
         for (size_t gi = 0; gi < groups.size();) {
             size_t ge = gi + 1;
-            while (ge < groups.size() && groups[ge].i == groups[gi].i && groups[ge].c == groups[gi].c && ge - gi < TF_JKP_W) ++ge;
+            while (ge < groups.size() && groups[ge].i == groups[gi].i && groups[ge].c == groups[gi].c && ge - gi < 2 * TF_JKP_W) ++ge;
             JKSuper sg{};
             sg.g0 = (int)gi; sg.ng = (int)(ge - gi); sg.c = groups[gi].c; sg.i = groups[gi].i;
             for (int a = 0; a < 4; ++a) sg.ke[a] = H.ke(a, sg.i);
@@ -1293,8 +1303,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                     OutRowP o{};
                     o.i = i; o.j = j; o.iI = H.sigma[i]; o.lamj = H.loc[j]; o.c = H.cls[i] ^ H.cls[j]; o.ncb = b.ncomp;
                     o.cartA = a.cart_off; o.cartB = b.cart_off;
-                    for (int t = 0; t < 4; ++t) o.secoff[t] = rowsec[4 * (size_t)lr + t];
-                    o.len = rowlen[lr]; o.slab_off = rows_c; o.dst_off = rowoff[lr];
+                    for (int t = 0; t < 4; ++t) o.secoff[t] = rowsec[6 * (size_t)lr + t];
+                    o.len = rowlen[lr]; o.slab_off = rows_c; o.ubase = rowoff[lr]; o.upos = rowsec[6 * (size_t)lr + 4]; o.unr = rowsec[6 * (size_t)lr + 5];
                     outsP.push_back(o);
                 }
             if (packed && !per_class)
@@ -1537,8 +1547,8 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
                 ctx->prof_used += 2;
             }
         }
-        hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)T.n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, ctx->d_rowoff, T.d_groups,
-                           T.d_supers, T.d_tasks, L, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+        hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)T.n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, T.d_groups,
+                           T.d_supers, T.d_tasks, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
     JKReduce R{};

@@ -14,6 +14,10 @@
 //     zeros (in the segment of k == i the slots beyond l == j hold zeros too).  The segments of a row are ordered by
 //     (class of k, k): four sections, so that a task -- one class of k against one class of l -- streams contiguous memory.
 //     All rows with the same (i, c) have the same shape.  ~N^4 / 4 bytes (+ padding) instead of the reference's 8 N^4.
+//   * rows are stored in UNITS of up to 8 rows (i; j0..j0+nr-1) -- consecutive j of one class, the row groups of the kernel -- with
+//     their segments interleaved: unit base + nr (secoff[a] + offA[k]) + p padcnt(k) + loc(l) for the row at position p.  What a
+//     wave reads in one step (the segment of k of its 8 rows) is then ONE contiguous run of memory (DRAM pages are opened for
+//     ~3 KB instead of ~400 bytes per row).
 //   * pair index of (k >= l), class c: cbase[c] + fullsec[c][class(k)] + offA[c][sigma(k)] + loc(l) -- the shape of a complete
 //     row; the packed density Pp and the transposed-Coulomb partials use it.
 //
@@ -35,8 +39,11 @@
 #include "tf_layout.hip.h"
 
 #define TF_JKP_JBB 8
-#define TF_JKP_CW 128            // columns per chunk (2 per lane)
+#define TF_JKP_CW 64             // columns per chunk (2 per lane of a half wave)
 #define TF_JKP_SEG 16            // segments of the super-group lists in the Jt reduction
+#ifndef TF_JKP_STAGES
+#define TF_JKP_STAGES 2           // register buffers of the load ring: the loads of STAGES - 1 steps are in flight (2 or 4)
+#endif
 
 
 // Weight proxy of the shard plan (tf_shard_plan_pairs works from shell dimensions alone): the row lengths of the unblocked
@@ -54,13 +61,14 @@ __host__ __device__ inline long long packed_row_len(long long i, long long j) { 
 struct JKGroup {
     int i, j0, nr, r0;           // rows r0..r0+nr-1 (local numbering) = pairs (i, j0..j0+nr-1), internal indices
     int c, lamj0;                // class of the rows; loc of j0
-    int roff[TF_JKP_JBB];        // start of row r relative to row 0, in doubles
-    int secoff[4];               // start of section a inside the rows of this group
+    int unr, p0;                 // rows of the storage unit that holds the group; position of the group's first row in it
+    long long ub;                // base of the unit in the tensor
+    int secoff[4];               // start of section a inside a row of this group
 };
-#define TF_JKP_W 4                // groups (waves) per workgroup: their Jt partials are merged in LDS before they are written
+#define TF_JKP_W 4                // waves per workgroup, two groups each: their Jt partials are merged in LDS before they are written
 #define TF_JKP_KB 4               // k steps per merge block
 static_assert(TF_JKP_KB <= TF_JKP_W, "one wave per merged row");
-// up to TF_JKP_W adjacent groups with the same i and class share one Jt partial (complete-row shape: NP[c] doubles at yoff)
+// up to 2 TF_JKP_W adjacent groups with the same i and class share one Jt partial (complete-row shape: NP[c] doubles at yoff)
 struct JKSuper { int g0, ng, c, i; long long yoff; int ke[4]; };   // ke[a] = cntA[a][i]: the rows reach the members kappa < ke[a] of class a
 struct JKTask { int super, w; };
 
@@ -171,26 +179,77 @@ __global__ void pack_density_kernel(const double *__restrict__ P, BLayout L, int
 // The kernel handles ND = 1 or 2 densities per pass.  Its eight "virtual rows" v = d * RB + r are RB = 8 / ND tensor rows times
 // ND densities: the loads of a tensor row are shared by the densities, all per-row state is indexed by v.  Arrays of the second
 // density follow those of the first at the strides given in JKWave.
+//
+// A wave works on TWO row groups at once: lanes 0-31 (half 0) on group 2w, lanes 32-63 (half 1) on group 2w + 1 of the super-group,
+// both on the same 64 columns (2 per lane) and the same AO k.  The segments of this layout are short (a triangle of classes: on
+// average half a class long), so 64-column chunks with 16 rows per wave keep far more lanes busy than 128 columns x 8 rows did
+// (N = 400: 1.66 instead of 2.60 million wave steps per build).  Everything that depends on the half lives in VGPRs.
+
+// 32-lane versions of the wave sums: the two halves of a wave reduce independently
+__device__ __forceinline__ double pair_step4(double a, double b)       // lanes with bit 2 clear: a[l] + a[l + 4]; set: b[l - 4] + b[l]
+{
+    double recv = dpp_merge<0x12C, 0x5>(a, a);                          // row_ror:12: banks 0,2 <- a[lane + 4]
+    recv = dpp_merge<0x124, 0xA>(recv, b);                              // row_ror:4:  banks 1,3 <- b[lane - 4]
+    const double keep = dpp_merge<TF_DPP_QUAD_IDENT, 0xA>(a, b);        // banks 1,3 keep b
+    return keep + recv;
+}
+__device__ __forceinline__ double quad_sum(double t)
+{
+    t += dpp_merge<TF_DPP_QUAD_XOR1, 0xF>(t, t);
+    t += dpp_merge<TF_DPP_QUAD_XOR2, 0xF>(t, t);
+    return t;
+}
+// eight per-lane values -> lane q of a half holds that half's total of value (q >> 2) & 7
+__device__ __forceinline__ double half_sum8(const double (&v)[8])
+{
+    const double w0 = pair_step16(v[0], v[4]), w1 = pair_step16(v[1], v[5]), w2 = pair_step16(v[2], v[6]), w3 = pair_step16(v[3], v[7]);
+    const double u0 = pair_step8(w0, w2), u1 = pair_step8(w1, w3);
+    return quad_sum(pair_step4(u0, u1));
+}
+__device__ __forceinline__ double half_sum1(double t)                   // every lane gets the total of its half
+{
+    t = pair_step16(t, t);
+    t += dpp_merge<TF_DPP_ROR8, 0xF>(t, t);
+    return sum8(t);
+}
+
+#define TF_BUF_OOB 0x80000000u       // lane offset beyond num_records (0x7fffffff) of buf_rsrc: loads return 0, stores are dropped
+template <int AUX>
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, unsigned uniform_off, double v)
+{
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v), rs, (int)lane_off, (int)uniform_off, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ double buf_load1(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, unsigned uniform_off)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_off, (int)uniform_off, AUX));
+}
 
 // Wave-uniform description of a task (lives in SGPRs).
 struct JKWave {
-    const double *T0, *X, *Pp;           // section a of the group's first row; densities [ND][N][N] (internal); packed densities (class
+    const double *Tb, *X, *Pp;           // section a of the unit of half 0; densities [ND][N][N] (internal); packed densities (class
                                          // base + section a) [ND][NPtot]
     const KInfo *kinfo;                  // kinfo[c] + cstart[a]: indexed by kappa
     long long NPtot;
-    int N, i, j0, nr, lamj0;             // internal indices of the rows; loc of j0
+    int N, i;                            // AOs; internal first index of the rows
     int kI0, c0, lam0, width, cm;        // first internal AO of the k class; first internal column, its loc, columns of the chunk;
                                          // cm = 1 when k and l are of the same class (the pair (k,k) exists)
-    unsigned roff8[TF_JKP_JBB];          // byte offset of row r from row 0
-    double *yg, *DIr_w, *DJr_w;          // density d: + d * ystride / dstrideI / dstrideJ
+    int unr0, p00, dub, dunr, dp0, sec;  // storage unit of half 0 (rows, position of its group) and half 1 minus half 0 (unit base in
+                                         // doubles, rows, position); sec = start of section a in a row
+    int rp;                              // row parts of this chunk inside a row part vector
+    double *yg, *DIr, *DJr;              // Jt partial; row parts of the workgroup's first group / row (density d: + d * ystride / dstrideI / dstrideJ)
     size_t RS, ystride, dstrideI, dstrideJ;
-    double ppij[TF_JKP_JBB];             // Pp_d[(i, j_r)] by virtual row
 };
 
-// Per-lane state: the two columns of the lane (loc lam, lam + 1 of class b; internal index lI, lI + 1)
+// Per-lane state: the half and its group, the two columns of the lane (loc lam, lam + 1 of class b; internal index lI, lI + 1)
 template <int ND>
 struct JKLane {
-    int lam, lI;
+    int h, q, lam, lI;
+    int nr, lamj0, r0, g;                // rows of this half's group (0: none), loc of its first j, its first local row, its index
+    unsigned xrow;                       // byte offset of X[j0][0]
+    unsigned djoff, dioff;               // byte offsets of the group's row parts of this chunk from U.DJr / U.DIr
+    double ppij[TF_JKP_JBB];             // Pp_d[(i, j_r)] by virtual row
     double2 pil[ND], pjl[TF_JKP_JBB];    // P_d[i][l];  P_d[j_r][l] by virtual row
     double2 colI[ND], colJ[TF_JKP_JBB];  // D_d[i][l], D_d[j_r][l] accumulators
 };
@@ -202,27 +261,32 @@ template <int ND>
 struct JKLoad { double2 m[TF_JKP_JBB / ND], pp[ND]; int cnt; };
 
 // MODE FULL: every lane has l < k (no masks); DIAG: a pair is present iff lam < cnt (the slot after an odd count reads 0).
-// ALLR: the group has all RB rows.
+// ALLR: both halves have a group with all RB rows.
 template <int ND, bool ALLR, int MODE>
-__device__ __forceinline__ void jkp_load(JKLoad<ND> &L, int lam, int lane, const JKWave &U, int kap)
+__device__ __forceinline__ void jkp_load(JKLoad<ND> &L, const JKLane<ND> &C, const JKWave &U, int kap)
 {
     constexpr int RB = TF_JKP_JBB / ND;
     const KInfo ki = U.kinfo[kap];
-    const long long bk = (long long)ki.offA + U.lam0;
+    const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);          // padded segment: the rows of a unit follow each other at this stride
     L.cnt = ki.cnt;
-    const bool v = (MODE == JKP_FULL) || lam < ki.cnt;
-    const __amdgpu_buffer_rsrc_t rt = buf_rsrc(U.T0 + bk);
-    const double2 zero = make_double2(0.0, 0.0);
+    const bool v = (MODE == JKP_FULL) || C.lam < ki.cnt;
+    const __amdgpu_buffer_rsrc_t rt = buf_rsrc(U.Tb + (long long)U.unr0 * ki.offA + (long long)U.p00 * pc + U.lam0);
+    const unsigned d1 = 8u * (unsigned)(U.dub + U.dunr * (U.sec + ki.offA) + U.dp0 * pc);   // half 1's unit relative to half 0's
+    // No branches around the loads (one basic block per step lets the compiler count the loads in flight exactly; with a branch per
+    // load it waits for ALL of them at every step and nothing is prefetched): a lane without a value loads from an offset beyond the
+    // descriptor's range, which the buffer unit answers with zeros without touching memory.
+    const unsigned voff = v ? 16u * (unsigned)C.q + (C.h ? d1 : 0u) : TF_BUF_OOB;
 #pragma unroll
-    for (int r = 0; r < RB; ++r) L.m[r] = (v && (ALLR || r < U.nr)) ? buf_load2<2>(rt, 16u * (unsigned)lane, U.roff8[r]) : zero;
+    for (int r = 0; r < RB; ++r) L.m[r] = buf_load2<2>(rt, (ALLR || r < C.nr) ? voff : TF_BUF_OOB, 8u * (unsigned)(r * pc));
+    const long long bk = (long long)ki.offA + U.lam0;
 #pragma unroll
-    for (int d = 0; d < ND; ++d) L.pp[d] = v ? buf_load2<0>(buf_rsrc(U.Pp + d * U.NPtot + bk), 16u * (unsigned)lane, 0u) : zero;
+    for (int d = 0; d < ND; ++d) L.pp[d] = buf_load2<0>(buf_rsrc(U.Pp + d * U.NPtot + bk), v ? 16u * (unsigned)C.q : TF_BUF_OOB, 0u);
 }
 
-// part 1: everything that needs only the lane's own P values (Jd, Jt, the row sums); part 2: the column sums, which need the
-// wave-uniform P[j_r][k], P[i][k] -- fetched through the scalar unit while part 1 runs.
+// part 1: everything that needs only the lane's own P values (Jd, Jt, the row sums); part 2: the column sums, which need
+// P[j_r][k] (per half: a broadcast vector load issued before part 1) and the wave-uniform P[i][k] (scalar unit).
 template <int ND>
-__device__ __forceinline__ void jkp_row1(const JKLane<ND> &C, const JKLoad<ND> &L, const JKWave &U, double (&jd)[TF_JKP_JBB],
+__device__ __forceinline__ void jkp_row1(const JKLane<ND> &C, const JKLoad<ND> &L, double (&jd)[TF_JKP_JBB],
                                          double (&rJ)[TF_JKP_JBB], double (&rI)[ND], double2 (&jt)[ND])
 {
     constexpr int RB = TF_JKP_JBB / ND;
@@ -235,7 +299,7 @@ __device__ __forceinline__ void jkp_row1(const JKLane<ND> &C, const JKLoad<ND> &
             const int v = d * RB + r;
             const double2 m = L.m[r];
             jd[v] += m.x * L.pp[d].x + m.y * L.pp[d].y;
-            jt[d].x += m.x * U.ppij[v]; jt[d].y += m.y * U.ppij[v];
+            jt[d].x += m.x * C.ppij[v]; jt[d].y += m.y * C.ppij[v];
             const double2 pj = C.pjl[v];
             rI[d] += m.x * pj.x + m.y * pj.y;
             rJ[v] = m.x * C.pil[d].x + m.y * C.pil[d].y;
@@ -261,6 +325,21 @@ __device__ __forceinline__ void jkp_row2(JKLane<ND> &C, const JKLoad<ND> &L, con
     }
 }
 
+// P_d[j_r][k] of the lane's half (one 8-byte broadcast load per virtual row) and the wave-uniform P_d[i][k]
+template <int ND, bool ALLR>
+__device__ __forceinline__ void jkp_p_k(const JKLane<ND> &C, const JKWave &U, int kI, double (&pjk)[TF_JKP_JBB], double (&pik)[ND])
+{
+    constexpr int RB = TF_JKP_JBB / ND;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const double *Pd = U.X + (size_t)d * U.N * U.N;
+        const __amdgpu_buffer_rsrc_t rx = buf_rsrc(Pd);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) pjk[d * RB + r] = buf_load1<0>(rx, (ALLR || r < C.nr) ? C.xrow : TF_BUF_OOB, 8u * (unsigned)(r * U.N + kI));
+        pik[d] = Pd[(size_t)U.i * U.N + kI];
+    }
+}
+
 // The segment of k == i (tasks whose k class is that of i): row r ends at l == j_r, where the element (ij|ij) counts half in K
 // and not at all in Jt.
 template <int ND>
@@ -268,8 +347,12 @@ __device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const d
                                          double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double (&rI)[ND], double2 (&jt2)[ND])
 {
     constexpr int RB = TF_JKP_JBB / ND;
-    const int i = U.i, lamlast = U.lamj0 + U.nr - 1;
-    const long long bk = U.kinfo[i - U.kI0].offA;
+    const int i = U.i, lamlast = C.lamj0 + C.nr - 1;
+    const KInfo kiL = U.kinfo[i - U.kI0];
+    const long long bk = kiL.offA;
+    const int pc = (kiL.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);
+    const long long d1 = (long long)U.dub + (long long)U.dunr * (U.sec + kiL.offA) + (long long)U.dp0 * pc;
+    const double *Tk = U.Tb + (long long)U.unr0 * kiL.offA + (long long)U.p00 * pc + (C.h ? d1 : 0);   // segment of k == i, first row of the lane's group
 #pragma unroll
     for (int d = 0; d < ND; ++d) { rI[d] = 0.0; jt2[d] = make_double2(0.0, 0.0); }
 #pragma unroll
@@ -280,7 +363,7 @@ __device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const d
         const bool valid = lam <= lamlast;
         double mrow[RB];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) mrow[r] = (r < U.nr && lam <= U.lamj0 + r) ? ld_stream(U.T0 + (U.roff8[r] >> 3) + bk + lam) : 0.0;
+        for (int r = 0; r < RB; ++r) mrow[r] = (r < C.nr && lam <= C.lamj0 + r) ? ld_stream(Tk + r * pc + lam) : 0.0;
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const double pp = valid ? U.Pp[d * U.NPtot + bk + lam] : 0.0;
@@ -290,9 +373,9 @@ __device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const d
             for (int r = 0; r < RB; ++r) {
                 const int v = d * RB + r;
                 const double mr = mrow[r];
-                const bool diag = (lam == U.lamj0 + r);
+                const bool diag = (lam == C.lamj0 + r);
                 jd[v] += mr * pp;
-                jt += diag ? 0.0 : mr * U.ppij[v];
+                jt += diag ? 0.0 : mr * C.ppij[v];
                 const double mk = diag ? 0.5 * mr : mr;
                 rI[d] += mk * (e ? C.pjl[v].y : C.pjl[v].x);
                 rJ[v] += mk * pil;
@@ -306,95 +389,96 @@ __device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const d
 }
 
 template <int ND, bool ALLR>
-__device__ __forceinline__ void jkp_row_sums(const JKWave &U, int kap, int lane, double (&rJ)[TF_JKP_JBB], const double (&rI)[ND])
+__device__ __forceinline__ void jkp_row_sums(const JKLane<ND> &C, const JKWave &U, int kap, double (&rJ)[TF_JKP_JBB], const double (&rI)[ND])
 {
     constexpr int RB = TF_JKP_JBB / ND;
-    const double tJ = wave_sum8(rJ);
-    const int v = lane >> 3, d = v / RB, r = v - d * RB;
-    if ((lane & 7) == 0 && (ALLR || r < U.nr)) U.DJr_w[d * U.dstrideJ + (size_t)r * U.RS + kap] = tJ;
+    const double tJ = half_sum8(rJ);
+    const int v = (C.q >> 2) & 7, d = v / RB, r = v - d * RB;
+    // (stores without branches as well: lanes that have nothing to store use an out-of-range offset)
+    buf_store1<0>(buf_rsrc(U.DJr + kap), ((C.q & 3) == 0 && r < C.nr) ? C.djoff + 8u * (unsigned)(d * U.dstrideJ + (size_t)r * U.RS) : TF_BUF_OOB, 0u, tJ);
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) {
-        const double tI = wave_sum1(rI[dd]);
-        if (lane == 0) U.DIr_w[dd * U.dstrideI + kap] = tI;
+        const double tI = half_sum1(rI[dd]);
+        buf_store1<0>(buf_rsrc(U.DIr + dd * U.dstrideI + kap), (C.q == 0 && C.nr > 0) ? C.dioff : TF_BUF_OOB, 0u, tI);
     }
 }
 
+// workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() also drains the vector memory loads in flight)
+__device__ __forceinline__ void jkp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Jt of the steps kb..kb+KB-1: the waves of the workgroup have left their partials in slots[kk][wave][d][lane]; wave w adds up
-// step kb + w and writes it (fixed order: bitwise reproducible).  Two barriers per block.
+// step kb + w over the waves and the two halves and writes it (fixed order: bitwise reproducible).  Two barriers per block.
 template <int ND, int MODE>
-__device__ __forceinline__ void jkp_merge_jt(const JKWave &U, double2 *slots, int ng, int w, int lane, int lam, int kb, int k1)
+__device__ __forceinline__ void jkp_merge_jt(const JKWave &U, double2 *slots, int nw, int w, int lane, int kb, int k1)
 {
-    __syncthreads();
+    jkp_lds_barrier();
     const int kap = kb + w;
     if (w < TF_JKP_KB && kap < k1) {
         const KInfo ki = U.kinfo[kap];
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             double2 t = slots[((w * TF_JKP_W) * ND + d) * 64 + lane];
-            for (int u = 1; u < ng; ++u) { const double2 x = slots[((w * TF_JKP_W + u) * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
-            if (MODE == JKP_FULL || lam < ki.cnt)
+            for (int u = 1; u < nw; ++u) { const double2 x = slots[((w * TF_JKP_W + u) * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
+            t.x = pair_step32(t.x, t.x); t.y = pair_step32(t.y, t.y);           // half 0 + half 1 (the same columns)
+            if (lane < 32 && (MODE == JKP_FULL || U.lam0 + 2 * lane < ki.cnt))
                 buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), 16u * (unsigned)lane, 0u, t);
         }
     }
-    __syncthreads();
+    jkp_lds_barrier();
 }
 
-template <int ND, bool ALLR>
-__device__ __forceinline__ void jkp_uniform_p(const JKWave &U, int kI, double (&pjk)[TF_JKP_JBB], double (&pik)[ND])
-{
-    constexpr int RB = TF_JKP_JBB / ND;
-#pragma unroll
-    for (int d = 0; d < ND; ++d) {
-        const double *Pd = U.X + (size_t)d * U.N * U.N;
-#pragma unroll
-        for (int r = 0; r < RB; ++r) pjk[d * RB + r] = (ALLR || r < U.nr) ? Pd[(size_t)(U.j0 + r) * U.N + kI] : 0.0;
-        pik[d] = Pd[(size_t)U.i * U.N + kI];
-    }
-}
+// Steps k0 <= kappa < k1 of a task in one mode.  The kernel is bound by memory latency, not by arithmetic: what counts is the number
+// of bytes a SIMD has in flight.  The loads of the next step are issued before a step is consumed, every step is ONE basic block
+// (no branch around a load or a store: see jkp_load), and the barriers of the Jt merge wait for LDS traffic only -- __syncthreads()
+// would drain the prefetched loads as well.  Every wave of the workgroup runs the same range (idle waves included): the barriers
+// must match.
 
-// Steps k0 <= kappa < k1 of a task in one mode.  The loads of step kappa + 1 are issued before step kappa is consumed, so a wave
-// always has a full row of requests in flight; the wave-uniform P[j_r][k], P[i][k] come through the scalar unit while part 1 runs.
-// Every wave of the workgroup runs the same range (idle waves included): the barriers of the Jt merge must match.
 template <int ND, bool ALLR, int MODE>
 __device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane<ND> &C, double (&jd)[TF_JKP_JBB], int k0, int k1, int lane, bool active,
-                                            double2 *slots, int ng, int w)
+                                            double2 *slots, int nw, int w)
 {
-    constexpr int JBB = TF_JKP_JBB;
+    constexpr int JBB = TF_JKP_JBB, S = TF_JKP_STAGES;
+    static_assert(TF_JKP_KB % S == 0, "the ring position of a step must be a compile-time constant");
     if (k0 >= k1) return;
-    JKLoad<ND> L, Nx;
-    if (active) jkp_load<ND, ALLR, MODE>(L, C.lam, lane, U, k0);
+    // ring of S register buffers: step kk of a merge block uses R[kk % S] and issues the loads of step kk + S - 1 into R[(kk + S - 1) % S].
+    // (A plain "L = Nx" copy at the end of a step would make every step wait for the loads it has just issued.)
+    JKLoad<ND> R[S];
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s) jkp_load<ND, ALLR, MODE>(R[s], C, U, min(k0 + s, k1 - 1));
+    }
     for (int kb = k0; kb < k1; kb += TF_JKP_KB) {
         if (active) {
-            const int ke = min(kb + TF_JKP_KB, k1);
-            for (int k = kb; k < ke; ++k) {
-                jkp_load<ND, ALLR, MODE>(Nx, C.lam, lane, U, min(k + 1, k1 - 1));
-                double pjk[JBB], pik[ND], rJ[JBB], rI[ND];
-                double2 jt[ND];
-                jkp_uniform_p<ND, ALLR>(U, U.kI0 + k, pjk, pik);
-                jkp_row1<ND>(C, L, U, jd, rJ, rI, jt);
 #pragma unroll
-                for (int d = 0; d < ND; ++d) slots[(((k - kb) * TF_JKP_W + w) * ND + d) * 64 + lane] = jt[d];
-                jkp_row_sums<ND, ALLR>(U, k, lane, rJ, rI);
-                jkp_row2<ND, MODE>(C, L, U, pjk, pik);
-                L = Nx;
+            for (int kk = 0; kk < TF_JKP_KB; ++kk) {
+                const int k = kb + kk;
+                if (k < k1) {
+                    double pjk[JBB], pik[ND], rJ[JBB], rI[ND];
+                    double2 jt[ND];
+                    // P[j_r][k] first: vector memory operations complete in order, and part 2 must not wait for the prefetched tensor loads
+                    jkp_p_k<ND, ALLR>(C, U, U.kI0 + k, pjk, pik);
+                    jkp_load<ND, ALLR, MODE>(R[(kk + S - 1) % S], C, U, min(k + S - 1, k1 - 1));
+                    jkp_row1<ND>(C, R[kk % S], jd, rJ, rI, jt);
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) slots[((kk * TF_JKP_W + w) * ND + d) * 64 + lane] = jt[d];
+                    jkp_row_sums<ND, ALLR>(C, U, k, rJ, rI);
+                    jkp_row2<ND, MODE>(C, R[kk % S], U, pjk, pik);
+                }
             }
         }
-        jkp_merge_jt<ND, MODE>(U, slots, ng, w, lane, C.lam, kb, k1);
+        jkp_merge_jt<ND, MODE>(U, slots, nw, w, lane, kb, k1);
     }
 }
 
 // kap0 <= kappa < kd1: masked steps; kd1 <= kappa < klim: unmasked; then (last) the segment of k == i.
 template <int ND, bool ALLR>
-__device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int wchunk, int lane, int group, int r0, bool active, double2 *slots, int ng,
+__device__ __forceinline__ void jkp_task(const JKWave &U, JKLane<ND> &C, int NW, int wchunk, int lane, bool active, double2 *slots, int nw,
                                          int w, int kap0, int kd1, int klim, bool last, double *__restrict__ Jd, size_t strideJd,
                                          double *__restrict__ DIc, size_t strideDIc, double *__restrict__ DJc, size_t strideDJc)
 {
     constexpr int JBB = TF_JKP_JBB, RB = JBB / ND;
     const int N = U.N, i = U.i;
-    JKLane<ND> C;
-    C.lam = U.lam0 + 2 * lane;
-    C.lI = U.c0 + 2 * lane;
-    const bool in0 = 2 * lane < U.width, in1 = 2 * lane + 1 < U.width;
+    const bool in0 = 2 * C.q < U.width, in1 = 2 * C.q + 1 < U.width;
     {
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
@@ -404,8 +488,8 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int wchunk, in
             C.colI[d] = make_double2(0.0, 0.0);
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const bool have = ALLR || r < U.nr;
-                const double *Pj = Pd + (size_t)(U.j0 + r) * N;
+                const bool have = r < C.nr;
+                const double *Pj = Pd + (C.xrow >> 3) + (size_t)r * N;
                 C.pjl[d * RB + r] = make_double2((in0 && have) ? Pj[C.lI] : 0.0, (in1 && have) ? Pj[C.lI + 1] : 0.0);
                 C.colJ[d * RB + r] = make_double2(0.0, 0.0);
             }
@@ -415,17 +499,17 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int wchunk, in
 #pragma unroll
     for (int v = 0; v < JBB; ++v) jd[v] = 0.0;
 
-    jkp_segment<ND, ALLR, JKP_DIAG>(U, C, jd, kap0, kd1, lane, active, slots, ng, w);
-    jkp_segment<ND, ALLR, JKP_FULL>(U, C, jd, kd1, klim, lane, active, slots, ng, w);
+    jkp_segment<ND, ALLR, JKP_DIAG>(U, C, jd, kap0, kd1, lane, active, slots, nw, w);
+    jkp_segment<ND, ALLR, JKP_FULL>(U, C, jd, kd1, klim, lane, active, slots, nw, w);
     if (last) {   // k == i: the rows end at different columns
         double2 jt[ND];
 #pragma unroll
         for (int d = 0; d < ND; ++d) jt[d] = make_double2(0.0, 0.0);
         if (active) {
             double pjk[JBB], pik[ND], rJ[JBB], rI[ND];
-            jkp_uniform_p<ND, ALLR>(U, i, pjk, pik);
+            jkp_p_k<ND, false>(C, U, i, pjk, pik);
             jkp_last<ND>(C, U, pjk, pik, jd, rJ, rI, jt);
-            jkp_row_sums<ND, ALLR>(U, i - U.kI0, lane, rJ, rI);
+            jkp_row_sums<ND, ALLR>(C, U, i - U.kI0, rJ, rI);
         }
 #pragma unroll
         for (int d = 0; d < ND; ++d) slots[(w * ND + d) * 64 + lane] = jt[d];
@@ -435,44 +519,48 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, int NW, int wchunk, in
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 double2 t = slots[d * 64 + lane];
-                for (int u = 1; u < ng; ++u) { const double2 x = slots[(u * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
-                if (C.lam < ki.cnt) buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), 16u * (unsigned)lane, 0u, t);
+                for (int u = 1; u < nw; ++u) { const double2 x = slots[(u * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
+                t.x = pair_step32(t.x, t.x); t.y = pair_step32(t.y, t.y);
+                if (lane < 32 && U.lam0 + 2 * lane < ki.cnt) buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), 16u * (unsigned)lane, 0u, t);
             }
         }
     }
     if (!active) return;
-    // column parts (every column of the chunk belongs to this task alone)
+    // column parts (every column of the chunk belongs to this task alone), per half: each half has its own group
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        if (e ? in1 : in0) {
+        if ((e ? in1 : in0) && C.nr > 0) {
             const int l = C.lI + e;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
-                DIc[d * strideDIc + (size_t)group * N + l] = e ? C.colI[d].y : C.colI[d].x;
+                DIc[d * strideDIc + (size_t)C.g * N + l] = e ? C.colI[d].y : C.colI[d].x;
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
-                    if (ALLR || r < U.nr) DJc[d * strideDJc + (size_t)(r0 + r) * N + l] = e ? C.colJ[d * RB + r].y : C.colJ[d * RB + r].x;
+                    if (r < C.nr) DJc[d * strideDJc + (size_t)(C.r0 + r) * N + l] = e ? C.colJ[d * RB + r].y : C.colJ[d * RB + r].x;
             }
         }
     }
     {
-        const double t = wave_sum8(jd);
-        const int v = lane >> 3, d = v / RB, r = v - d * RB;
-        if ((lane & 7) == 0 && (ALLR || r < U.nr)) Jd[d * strideJd + (size_t)(r0 + r) * NW + wchunk] = t;
+        const double t = half_sum8(jd);
+        const int v = (C.q >> 2) & 7, d = v / RB, r = v - d * RB;
+        if ((C.q & 3) == 0 && r < C.nr) Jd[d * strideJd + (size_t)(C.r0 + r) * NW + wchunk] = t;
     }
 }
 
 // Strides (in doubles) between the arrays of density 0 and density 1 of a two-density pass
 struct JKStrides { size_t P, Pp, y, Jd, DIc, DIr, DJc, DJr; };
 
-// One workgroup per task (super-group, chunk): wave w owns group g0 + w (idle if the super-group has fewer).  Only tasks with at
-// least one step exist (kap0[c][w] < cntA[a][i]).  ND densities per pass: groups of 8 / ND rows.
+// One workgroup per task (super-group, chunk): wave w owns the groups g0 + 2w (half 0) and g0 + 2w + 1 (half 1), idle if the
+// super-group has fewer.  Only tasks with at least one step exist (kap0[c][w] < cntA[a][i]).  ND densities per pass: groups of
+// 8 / ND rows.
 // Outputs: Jd [n_rows][NW] per-task partials; ypart: Jt partials per super-group; DIc [G][N], DJc [n_rows][N]: column parts
 // (l-indexed); DIr [G][RS], DJr [n_rows][RS]: row parts per task (k-indexed: entry rpoff[c][w] + kappa, written for every step).
 template <int ND>
-__global__ __launch_bounds__(64 * TF_JKP_W) void jk_packed_kernel(const double *__restrict__ T, const long long *__restrict__ rowoff,
-                                                                  const JKGroup *__restrict__ groups, const JKSuper *__restrict__ supers,
+__global__ __launch_bounds__(64 * TF_JKP_W, TF_JKP_STAGES > 2 ? 1 : 2) void jk_packed_kernel(const double *__restrict__ T, const JKGroup *__restrict__ groups,
+                                                                  const JKSuper *__restrict__ supers,
                                                                   const JKTask *__restrict__ tasks, BLayout L,
+                                                                  const KInfo *__restrict__ kinfo /* = L.kinfo: a __restrict__ kernel
+                                                                  argument is read through the scalar unit, a pointer inside L is not */,
                                                                   const double *__restrict__ X, const double *__restrict__ Pp,
                                                                   double *__restrict__ Jd, double *__restrict__ ypart,
                                                                   double *__restrict__ DIc, double *__restrict__ DIr,
@@ -483,42 +571,66 @@ __global__ __launch_bounds__(64 * TF_JKP_W) void jk_packed_kernel(const double *
     const JKTask t = tasks[blockIdx.x];
     const JKSuper sg = supers[t.super];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const bool active = w < sg.ng;
-    const int gi = sg.g0 + (active ? w : 0);
-    const JKGroup g = groups[gi];
+    const int nw = (sg.ng + 1) >> 1;                                   // waves with at least one group
+    const bool active = w < nw;
+    const int ga = sg.g0 + (active ? 2 * w : 0);
+    const bool hasB = active && 2 * w + 1 < sg.ng;
+    // half 0 takes the group that lies lower in memory (the lane offsets of half 1 are unsigned): a lower unit, or -- two-density
+    // passes, whose groups of 4 are halves of one storage unit -- the lower position in the unit
+    int ia = ga, ib = hasB ? ga + 1 : ga;
+    {
+        const long long ua = groups[ia].ub, ub = groups[ib].ub;
+        if (ub < ua || (ub == ua && groups[ib].p0 < groups[ia].p0)) { const int tswap = ia; ia = ib; ib = tswap; }
+        ia = __builtin_amdgcn_readfirstlane(ia); ib = __builtin_amdgcn_readfirstlane(ib);   // (wave-uniform: keeps the group records in SGPRs)
+    }
+    const JKGroup gA = groups[ia], gB = groups[ib];
     const int N = L.N, NW = L.NW, c = sg.c;
     const int b = L.chunk_cls[t.w], a = b ^ c;
     JKWave U;
-    U.N = N; U.i = g.i; U.j0 = g.j0; U.nr = g.nr; U.lamj0 = g.lamj0;
+    U.N = N; U.i = __builtin_amdgcn_readfirstlane(gA.i);
     U.kI0 = bl_cstart(L, a); U.c0 = L.chunk_c0[t.w]; U.lam0 = U.c0 - bl_cstart(L, b); U.width = L.chunk_width[t.w]; U.cm = (c == 0) ? 1 : 0;
-    U.T0 = T + rowoff[g.r0] + groups[gi].secoff[a]; U.X = X; U.NPtot = (long long)S.Pp;   // (table reads from memory: a is a run-time index)
+    U.sec = groups[ia].secoff[a];                                       // (table read from memory: a is a run-time index)
+    U.unr0 = gA.unr; U.p00 = gA.p0;
+    U.dub = (int)(gB.ub - gA.ub); U.dunr = gB.unr - gA.unr; U.dp0 = gB.p0 - gA.p0;
+    U.Tb = T + gA.ub + (long long)gA.unr * U.sec; U.X = X; U.NPtot = (long long)S.Pp;
     const long long pbase = bl_cbase(L, c) + bl_fullsec(L, c, a);
     U.Pp = Pp + pbase;
-    U.kinfo = L.kinfo + (size_t)c * N + U.kI0;
+    U.kinfo = kinfo + (size_t)c * N + U.kI0;
     U.yg = ypart + sg.yoff + bl_fullsec(L, c, a); U.ystride = S.y;
     U.RS = (size_t)L.RS;
-    const int rp = L.rpoff[c * NW + t.w];
-    U.DIr_w = DIr + (size_t)gi * L.RS + rp; U.dstrideI = S.DIr;
-    U.DJr_w = DJr + (size_t)g.r0 * L.RS + rp; U.dstrideJ = S.DJr;
-#pragma unroll
-    for (int r = 0; r < JBB; ++r) U.roff8[r] = 8u * (unsigned)g.roff[r < RB ? r : 0];
+    U.rp = L.rpoff[c * NW + t.w];
+    // row parts: uniform bases at the lower of the two groups / rows, small per-lane offsets
+    const int gmin = min(ia, ib), rmin = min(gA.r0, gB.r0);
+    U.DIr = DIr + (size_t)gmin * L.RS + U.rp; U.dstrideI = S.DIr;
+    U.DJr = DJr + (size_t)rmin * L.RS + U.rp; U.dstrideJ = S.DJr;
+    JKLane<ND> C;
+    C.h = lane >> 5; C.q = lane & 31;
+    C.lam = U.lam0 + 2 * C.q; C.lI = U.c0 + 2 * C.q;
+    const bool mine = C.h ? hasB : active;
+    C.nr = mine ? (C.h ? gB.nr : gA.nr) : 0;
+    C.lamj0 = C.h ? gB.lamj0 : gA.lamj0;
+    C.r0 = C.h ? gB.r0 : gA.r0;
+    C.g = C.h ? ib : ia;
+    C.xrow = 8u * (unsigned)((C.h ? gB.j0 : gA.j0) * N);
+    C.dioff = 8u * (unsigned)((C.g - gmin) * L.RS);
+    C.djoff = 8u * (unsigned)((C.r0 - rmin) * L.RS);
     {
         // Pp[(i, j_r)]: pair index of (i, j_r) -- i is the larger original index of the row
-        const int ci = L.clsI[g.i];
-        const long long pij = bl_cbase(L, c) + bl_fullsec(L, c, ci) + L.kinfo[(size_t)c * N + g.i].offA + g.lamj0;
+        const int ci = L.clsI[gA.i];
+        const long long pij = bl_cbase(L, c) + bl_fullsec(L, c, ci) + kinfo[(size_t)c * N + gA.i].offA + C.lamj0;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int r = 0; r < RB; ++r) U.ppij[d * RB + r] = (r < g.nr) ? Pp[d * S.Pp + pij + r] : 0.0;
+            for (int r = 0; r < RB; ++r) C.ppij[d * RB + r] = (r < C.nr) ? Pp[d * S.Pp + pij + r] : 0.0;
     }
     const int kap0 = L.kap0[c * NW + t.w], ke = supers[t.super].ke[a];
-    const bool last = (a == L.clsI[g.i]);
+    const bool last = (a == L.clsI[gA.i]);
     const int klim = ke - (last ? 1 : 0);
     const int kd1 = min(max(L.kapF[c * NW + t.w], kap0), klim);
-    if (g.nr == RB)
-        jkp_task<ND, true>(U, NW, t.w, lane, gi, g.r0, active, slots, sg.ng, w, kap0, kd1, klim, last, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
+    if (hasB && gA.nr == RB && gB.nr == RB)
+        jkp_task<ND, true>(U, C, NW, t.w, lane, active, slots, nw, w, kap0, kd1, klim, last, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
     else
-        jkp_task<ND, false>(U, NW, t.w, lane, gi, g.r0, active, slots, sg.ng, w, kap0, kd1, klim, last, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
+        jkp_task<ND, false>(U, C, NW, t.w, lane, active, slots, nw, w, kap0, kd1, klim, last, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
 }
 
 // Jt partial sums over the pair index q of class c: the super-groups of a class are sorted by descending original i, so those whose
@@ -659,9 +771,10 @@ struct OutRowP {
     int c, ncb;            // class of the row; components of the second bra shell
     int cartA, cartB;      // first Cartesian AO of the two bra shells
     int secoff[4];         // start of section a in the stored row
-    int len, pad;          // stored doubles of the row
+    int len;               // doubles of the row
+    int unr, upos, pad;    // rows of the row's storage unit, its position in it
     long long slab_off;    // first slab row of this bra pair
-    long long dst_off;     // offset of the row in the stored tensor
+    long long ubase;       // base of the unit in the stored tensor
 };
 
 // tensor row (i,j) = bra transform of the slab rows; pad slots and the slots beyond l == j in the segment of k == i <- 0.
@@ -706,10 +819,12 @@ __global__ __launch_bounds__(256) void xform_bra_store_packed(const double *__re
             s += sValA[qa] * t;
         }
     }
-    eri[R.dst_off + x] = s;
+    const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);
+    eri[R.ubase + (long long)R.unr * (best + ki.offA) + (long long)R.upos * pc + lam] = s;
 }
 
-// (ij|kl) from the stored tensor, original indices; rows owned by another rank read as 0 (sum over ranks = the tensor)
+// (ij|kl) from the stored tensor, original indices; rows owned by another rank read as 0 (sum over ranks = the tensor).
+// rowoff[r]: base of the storage unit of local row r; rowsec[6 r ..]: secoff[4], position in the unit, rows of the unit
 __device__ __forceinline__ double packed_element(const double *__restrict__ eri, const int *__restrict__ rowmap,
                                                  const long long *__restrict__ rowoff, const int *__restrict__ rowsec, const BLayout &L,
                                                  int i, int j, int k, int l)
@@ -726,7 +841,10 @@ __device__ __forceinline__ double packed_element(const double *__restrict__ eri,
     const int r = rowmap[(size_t)h2 * (h2 + 1) / 2 + l2];
     if (r < 0) return 0.0;
     const int a = ao_cls(wc1);
-    return eri[rowoff[r] + rowsec[4 * (size_t)r + a] + L.kinfo[(size_t)c * L.N + ao_sigma(L, wc1)].offA + ao_loc(wc2)];
+    const KInfo ki = L.kinfo[(size_t)c * L.N + ao_sigma(L, wc1)];
+    const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);
+    const int *rs = rowsec + 6 * (size_t)r;                                  // secoff[4], position in the unit, rows of the unit
+    return eri[rowoff[r] + (long long)rs[5] * (rs[a] + ki.offA) + (long long)rs[4] * pc + ao_loc(wc2)];
 }
 
 // packed -> dense N^4 with all images (what the reference leaves in ERI_AO, pyx:1335-1342).
