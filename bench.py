@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+FP64_VECTOR_PEAK_FLOPS = 78.6e12 # MI355X FP64 vector peak (half the 157.3 TFLOP/s FP32 vector figure of MI355X_MICROARCH.md)
 ANCHOR_N2_CCPVTZ = -108.9834703056   # SURVEY.md section 6.2 (reference engine + reference tuna_scf.py, golden/c2)
 
 
@@ -49,19 +50,9 @@ def build_workload(name: str):
     return atoms, shells, mol.expand_cartesian_aos(shells), nocc, desc
 
 
-def cpu_baseline_fock(N_workload: int, budget_s: float = 12.0):
-    """The reference's CPU Fock build -- np.einsum("ijkl,kl->ij") + np.einsum("ilkj,kl->ij"), optimize=True
-    (scf:70, scf:42, restated in oracle/scf_oracle.py) -- timed on a BOUNDED dense sample tensor and scaled by N^4."""
+def _time_fock_einsums(Ns: int, budget_s: float, max_n: int = 200):
+    """seconds per J+K build with the reference's einsum strings on a dense random Ns^4 tensor"""
     from oracle import scf_oracle as so
-    import tuna_amd
-    # BLAS threads = the CPUs this process may use (cgroup quota): more threads than that only spin and get the process throttled
-    threads = tuna_amd.cpu_quota()
-    try:
-        from threadpoolctl import threadpool_limits
-        pool = threadpool_limits(limits=threads)
-    except Exception:
-        pool = None
-    Ns = min(N_workload, 96)
     rng = np.random.default_rng(0)
     T = rng.standard_normal((Ns, Ns, Ns, Ns))
     A = rng.standard_normal((Ns, Ns))
@@ -73,30 +64,69 @@ def cpu_baseline_fock(N_workload: int, budget_s: float = 12.0):
         so.coulomb(P, T)
         so.exchange(P, T)
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 200:
+        if time.perf_counter() - t0 > budget_s or n >= max_n:
             break
-    per_build = (time.perf_counter() - t0) / n
+    return (time.perf_counter() - t0) / n, n
+
+
+def cpu_baseline_fock(N_workload: int, budget_s: float = 9.0):
+    """The reference's CPU Fock build -- np.einsum("ijkl,kl->ij") + np.einsum("ilkj,kl->ij"), optimize=True
+    (scf:70, scf:42, restated in oracle/scf_oracle.py) -- timed on BOUNDED dense sample tensors (96^4 and 144^4: the second size
+    shows how far the N^4 scaling to the workload size holds) with all the CPUs this process may use, and at TUNA's default of 4
+    threads (tuna_calc.py:153)."""
+    import tuna_amd
+    # BLAS threads = the CPUs this process may use (cgroup quota): more threads than that only spin and get the process throttled
+    threads = tuna_amd.cpu_quota()
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    Ns = min(N_workload, 96)
+    Ns2 = min(N_workload, 144)
+    pool = threadpool_limits(limits=threads) if threadpool_limits else None
+    per_build, n = _time_fock_einsums(Ns, budget_s)
+    per_build2, n2 = _time_fock_einsums(Ns2, 0.6 * budget_s, 12) if Ns2 > Ns else (per_build, n)
+    if pool is not None:
+        pool.restore_original_limits()
+    pool = threadpool_limits(limits=min(4, threads)) if threadpool_limits else None
+    per_build4, n4 = _time_fock_einsums(Ns, 0.4 * budget_s, 60)
     if pool is not None:
         pool.restore_original_limits()
         tuna_amd.limit_host_threads()
     scaled = per_build * (N_workload / Ns) ** 4
+    scaled2 = per_build2 * (N_workload / Ns2) ** 4
     return {"value": 1.0 / scaled, "unit": "Fock builds/s", "cores": int(threads), "kind": "port",
             "sample": f"{n} J+K builds with the reference einsum strings on a dense random {Ns}^4 f64 tensor "
                       f"({per_build * 1e3:.1f} ms each), scaled by (N/{Ns})^4 to N = {N_workload}",
-            "seconds_per_build_at_workload_size": scaled}
+            "seconds_per_build_at_workload_size": scaled,
+            "second_sample": {"n": Ns2, "builds": n2, "ms_per_build": per_build2 * 1e3, "scaled_seconds_per_build_at_workload_size": scaled2,
+                              "ratio_to_first_sample": scaled2 / scaled,
+                              "note": "ratio 1 = perfect N^4 scaling between the two sample sizes; above 1 the strided exchange einsum is "
+                                      "losing cache locality, so the N^4 extrapolation from the first sample flatters the CPU"},
+            "tuna_default_4_threads": {"threads": int(min(4, threads)), "builds": n4, "ms_per_build_sample": per_build4 * 1e3,
+                                       "value": 1.0 / (per_build4 * (N_workload / Ns) ** 4), "unit": "Fock builds/s"}}
 
 
 def cpu_baseline_eri(aos, limit_s: float = 20.0):
-    """ERI build on the host for the SCF leg: the compiled reference engine when oracle/_ref is present, else the C port."""
+    """ERI build on the host for the SCF leg: the compiled reference engine when oracle/_ref is present, else the C port -- with all
+    the CPUs of the process and with one thread (the reference's OpenMP loop scales very differently from host to host: in the
+    8-vCPU build container of SURVEY.md section 6.2 N2/cc-pVTZ takes 1.8 s on 1 thread, 0.7 s on 4 and 1.25-1.44 s on 8 -- oversubscribed
+    vCPUs -- while a GPU box's 16 dedicated cores run it in well under 0.1 s)."""
     from oracle import oracle as orc
     if aos.n > 80:
         return None
     kind = "reference" if orc.ref_engine() is not None else "port"
-    t0 = time.perf_counter()
     import tuna_amd
     cores = tuna_amd.cpu_quota()
-    (orc.ref_eri if kind == "reference" else orc.eri)(aos, cores)
-    return {"seconds": time.perf_counter() - t0, "kind": kind, "cores": cores}
+    fn = orc.ref_eri if kind == "reference" else orc.eri
+    fn(aos, cores)                                               # (first call: library load, page faults of the output tensor)
+    t0 = time.perf_counter()
+    fn(aos, cores)
+    t_all = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    fn(aos, 1)
+    t_one = time.perf_counter() - t0
+    return {"seconds": t_all, "kind": kind, "cores": cores, "seconds_1_thread": t_one, "speedup_over_1_thread": t_one / t_all}
 
 
 JK_KERNEL = {"packed": "jk_packed_kernel", "rows": "tfk::jk_rows_kernel"}
@@ -109,13 +139,17 @@ def pmc_traffic(workload: str, world: int, layout: str):
     profiled run of the same workload; null when no such profile is committed."""
     if world != 1:
         return None, None
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_{workload.replace('-', '')}_{layout}.json")
-    try:
-        d = json.load(open(path))
-        k = [v for name, v in d.items() if JK_KERNEL[layout] in name][0]
-        return (k["FETCH_SIZE"]["mean_KB"] * 1024.0 * 2.0 + k["WRITE_SIZE"]["mean_KB"] * 1024.0), os.path.relpath(path, ROOT)
-    except Exception:
-        return None, None
+    for rnd in ("r02", "r01"):
+        if rnd == "r01" and layout == "packed":
+            break                                                    # (round 1's packed layout was a different one)
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload.replace('-', '')}_{layout}.json")
+        try:
+            d = json.load(open(path))
+            k = [v for name, v in d.items() if JK_KERNEL[layout] in name][0]
+            return (k["FETCH_SIZE"]["mean_KB"] * 1024.0 * 2.0 + k["WRITE_SIZE"]["mean_KB"] * 1024.0), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -213,9 +247,13 @@ def main():
         traffic, traffic_src = pmc_traffic(args.workload, world, layout)
         alg_bytes = 8.0 * N ** 4 / world                    # 8 N^4 bytes per build, per GPU 8 N^4 / G
         stored_bytes = float(st["bytes"])
-        achieved = alg_bytes / kernel_avg_s / 1e9
-        storage = {"packed": "8-fold symmetry-unique values of the spherical tensor, row (i>=j) = pairs (k>=l) <= (i,j), f64, "
-                             "sharded by (ij) shell pair over ranks",
+        # physical bytes of one launch of the J/K kernel: the PMC counters of the profiled run of this workload when committed,
+        # else the stored tensor (read once; the partial sums it writes come on top)
+        phys_bytes = traffic if traffic is not None else stored_bytes
+        achieved = phys_bytes / kernel_avg_s / 1e9
+        storage = {"packed": "parity-blocked 8-fold symmetry-unique values of the spherical tensor: row (i>=j) keeps the pairs (k>=l) <= (i,j) "
+                             "whose x/y reflection parity class equals that of (i,j) -- the others are exact zeros (pyx:1324-1327) -- f64, "
+                             "units of 8 interleaved rows, sharded by (ij) shell pair over ranks",
                    "rows": "rows (i>=j) x full (k,l) of the spherical tensor, f64, sharded by (ij) shell pair over ranks"}[layout]
         out = {
             "metric": "Fock builds/sec (J+K from the HBM-resident ERI tensor, one density) + SCF wall time",
@@ -226,27 +264,49 @@ def main():
                        "n_shells": eng.n_shell, "n_densities": nd, "layout": layout, "storage": storage,
                        "stored_bytes_per_gpu": stored_bytes, "parallelism": f"ij-row shards x{world} + RCCL all-reduce of [J;K]" if world > 1 else "1 GPU",
                        "result_ok": ok},
+            # roofline of the dominant kernel on PHYSICAL bytes (a fraction of the 8 TB/s HBM peak, <= 1); the reference's dense 8 N^4
+            # bytes per build that the same launch stands for are reported separately
             "roofline": {"bound": "hbm", "kernel": JK_KERNEL[layout], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_avg_ms": 1e3 * kernel_avg_s,
-                         "stored_bytes_per_launch": stored_bytes, "achieved_on_stored_bytes": stored_bytes / kernel_avg_s / 1e9,
+                         "kernel_avg_ms": 1e3 * kernel_avg_s, "stored_bytes_per_launch": stored_bytes,
+                         "achieved_on_stored_bytes": stored_bytes / kernel_avg_s / 1e9,
                          "frac_on_stored_bytes": stored_bytes / kernel_avg_s / 1e9 / HBM_PEAK_GBS,
-                         "note": "achieved prices the 8*N^4 algorithmic bytes of SURVEY 8d; the kernel physically streams the stored "
-                                 "symmetry-unique part once (stored_bytes: 1/8 of them in the packed layout, 1/2 in the rows layout) plus its "
-                                 "partial sums, so frac exceeds 1; frac_on_stored_bytes and traffic are the physical figures"},
+                         "algorithmic_equivalent": {"bytes_per_launch": alg_bytes, "GBs": alg_bytes / kernel_avg_s / 1e9,
+                                                    "reduction_vs_dense": alg_bytes / stored_bytes,
+                                                    "permutational_symmetry": 8.0 if layout == "packed" else 2.0,
+                                                    "parity_zeros_and_padding": alg_bytes / stored_bytes / (8.0 if layout == "packed" else 2.0),
+                                                    "note": "SURVEY 8d prices a build at the reference's dense 8 N^4 bytes; the kernel streams "
+                                                            "1/reduction_vs_dense of them (8-fold permutational symmetry x the x/y parity rule, less padding)"},
+                         "note": "achieved = physical HBM bytes per launch (traffic when a PMC profile of this workload is committed, else the "
+                                 "stored tensor) / average kernel time from HIP events on the launch stream"},
             "eri_build": {"wall_s": eri_wall, "cold_wall_s": eri_wall_cold, "device_s": {k: float(v) for k, v in eri_t.items() if k.endswith("_s")},
                           "shell_quartets": eri_t["shell_quartets"], "primitive_shell_quartets": eri_t["primitive_shell_quartets"],
                           "component_quartets": eri_t["component_quartets"],
                           "component_quartets_per_s": eri_t["component_quartets"] / max(eri_t["total_s"], 1e-12),
+                          "nominal_flops": eri_t.get("nominal_flops"),
+                          "gflops": (eri_t["nominal_flops"] / max(eri_t["cart_kernel_s"], 1e-12) / 1e9) if eri_t.get("nominal_flops") else None,
+                          "frac_of_fp64_vector_peak": (eri_t["nominal_flops"] / max(eri_t["cart_kernel_s"], 1e-12) / FP64_VECTOR_PEAK_FLOPS)
+                          if eri_t.get("nominal_flops") else None,
+                          "flops_note": "nominal_flops = the reference algorithm's count for the quartets evaluated (SURVEY 8d(ii): per primitive AO "
+                                        "quartet 8 x inner terms of the loop nest pyx:1179-1217 + 6 (L+1) + 3 (L+1)^2 / 2 + 60), divided by the time of "
+                                        "the ERI kernels; the kernels factorise the sum per shell quartet and execute fewer operations than that",
                           "note": "quartets actually evaluated on this rank (packed layout: ket shell pairs up to the bra's first shell); "
                                   "FP64-vector / latency-bound work (DESIGN.md section 4.2), not priced against HBM or MFMA"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fock(N)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        if world == 1 and not args.no_scf:
-            out["scf_on_workload"] = scf_on_workload(eng, atoms, shells, nocc, desc)    # the tensor of the timed builds is still resident
-            out["scf"] = scf_leg(eng, args)
+    # SCF wall time, the second half of the metric: collective when the tensor is sharded (every rank runs the native cycle on its
+    # rows; one all-reduce of the partial [J;K] per Fock build through torch.distributed / RCCL), so every rank takes part
+    if not args.no_scf:
+        if world > 1:
+            from tuna_amd import distributed as tdist
+            tdist.attach_allreduce(eng)
+        scf_w = scf_on_workload(eng, atoms, shells, nocc, desc)       # the tensor of the timed builds is still resident
+        scf_c = scf_leg(eng, args, rank, world)
+        if rank == 0:
+            out["scf_on_workload"], out["scf"] = scf_w, scf_c
+    if rank == 0:
         print(json.dumps(out))
     eng.close()
     if world > 1:
@@ -283,7 +343,7 @@ def scf_on_workload(eng, atoms, shells, nocc, desc):
     return res
 
 
-def scf_leg(eng, args):
+def scf_leg(eng, args, rank=0, world=1):
     """SCF wall time on BASELINE.json configs[1] (N2 RHF/cc-pVTZ): ERI build + native RHF (EXTREME thresholds, core guess,
     DIIS 6, no damping) on the GPU, energy checked against the reference anchor; CPU ERI build beside it."""
     from tuna_amd import molecule as mol
@@ -311,12 +371,18 @@ def scf_leg(eng, args):
     dP = torch.from_numpy(r["P"]).to(dev)
     dJK = torch.zeros((2, eng.N, eng.N), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(5):
+    import torch.distributed as dist
+
+    def one_build():
         eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, stream)
+        if world > 1:
+            dist.all_reduce(dJK)
+    for _ in range(5):
+        one_build()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     for _ in range(200):
-        eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, stream)
+        one_build()
     torch.cuda.synchronize()
     fps = 200 / (time.perf_counter() - t2)
     out = {"workload": desc, "energy_Eh": r["energy"], "abs_error_vs_reference_anchor_Eh": abs(r["energy"] - ANCHOR_N2_CCPVTZ),
@@ -325,7 +391,7 @@ def scf_leg(eng, args):
            "note": "wall times of the 3rd repetition in this process (1e integrals + orthogonaliser + core guess + EXTREME RHF in scf_wall_s)",
            "fock_kernel_s": r["fock_seconds"], "eigensolver_s": r["eig_seconds"], "fock_builds_per_s": fps,
            "cpu_reference_fock_builds_per_s_8core_container": 23.4}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_eri_build"] = cpu_baseline_eri(aos)
     return out
 

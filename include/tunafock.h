@@ -130,6 +130,14 @@ int tf_eri_element(tf_ctx *ctx, const double *origin, const int32_t *lmn, const 
  * [n_dens,N,N].  With world > 1 the result is this rank's PARTIAL J and K (sum over ranks =
  * full matrices); the caller all-reduces (RCCL) -- see tuna_amd/distributed.py. */
 int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K);
+/* N > 1 ranks: every rank holds the tensor rows of its bra shell pairs, a Fock build gives partial J and K,
+ * and ONE all-reduce of the stacked [J;K] completes them.  The native SCF cycles (tf_scf_rhf / tf_scf_uhf) call this hook once per
+ * Fock build on a device buffer of `count` doubles; the caller performs sum-all-reduce over its ranks ordered after / before the work
+ * on `stream` (tuna_amd: torch.distributed over RCCL, see tuna_amd/distributed.py).  Returns 0 on success.  Without a registered
+ * hook the SCF entry points refuse a sharded tensor. */
+typedef int (*tf_allreduce_fn)(void *user, double *device_buf, int64_t count, void *stream);
+int tf_set_allreduce(tf_ctx *ctx, tf_allreduce_fn fn, void *user);
+
 /* Same with device pointers, asynchronous on `stream` (a hipStream_t, may be NULL for the
  * default stream).  Inputs already in HBM; nothing is synchronised or copied.  With the packed
  * layout the densities must be symmetric here (every SCF density is); tf_fock_jk itself also
@@ -233,6 +241,13 @@ int tf_eri_timings(const tf_ctx *ctx, double *seconds4);
 /* Work counters of the last tf_build_eri: [0] shell quartets, [1] primitive shell quartets,
  * [2] Cartesian component quartets. */
 int tf_eri_counts(const tf_ctx *ctx, int64_t *counts3);
+/* The reference algorithm's floating-point operation count for the quartets the last tf_build_eri evaluated (SURVEY.md section 8d(ii):
+ * per primitive AO quartet that passes the parity test pyx:1324-1327, 8 x the inner terms of the loop nest pyx:1179-1217 plus the
+ * Boys / R table cost 6 (L+1) + 3 (L+1)^2 / 2 + 60).  The device kernels factorise the sums and execute fewer operations; the
+ * figure prices the build against the FP64 vector peak. */
+int tf_eri_flops(const tf_ctx *ctx, double *nominal_flops);
+/* Alignment unit (in doubles) of the stored segments of the packed, parity-blocked tensor layout. */
+int tf_segment_pad(void);
 
 /* Seconds per symmetric eigensolve (random n x n matrix) of the solver variants considered for a12
  * (0 = rocsolver dsyevd, 1 = dsyev, 2 = dsyevj); instrumentation only. */

@@ -278,3 +278,75 @@ def test_random_contracted_bases_against_oracle(engine, seed):
     J, K = engine.fock_jk(P)
     tol = 1e-10 * max(1.0, scale) * engine.N
     assert np.abs(J - so.coulomb(P, Eos)).max() < tol and np.abs(K - so.exchange(P, Eos)).max() < tol
+
+
+def _shell_quartet_blocks_against_oracle(engine, shells, n_quartets, seed, spherical):
+    """Random shell quartets (A B|C D) of the resident tensor, every element of each block, against the C oracle run on the four
+    shells alone (the oracle restates the reference per AO quartet, so a four-shell basis gives exactly the tensor's values)."""
+    from tuna_amd import spherical as sph
+    rng = np.random.default_rng(seed)
+    dim = [(s.n_sph if spherical else s.n_cart) for s in shells]
+    off = np.concatenate([[0], np.cumsum(dim)])
+    worst, n_checked = 0.0, 0
+    for _ in range(n_quartets):
+        q = [int(x) for x in rng.integers(0, len(shells), size=4)]
+        sub = [shells[x] for x in q]
+        aos4 = mol.expand_cartesian_aos(sub)
+        Eo = orc.eri(aos4, 2)
+        nc = [s.n_cart for s in sub]
+        co = np.concatenate([[0], np.cumsum(nc)])
+        blk = Eo[co[0]:co[1], co[1]:co[2], co[2]:co[3], co[3]:co[4]]
+        if spherical:
+            U = [sph.spherical_block(s.L) for s in sub]
+            blk = np.einsum("ia,jb,kc,ld,abcd->ijkl", U[0], U[1], U[2], U[3], blk, optimize=True)
+        idx = np.stack(np.meshgrid(*[np.arange(off[x], off[x + 1]) for x in q], indexing="ij"), axis=-1).reshape(-1, 4).astype(np.int32)
+        got = engine.sample_eri(idx).reshape(blk.shape)
+        worst = max(worst, float(np.abs(got - blk).max()))
+        n_checked += blk.size
+    return worst, n_checked
+
+
+def test_bench_workload_tensor_against_oracle(engine):
+    """The 400-AO synthetic tensor of bench.py itself (per-class ERI kernels: eri_fact_kernel / eri_multi_kernel, fused ket transform,
+    parity-blocked rows) pinned to the oracle: every element of 150 random shell-quartet blocks (s..f shells, both atoms)."""
+    counts = mol.synthetic_counts(400)
+    atoms = mol.make_atoms(["AR", "AR"], 7.1)
+    shells = mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)})
+    engine.set_basis(mol.expand_cartesian_aos(shells)).build_eri(True)
+    assert engine.N == 400
+    worst, n = _shell_quartet_blocks_against_oracle(engine, shells, 150, 21, True)
+    assert n >= 2000 and worst < TOL_INT, (worst, n)
+
+
+def test_per_class_kernels_cartesian_tensor_against_oracle(engine, monkeypatch):
+    """The per-class kernels on ONE context with Cartesian output (no spherical transform in between): synthetic 200-AO basis."""
+    monkeypatch.setenv("TF_ERI_MODE", "class")
+    counts = mol.synthetic_counts(200)
+    atoms = mol.make_atoms(["AR", "AR"], 7.1)
+    shells = mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)})
+    engine.set_basis(mol.expand_cartesian_aos(shells)).build_eri(False)
+    worst, n = _shell_quartet_blocks_against_oracle(engine, shells, 120, 22, False)
+    assert n >= 2000 and worst < TOL_INT, (worst, n)
+
+
+@pytest.mark.parametrize("tag", ["high_l", "c4_co_def2tzvp"])
+@pytest.mark.parametrize("mode", ["class", "generic"])
+def test_full_tensor_both_eri_modes(engine, monkeypatch, tag, mode):
+    """Every element of the spherical and Cartesian tensors with the ERI launch mode forced (TF_ERI_MODE): the per-class kernels
+    (eri_class_kernel for the contracted classes, eri_fact / eri_multi for the uncontracted ones) and the small-problem kernel
+    (eri_cfact_kernel) must agree with the oracle on the same system, one context."""
+    monkeypatch.setenv("TF_ERI_MODE", mode)
+    atoms, shells, aos, _ = make_system(tag)
+    engine.set_basis(aos)
+    Eo = orc.eri(aos)
+    engine.build_eri(spherical=False)
+    assert np.abs(engine.copy_eri() - Eo).max() < TOL_INT
+    U = engine.sph_matrix()
+    engine.build_eri(spherical=True)
+    Eos = so.eri_to_spherical(U, Eo)
+    assert np.abs(engine.copy_eri() - Eos).max() < TOL_INT
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((engine.N, engine.N))
+    P = A + A.T
+    J, K = engine.fock_jk(P)
+    assert np.abs(J - so.coulomb(P, Eos)).max() < 1e-10 and np.abs(K - so.exchange(P, Eos)).max() < 1e-10

@@ -37,10 +37,14 @@ def _rank_main(rank, world, port, tag, mode, layout, ret):
             assert st["layout"] == layout
             owner = tdist.row_owner_matrix(shells, world, layout=layout)
             assert rows == int((owner == rank).sum())                 # the library followed the shared plan
-            J, K = eng.fock_jk(g["P_rand"])                            # partial sums over this rank's rows
-            jk = torch.from_numpy(np.stack([J, K]))
-            tdist.all_reduce_jk_(jk)
-            Jf, Kf = jk.numpy()
+            fock = tdist.ShardedFock(eng)                              # partial sums over this rank's rows + ONE all-reduce
+            Jf, Kf = fock(g["P_rand"])
+            # two densities in one fused pass (what a UHF build issues): the second one a scaled, shifted copy
+            P2 = np.stack([g["P_rand"], 0.5 * g["P_rand"] + 0.25 * np.diag(np.diag(g["P_rand"]))])
+            J2, K2 = fock(P2)
+            assert np.abs(J2[0] - Jf).max() < 1e-10 and np.abs(K2[0] - Kf).max() < 1e-10
+            Jd, Kd = fock(P2[1])
+            assert np.abs(J2[1] - Jd).max() < 1e-10 and np.abs(K2[1] - Kd).max() < 1e-10
             # a sample of the tensor: rows owned elsewhere read as zero here, the sum over ranks is the reference value
             v = torch.from_numpy(eng.sample_eri(g["eri_sph_idx"][:2000]))
             dist.all_reduce(v)
@@ -64,6 +68,75 @@ def test_two_ranks_on_one_card(tag, mode, layout):
         assert eJ < 1e-10 and eK < 1e-10 and eV < 1e-12
     n_total = res[0][3] + res[1][3]
     assert abs(res[0][3] - res[1][3]) <= 0.05 * n_total                # the plan balances the stored bytes
+
+
+def _rank_scf(rank, world, port, kind, tag, ret):
+    """One rank of a native SCF cycle on a sharded tensor: tf_scf_rhf / tf_scf_uhf with the registered all-reduce of the partial
+    [J;K] (tuna_amd.distributed.attach_allreduce; gloo here, two ranks sharing one card)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import UHF_SYSTEMS, atom_arrays, make_system
+        from oracle import scf_oracle as so
+        from tuna_amd import distributed as tdist, molecule as mol
+        from tuna_amd.engine import Engine, SCF_CONVERGENCE
+        with Engine(0, rank, world) as eng:
+            if kind == "rhf":
+                atoms, shells, aos, nocc = make_system(tag)
+                eng.set_basis(aos).build_eri(True)
+                xyz, chg, org = atom_arrays(atoms)
+                S, T, V, _, _ = eng.one_electron(xyz, chg, org, spherical=True)
+                X, _, _ = eng.orthogonaliser(S)
+                P0, E0 = so.core_guess(T, V, X, nocc)
+                ranges = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
+                try:
+                    eng.scf_rhf(S, T, V, P0, E0, nocc, mol.nuclear_repulsion(atoms), X=X, conv="extreme", damping="dynamic", n_atom_ao=ranges)
+                    refused = False
+                except Exception as e:                               # no all-reduce registered yet: partial sums must not be used
+                    refused = "tf_set_allreduce" in str(e)
+                tdist.attach_allreduce(eng)
+                r = eng.scf_rhf(S, T, V, P0, E0, nocc, mol.nuclear_repulsion(atoms), X=X, conv="extreme", damping="dynamic", n_atom_ao=ranges)
+                ret[rank] = (refused, r["energy"], r["n_iter"], r["table"], r["epsilons"])
+            else:
+                from tuna_amd import scf
+                from tuna_amd.energy import Calculation, build_molecule_and_integrals
+                sym, R, basis, na, nb = UHF_SYSTEMS[tag]
+                calc = Calculation(basis=basis, SCF_conv=SCF_CONVERGENCE["extreme"], multiplicity=na - nb + 1, damping=False, core_guess=True)
+                molecule, integrals, X, guess, _ = build_molecule_and_integrals(sym, R, calc, eng)
+                out = scf.run_self_consistent_field_cycle(molecule, calc, integrals, 0.0, X, guess)   # attaches the all-reduce itself
+                ret[rank] = (True, out.energy, out.n_iterations, out.table, np.concatenate((out.epsilons_alpha, out.epsilons_beta)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,tag", [("rhf", "n2_ccpvdz"), ("rhf", "c4_co_def2tzvp"), ("uhf", "oh_doublet_ccpvdz")])
+def test_native_scf_cycle_on_a_sharded_tensor(kind, tag, golden, uhf_golden):
+    """The native cycles with the tensor split over two ranks: per iteration ONE all-reduce of the stacked [J;K], everything else on
+    the device of each rank -- same trajectory as the reference run (golden) on every rank."""
+    import torch.multiprocessing as mp
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rank_scf, args=(world, _free_port(), kind, tag, ret), nprocs=world, join=True)
+        res = dict(ret)
+    assert set(res) == {0, 1}
+    if kind == "rhf":
+        g = golden(tag)
+        ref_E, ref_table = float(g["scf_energy"]), g["scf_table"]
+    else:
+        g = uhf_golden[tag]
+        ref_E, ref_table = float(g["scf_energy_nodamp"]) - float(g["V_NN"]), g["scf_table_nodamp"]
+    for rank, (refused, E, n_iter, table, eps) in res.items():
+        assert refused                                               # without the hook a sharded tensor is refused
+        assert abs(E - ref_E) < 1e-8
+        assert abs(n_iter - len(ref_table)) <= 1
+    assert abs(res[0][1] - res[1][1]) < 1e-10 and res[0][2] == res[1][2]
+    np.testing.assert_allclose(res[0][3][:, 1], res[1][3][:, 1], atol=1e-9)          # both ranks walk the same trajectory
+    n = min(res[0][2], len(ref_table))
+    if kind == "rhf":
+        np.testing.assert_allclose(res[0][3][:n, 1], ref_table[:n, 1], atol=1e-8)
+        np.testing.assert_allclose(res[0][3][:n, 6], ref_table[:n, 6], atol=1e-6)    # damping factors
 
 
 def test_jk_kernel_variants_agree(golden):

@@ -38,12 +38,14 @@ class ScfUhfResult(C.Structure):                          # tf_scf_uhf_result
                 ("F_spin", C.c_void_p * 2)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)     # tf_allreduce_fn
+
 EXPORTS = ["tf_create", "tf_destroy", "tf_last_error", "tf_version", "tf_normalize", "tf_set_basis", "tf_get_norms",
            "tf_dims", "tf_get_sph_matrix", "tf_one_electron", "tf_cross_overlap", "tf_build_eri", "tf_eri_storage",
            "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf", "tf_scf_uhf",
            "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts", "tf_shard_plan", "tf_jk_profile",
            "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_ao_to_mo", "tf_mp2_rhf", "tf_dft_setup", "tf_dft_vxc",
-           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs", "tf_packed_pad"]
+           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs", "tf_packed_pad", "tf_eri_flops", "tf_segment_pad", "tf_set_allreduce"]
 
 _lib = None
 
@@ -82,6 +84,9 @@ def lib():
     L.tf_eri_layout.restype = ci; L.tf_eri_layout.argtypes = [vp]
     L.tf_packed_pad.restype = ci; L.tf_packed_pad.argtypes = []
     L.tf_eri_storage.restype = ci; L.tf_eri_storage.argtypes = [vp, lp, lp, ip, ip]
+    L.tf_eri_flops.restype = ci; L.tf_eri_flops.argtypes = [vp, vp]
+    L.tf_segment_pad.restype = ci; L.tf_segment_pad.argtypes = []
+    L.tf_set_allreduce.restype = ci; L.tf_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     L.tf_copy_eri.restype = ci; L.tf_copy_eri.argtypes = [vp, vp]
     L.tf_sample_eri.restype = ci; L.tf_sample_eri.argtypes = [vp, C.c_int64, vp, vp]
     L.tf_eri_element.restype = ci; L.tf_eri_element.argtypes = [vp, vp, vp, vp, vp, vp, dp]

@@ -95,8 +95,13 @@ struct tf_ctx {
     bool prof_jk = false;
     std::vector<hipEvent_t> prof_ev;     // pairs (before, after) around the row kernel, on the launch stream
     size_t prof_used = 0;
+    tf_allreduce_fn allreduce = nullptr;  // completes partial [J;K] over the ranks of a sharded tensor (tf_set_allreduce)
+    void *allreduce_user = nullptr;
+    double *d_jkstage = nullptr;          // [2][nd][N][N] staging buffer of that exchange step
+    size_t jkstage_doubles = 0;
     double eri_seconds[4] = {0, 0, 0, 0};
     long long eri_counts[3] = {0, 0, 0};
+    double eri_nominal_flops = 0.0;      // the reference algorithm's operation count for the quartets of the last build
     tfscf::Workspace scf;
     tfdft::Grid grid;                    // Kohn-Sham integration grid with the AOs evaluated on it (tf_dft_setup)
     // persistent helpers of tf_build_eri (creating streams / freeing GiB-sized buffers costs tens of ms per call)
@@ -432,6 +437,7 @@ void tf_destroy(tf_ctx *ctx)
         for (int k = 0; k < tf_ctx::NSTREAM_MAX; ++k) { (void)hipStreamDestroy(ctx->streams[k]); (void)hipEventDestroy(ctx->sev[k]); }
     for (int k = 0; k < 3; ++k)
         if (ctx->scr[k]) (void)hipFree(ctx->scr[k]);
+    if (ctx->d_jkstage) (void)hipFree(ctx->d_jkstage);
     if (ctx->d_lrec) (void)hipFree(ctx->d_lrec);
     if (ctx->d_tup) (void)hipFree(ctx->d_tup);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
@@ -623,6 +629,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     if (rc) return rc;
     DBG("csr uploaded");
     const int Nc = bs.n_cart, N = spherical ? bs.n_sph : bs.n_cart, ld = (N + 1) & ~1;
+    if (ctx->grid.G > 0 && ctx->grid.N != N) tfdft::release(ctx->grid);   // (a grid of the other AO representation)
     ctx->spherical = spherical; ctx->N = N; ctx->ld = ld;
     const int npairs = (int)bs.pairs.size();
 
@@ -882,6 +889,39 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         cum_comp[A + 1] += (long long)bs.shells[A].ncomp * bs.shells[bs.pairs[p].B].ncomp;
     }
     for (int a = 0; a < nsh; ++a) { cum_pairs[a + 1] += cum_pairs[a]; cum_pp[a + 1] += cum_pp[a]; cum_comp[a + 1] += cum_comp[a]; }
+    // Nominal operation count of the reference algorithm for the quartets this build evaluates: per primitive
+    // AO quartet that passes the parity test (pyx:1324-1327), 8 x the inner terms of the loop nest pyx:1179-1217 -- (lx12/2+1)(lx34/2+1)
+    // (ly12/2+1)(ly34/2+1)(lz12+1)(lz34+1), a product of a bra and a ket factor -- plus the Boys / R table cost 6 (L+1) + 3 (L+1)^2 / 2 + 60.
+    // Per shell pair and parity class c: W = sum of its factor over the component pairs of the class, n = their number.
+    std::vector<std::array<double, 4>> pairW(npairs), pairNc(npairs);
+    for (int p = 0; p < npairs; ++p) {
+        const tf::Shell &sa = bs.shells[bs.pairs[p].A], &sb = bs.shells[bs.pairs[p].B];
+        pairW[p] = {0, 0, 0, 0}; pairNc[p] = {0, 0, 0, 0};
+        for (int ca = 0; ca < sa.ncomp; ++ca)
+            for (int cb = 0; cb < sb.ncomp; ++cb) {
+                const int u = sa.comp_off + ca, v = sb.comp_off + cb;
+                const int lx = bs.c_lx[u] + bs.c_lx[v], ly = bs.c_ly[u] + bs.c_ly[v], lz = bs.c_lz[u] + bs.c_lz[v];
+                const int c = (lx & 1) | ((ly & 1) << 1);
+                pairW[p][c] += (double)((lx / 2 + 1) * (ly / 2 + 1) * (lz + 1));
+                pairNc[p][c] += 1.0;
+            }
+    }
+    // prefix sums over the first shell A of the ket pairs (the pair list is A-major): npp x W per class, and npp x n per class and Lc + Ld
+    std::vector<std::array<double, 4>> cumW(nsh + 1, std::array<double, 4>{0, 0, 0, 0});
+    std::vector<std::array<double, 44>> cumNL(nsh + 1);
+    for (auto &x : cumNL) x.fill(0.0);
+    for (int p = 0; p < npairs; ++p) {
+        const int A = bs.pairs[p].A, lcd = std::min(10, bs.pairs[p].La + bs.pairs[p].Lb);
+        for (int c = 0; c < 4; ++c) {
+            cumW[A + 1][c] += (double)bs.pairs[p].npp * pairW[p][c];
+            cumNL[A + 1][4 * lcd + c] += (double)bs.pairs[p].npp * pairNc[p][c];
+        }
+    }
+    for (int a = 0; a < nsh; ++a) {
+        for (int c = 0; c < 4; ++c) cumW[a + 1][c] += cumW[a][c];
+        for (int x = 0; x < 44; ++x) cumNL[a + 1][x] += cumNL[a][x];
+    }
+    double nominal_flops = 0.0;
     DBG("slab buffers allocated");
     auto t_wall0 = std::chrono::steady_clock::now();
     // class-sorted ket lists on the device (one contiguous range per class)
@@ -1318,6 +1358,17 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             n_quart += cum_pairs[Alim];
             n_primq += (long long)bs.pairs[p].npp * cum_pp[Alim];
             n_compq += nr * cum_comp[Alim];
+            {
+                const double npp_ab = (double)bs.pairs[p].npp;
+                const int lab = bs.pairs[p].La + bs.pairs[p].Lb;
+                for (int c = 0; c < 4; ++c) {
+                    nominal_flops += 8.0 * npp_ab * pairW[p][c] * cumW[Alim][c];
+                    for (int lcd = 0; lcd <= 10; ++lcd) {
+                        const double L1 = (double)(lab + lcd + 1);
+                        nominal_flops += npp_ab * pairNc[p][c] * cumNL[Alim][4 * lcd + c] * (6.0 * L1 + 1.5 * L1 * L1 + 60.0);
+                    }
+                }
+            }
             ++cursor;
         }
         // the previous slab's kernels (stream 0 and the class streams) read these buffers: drain before overwriting
@@ -1405,6 +1456,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     t_stage[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall0).count();
     std::copy(t_stage, t_stage + 4, ctx->eri_seconds);
     ctx->eri_counts[0] = n_quart; ctx->eri_counts[1] = n_primq; ctx->eri_counts[2] = n_compq;
+    ctx->eri_nominal_flops = nominal_flops;
 
     DBG("scratch freed");
     // ---- J/K scratch
@@ -1471,6 +1523,15 @@ int tf_eri_counts(const tf_ctx *ctx, int64_t *c3)
     for (int i = 0; i < 3; ++i) c3[i] = ctx->eri_counts[i];
     return TF_OK;
 }
+
+int tf_eri_flops(const tf_ctx *ctx, double *nominal_flops)
+{
+    if (!ctx || !nominal_flops) return TF_EINVAL;
+    *nominal_flops = ctx->eri_nominal_flops;
+    return TF_OK;
+}
+
+int tf_segment_pad(void) { return TF_SEG_PAD; }
 
 int tf_copy_eri(tf_ctx *ctx, double *host_out)
 {
@@ -1668,11 +1729,46 @@ static int launch_jk(tf_ctx *ctx, int nd, const double *const *dP, double *const
     return TF_OK;
 }
 
+// The single exchange step of a sharded Fock build: the partial J and K of nd densities are stacked in one
+// staging buffer [2][nd][N][N] and summed over the ranks by the caller's all-reduce (torch.distributed over RCCL in tuna_amd).
+static int allreduce_jk(tf_ctx *ctx, int nd, double *const *dJ, double *const *dK, hipStream_t st)
+{
+    if (ctx->world == 1) return TF_OK;
+    if (!ctx->allreduce)
+        TF_FAIL(ctx, TF_EINVAL, "the tensor is sharded over %d ranks: register the all-reduce of the partial [J;K] with tf_set_allreduce", ctx->world);
+    const size_t nn = (size_t)ctx->N * ctx->N, need = 2 * (size_t)nd * nn;
+    if (ctx->jkstage_doubles < need) {
+        if (ctx->d_jkstage) (void)hipFree(ctx->d_jkstage);
+        ctx->d_jkstage = nullptr; ctx->jkstage_doubles = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_jkstage, need * sizeof(double)));
+        ctx->jkstage_doubles = need;
+    }
+    for (int d = 0; d < nd; ++d) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_jkstage + (size_t)d * nn, dJ[d], nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_jkstage + (size_t)(nd + d) * nn, dK[d], nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    const int rc = ctx->allreduce(ctx->allreduce_user, ctx->d_jkstage, (int64_t)need, (void *)st);
+    if (rc) TF_FAIL(ctx, TF_ENODEVICE, "the registered all-reduce failed (code %d)", rc);
+    for (int d = 0; d < nd; ++d) {
+        HIPCHK(ctx, hipMemcpyAsync(dJ[d], ctx->d_jkstage + (size_t)d * nn, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(dK[d], ctx->d_jkstage + (size_t)(nd + d) * nn, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    return TF_OK;
+}
+
+int tf_set_allreduce(tf_ctx *ctx, tf_allreduce_fn fn, void *user)
+{
+    if (!ctx) return TF_EINVAL;
+    ctx->allreduce = fn; ctx->allreduce_user = user;
+    return TF_OK;
+}
+
 int tf_fock_jk_device(tf_ctx *ctx, int n_dens, const double *dP, double *dJ, double *dK, void *stream)
 {
     if (!ctx) return TF_EINVAL;
     if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: call tf_build_eri first");
     if (n_dens < 1 || !dP || !dJ || !dK) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nn = (size_t)ctx->N * ctx->N;
     for (int d = 0; d < n_dens; d += 2) {                       // densities go through the tensor two at a time
         const int nd = std::min(2, n_dens - d);
@@ -1871,6 +1967,8 @@ int tf_dft_vxc(tf_ctx *ctx, const double *P, double *Vxc, double *n_elec, double
 {
     if (!ctx) return TF_EINVAL;
     if (ctx->grid.G <= 0) TF_FAIL(ctx, TF_EINVAL, "tf_dft_vxc: call tf_dft_setup first");
+    if (!ctx->have_eri || ctx->grid.N != ctx->N)
+        TF_FAIL(ctx, TF_EINVAL, "tf_dft_vxc: the grid was set up for a different tensor (call tf_build_eri, then tf_dft_setup again)");
     if (!P || !Vxc) TF_FAIL(ctx, TF_EINVAL, "tf_dft_vxc: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nn = (size_t)ctx->N * ctx->N;
@@ -1984,7 +2082,8 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
     auto jk = [&](const double *dP, double *dJ, double *dK, hipStream_t st) {
         const double *p[2] = {dP, dP};
         double *j[2] = {dJ, dJ}, *k[2] = {dK, dK};
-        return launch_jk(ctx, 1, p, j, k, st);
+        int rcj = launch_jk(ctx, 1, p, j, k, st);
+        return rcj ? rcj : allreduce_jk(ctx, 1, j, k, st);
     };
     tfscf::XCFn xc;
     if (ctx->grid.G > 0) {
@@ -1992,7 +2091,7 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
         xc = [&](const double *dP, double *dV, double *o3) { return tfdft::vxc(ctx->scf.blas, ctx->grid, dP, dV, o3, msg); };
     }
     int rc = tfscf::run_rhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0, E0, n_occ, V_NN, jk, ctx->world, *out, msg, xc);
-    if (rc) ctx->err = msg;
+    if (rc && !msg.empty()) ctx->err = msg;
     return rc;
 }
 
@@ -2010,13 +2109,14 @@ int tf_scf_uhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
     auto jk2 = [&](const double *dPa, const double *dPb, double *dJa, double *dJb, double *dKa, double *dKb, hipStream_t st) {
         const double *p[2] = {dPa, dPb};
         double *j[2] = {dJa, dJb}, *k[2] = {dKa, dKb};
-        return launch_jk(ctx, 2, p, j, k, st);
+        int rcj = launch_jk(ctx, 2, p, j, k, st);
+        return rcj ? rcj : allreduce_jk(ctx, 2, j, k, st);
     };
     tfscf::UhfOut uo;
     for (int sp = 0; sp < 2; ++sp) { uo.P[sp] = out->P_spin[sp]; uo.C[sp] = out->C_spin[sp]; uo.eps[sp] = out->eps_spin[sp]; uo.F[sp] = out->F_spin[sp]; }
     int rc = tfscf::run_uhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0_alpha, P0_beta, E0, n_alpha, n_beta, V_NN, jk2, ctx->world,
                             out->common, uo, msg);
-    if (rc) ctx->err = msg;
+    if (rc && !msg.empty()) ctx->err = msg;
     return rc;
 }
 

@@ -703,8 +703,11 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                    const double *X, const double *P0, double E0, int n_occ, double V_NN, const JKFn &jk, int world,
                    tf_scf_result &out, std::string &msg, const XCFn &xc = XCFn())
 {
-    if (world != 1) { msg = "tf_scf_rhf runs on one GPU; use tuna_amd.scf (torch.distributed all-reduce) for sharded tensors"; return TF_EINVAL; }
-    const int max_diis = std::max(1, std::min(8, (int)o.max_diis));
+    // world > 1: the J/K hook completes the partial sums of this rank's tensor rows with the registered all-reduce (tf_set_allreduce);
+    // every rank then runs the O(N^3) steps redundantly on identical data
+    (void)world;
+    if (o.max_diis > 8) { msg = "tf_scf_rhf: at most 8 DIIS matrices are supported by the native cycle (the reference keeps any `DIIS n`)"; return TF_EINVAL; }
+    const int max_diis = std::max(1, (int)o.max_diis);
     const int n_mats = 22 + 2 * max_diis;
     int rc = ensure(w, n, n_mats, msg);
     if (rc) return rc;
@@ -848,7 +851,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         }
         const int tf = span_begin(0);
         rc = jk(dP, dJ, dK, 0);
-        if (rc) { msg = "J/K launch failed"; return rc; }
+        if (rc) { msg.clear(); return rc; }                          // (the hook has left its message in the context)
         span_end(tf);
         hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, 0, dH, dJ, dK, o.hfx, t1, (int)nn);
         if (xc) hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, t1, 1.0, dVxc, t1, (int)nn);        // + V_XC, scf:525
@@ -1013,8 +1016,9 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                    const double *X, const double *Pa0, const double *Pb0, double E0, int n_alpha, int n_beta, double V_NN, const JK2Fn &jk2,
                    int world, tf_scf_result &out, const UhfOut &uo, std::string &msg)
 {
-    if (world != 1) { msg = "tf_scf_uhf runs on one GPU; use tuna_amd.scf (torch.distributed all-reduce) for sharded tensors"; return TF_EINVAL; }
-    const int max_diis = std::max(1, std::min(8, (int)o.max_diis));
+    (void)world;                                                    // (sharded tensors: see run_rhf)
+    if (o.max_diis > 8) { msg = "tf_scf_uhf: at most 8 DIIS matrices are supported by the native cycle (the reference keeps any `DIIS n`)"; return TF_EINVAL; }
+    const int max_diis = std::max(1, (int)o.max_diis);
     const int n_fixed = 30;
     const int n_mats = n_fixed + 4 * max_diis;
     int rc = ensure(w, n, n_mats, msg);
@@ -1139,7 +1143,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         // Fock matrices (scf:542-589): F_s = H + J_alpha + J_beta - HFX K_s, symmetrised
         const int tf = span_begin(0);
         rc = jk2(dP[0], dP[1], dJ[0], dJ[1], dK[0], dK[1], 0);
-        if (rc) { msg = "J/K launch failed"; return rc; }
+        if (rc) { msg.clear(); return rc; }
         span_end(tf);
         hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dJ[0], 1.0, dJ[1], dJt, (int)nn);
         if (n_hist == max_diis) {                                   // trim the history to max_diis entries (scf:1216-1219)

@@ -83,22 +83,83 @@ def all_reduce_jk_(jk, group=None):
     return jk
 
 
+class _DeviceBuffer:
+    """A device allocation owned by libtunafock, exposed through the CUDA array interface so that torch can alias it."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def attach_allreduce(engine, group=None):
+    """Registers the exchange step of a sharded Fock build with the library (tf_set_allreduce): the native SCF cycles then run
+    on a tensor spread over the ranks of `group` -- per iteration ONE sum-all-reduce of the stacked partial [J;K], on the device
+    buffer the library hands over.  Backend "nccl" (= RCCL over xGMI): torch.distributed orders the collective after the
+    library's work (the legacy default stream, which is torch's current stream) and the library's next launch after it.  Backend
+    "gloo" (CPU tests, several ranks sharing one card): the buffer is staged through the host."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        raise _lib.TunaError("attach_allreduce: torch.distributed is not initialised (one process per GPU, backend nccl)")
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", engine.device)
+
+    def hook(user, buf, count, stream):
+        try:
+            t = torch.as_tensor(_DeviceBuffer(buf, count), device=device)
+            if backend == "nccl":
+                dist.all_reduce(t, group=group)
+            else:
+                torch.cuda.synchronize(device)
+                h = t.cpu()
+                dist.all_reduce(h, group=group)
+                t.copy_(h)
+                torch.cuda.synchronize(device)
+            return 0
+        except Exception:                                   # no exception may cross the C ABI
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    engine.set_allreduce(hook)
+    return engine
+
+
 class ShardedFock:
-    """Fock builds over a sharded tensor: engine.fock_jk_device on this rank's rows + all-reduce."""
+    """Fock builds over a sharded tensor: engine.fock_jk_device on this rank's rows + ONE all-reduce of the stacked [J;K];
+    one [N,N] density or several [n,N,N] (a UHF build passes alpha and beta)."""
 
     def __init__(self, engine, device=None):
         import torch
         self.engine = engine
         self.device = device if device is not None else torch.device("cuda", engine.device)
-        N = engine.N
-        self._P = torch.zeros((N, N), dtype=torch.float64, device=self.device)
-        self._JK = torch.zeros((2, N, N), dtype=torch.float64, device=self.device)
+        self._bufs = {}
+
+    def _buffers(self, nd):
+        import torch
+        if nd not in self._bufs:
+            N = self.engine.N
+            self._bufs[nd] = (torch.zeros((nd, N, N), dtype=torch.float64, device=self.device),
+                              torch.zeros((2, nd, N, N), dtype=torch.float64, device=self.device))
+        return self._bufs[nd]
 
     def __call__(self, P: np.ndarray):
         import torch
-        self._P.copy_(torch.from_numpy(np.ascontiguousarray(P, dtype=np.float64)))
-        stream = torch.cuda.current_stream().cuda_stream
-        self.engine.fock_jk_device(self._P.data_ptr(), self._JK[0].data_ptr(), self._JK[1].data_ptr(), 1, stream)
-        all_reduce_jk_(self._JK)
-        out = self._JK.cpu().numpy()
-        return out[0], out[1]
+        import torch.distributed as dist
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        single = P.ndim == 2
+        Pn = P[None] if single else P
+        dP, dJK = self._buffers(Pn.shape[0])
+        dP.copy_(torch.from_numpy(Pn))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.engine.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), Pn.shape[0], stream)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(dJK)
+                out = dJK.cpu().numpy()
+            else:                                           # gloo: reduce on the host
+                h = dJK.cpu()
+                dist.all_reduce(h)
+                out = h.numpy()
+        else:
+            out = dJK.cpu().numpy()
+        return (out[0, 0], out[1, 0]) if single else (out[0], out[1])

@@ -117,8 +117,11 @@ class Engine:
         self._check(self._L.tf_eri_timings(self._ctx, ptr(t)))
         c = np.zeros(3, dtype=np.int64)
         self._check(self._L.tf_eri_counts(self._ctx, ptr(c)))
+        f = np.zeros(1)
+        self._check(self._L.tf_eri_flops(self._ctx, ptr(f)))
         return {"total_s": t[0], "cart_kernel_s": t[1], "ket_transform_s": t[2], "bra_transform_s": t[3],
-                "shell_quartets": int(c[0]), "primitive_shell_quartets": int(c[1]), "component_quartets": int(c[2])}
+                "shell_quartets": int(c[0]), "primitive_shell_quartets": int(c[1]), "component_quartets": int(c[2]),
+                "nominal_flops": float(f[0])}
 
     def copy_eri(self, out: np.ndarray | None = None) -> np.ndarray:
         N = self.N
@@ -243,6 +246,14 @@ class Engine:
         o.n_atom_ao[0] = n_atom_ao[0]
         o.n_atom_ao[1] = n_atom_ao[1] if len(n_atom_ao) > 1 else 0
         return o
+
+    def set_allreduce(self, hook):
+        """tf_set_allreduce: hook(user, device_ptr, count, stream) -> 0 sums `count` doubles at `device_ptr` over the ranks that share
+        the tensor (tuna_amd.distributed.attach_allreduce builds it on torch.distributed); None removes it."""
+        from ._lib import ALLREDUCE_FN
+        self._allreduce_keepalive = ALLREDUCE_FN(hook) if hook is not None else ALLREDUCE_FN()
+        self._check(self._L.tf_set_allreduce(self._ctx, self._allreduce_keepalive, None))
+        self.has_allreduce = hook is not None
 
     def scf_rhf(self, S, T, V, P0, E0, n_occ, V_NN, *, X=None, Fext=None, max_iter=100, **opts):
         N = self.N

@@ -30,7 +30,7 @@ class DeviceERI:
     def __init__(self, engine: Engine, sharded_fock=None):
         self.engine = engine
         self.shape = (engine.N,) * 4
-        self._fock = sharded_fock           # tuna_amd.distributed.ShardedFock when world > 1
+        self._fock = sharded_fock           # tuna_amd.distributed.ShardedFock when world > 1 (built on first use otherwise)
         self._key = None
         self._jk = None
         self.n_builds = 0
@@ -39,13 +39,24 @@ class DeviceERI:
         P = np.ascontiguousarray(P, dtype=np.float64)
         key = (P.shape, P.tobytes())
         if key != self._key:
+            if self.engine.world > 1 and self._fock is None:
+                # a rank's own pass gives PARTIAL sums only: never hand those out as J and K
+                from . import distributed as tdist
+                import torch.distributed as dist
+                if not (dist.is_available() and dist.is_initialized()):
+                    raise TunaError(f"the tensor is sharded over {self.engine.world} ranks but torch.distributed is not initialised: "
+                                    "a Fock build needs the all-reduce of the partial [J;K]")
+                self._fock = tdist.ShardedFock(self.engine)
             self._jk = self._fock(P) if self._fock is not None else self.engine.fock_jk(P)
             self._key = key
             self.n_builds += 1
         return self._jk
 
     def dense(self):
-        """The reference's dense float64[N,N,N,N] (for post-SCF consumers); moderate N only."""
+        """The reference's dense float64[N,N,N,N] (for post-SCF consumers); moderate N only, one rank only (a rank of a sharded
+        tensor holds zeros for the rows of the others)."""
+        if self.engine.world > 1:
+            raise TunaError("DeviceERI.dense(): the tensor is sharded over several ranks; sum engine.copy_eri() over the ranks instead")
         return self.engine.copy_eri()
 
 
@@ -234,7 +245,11 @@ def run_self_consistent_field_cycle(molecule, calculation, integrals: Integrals,
         log(f" Using \"{o['conv']['name']}\" SCF convergence criteria.")
         log(SCF_TABLE_HEADER)
     Fext = integrals.F + integrals.G
-    if eng.world == 1:
+    import os
+    if eng.world > 1 and not getattr(eng, "has_allreduce", False) and not os.environ.get("TUNA_AMD_HOST_SCF"):
+        from . import distributed as tdist
+        tdist.attach_allreduce(eng)                          # sharded tensor: the native cycle all-reduces the partial [J;K] per build
+    if eng.world == 1 or not os.environ.get("TUNA_AMD_HOST_SCF"):
         try:
             r = eng.scf_rhf(integrals.S, integrals.T, integrals.V_NE, P, E, molecule.n_doubly_occ, V_NN, X=X,
                             Fext=Fext if np.any(Fext) else None, n_atom_ao=molecule.partition_ranges, **o)
@@ -258,8 +273,11 @@ def run_self_consistent_field_cycle(molecule, calculation, integrals: Integrals,
 
 def _python_level_cycle(molecule, calculation, integrals, V_NN, X, P, E, o):
     """The iteration order of scf:1072-1154 with device Fock builds (sharded tensor + all-reduce) and rocSOLVER
-    diagonalisations; used when the tensor is spread over several ranks.  Every rank runs it redundantly."""
+    diagonalisations, orchestrated from the host: the cross-check of the native cycle (TUNA_AMD_HOST_SCF=1 selects it for a
+    sharded tensor).  Hartree-Fock only.  Every rank runs it redundantly."""
     import time
+    if getattr(calculation, "DFT_calculation", False):
+        raise TunaError("the host-orchestrated cycle is Hartree-Fock only: Kohn-Sham runs in the native cycle (tf_scf_rhf)")
     S, T, V = integrals.S, integrals.T, integrals.V_NE
     Fext = integrals.F + integrals.G
     eng = integrals.ERI_AO.engine
@@ -331,8 +349,11 @@ def _run_unrestricted(molecule, calculation, integrals, V_NN, X, guess_objects, 
     (tf_scf_uhf); a sharded tensor (world > 1) or TUNA_AMD_HOST_UHF=1: the host-orchestrated loop below."""
     import os
     eng = _device(integrals.ERI_AO).engine
-    if eng.world != 1 or os.environ.get("TUNA_AMD_HOST_UHF"):
+    if os.environ.get("TUNA_AMD_HOST_UHF"):
         return _python_level_unrestricted(molecule, calculation, integrals, V_NN, X, guess_objects, silent, log)
+    if eng.world > 1 and not getattr(eng, "has_allreduce", False):
+        from . import distributed as tdist
+        tdist.attach_allreduce(eng)
     _, Pa, Pb, E = guess_objects
     o = _opts(calculation)
     if not silent:
