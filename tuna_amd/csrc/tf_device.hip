@@ -60,6 +60,8 @@ struct tf_ctx {
     int layout = 0;
     long long n_elems = 0;              // stored doubles
     long long *d_rowoff = nullptr;
+    JKRec *d_rrec = nullptr;            // per local row: class and walk limits; rows by second index x: d_jrows[d_jptr[x] .. d_jptr[x + 1])
+    int *d_jptr = nullptr, *d_jrows = nullptr;
     int *d_rowsec = nullptr;            // [n_rows][6]: start of section a inside local row r; position in its storage unit, rows of the unit
     // parity-blocked layout tables (tf_layout.hip.h), host mirror and device view
     struct HostLayout {
@@ -86,6 +88,7 @@ struct tf_ctx {
         JKTask *d_tasks = nullptr;
         JKSuper *d_supers = nullptr;
         int *d_gfirst = nullptr;        // [2][N]: first / one-past-last group with i == a
+        JKRec *d_grec = nullptr;        // per group: class and walk limits (jk_reduce_kernel)
         int n_groups = 0, n_tasks = 0, n_supers = 0, nseg = 1;
         long long ypart_len = 0;
         JKJtPlan jp{};
@@ -162,10 +165,13 @@ static void free_eri(tf_ctx *ctx)
                     (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ, (void *)ctx->d_Jt, (void *)ctx->d_D})
         if (p) (void)hipFree(p);
     for (auto &t : ctx->jkt) {
-        for (void *p : {(void *)t.d_groups, (void *)t.d_tasks, (void *)t.d_supers, (void *)t.d_gfirst})
+        for (void *p : {(void *)t.d_groups, (void *)t.d_tasks, (void *)t.d_supers, (void *)t.d_gfirst, (void *)t.d_grec})
             if (p) (void)hipFree(p);
         t = tf_ctx::JKTables();
     }
+    for (void *p : {(void *)ctx->d_rrec, (void *)ctx->d_jptr, (void *)ctx->d_jrows})
+        if (p) (void)hipFree(p);
+    ctx->d_rrec = nullptr; ctx->d_jptr = nullptr; ctx->d_jrows = nullptr;
     for (void *p : ctx->layout_allocs) (void)hipFree(p);
     ctx->layout_allocs.clear();
     if (ctx->d_rowsec) { (void)hipFree(ctx->d_rowsec); ctx->d_rowsec = nullptr; }
@@ -811,7 +817,14 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             for (size_t t = 0; t < ord.size(); ++t) sorted[t] = tasks[ord[t]];
             tasks.swap(sorted);
         }
+        std::vector<JKRec> grec(groups.size());
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            grec[gi] = JKRec{};
+            grec[gi].c = groups[gi].c;
+            for (int a = 0; a < 4; ++a) grec[gi].ke[a] = H.ke(a, groups[gi].i);
+        }
         int rc2;
+        if ((rc2 = upload(ctx, grec, &T.d_grec, false))) return rc2;
         if ((rc2 = upload(ctx, groups, &T.d_groups, false)) || (rc2 = upload(ctx, gfirst, &T.d_gfirst, false)) ||
             (rc2 = upload(ctx, tasks, &T.d_tasks, false)) || (rc2 = upload(ctx, supers, &T.d_supers, false)))
             return rc2;
@@ -845,6 +858,27 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             return rc;
         ctx->db.bl = ctx->bl;
         ctx->db.RLS = H.RLS;
+        // reduction tables: per row its class and walk limits; the rows (z, x), z != x, listed by their second index x (internal)
+        std::vector<JKRec> rrec(row_ij.size());
+        std::vector<int> jptr((size_t)N + 1, 0), jrows;
+        for (size_t r = 0; r < row_ij.size(); ++r) {
+            const int iI = H.sigma[row_ij[r].x], jI = H.sigma[row_ij[r].y];
+            rrec[r] = JKRec{};
+            rrec[r].c = H.clsI[iI] ^ H.clsI[jI];
+            for (int a = 0; a < 4; ++a) rrec[r].ke[a] = H.ke(a, iI);
+            if (iI != jI) ++jptr[jI + 1];
+        }
+        for (int x = 0; x < N; ++x) jptr[x + 1] += jptr[x];
+        jrows.assign((size_t)std::max(1, jptr[N]), 0);
+        {
+            std::vector<int> fill(jptr.begin(), jptr.end() - 1);
+            for (size_t r = 0; r < row_ij.size(); ++r) {            // (ascending local row: a fixed summation order)
+                const int iI = H.sigma[row_ij[r].x], jI = H.sigma[row_ij[r].y];
+                if (iI != jI) jrows[fill[jI]++] = (int)r;
+            }
+        }
+        if ((rc = upload(ctx, rrec, &ctx->d_rrec, false)) || (rc = upload(ctx, jptr, &ctx->d_jptr, false)) || (rc = upload(ctx, jrows, &ctx->d_jrows, false)))
+            return rc;
     }
 
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
@@ -1464,6 +1498,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // (sized for two densities per pass)
     const int NWjk = packed ? std::max(1, H.NW) : 1;                // column chunks of jk_packed_kernel
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
+    HIPCHK(ctx, hipMemset(ctx->d_Jrow, 0, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     if (packed) {
         // everything sized for a two-density pass (second density behind the first)
         const size_t npr = (size_t)std::max<long long>(1, H.NPtot);    // padded pair index space
@@ -1475,8 +1510,15 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         HIPCHK(ctx, hipMemset(ctx->d_Pp, 0, 2 * npr * sizeof(double)));   // pad slots stay zero
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_ypart, std::max<size_t>(1, ny) * sizeof(double)));
         // column parts [.][N] followed by the row parts [.][RS]
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, std::max<size_t>(1, ng) * (size_t)(N + H.RS) * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * (size_t)(N + H.RS) * sizeof(double)));
+        const size_t di_bytes = std::max<size_t>(1, ng) * (size_t)(N + H.RS) * sizeof(double);
+        const size_t dj_bytes = 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * (size_t)(N + H.RS) * sizeof(double);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, di_bytes));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, dj_bytes));
+        // The set of partial-sum entries a pass writes does not depend on the density; entries outside it are never written and are
+        // zeroed once here, so that nothing depends on what the allocator hands out.
+        HIPCHK(ctx, hipMemset(ctx->d_DI, 0, di_bytes));
+        HIPCHK(ctx, hipMemset(ctx->d_DJ, 0, dj_bytes));
+        HIPCHK(ctx, hipMemset(ctx->d_ypart, 0, std::max<size_t>(1, ny) * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jt, 2 * (size_t)nsegmax * npr * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_D, 2 * nn * sizeof(double)));
     } else
@@ -1595,6 +1637,17 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
     S.P = nn; S.Pp = npr; S.y = (size_t)T.ypart_len; S.Jd = nrows * NW;
     S.DIc = ng * N; S.DIr = ng * (size_t)L.RS; S.DJc = nrows * N; S.DJr = nrows * (size_t)L.RS;
     double *DIc = ctx->d_DI, *DIr = ctx->d_DI + ND * S.DIc, *DJc = ctx->d_DJ, *DJr = ctx->d_DJ + ND * S.DJc;
+    static const int poison = getenv("TF_JK_POISON") ? atoi(getenv("TF_JK_POISON")) : 0;
+    if (poison) {
+        // test mode: the partial-sum buffers are filled with NaNs before the pass, so that a reduction that reads an entry no task
+        // wrote shows up as a NaN in J or K whatever the allocator handed out (bit mask: 1 DIc, 2 DIr, 4 DJc, 8 DJr, 16 Jd, 32 ypart)
+        if (poison & 1) (void)hipMemsetAsync(DIc, 0xFF, (size_t)ND * S.DIc * sizeof(double), st);
+        if (poison & 2) (void)hipMemsetAsync(DIr, 0xFF, (size_t)ND * S.DIr * sizeof(double), st);
+        if (poison & 4) (void)hipMemsetAsync(DJc, 0xFF, (size_t)ND * S.DJc * sizeof(double), st);
+        if (poison & 8) (void)hipMemsetAsync(DJr, 0xFF, (size_t)ND * S.DJr * sizeof(double), st);
+        if (poison & 16) (void)hipMemsetAsync(ctx->d_Jrow, 0xFF, (size_t)ND * S.Jd * sizeof(double), st);
+        if (poison & 32) (void)hipMemsetAsync(ctx->d_ypart, 0xFF, (size_t)ND * S.y * sizeof(double), st);
+    }
     if (T.n_tasks > 0) {
         hipEvent_t ev_after = nullptr;
         if (ctx->prof_jk) {
@@ -1754,6 +1807,39 @@ static int allreduce_jk(tf_ctx *ctx, int nd, double *const *dJ, double *const *d
         HIPCHK(ctx, hipMemcpyAsync(dK[d], ctx->d_jkstage + (size_t)(nd + d) * nn, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
     return TF_OK;
+}
+
+// Debug / test aid: copies of the partial-sum buffers of the last packed J/K pass and of its group table (one density):
+// which = 0 DIc [groups][N], 1 DIr [groups][RS], 2 DJc [rows][N], 3 DJr [rows][RS]; returns the number of doubles copied (<= n) or < 0.
+long long tf_debug_partials(tf_ctx *ctx, int which, double *host, long long n)
+{
+    if (!ctx || !ctx->have_eri || ctx->layout != 1 || !host) return TF_EINVAL;
+    const tf_ctx::JKTables &T = ctx->jkt[0];
+    const size_t ng = (size_t)std::max(1, T.n_groups), nrows = (size_t)std::max<long long>(1, ctx->n_rows), N = (size_t)ctx->N, RS = (size_t)ctx->bl.RS;
+    const double *src = nullptr; size_t cnt = 0;
+    switch (which) {
+    case 0: src = ctx->d_DI; cnt = ng * N; break;
+    case 1: src = ctx->d_DI + ng * N; cnt = ng * RS; break;
+    case 2: src = ctx->d_DJ; cnt = nrows * N; break;
+    case 3: src = ctx->d_DJ + nrows * N; cnt = nrows * RS; break;
+    case 4: src = ctx->d_D; cnt = N * N; break;
+    case 5: src = reinterpret_cast<const double *>(T.d_grec); cnt = ng * 4; break;       // JKRec = 32 bytes = 4 doubles
+    case 6: src = reinterpret_cast<const double *>(ctx->d_rrec); cnt = nrows * 4; break;
+    default: return TF_EINVAL;
+    }
+    cnt = std::min<size_t>(cnt, (size_t)n);
+    if (hipMemcpy(host, src, cnt * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return TF_ENODEVICE;
+    return (long long)cnt;
+}
+// group table of the one-density pass: per group {i, j0, nr, r0, c} (internal indices); returns the number of groups
+int tf_debug_groups(tf_ctx *ctx, int32_t *out5, int max_groups)
+{
+    if (!ctx || !ctx->have_eri || ctx->layout != 1) return TF_EINVAL;
+    const tf_ctx::JKTables &T = ctx->jkt[0];
+    std::vector<JKGroup> g((size_t)T.n_groups);
+    if (T.n_groups && hipMemcpy(g.data(), T.d_groups, g.size() * sizeof(JKGroup), hipMemcpyDeviceToHost) != hipSuccess) return TF_ENODEVICE;
+    for (int k = 0; k < T.n_groups && k < max_groups; ++k) { out5[5 * k] = g[k].i; out5[5 * k + 1] = g[k].j0; out5[5 * k + 2] = g[k].nr; out5[5 * k + 3] = g[k].r0; out5[5 * k + 4] = g[k].c; }
+    return T.n_groups;
 }
 
 int tf_set_allreduce(tf_ctx *ctx, tf_allreduce_fn fn, void *user)

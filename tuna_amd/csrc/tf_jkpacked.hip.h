@@ -708,6 +708,9 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double *sPart, co
 // Both reductions of all densities of a pass in ONE launch (they are independent and each alone leaves most of the chip idle):
 // per density first the N * ceil(N/64) exchange blocks, then the Jt blocks.  Fixed summation order inside every block: bitwise
 // reproducible.
+// class and walk limits of a group or a row (host tables; debug dumps)
+struct JKRec { int ke[4]; int c, pad[3]; };
+
 struct JKReduce {
     const double *ypart, *DIc, *DIr, *DJc, *DJr;
     double *Jt, *D[2];
