@@ -60,12 +60,11 @@ struct tf_ctx {
     int layout = 0;
     long long n_elems = 0;              // stored doubles
     long long *d_rowoff = nullptr;
-    JKRec *d_rrec = nullptr;            // per local row: class and walk limits; rows by second index x: d_jrows[d_jptr[x] .. d_jptr[x + 1])
-    int *d_jptr = nullptr, *d_jrows = nullptr;
+    int *d_jptr = nullptr, *d_jrows = nullptr;   // rows by second index x (internal): d_jrows[d_jptr[x] .. d_jptr[x + 1])
     int *d_rowsec = nullptr;            // [n_rows][6]: start of section a inside local row r; position in its storage unit, rows of the unit
     // parity-blocked layout tables (tf_layout.hip.h), host mirror and device view
     struct HostLayout {
-        int N = 0, NW = 0, RS = 0;
+        int N = 0, NW = 0, RS = 0, MC = 1;
         int cstart[4] = {}, csize[4] = {}, corder[4] = {}, wfirst[5] = {}, fullsec[4][4] = {}, gbase[4] = {};
         long long cbase[4] = {}, NP[4] = {}, NPtot = 0, RLS = 0;
         std::vector<int> cls, loc, sigma, ao, origI, clsI, cntA, kap0, kapF, rpoff, chunk_c0, chunk_width, chunk_cls, chunk_of, gk;
@@ -88,7 +87,6 @@ struct tf_ctx {
         JKTask *d_tasks = nullptr;
         JKSuper *d_supers = nullptr;
         int *d_gfirst = nullptr;        // [2][N]: first / one-past-last group with i == a
-        JKRec *d_grec = nullptr;        // per group: class and walk limits (jk_reduce_kernel)
         int n_groups = 0, n_tasks = 0, n_supers = 0, nseg = 1;
         long long ypart_len = 0;
         JKJtPlan jp{};
@@ -165,13 +163,13 @@ static void free_eri(tf_ctx *ctx)
                     (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ, (void *)ctx->d_Jt, (void *)ctx->d_D})
         if (p) (void)hipFree(p);
     for (auto &t : ctx->jkt) {
-        for (void *p : {(void *)t.d_groups, (void *)t.d_tasks, (void *)t.d_supers, (void *)t.d_gfirst, (void *)t.d_grec})
+        for (void *p : {(void *)t.d_groups, (void *)t.d_tasks, (void *)t.d_supers, (void *)t.d_gfirst})
             if (p) (void)hipFree(p);
         t = tf_ctx::JKTables();
     }
-    for (void *p : {(void *)ctx->d_rrec, (void *)ctx->d_jptr, (void *)ctx->d_jrows})
+    for (void *p : {(void *)ctx->d_jptr, (void *)ctx->d_jrows})
         if (p) (void)hipFree(p);
-    ctx->d_rrec = nullptr; ctx->d_jptr = nullptr; ctx->d_jrows = nullptr;
+    ctx->d_jptr = nullptr; ctx->d_jrows = nullptr;
     for (void *p : ctx->layout_allocs) (void)hipFree(p);
     ctx->layout_allocs.clear();
     if (ctx->d_rowsec) { (void)hipFree(ctx->d_rowsec); ctx->d_rowsec = nullptr; }
@@ -270,9 +268,12 @@ static int build_blocked_layout(tf_ctx *ctx, const std::vector<int> &cls)
     H.NW = (int)H.chunk_cls.size();
     const int NW = H.NW;
     H.kap0.assign((size_t)4 * std::max(NW, 1), 0); H.kapF.assign((size_t)4 * std::max(NW, 1), 0); H.rpoff.assign((size_t)4 * std::max(NW, 1), 0);
-    H.RS = 1;
+    // row parts of a group / row: a dense [MC][N] block, MC = most chunks of one class; the task of chunk number s of its class writes
+    // slot s at the internal index of k: rpoff[c][w] = s N + cstart[class of k] (+ kappa)
+    H.MC = 1;
+    for (int b = 0; b < 4; ++b) H.MC = std::max(H.MC, H.wfirst[b + 1] - H.wfirst[b]);
+    H.RS = H.MC * N;
     for (int c = 0; c < 4; ++c) {
-        int o = 0;
         for (int w = 0; w < NW; ++w) {
             const int b = H.chunk_cls[w], a = b ^ c, lam0 = H.chunk_c0[w] - H.cstart[b];
             const int cm = (c == 0) ? 1 : 0;
@@ -282,10 +283,9 @@ static int build_blocked_layout(tf_ctx *ctx, const std::vector<int> &cls)
                 if (n > lam0) k0 = kk;
                 if (H.chunk_width[w] == TF_JKP_CW && n - cm >= lam0 + TF_JKP_CW) kF = kk;
             }
-            H.kap0[(size_t)c * NW + w] = k0; H.kapF[(size_t)c * NW + w] = kF; H.rpoff[(size_t)c * NW + w] = o;
-            o += H.csize[a];
+            H.kap0[(size_t)c * NW + w] = k0; H.kapF[(size_t)c * NW + w] = kF;
+            H.rpoff[(size_t)c * NW + w] = (w - H.wfirst[b]) * N + H.cstart[a];
         }
-        H.RS = std::max(H.RS, o);
     }
     // device copy
     BLayout L{};
@@ -817,14 +817,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             for (size_t t = 0; t < ord.size(); ++t) sorted[t] = tasks[ord[t]];
             tasks.swap(sorted);
         }
-        std::vector<JKRec> grec(groups.size());
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            grec[gi] = JKRec{};
-            grec[gi].c = groups[gi].c;
-            for (int a = 0; a < 4; ++a) grec[gi].ke[a] = H.ke(a, groups[gi].i);
-        }
         int rc2;
-        if ((rc2 = upload(ctx, grec, &T.d_grec, false))) return rc2;
         if ((rc2 = upload(ctx, groups, &T.d_groups, false)) || (rc2 = upload(ctx, gfirst, &T.d_gfirst, false)) ||
             (rc2 = upload(ctx, tasks, &T.d_tasks, false)) || (rc2 = upload(ctx, supers, &T.d_supers, false)))
             return rc2;
@@ -858,14 +851,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             return rc;
         ctx->db.bl = ctx->bl;
         ctx->db.RLS = H.RLS;
-        // reduction tables: per row its class and walk limits; the rows (z, x), z != x, listed by their second index x (internal)
-        std::vector<JKRec> rrec(row_ij.size());
+        // reduction table: the rows (z, x), z != x, listed by their second index x (internal)
         std::vector<int> jptr((size_t)N + 1, 0), jrows;
         for (size_t r = 0; r < row_ij.size(); ++r) {
             const int iI = H.sigma[row_ij[r].x], jI = H.sigma[row_ij[r].y];
-            rrec[r] = JKRec{};
-            rrec[r].c = H.clsI[iI] ^ H.clsI[jI];
-            for (int a = 0; a < 4; ++a) rrec[r].ke[a] = H.ke(a, iI);
             if (iI != jI) ++jptr[jI + 1];
         }
         for (int x = 0; x < N; ++x) jptr[x + 1] += jptr[x];
@@ -877,8 +866,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 if (iI != jI) jrows[fill[jI]++] = (int)r;
             }
         }
-        if ((rc = upload(ctx, rrec, &ctx->d_rrec, false)) || (rc = upload(ctx, jptr, &ctx->d_jptr, false)) || (rc = upload(ctx, jrows, &ctx->d_jrows, false)))
-            return rc;
+        if ((rc = upload(ctx, jptr, &ctx->d_jptr, false)) || (rc = upload(ctx, jrows, &ctx->d_jrows, false))) return rc;
     }
 
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
@@ -1510,14 +1498,16 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         HIPCHK(ctx, hipMemset(ctx->d_Pp, 0, 2 * npr * sizeof(double)));   // pad slots stay zero
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_ypart, std::max<size_t>(1, ny) * sizeof(double)));
         // column parts [.][N] followed by the row parts [.][RS]
-        const size_t di_bytes = std::max<size_t>(1, ng) * (size_t)(N + H.RS) * sizeof(double);
-        const size_t dj_bytes = 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * (size_t)(N + H.RS) * sizeof(double);
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, di_bytes));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, dj_bytes));
-        // The set of partial-sum entries a pass writes does not depend on the density; entries outside it are never written and are
-        // zeroed once here, so that nothing depends on what the allocator hands out.
-        HIPCHK(ctx, hipMemset(ctx->d_DI, 0, di_bytes));
-        HIPCHK(ctx, hipMemset(ctx->d_DJ, 0, dj_bytes));
+        // partial sums: [one-density pass | two-density pass], each [column parts | row parts] per density.  The passes have separate
+        // regions (their groups differ), every region is zeroed once: the set of entries a pass writes does not depend on the density,
+        // and the reductions rely on the entries no task writes being zero.
+        const size_t per_g = (size_t)(N + H.RS), nr1 = std::max<size_t>(1, (size_t)ctx->n_rows);
+        const size_t di_doubles = ((size_t)std::max(1, ctx->jkt[0].n_groups) + 2 * (size_t)std::max(1, ctx->jkt[1].n_groups)) * per_g;
+        const size_t dj_doubles = 3 * nr1 * per_g;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, di_doubles * sizeof(double)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, dj_doubles * sizeof(double)));
+        HIPCHK(ctx, hipMemset(ctx->d_DI, 0, di_doubles * sizeof(double)));
+        HIPCHK(ctx, hipMemset(ctx->d_DJ, 0, dj_doubles * sizeof(double)));
         HIPCHK(ctx, hipMemset(ctx->d_ypart, 0, std::max<size_t>(1, ny) * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jt, 2 * (size_t)nsegmax * npr * sizeof(double)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_D, 2 * nn * sizeof(double)));
@@ -1636,18 +1626,11 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
     JKStrides S{};
     S.P = nn; S.Pp = npr; S.y = (size_t)T.ypart_len; S.Jd = nrows * NW;
     S.DIc = ng * N; S.DIr = ng * (size_t)L.RS; S.DJc = nrows * N; S.DJr = nrows * (size_t)L.RS;
-    double *DIc = ctx->d_DI, *DIr = ctx->d_DI + ND * S.DIc, *DJc = ctx->d_DJ, *DJr = ctx->d_DJ + ND * S.DJc;
-    static const int poison = getenv("TF_JK_POISON") ? atoi(getenv("TF_JK_POISON")) : 0;
-    if (poison) {
-        // test mode: the partial-sum buffers are filled with NaNs before the pass, so that a reduction that reads an entry no task
-        // wrote shows up as a NaN in J or K whatever the allocator handed out (bit mask: 1 DIc, 2 DIr, 4 DJc, 8 DJr, 16 Jd, 32 ypart)
-        if (poison & 1) (void)hipMemsetAsync(DIc, 0xFF, (size_t)ND * S.DIc * sizeof(double), st);
-        if (poison & 2) (void)hipMemsetAsync(DIr, 0xFF, (size_t)ND * S.DIr * sizeof(double), st);
-        if (poison & 4) (void)hipMemsetAsync(DJc, 0xFF, (size_t)ND * S.DJc * sizeof(double), st);
-        if (poison & 8) (void)hipMemsetAsync(DJr, 0xFF, (size_t)ND * S.DJr * sizeof(double), st);
-        if (poison & 16) (void)hipMemsetAsync(ctx->d_Jrow, 0xFF, (size_t)ND * S.Jd * sizeof(double), st);
-        if (poison & 32) (void)hipMemsetAsync(ctx->d_ypart, 0xFF, (size_t)ND * S.y * sizeof(double), st);
-    }
+    // region of this pass type inside the partial buffers (tf_build_eri: [one-density pass | two-density pass])
+    const size_t per_g = (size_t)(N + L.RS);
+    double *DI0 = ctx->d_DI + (ND == 2 ? (size_t)std::max(1, ctx->jkt[0].n_groups) * per_g : 0);
+    double *DJ0 = ctx->d_DJ + (ND == 2 ? nrows * per_g : 0);
+    double *DIc = DI0, *DIr = DI0 + ND * S.DIc, *DJc = DJ0, *DJr = DJ0 + ND * S.DJc;
     if (T.n_tasks > 0) {
         hipEvent_t ev_after = nullptr;
         if (ctx->prof_jk) {
@@ -1666,12 +1649,12 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
     JKReduce R{};
-    R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.groups = T.d_groups; R.nseg = T.nseg; R.jp = T.jp;
+    R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.MC = ctx->hl.MC; R.nseg = T.nseg; R.jp = T.jp;
     R.Jt = ctx->d_Jt; R.sJt = (size_t)T.nseg * npr;
     R.DIc = DIc; R.sDIc = S.DIc; R.DIr = DIr; R.sDIr = S.DIr; R.DJc = DJc; R.sDJc = S.DJc; R.DJr = DJr; R.sDJr = S.DJr;
-    R.gfirst = T.d_gfirst; R.rowmap = ctx->d_rowmap;
+    R.gfirst = T.d_gfirst; R.jptr = ctx->d_jptr; R.jrows = ctx->d_jrows;
     for (int d = 0; d < ND; ++d) R.D[d] = dDout[d];
-    const unsigned nblk = (unsigned)ND * ((unsigned)N * ((N + 63) / 64) + (unsigned)T.jp.bfirst[4] * T.nseg);
+    const unsigned nblk = (unsigned)ND * ((unsigned)N * ((N + 127) / 128) + (unsigned)T.jp.bfirst[4] * T.nseg);
     hipLaunchKernelGGL(jk_reduce_kernel, dim3(nblk), dim3(256), 0, st, R, L);
     return TF_OK;
 }
@@ -1823,8 +1806,6 @@ long long tf_debug_partials(tf_ctx *ctx, int which, double *host, long long n)
     case 2: src = ctx->d_DJ; cnt = nrows * N; break;
     case 3: src = ctx->d_DJ + nrows * N; cnt = nrows * RS; break;
     case 4: src = ctx->d_D; cnt = N * N; break;
-    case 5: src = reinterpret_cast<const double *>(T.d_grec); cnt = ng * 4; break;       // JKRec = 32 bytes = 4 doubles
-    case 6: src = reinterpret_cast<const double *>(ctx->d_rrec); cnt = nrows * 4; break;
     default: return TF_EINVAL;
     }
     cnt = std::min<size_t>(cnt, (size_t)n);

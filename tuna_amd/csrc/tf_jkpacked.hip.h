@@ -659,79 +659,94 @@ __device__ __forceinline__ void jt_reduce_block(int bx, int by, int nseg, const 
     out[(size_t)by * L.NPtot + bl_cbase(L, c) + q] = s;
 }
 
-// D[x][y] (internal indices) = sum over the groups whose rows have first index x of (column part + row parts of the chunks)[y]
-//                            + the same over the owned rows (z, x) with second index x.
-// A part exists only where a task wrote it: column part of chunk w for a bra index i of class-c rows iff kap0[c][w] < cntA[a][i]
-// (a = class of the chunk ^ c); row part (w, kappa) iff kap0[c][w] <= kappa < cntA[class of k][i].
-// Block (x, bx) of an (N, ceil(N/64)) grid, 256 threads = 4 slices x 64 columns; gfirst[x]..gfirst[N+x] are the groups with i == x.
-__device__ __forceinline__ double kd_parts(const BLayout &L, int c, int ibra, int y, int cy, int ly, int wy, const double *__restrict__ colp,
-                                           const double *__restrict__ rowp)
+// D[x][y] (internal indices) = sum over the groups whose rows have first index x of (column part + row parts)[y]
+//                            + the same over the owned rows (z, x) with second index x (jrows[jptr[x] .. jptr[x + 1])).
+// The row parts of a group / row are a dense [MC][N] block (MC = most chunks of one class): the task of chunk number s of its class
+// writes slot s at the internal index of k, so the parts that belong to output column y are simply column y of every slot.  No
+// validity tests: the set of entries a pass writes does not depend on the density, the buffers are zeroed once at allocation, and
+// entries no task writes stay zero.  Block (x, bx) of an (N, ceil(N/128)) grid, 256 threads = 4 slices x 64 lanes x 2 columns;
+// four partial vectors at a time so that their loads are in flight together; fixed summation order: bitwise reproducible.
+__device__ __forceinline__ double2 kd_vec(const double *__restrict__ colp, const double *__restrict__ rowp, int N, int MC, int y, bool two)
 {
-    const int N = L.N, NW = L.NW;
-    double t = 0.0;
-    if (L.kap0[c * NW + wy] < L.cntA[(cy ^ c) * N + ibra]) t = colp[y];
-    if (ly < L.cntA[cy * N + ibra]) {
-        const int bcl = cy ^ c;
-        for (int w = bl_wfirst(L, bcl); w < bl_wfirst(L, bcl + 1); ++w)
-            if (L.kap0[c * NW + w] <= ly) t += rowp[L.rpoff[c * NW + w] + ly];
+    double2 t = two ? *reinterpret_cast<const double2 *>(colp + y) : make_double2(colp[y], 0.0);
+    for (int sl = 0; sl < MC; ++sl) {
+        const double2 v = two ? *reinterpret_cast<const double2 *>(rowp + (size_t)sl * N + y) : make_double2(rowp[(size_t)sl * N + y], 0.0);
+        t.x += v.x; t.y += v.y;
     }
     return t;
 }
 
-__device__ __forceinline__ void kd_reduce_block(int x, int bx, double *sPart, const double *__restrict__ DIc, const double *__restrict__ DIr,
-                                                const double *__restrict__ DJc, const double *__restrict__ DJr, const BLayout &L,
-                                                const JKGroup *__restrict__ groups, const int *__restrict__ gfirst,
-                                                const int *__restrict__ rowmap, double *__restrict__ D)
+__device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, const double *__restrict__ DIc, const double *__restrict__ DIr,
+                                                const double *__restrict__ DJc, const double *__restrict__ DJr, int N, int MC,
+                                                const int *__restrict__ gfirst, const int *__restrict__ jptr, const int *__restrict__ jrows,
+                                                double *__restrict__ D)
 {
-    const int N = L.N;
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int y = bx * 64 + lane;
-    double s = 0.0;
+    const int y = bx * 128 + 2 * lane;
+    const size_t RS = (size_t)MC * N;
+    const bool two = ((N & 1) == 0) && y + 1 < N;           // 16-byte loads need even row strides
+    double2 s = make_double2(0.0, 0.0);
     if (y < N) {
-        const int cy = L.clsI[y], ly = y - bl_cstart(L, cy), wy = L.chunk_of[y];
-        const int xo = L.origI[x], cx = L.clsI[x];
-        for (int g = gfirst[x] + sl, ge = gfirst[N + x]; g < ge; g += 4)
-            s += kd_parts(L, groups[g].c, x, y, cy, ly, wy, DIc + (size_t)g * N, DIr + (size_t)g * L.RS);
-        for (int z = sl; z < N; z += 4) {
-            if (L.origI[z] <= xo) continue;
-            const int hi = max(z, x), lo = min(z, x);
-            const int r = rowmap[(size_t)hi * (hi + 1) / 2 + lo];
-            if (r < 0) continue;
-            s += kd_parts(L, L.clsI[z] ^ cx, z, y, cy, ly, wy, DJc + (size_t)r * N, DJr + (size_t)r * L.RS);
+        for (int pass = 0; pass < (two || y + 1 >= N ? 1 : 2); ++pass) {
+            const int yy = y + pass;
+            double2 acc = make_double2(0.0, 0.0);
+            for (int g0 = gfirst[x] + sl, ge = gfirst[N + x]; g0 < ge; g0 += 16) {
+                double2 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + 4 * u;
+                    t[u] = (g < ge) ? kd_vec(DIc + (size_t)g * N, DIr + (size_t)g * RS, N, MC, yy, two) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += t[u].x; acc.y += t[u].y; }
+            }
+            for (int p0 = jptr[x] + sl, pe = jptr[x + 1]; p0 < pe; p0 += 16) {
+                double2 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p = p0 + 4 * u;
+                    const int r = (p < pe) ? jrows[p] : -1;
+                    t[u] = (r >= 0) ? kd_vec(DJc + (size_t)r * N, DJr + (size_t)r * RS, N, MC, yy, two) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc.x += t[u].x; acc.y += t[u].y; }
+            }
+            if (pass == 0) s = acc; else s.y = acc.x;
         }
     }
     sPart[threadIdx.x] = s;
     __syncthreads();
-    if (sl == 0 && y < N) D[(size_t)x * N + y] = ((sPart[lane] + sPart[64 + lane]) + sPart[128 + lane]) + sPart[192 + lane];
+    if (sl == 0 && y < N) {
+        const double2 a0 = sPart[lane], a1 = sPart[64 + lane], a2 = sPart[128 + lane], a3 = sPart[192 + lane];
+        D[(size_t)x * N + y] = ((a0.x + a1.x) + a2.x) + a3.x;
+        if (y + 1 < N) D[(size_t)x * N + y + 1] = ((a0.y + a1.y) + a2.y) + a3.y;
+    }
 }
 
 // Both reductions of all densities of a pass in ONE launch (they are independent and each alone leaves most of the chip idle):
 // per density first the N * ceil(N/64) exchange blocks, then the Jt blocks.  Fixed summation order inside every block: bitwise
 // reproducible.
-// class and walk limits of a group or a row (host tables; debug dumps)
-struct JKRec { int ke[4]; int c, pad[3]; };
-
 struct JKReduce {
     const double *ypart, *DIc, *DIr, *DJc, *DJr;
     double *Jt, *D[2];
     const JKSuper *supers;
-    const JKGroup *groups;
-    const int *gfirst, *rowmap;
+    const int *gfirst, *jptr, *jrows;
+    int MC;                                              // slots of a row part vector: most chunks of one class
     JKJtPlan jp;
     size_t sy, sJt, sDIc, sDIr, sDJc, sDJr;              // strides between densities
     int nseg;
 };
 __global__ __launch_bounds__(256) void jk_reduce_kernel(JKReduce R, BLayout L)
 {
-    __shared__ double sPart[256];
-    const int gxK = (L.N + 63) / 64, nK = L.N * gxK;
+    __shared__ double2 sPart[256];
+    const int gxK = (L.N + 127) / 128, nK = L.N * gxK;
     const int gxJ = R.jp.bfirst[4], nJ = gxJ * R.nseg;
     int b = blockIdx.x;
     const int d = b / (nK + nJ);
     b -= d * (nK + nJ);
     if (b < nK)
-        kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, L, R.groups,
-                        R.gfirst, R.rowmap, R.D[d]);
+        kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, L.N, R.MC,
+                        R.gfirst, R.jptr, R.jrows, R.D[d]);
     else {
         b -= nK;
         jt_reduce_block(b % gxJ, b / gxJ, R.nseg, R.ypart + d * R.sy, R.supers, R.jp, L, R.Jt + d * R.sJt);
