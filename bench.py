@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+FP64_MATRIX_PEAK_FLOPS = 78.6e12 # MI355X FP64 matrix (MFMA) peak: the FP64 matrix cores run at the FP64 vector rate on CDNA4
 FP64_VECTOR_PEAK_FLOPS = 78.6e12 # MI355X FP64 vector peak (half the 157.3 TFLOP/s FP32 vector figure of MI355X_MICROARCH.md)
 ANCHOR_N2_CCPVTZ = -108.9834703056   # SURVEY.md section 6.2 (reference engine + reference tuna_scf.py, golden/c2)
 
@@ -334,13 +335,31 @@ def scf_on_workload(eng, atoms, shells, nocc, desc):
             r = eng.scf_rhf(S, T, V, P0, float(np.sum(P0 * (T + V))), nocc, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping="none",
                             n_atom_ao=nao, max_iter=200)
             t2 = time.perf_counter()
+            orbitals = (r["C"], r["epsilons"])
             best = {"energy_Eh": r["energy"], "iterations": r["n_iter"], "setup_wall_s": t1 - t0, "scf_wall_s": t2 - t1,
                     "ms_per_iteration": 1e3 * (t2 - t1) / r["n_iter"], "fock_kernels_ms_per_iteration": 1e3 * r["fock_seconds"] / r["n_iter"],
                     "eigen_ms_per_iteration": 1e3 * r["eig_seconds"] / r["n_iter"], "smallest_overlap_eigenvalue": smin}
         res.update(best)
+        if eng.world == 1:
+            res["mp2"] = mp2_leg(eng, orbitals[0], orbitals[1], nocc)
     except TunaError as e:      # e.g. a synthetic basis too linearly dependent for an SCF: the Fock-build numbers stand on their own
         res["error"] = str(e)
     return res
+
+
+def mp2_leg(eng, C, eps, nocc):
+    """The GEMM-shaped consumer of the resident tensor (BASELINE config 5's step at the workload size):
+    AO->MO transformation of the (ia|jb) block + RMP2 energy with the converged orbitals, priced against the FP64 MATRIX peak."""
+    N = eng.N
+    o, v = nocc, N - nocc
+    eng.mp2_rhf(C, eps, nocc)                                     # (rocBLAS kernel selection / first-call allocations)
+    r = eng.mp2_rhf(C, eps, nocc)
+    rows = N * (N + 1) // 2
+    flops = rows * (2.0 * o * N * N + 2.0 * o * N * v) + 2.0 * o * N * N * o * v + o * 2.0 * v * N * o * v
+    return {"E_MP2_Eh": r["E_MP2"], "seconds": r["seconds"], "flops": flops, "tflops": flops / r["seconds"] / 1e12,
+            "frac_of_fp64_matrix_peak": flops / r["seconds"] / FP64_MATRIX_PEAK_FLOPS,
+            "note": "ovov-only transformation on the stored (i >= j) rows: two batched GEMMs per row (ket half), unpack, two GEMMs (bra half), "
+                    "all through rocBLAS dgemm = v_mfma_f64_16x16x4_f64; flops = rows (2 o N^2 + 2 o N v) + 2 o^2 N^2 v + 2 o^2 v^2 N"}
 
 
 def scf_leg(eng, args, rank=0, world=1):

@@ -1,4 +1,5 @@
 """GPU: the Python face that mirrors the reference's module/function names (seams 1 and 2 of SURVEY.md section 8b)."""
+import os
 import numpy as np
 import pytest
 
@@ -113,3 +114,52 @@ def test_default_keywords_reproduce_reference_run(golden, line, tag, conv):
                 # ~1e-6 (they span very few independent directions) and the extrapolated iterate is noise-driven in the reference too
     np.testing.assert_allclose(out.table[:n, 1], ref[:n, 1], atol=1e-8)       # E_total per iteration
     np.testing.assert_allclose(out.table[:n, 6], ref[:n, 6], atol=1e-6)       # damping factors
+
+
+def _numbers_and_text(line):
+    """A printed line split into its words; numeric words as floats (compared with a tolerance), the rest verbatim."""
+    out = []
+    for w in line.split():
+        try:
+            out.append(float(w))
+        except ValueError:
+            out.append(w)
+    return out
+
+
+@pytest.mark.parametrize("tag", ["c1_h2_sto3g", "n2_ccpvdz", "c2_n2_ccpvtz", "c3_ar2_ccpvqz"])
+def test_printed_scf_block_matches_the_reference_text(tag):
+    """The text the reference prints around the SCF of a default single-point run -- criteria and convergence-acceleration lines, the
+    iteration table between its spacers, "converged in N cycles", the Hartree-Fock energy and the final energy line -- generated by
+    the reference's own format strings (tools/make_golden_text.py -> tests/golden/output_text.json) against what the same input line
+    prints here: same lines, same layout (column positions included), numbers within 2e-9 (1e-6 in the damping column)."""
+    import json
+    from tuna_amd import energy
+    path = os.path.join(os.path.dirname(__file__), "golden", "output_text.json")
+    gold = json.load(open(path))
+    if tag not in gold:
+        pytest.skip(f"{tag} not in output_text.json")
+    ref_lines = gold[tag]["lines"]
+    printed = []
+    energy.run(gold[tag]["input_line"], silent=False, log=lambda msg: printed.append(msg))
+    got = "\n".join(printed).split("\n")
+    start = next(k for k, l in enumerate(got) if l.startswith(" Beginning self-consistent field cycle"))
+    got = got[start:]
+    while ref_lines and ref_lines[-1] == "":
+        ref_lines = ref_lines[:-1]
+    while got and got[-1] == "":
+        got = got[:-1]
+    assert len(got) == len(ref_lines), ("\n".join(got), "\n".join(ref_lines))
+    for a, b in zip(got, ref_lines):
+        ta, tb = _numbers_and_text(a), _numbers_and_text(b)
+        assert len(ta) == len(tb), (a, b)
+        numeric = any(isinstance(x, float) for x in tb)
+        if not numeric:
+            assert a == b, (a, b)
+            continue
+        assert len(a) == len(b), (a, b)                       # same field widths
+        for k, (x, y) in enumerate(zip(ta, tb)):
+            if isinstance(y, float):
+                assert isinstance(x, float) and abs(x - y) <= (1.1e-3 if (len(tb) == 7 and k == 6) else 2e-9), (a, b)
+            else:
+                assert x == y, (a, b)

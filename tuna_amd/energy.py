@@ -238,7 +238,7 @@ def calculate_energy(symbols, R_bohr, calc: Calculation, engine: Engine | None =
                 log(f"  Opposite spin contribution:         {r['E_OS']:13.10f}")
                 log(f"\n  MP2 correlation energy:             {r['E_MP2']:13.10f}")
         if not silent:
-            log("\n Final single point energy: " + f"{out.energy:16.10f}")              # kernel:1305
+            log(" Final single point energy:        " + f"{out.energy:16.10f}")        # kernel:1305
         out.integrals = integrals if not own else None      # the device tensor dies with an engine we own
         return out
     finally:

@@ -150,6 +150,35 @@ def format_output_line(E_total, delta_E, max_DP, RMS_DP, damping_factor, step, c
 
 
 SCF_TABLE_HEADER = "  Step          E                 DE             RMS(DP)          MAX(DP)           Error       Damping"   # scf:1328
+BIG_SPACER = " " + "~" * 104                               # log_big_spacer, tuna_util.py:1101-1119
+SPACER = " " + "~" * 51                                    # log_spacer, tuna_util.py:1072-1090
+
+
+def log_cycle_header(calculation, o, log):
+    """What the reference prints before the first iteration (scf:1313-1329): criteria, convergence acceleration
+    (log_convergence_acceleration scf:118-166), title and column header between big spacers."""
+    log(" Beginning self-consistent field cycle...\n")
+    log(f" Using \"{o['conv']['name']}\" SCF convergence criteria.")
+    damping, static = o["damping"] != "none", o["damping"] == "static"
+    if o["diis"]:
+        tail = (", with static damping." if static else ", with dynamic damping.") if damping else "."
+        log(f" Using DIIS, storing {o['max_diis']} matrices, for convergence acceleration" + tail)
+    elif damping:
+        log(" Using static damping for convergence acceleration." if static else " Using dynamic damping for convergence acceleration.")
+    log("")
+    log(BIG_SPACER)
+    log("                                   Self-consistent Field Cycle Iterations")
+    log(BIG_SPACER)
+    log(SCF_TABLE_HEADER)
+    log(BIG_SPACER)
+
+
+def log_cycle_rows(r, log):
+    """One line per iteration (format_output_line scf:83-107), then the closing spacer and message of check_convergence (scf:324-330)."""
+    for row in r["table"]:
+        log(format_output_line(row[1], row[2], row[4], row[3], row[6], row[0], row[5]))
+    log(BIG_SPACER)
+    log(f"\n Self-consistent field converged in {r['n_iter']} cycles!\n")
 
 
 @dataclass
@@ -241,9 +270,7 @@ def run_self_consistent_field_cycle(molecule, calculation, integrals: Integrals,
     eng = eri.engine
     o = _opts(calculation)
     if not silent:
-        log(" Beginning self-consistent field cycle...\n")
-        log(f" Using \"{o['conv']['name']}\" SCF convergence criteria.")
-        log(SCF_TABLE_HEADER)
+        log_cycle_header(calculation, o, log)
     Fext = integrals.F + integrals.G
     import os
     if eng.world > 1 and not getattr(eng, "has_allreduce", False) and not os.environ.get("TUNA_AMD_HOST_SCF"):
@@ -261,9 +288,7 @@ def run_self_consistent_field_cycle(molecule, calculation, integrals: Integrals,
     else:
         r = _python_level_cycle(molecule, calculation, integrals, V_NN, X, P, E, o)
     if not silent:
-        for row in r["table"]:
-            log(format_output_line(row[1], row[2], row[4], row[3], row[6], row[0], row[5]))
-        log(f"\n Self-consistent field converged in {r['n_iter']} cycles!\n")
+        log_cycle_rows(r, log)
     c = r["components"]
     Pf, Cm, eps, F = r["P"], r["C"], r["epsilons"], r["F"]
     return Output(r["energy"], c[0], c[1], c[2], c[3], c[4], c[5], c[6], Pf, Pf / 2, Pf / 2, integrals.S, X, Cm, Cm, Cm, eps, eps, eps,
@@ -357,7 +382,7 @@ def _run_unrestricted(molecule, calculation, integrals, V_NN, X, guess_objects, 
     _, Pa, Pb, E = guess_objects
     o = _opts(calculation)
     if not silent:
-        log(SCF_TABLE_HEADER)
+        log_cycle_header(calculation, o, log)
     Fext = integrals.F + integrals.G
     try:
         r = eng.scf_uhf(integrals.S, integrals.T, integrals.V_NE, Pa, Pb, E, molecule.n_alpha, molecule.n_beta, V_NN, X=X,
@@ -368,9 +393,7 @@ def _run_unrestricted(molecule, calculation, integrals, V_NN, X, guess_objects, 
                 log(format_output_line(row[1], row[2], row[4], row[3], row[6], row[0], row[5]))
         raise
     if not silent:
-        for row in r["table"]:
-            log(format_output_line(row[1], row[2], row[4], row[3], row[6], row[0], row[5]))
-        log(f"\n Self-consistent field converged in {r['n_iter']} cycles!\n")
+        log_cycle_rows(r, log)
     c = r["components"]
     (Pa, Pb), (Ca, Cb), (Fa, Fb), (eps_a, eps_b) = r["P_spin"], r["C_spin"], r["F_spin"], r["epsilons_spin"]
     eps = np.concatenate((eps_a, eps_b))
@@ -419,7 +442,7 @@ def _python_level_unrestricted(molecule, calculation, integrals, V_NN, X, guess_
         return factor * P_old_spin + (1 - factor) * P_new, factor
 
     if not silent:
-        log(SCF_TABLE_HEADER)
+        log_cycle_header(calculation, o, log)
     for step in range(1, o["max_iter"] + 1):
         E_old, P_old, Pa_old, Pb_old = E, P, Pa, Pb
         Fa, Fb, Ja, Jb, Ka, Kb = construct_unrestricted_Fock_matrices(integrals, Pa, Pb, o["hfx"])
@@ -464,6 +487,7 @@ def _python_level_unrestricted(molecule, calculation, integrals, V_NN, X, guess_
             order = np.argsort(eps)
             C_all = np.concatenate((Ca, Cb), axis=1)[:, order]
             if not silent:
+                log(BIG_SPACER)
                 log(f"\n Self-consistent field converged in {step} cycles!\n")
             return Output(E + V_NN, comps[0], comps[1], comps[2], comps[3], comps[4], comps[5], comps[6], P, Pa, Pb, S, X, C_all, Ca, Cb,
                           eps[order], eps_a, eps_b, None, None, None, Fa, Fb, integrals.T, integrals.V_NE, integrals, 0, step,
