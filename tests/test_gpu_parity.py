@@ -369,3 +369,21 @@ def test_alternating_one_and_two_density_passes(engine, golden):
             assert np.abs(X - Y).max() < 1e-10
         J, K = engine.fock_jk(g["P_rand"])
         assert np.abs(J - g["J_rand"]).max() < 1e-10 and np.abs(K - g["K_rand"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("parts", [2, 3, 5])
+def test_cut_walks_give_the_same_fock_matrices(engine, golden, monkeypatch, parts):
+    """Several ranks cut the k walks of the Fock kernel into parts (shorter tasks: TF_JK_PARTS forces it on one rank): one plane of
+    column parts and of Jd per part, the segment of k == i in the last part -- same J and K, for one and for two densities."""
+    monkeypatch.setenv("TF_JK_PARTS", str(parts))
+    for tag in ("n2_ccpvdz", "c2_n2_ccpvtz"):
+        g = golden(tag)
+        atoms, shells, aos, nocc = make_system(tag)
+        engine.set_basis(aos).build_eri(True)
+        J, K = engine.fock_jk(g["P_rand"])
+        assert np.abs(J - g["J_rand"]).max() < 1e-10 and np.abs(K - g["K_rand"]).max() < 1e-10
+        P2 = np.stack([g["P_rand"], 0.5 * g["P_rand"] + 0.25 * np.diag(np.diag(g["P_rand"]))])
+        J2, K2 = engine.fock_jk(P2)
+        assert np.abs(J2[0] - J).max() < 1e-10 and np.abs(K2[0] - K).max() < 1e-10
+        J1, K1 = engine.fock_jk(P2[1])
+        assert np.abs(J2[1] - J1).max() < 1e-10 and np.abs(K2[1] - K1).max() < 1e-10

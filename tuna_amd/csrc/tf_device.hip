@@ -65,6 +65,7 @@ struct tf_ctx {
     // parity-blocked layout tables (tf_layout.hip.h), host mirror and device view
     struct HostLayout {
         int N = 0, NW = 0, RS = 0, MC = 1;
+        int KS = 1 << 30, MP = 1;                                  // steps per part and parts of a cut walk (several ranks: shorter tasks)
         int cstart[4] = {}, csize[4] = {}, corder[4] = {}, wfirst[5] = {}, fullsec[4][4] = {}, gbase[4] = {};
         long long cbase[4] = {}, NP[4] = {}, NPtot = 0, RLS = 0;
         std::vector<int> cls, loc, sigma, ao, origI, clsI, cntA, kap0, kapF, rpoff, chunk_c0, chunk_width, chunk_cls, chunk_of, gk;
@@ -88,6 +89,7 @@ struct tf_ctx {
         JKSuper *d_supers = nullptr;
         int *d_gfirst = nullptr;        // [2][N]: first / one-past-last group with i == a
         int n_groups = 0, n_tasks = 0, n_supers = 0, nseg = 1;
+        int bucket[4] = {0, 0, 0, 0};   // tasks [bucket[b], bucket[b + 1]) run with 4, 2, 1 waves per workgroup (b = 0, 1, 2)
         long long ypart_len = 0;
         JKJtPlan jp{};
     } jkt[2];
@@ -273,6 +275,17 @@ static int build_blocked_layout(tf_ctx *ctx, const std::vector<int> &cls)
     H.MC = 1;
     for (int b = 0; b < 4; ++b) H.MC = std::max(H.MC, H.wfirst[b + 1] - H.wfirst[b]);
     H.RS = H.MC * N;
+    {
+        // Several ranks: a rank has 1/world of the tasks but every task walks as long as before, so the longest walks bound the pass
+        // (N = 400, 8 ranks: 0.58 ms against 0.24 ms at perfect balance).  The walks are cut into MP parts of KS steps; the price is one
+        // plane of column parts (and of Jd) per part.
+        int parts = ctx->world >= 4 ? 4 : (ctx->world >= 2 ? 2 : 1);
+        if (const char *e = getenv("TF_JK_PARTS")) parts = std::max(1, std::min(8, atoi(e)));
+        int longest = 1;
+        for (int a = 0; a < 4; ++a) longest = std::max(longest, H.csize[a]);
+        H.MP = std::max(1, std::min(parts, longest));
+        H.KS = (longest + H.MP - 1) / H.MP;
+    }
     for (int c = 0; c < 4; ++c) {
         for (int w = 0; w < NW; ++w) {
             const int b = H.chunk_cls[w], a = b ^ c, lam0 = H.chunk_c0[w] - H.cstart[b];
@@ -806,15 +819,29 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         for (size_t si = 0; si < supers.size(); ++si)
             for (int w = 0; w < H.NW; ++w)
                 if (H.task_exists(supers[si].c, w, supers[si].i)) {
-                    tasks.push_back(JKTask{(int)si, w});
-                    steps.push_back(H.ke(H.chunk_cls[w] ^ supers[si].c, supers[si].i) - H.kap0[(size_t)supers[si].c * H.NW + w]);
+                    const int walk = H.ke(H.chunk_cls[w] ^ supers[si].c, supers[si].i) - H.kap0[(size_t)supers[si].c * H.NW + w];
+                    for (int part = 0; part * H.KS < walk; ++part) {
+                        tasks.push_back(JKTask{(int)si, w, part, 0});
+                        steps.push_back(std::min(H.KS, walk - part * H.KS));
+                    }
                 }
         {
+            // workgroups of 4, 2 or 1 waves (two groups per wave): a rank of several holds few groups per (i, class), and a wave without
+            // a group would only sit in the barriers of its workgroup and occupy a SIMD slot.  One launch per workgroup size; inside
+            // a launch longest first.
+            auto waves = [&](int t) { const int nwv = (supers[tasks[t].super].ng + 1) / 2; return nwv > 2 ? 4 : nwv; };
             std::vector<int> ord(tasks.size());
             std::iota(ord.begin(), ord.end(), 0);
-            std::stable_sort(ord.begin(), ord.end(), [&](int u, int v) { return steps[u] > steps[v]; });
+            std::stable_sort(ord.begin(), ord.end(), [&](int u, int v) { return waves(u) != waves(v) ? waves(u) > waves(v) : steps[u] > steps[v]; });
             std::vector<JKTask> sorted(tasks.size());
-            for (size_t t = 0; t < ord.size(); ++t) sorted[t] = tasks[ord[t]];
+            T.bucket[0] = 0; T.bucket[1] = T.bucket[2] = T.bucket[3] = (int)tasks.size();
+            for (size_t t = 0; t < ord.size(); ++t) {
+                sorted[t] = tasks[ord[t]];
+                const int wv = waves(ord[t]);
+                if (wv <= 2 && T.bucket[1] == (int)tasks.size()) T.bucket[1] = (int)t;
+                if (wv <= 1 && T.bucket[2] == (int)tasks.size()) T.bucket[2] = (int)t;
+            }
+            if (T.bucket[2] < T.bucket[1]) T.bucket[1] = T.bucket[2];
             tasks.swap(sorted);
         }
         int rc2;
@@ -1484,7 +1511,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // ---- J/K scratch
     const size_t nn = (size_t)N * N;
     // (sized for two densities per pass)
-    const int NWjk = packed ? std::max(1, H.NW) : 1;                // column chunks of jk_packed_kernel
+    const int NWjk = packed ? std::max(1, H.NW) * H.MP : 1;         // column chunks of jk_packed_kernel x parts of a walk
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     HIPCHK(ctx, hipMemset(ctx->d_Jrow, 0, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     if (packed) {
@@ -1501,7 +1528,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         // partial sums: [one-density pass | two-density pass], each [column parts | row parts] per density.  The passes have separate
         // regions (their groups differ), every region is zeroed once: the set of entries a pass writes does not depend on the density,
         // and the reductions rely on the entries no task writes being zero.
-        const size_t per_g = (size_t)(N + H.RS), nr1 = std::max<size_t>(1, (size_t)ctx->n_rows);
+        const size_t per_g = (size_t)N * H.MP + H.RS, nr1 = std::max<size_t>(1, (size_t)ctx->n_rows);
         const size_t di_doubles = ((size_t)std::max(1, ctx->jkt[0].n_groups) + 2 * (size_t)std::max(1, ctx->jkt[1].n_groups)) * per_g;
         const size_t dj_doubles = 3 * nr1 * per_g;
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, di_doubles * sizeof(double)));
@@ -1624,10 +1651,13 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
     const size_t ng = (size_t)std::max(1, T.n_groups);
     // layout of the partial arrays: [column parts of density 0 | .. density 1 | row parts of density 0 | .. density 1]
     JKStrides S{};
-    S.P = nn; S.Pp = npr; S.y = (size_t)T.ypart_len; S.Jd = nrows * NW;
-    S.DIc = ng * N; S.DIr = ng * (size_t)L.RS; S.DJc = nrows * N; S.DJr = nrows * (size_t)L.RS;
+    const int MP = ctx->hl.MP;
+    S.KS = ctx->hl.KS; S.MP = MP;
+    S.planeJd = nrows * NW; S.planeI = ng * N; S.planeJ = nrows * N;
+    S.P = nn; S.Pp = npr; S.y = (size_t)T.ypart_len; S.Jd = MP * S.planeJd;
+    S.DIc = MP * S.planeI; S.DIr = ng * (size_t)L.RS; S.DJc = MP * S.planeJ; S.DJr = nrows * (size_t)L.RS;
     // region of this pass type inside the partial buffers (tf_build_eri: [one-density pass | two-density pass])
-    const size_t per_g = (size_t)(N + L.RS);
+    const size_t per_g = (size_t)N * MP + L.RS;
     double *DI0 = ctx->d_DI + (ND == 2 ? (size_t)std::max(1, ctx->jkt[0].n_groups) * per_g : 0);
     double *DJ0 = ctx->d_DJ + (ND == 2 ? nrows * per_g : 0);
     double *DIc = DI0, *DIr = DI0 + ND * S.DIc, *DJc = DJ0, *DJr = DJ0 + ND * S.DJc;
@@ -1644,12 +1674,16 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
                 ctx->prof_used += 2;
             }
         }
-        hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)T.n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, T.d_groups,
-                           T.d_supers, T.d_tasks, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+        for (int b = 0; b < 3; ++b) {
+            const int t0 = T.bucket[b], t1 = T.bucket[b + 1];
+            if (t1 > t0)
+                hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)(t1 - t0)), dim3(64 * (TF_JKP_W >> b)), 0, st, ctx->d_eri, T.d_groups,
+                                   T.d_supers, T.d_tasks + t0, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+        }
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
     JKReduce R{};
-    R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.MC = ctx->hl.MC; R.nseg = T.nseg; R.jp = T.jp;
+    R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.MC = ctx->hl.MC; R.MP = MP; R.planeI = S.planeI; R.planeJ = S.planeJ; R.nseg = T.nseg; R.jp = T.jp;
     R.Jt = ctx->d_Jt; R.sJt = (size_t)T.nseg * npr;
     R.DIc = DIc; R.sDIc = S.DIc; R.DIr = DIr; R.sDIr = S.DIr; R.DJc = DJc; R.sDJc = S.DJc; R.DJr = DJr; R.sDJr = S.DJr;
     R.gfirst = T.d_gfirst; R.jptr = ctx->d_jptr; R.jrows = ctx->d_jrows;
@@ -1678,8 +1712,8 @@ static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double
         if (rc) return rc;
         const int nseg = ctx->jkt[1].nseg;
         for (int d = 0; d < 2; ++d)
-            hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, dD[d], dD[d], ctx->d_Jrow + d * nrows * NW,
-                               ctx->d_Jt + (size_t)d * nseg * npr, nseg, ctx->d_rowmap, L, dJ[d], dK[d]);
+            hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, dD[d], dD[d], ctx->d_Jrow + d * ctx->hl.MP * nrows * NW, nrows * NW,
+                               ctx->hl.KS, ctx->hl.MP, ctx->d_Jt + (size_t)d * nseg * npr, nseg, ctx->d_rowmap, L, dJ[d], dK[d]);
         return TF_OK;
     }
     for (int d = 0; d < nd; ++d)                                 // one density per pass over the packed tensor
@@ -1691,8 +1725,8 @@ static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double
         int rc = jk_packed_pass<1>(ctx, st, dDp);
         if (rc) return rc;
         if (general && pass == 0) continue;
-        hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, ctx->d_D, dD, ctx->d_Jrow, ctx->d_Jt, ctx->jkt[0].nseg, ctx->d_rowmap, L,
-                           dJ[d], dK[d]);
+        hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, ctx->d_D, dD, ctx->d_Jrow, nrows * NW, ctx->hl.KS, ctx->hl.MP, ctx->d_Jt,
+                           ctx->jkt[0].nseg, ctx->d_rowmap, L, dJ[d], dK[d]);
       }
     return TF_OK;
 }

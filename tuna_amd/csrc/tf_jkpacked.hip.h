@@ -67,10 +67,9 @@ struct JKGroup {
 };
 #define TF_JKP_W 4                // waves per workgroup, two groups each: their Jt partials are merged in LDS before they are written
 #define TF_JKP_KB 4               // k steps per merge block
-static_assert(TF_JKP_KB <= TF_JKP_W, "one wave per merged row");
 // up to 2 TF_JKP_W adjacent groups with the same i and class share one Jt partial (complete-row shape: NP[c] doubles at yoff)
 struct JKSuper { int g0, ng, c, i; long long yoff; int ke[4]; };   // ke[a] = cntA[a][i]: the rows reach the members kappa < ke[a] of class a
-struct JKTask { int super, w; };
+struct JKTask { int super, w, part, pad; };   // part: which stretch of KS steps of the walk (the walks are cut for several ranks: shorter tasks)
 
 __device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
 
@@ -412,13 +411,15 @@ template <int ND, int MODE>
 __device__ __forceinline__ void jkp_merge_jt(const JKWave &U, double2 *slots, int nw, int w, int lane, int kb, int k1)
 {
     jkp_lds_barrier();
-    const int kap = kb + w;
-    if (w < TF_JKP_KB && kap < k1) {
+    const int nwg = (int)(blockDim.x >> 6);                          // waves of this workgroup (4, 2 or 1): each merges every nwg-th step
+    for (int kk = w; kk < TF_JKP_KB; kk += nwg) {
+        const int kap = kb + kk;
+        if (kap >= k1) break;
         const KInfo ki = U.kinfo[kap];
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            double2 t = slots[((w * TF_JKP_W) * ND + d) * 64 + lane];
-            for (int u = 1; u < nw; ++u) { const double2 x = slots[((w * TF_JKP_W + u) * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
+            double2 t = slots[((kk * TF_JKP_W) * ND + d) * 64 + lane];
+            for (int u = 1; u < nw; ++u) { const double2 x = slots[((kk * TF_JKP_W + u) * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
             t.x = pair_step32(t.x, t.x); t.y = pair_step32(t.y, t.y);           // half 0 + half 1 (the same columns)
             if (lane < 32 && (MODE == JKP_FULL || U.lam0 + 2 * lane < ki.cnt))
                 buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), 16u * (unsigned)lane, 0u, t);
@@ -548,7 +549,8 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, JKLane<ND> &C, int NW,
 }
 
 // Strides (in doubles) between the arrays of density 0 and density 1 of a two-density pass
-struct JKStrides { size_t P, Pp, y, Jd, DIc, DIr, DJc, DJr; };
+struct JKStrides { size_t P, Pp, y, Jd, DIc, DIr, DJc, DJr;      // between the arrays of density 0 and density 1
+                   size_t planeJd, planeI, planeJ; int KS, MP; };  // between the column-part / Jd planes of the parts of a walk; steps per part, parts
 
 // One workgroup per task (super-group, chunk): wave w owns the groups g0 + 2w (half 0) and g0 + 2w + 1 (half 1), idle if the
 // super-group has fewer.  Only tasks with at least one step exist (kap0[c][w] < cntA[a][i]).  ND densities per pass: groups of
@@ -623,10 +625,13 @@ __global__ __launch_bounds__(64 * TF_JKP_W, TF_JKP_STAGES > 2 ? 1 : 2) void jk_p
 #pragma unroll
             for (int r = 0; r < RB; ++r) C.ppij[d * RB + r] = (r < C.nr) ? Pp[d * S.Pp + pij + r] : 0.0;
     }
-    const int kap0 = L.kap0[c * NW + t.w], ke = supers[t.super].ke[a];
-    const bool last = (a == L.clsI[gA.i]);
-    const int klim = ke - (last ? 1 : 0);
+    // the walk kap0 <= kappa < ke of (super-group, chunk), part t.part of it: KS steps; the segment of k == i belongs to the last part
+    const int kap00 = L.kap0[c * NW + t.w], ke = supers[t.super].ke[a];
+    const int kap0 = kap00 + t.part * S.KS, kend = min(ke, kap0 + S.KS);
+    const bool last = (a == L.clsI[gA.i]) && kend == ke;
+    const int klim = kend - (last ? 1 : 0);
     const int kd1 = min(max(L.kapF[c * NW + t.w], kap0), klim);
+    Jd += (size_t)t.part * S.planeJd; DIc += (size_t)t.part * S.planeI; DJc += (size_t)t.part * S.planeJ;   // column parts and Jd: one plane per part
     if (hasB && gA.nr == RB && gB.nr == RB)
         jkp_task<ND, true>(U, C, NW, t.w, lane, active, slots, nw, w, kap0, kd1, klim, last, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
     else
@@ -677,7 +682,8 @@ __device__ __forceinline__ double2 kd_vec(const double *__restrict__ colp, const
 }
 
 __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, const double *__restrict__ DIc, const double *__restrict__ DIr,
-                                                const double *__restrict__ DJc, const double *__restrict__ DJr, int N, int MC,
+                                                const double *__restrict__ DJc, const double *__restrict__ DJr, int N, int MC, int MP,
+                                                size_t planeI, size_t planeJ,
                                                 const int *__restrict__ gfirst, const int *__restrict__ jptr, const int *__restrict__ jrows,
                                                 double *__restrict__ D)
 {
@@ -696,6 +702,8 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, c
                 for (int u = 0; u < 4; ++u) {
                     const int g = g0 + 4 * u;
                     t[u] = (g < ge) ? kd_vec(DIc + (size_t)g * N, DIr + (size_t)g * RS, N, MC, yy, two) : make_double2(0.0, 0.0);
+                    for (int pl = 1; pl < MP; ++pl)                 // column parts of the further parts of a cut walk
+                        if (g < ge) { const double2 v = kd_vec(DIc + pl * planeI + (size_t)g * N, DIr, N, 0, yy, two); t[u].x += v.x; t[u].y += v.y; }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { acc.x += t[u].x; acc.y += t[u].y; }
@@ -707,6 +715,8 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, c
                     const int p = p0 + 4 * u;
                     const int r = (p < pe) ? jrows[p] : -1;
                     t[u] = (r >= 0) ? kd_vec(DJc + (size_t)r * N, DJr + (size_t)r * RS, N, MC, yy, two) : make_double2(0.0, 0.0);
+                    for (int pl = 1; pl < MP; ++pl)
+                        if (r >= 0) { const double2 v = kd_vec(DJc + pl * planeJ + (size_t)r * N, DJr, N, 0, yy, two); t[u].x += v.x; t[u].y += v.y; }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { acc.x += t[u].x; acc.y += t[u].y; }
@@ -731,7 +741,8 @@ struct JKReduce {
     double *Jt, *D[2];
     const JKSuper *supers;
     const int *gfirst, *jptr, *jrows;
-    int MC;                                              // slots of a row part vector: most chunks of one class
+    int MC, MP;                                          // slots of a row part vector: most chunks of one class; parts of a walk
+    size_t planeI, planeJ;                               // between the column-part planes of the parts
     JKJtPlan jp;
     size_t sy, sJt, sDIc, sDIr, sDJc, sDJr;              // strides between densities
     int nseg;
@@ -745,8 +756,8 @@ __global__ __launch_bounds__(256) void jk_reduce_kernel(JKReduce R, BLayout L)
     const int d = b / (nK + nJ);
     b -= d * (nK + nJ);
     if (b < nK)
-        kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, L.N, R.MC,
-                        R.gfirst, R.jptr, R.jrows, R.D[d]);
+        kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, L.N, R.MC, R.MP,
+                        R.planeI, R.planeJ, R.gfirst, R.jptr, R.jrows, R.D[d]);
     else {
         b -= nK;
         jt_reduce_block(b % gxJ, b / gxJ, R.nseg, R.ypart + d * R.sy, R.supers, R.jp, L, R.Jt + d * R.sJt);
@@ -756,7 +767,7 @@ __global__ __launch_bounds__(256) void jk_reduce_kernel(JKReduce R, BLayout L)
 // Original indices (a, b): K = D + D2^T (D2 = D for a symmetric density; for a general one D = D(P^T), D2 = D(P));
 // J[a][b] = sum over the chunks with a task of Jd[row(ab)] (owned rows) + sum_s Jt_s[pair(ab)]
 __global__ void jk_packed_final_kernel(const double *__restrict__ D, const double *__restrict__ D2, const double *__restrict__ Jd,
-                                       const double *__restrict__ Jt, int nseg, const int *__restrict__ rowmap, BLayout L,
+                                       size_t planeJd, int KS, int MP, const double *__restrict__ Jt, int nseg, const int *__restrict__ rowmap, BLayout L,
                                        double *__restrict__ J, double *__restrict__ K)
 {
     const int N = L.N, NW = L.NW;
@@ -775,7 +786,8 @@ __global__ void jk_packed_final_kernel(const double *__restrict__ D, const doubl
     double s = 0.0;
     if (r >= 0)
         for (int w = 0; w < NW; ++w)
-            if (L.kap0[c * NW + w] < L.cntA[(L.chunk_cls[w] ^ c) * N + shi]) s += Jd[(size_t)r * NW + w];
+            for (int pl = 0; pl < MP; ++pl)
+                if (L.kap0[c * NW + w] + pl * KS < L.cntA[(L.chunk_cls[w] ^ c) * N + shi]) s += Jd[pl * planeJd + (size_t)r * NW + w];
     for (int t = 0; t < nseg; ++t) s += Jt[(size_t)t * L.NPtot + q];
     J[e] = s;
 }
