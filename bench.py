@@ -358,7 +358,7 @@ def mp2_leg(eng, C, eps, nocc):
     flops = rows * (2.0 * o * N * N + 2.0 * o * N * v) + 2.0 * o * N * N * o * v + o * 2.0 * v * N * o * v
     return {"E_MP2_Eh": r["E_MP2"], "seconds": r["seconds"], "flops": flops, "tflops": flops / r["seconds"] / 1e12,
             "frac_of_fp64_matrix_peak": flops / r["seconds"] / FP64_MATRIX_PEAK_FLOPS,
-            "note": "ovov-only transformation on the stored (i >= j) rows: two batched GEMMs per row (ket half), unpack, two GEMMs (bra half), "
+            "note": "ovov-only transformation on the stored (i >= j) rows, each expanded to the symmetric matrix of its stored pairs (kl) <= (ij) -- the other half of the tensor is the transposed result: two batched GEMMs per row (ket half), unpack, two GEMMs (bra half), "
                     "all through rocBLAS dgemm = v_mfma_f64_16x16x4_f64; flops = rows (2 o N^2 + 2 o N v) + 2 o^2 N^2 v + 2 o^2 v^2 N"}
 
 

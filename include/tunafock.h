@@ -221,12 +221,17 @@ int tf_dft_clear(tf_ctx *ctx);
 
 /* out[p,q,r,s] = sum_{mu nu la si} C1[mu,p] C2[nu,q] C3[la,r] C4[si,s] (mu nu|la si)  -- chemists' (pq|rs), host out
  * [n1,n2,n3,n4]; C_k are [N, n_k] row-major host matrices (columns = orbitals).  With all four = the full MO matrix
- * this is transform_ERI_AO_to_MO (tuna_ci.py:204-255); every quarter step is an f64 GEMM (rocBLAS / MFMA). */
+ * this is transform_ERI_AO_to_MO (tuna_ci.py:204-255); every quarter step is an f64 GEMM (rocBLAS / MFMA).
+ * Packed layout: a stored row holds the pairs (la si) <= (mu nu); it is transformed as it lies (one read of every stored value,
+ * own rows only) and the other half of the tensor is the transposed result -- two transformations unless (C1, C2) = (C3, C4).
+ * world > 1: every rank transforms the rows it owns and the hook of tf_set_allreduce sums the result (all ranks call; without
+ * the hook the call is refused, TF_EINVAL). */
 int tf_ao_to_mo(tf_ctx *ctx, int n1, const double *C1, int n2, const double *C2, int n3, const double *C3, int n4, const double *C4,
                 double *out);
 /* Restricted MP2 correlation energy components from canonical orbitals C [N,N], eps [N] (tuna_mp.py:834-906, energy part):
  * *e_os = sum g^2/D, *e_ss = sum g (g - g^T_ab)/D over (ia|jb) with i,j in [n_frozen, n_occ), a,b >= n_occ;
- * E_MP2 = e_os + e_ss.  seconds (may be NULL): wall time of transform + energy. */
+ * E_MP2 = e_os + e_ss.  seconds (may be NULL): wall time of transform + energy.  world > 1: as tf_ao_to_mo (one all-reduce of
+ * the (ia|jb) block, then every rank evaluates the same sums). */
 int tf_mp2_rhf(tf_ctx *ctx, int n_occ, int n_frozen, const double *C, const double *eps, double *e_os, double *e_ss, double *seconds);
 
 /* eps[N], C[N,N] = eigenpairs of the Fock matrix in the orthogonalised basis, C = X C' (diagonalise_Fock_matrix,

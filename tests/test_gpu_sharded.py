@@ -139,6 +139,65 @@ def test_native_scf_cycle_on_a_sharded_tensor(kind, tag, golden, uhf_golden):
         np.testing.assert_allclose(res[0][3][:n, 6], ref_table[:n, 6], atol=1e-6)    # damping factors
 
 
+def _rank_mp2(rank, world, port, tag, layout, ret):
+    """One rank of an RMP2 / AO->MO transformation on a sharded tensor: every rank transforms the rows it owns, one all-reduce of the
+    transformed tensor (the hook of attach_allreduce)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import make_system
+        from tuna_amd import distributed as tdist
+        from tuna_amd.engine import Engine
+        gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "mp2_systems.npz"))
+        g = {k.split("__", 1)[1]: gold[k] for k in gold.files if k.startswith(tag + "__")}
+        atoms, shells, aos, nocc = make_system({"n2_sto3g": "n2_sto3g", "n2_ccpvdz": "n2_ccpvdz", "c5_n2_ccpvtz": "c2_n2_ccpvtz"}[tag])
+        with Engine(0, rank, world) as eng:
+            eng.set_basis(aos).build_eri(True, layout=layout)
+            try:
+                eng.mp2_rhf(g["C"], g["eps"], nocc)
+                refused = False
+            except Exception as e:                                   # partial sums must not be returned as the result
+                refused = "tf_set_allreduce" in str(e)
+            tdist.attach_allreduce(eng)
+            r = eng.mp2_rhf(g["C"], g["eps"], nocc)
+            rng = np.random.default_rng(3)
+            N = eng.N
+            Cs = [rng.standard_normal((N, n)) for n in (2, 3, 4, 2)]
+            mixed = eng.ao_to_mo(*Cs)
+            same = eng.ao_to_mo(g["C"]) if N <= 30 else None
+            ret[rank] = (refused, r["E_OS"], r["E_SS"], mixed, same)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag,layout", [("n2_sto3g", "packed"), ("n2_ccpvdz", "packed"), ("n2_ccpvdz", "rows"), ("c5_n2_ccpvtz", "packed")])
+def test_mp2_on_a_sharded_tensor(tag, layout, engine, mp2_golden):
+    """RMP2 (BASELINE config 5) and a mixed-block AO->MO transformation with the tensor split over two ranks equal the reference's
+    values and the one-GPU transformation."""
+    import torch.multiprocessing as mp
+    from conftest import make_system
+    world = 2
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rank_mp2, args=(world, _free_port(), tag, layout, ret), nprocs=world, join=True)
+        res = dict(ret)
+    assert set(res) == {0, 1}
+    g = mp2_golden[tag]
+    atoms, shells, aos, nocc = make_system({"n2_sto3g": "n2_sto3g", "n2_ccpvdz": "n2_ccpvdz", "c5_n2_ccpvtz": "c2_n2_ccpvtz"}[tag])
+    engine.set_basis(aos).build_eri(True)
+    rng = np.random.default_rng(3)
+    Cs = [rng.standard_normal((engine.N, n)) for n in (2, 3, 4, 2)]
+    one_gpu = engine.ao_to_mo(*Cs)
+    for rank, (refused, e_os, e_ss, mixed, same) in res.items():
+        assert refused
+        assert abs(e_os - float(g["E_OS"])) < 1e-10 and abs(e_ss - float(g["E_SS"])) < 1e-10
+        assert np.abs(mixed - one_gpu).max() < 1e-11 * max(1.0, np.abs(one_gpu).max())
+        if same is not None:
+            idx = g["mo_idx"]
+            assert np.abs(same[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] - g["mo_val"]).max() < 1e-11
+
+
 def test_jk_kernel_variants_agree(golden):
     """jk_rows_kernel<NLC,JB,ND> instantiations that production sizes on one GPU never select (NLC = 2, 4: N > 512) must give
     the same J/K bit for bit as the default one on a small tensor (TF_JK_FORCE_NLC / TF_JK_FORCE_JB test hooks)."""

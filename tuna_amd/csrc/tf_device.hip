@@ -2094,20 +2094,56 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     std::string msg;
     int rc = tfscf::ensure(ctx->scf, N, 6, msg);
     if (rc) { ctx->err = msg; return rc; }
-    double *dC[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (ctx->world > 1 && !ctx->allreduce)
+        TF_FAIL(ctx, TF_EINVAL, "AO->MO transformation of a sharded tensor (world > 1) needs the all-reduce hook (tf_set_allreduce)");
+    const bool packed = ctx->layout == 1;
+    double *dC[4] = {nullptr, nullptr, nullptr, nullptr}, *dG[2] = {nullptr, nullptr};
     const double *hC[4] = {C1, C2, C3, C4};
     const int nk[4] = {n1, n2, n3, n4};
+    const size_t total = (size_t)n1 * n2 * n3 * n4;
+    // packed rows hold the pairs (kl) <= (ij): out[pq][rs] = G(C1 C2 C3 C4)[pq][rs] + G(C3 C4 C1 C2)[rs][pq]; one transformation
+    // serves both terms when the two coefficient pairs are the same matrices ((ia|jb), (pq|rs) with one C)
+    const bool same_pairs = n1 == n3 && n2 == n4 && std::memcmp(C1, C3, (size_t)N * n1 * sizeof(double)) == 0 &&
+                            std::memcmp(C2, C4, (size_t)N * n2 * sizeof(double)) == 0;
+    double secs = 0.0;
+    auto cleanup = [&]() { for (int k = 0; k < 4; ++k) if (dC[k]) (void)hipFree(dC[k]); for (int k = 0; k < 2; ++k) if (dG[k]) (void)hipFree(dG[k]); };
+    auto fail = [&](int code, const std::string &m) { ctx->err = m; cleanup(); if (*d_out) { (void)hipFree(*d_out); *d_out = nullptr; } return code; };
+    *d_out = nullptr;
     for (int k = 0; k < 4; ++k) {
-        HIPCHK(ctx, hipMalloc((void **)&dC[k], (size_t)N * nk[k] * sizeof(double)));
-        HIPCHK(ctx, hipMemcpy(dC[k], hC[k], (size_t)N * nk[k] * sizeof(double), hipMemcpyHostToDevice));
+        if (hipMalloc((void **)&dC[k], (size_t)N * nk[k] * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+        if (hipMemcpy(dC[k], hC[k], (size_t)N * nk[k] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation: copy failed");
     }
-    HIPCHK(ctx, hipMalloc((void **)d_out, (size_t)n1 * n2 * n3 * n4 * sizeof(double)));
-    rc = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, ctx->layout == 1 ? ctx->d_rowoff : nullptr, ctx->d_rowsec, ctx->bl,
-                          ctx->d_row_ij, ctx->n_rows, N, ctx->ld, dC[0], n1, dC[1], n2, dC[2], n3, dC[3], n4,
-                          *d_out, seconds, msg);
-    for (int k = 0; k < 4; ++k) (void)hipFree(dC[k]);
-    if (rc) { ctx->err = msg; (void)hipFree(*d_out); *d_out = nullptr; }
-    return rc;
+    if (hipMalloc((void **)d_out, total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+    auto run = [&](int a, int b, int c, int d, double *dst) {
+        double s1 = 0.0;
+        int r = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, packed ? ctx->d_rowoff : nullptr, ctx->d_rowsec, ctx->bl, ctx->hl.RLS,
+                                 ctx->d_row_ij, ctx->n_rows, N, ctx->ld, dC[a], nk[a], dC[b], nk[b], dC[c], nk[c], dC[d], nk[d], dst, &s1, msg);
+        secs += s1;
+        return r;
+    };
+    if (!packed) {
+        if ((rc = run(0, 1, 2, 3, *d_out))) return fail(rc, msg);
+    } else {
+        if (hipMalloc((void **)&dG[0], total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+        if ((rc = run(0, 1, 2, 3, dG[0]))) return fail(rc, msg);
+        if (!same_pairs) {
+            if (hipMalloc((void **)&dG[1], total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+            if ((rc = run(2, 3, 0, 1, dG[1]))) return fail(rc, msg);
+        }
+        const long long A = (long long)n1 * n2, B = (long long)n3 * n4;
+        hipLaunchKernelGGL(add_transposed_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)((A + 31) / 32)), dim3(32, 8), 0, 0, dG[0],
+                           same_pairs ? dG[0] : dG[1], A, B, *d_out);
+        if (hipGetLastError() != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation: launch failed");
+    }
+    if (ctx->world > 1) {                                   // every rank transformed its own rows: the sum is the tensor
+        if (hipDeviceSynchronize() != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation failed on the device");
+        const int arc = ctx->allreduce(ctx->allreduce_user, *d_out, (long long)total, nullptr);
+        if (arc) return fail(TF_ENODEVICE, "AO->MO transformation: the all-reduce hook failed (code " + std::to_string(arc) + ")");
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation failed on the device");
+    cleanup();
+    if (seconds) *seconds = secs;
+    return TF_OK;
 }
 
 int tf_ao_to_mo(tf_ctx *ctx, int n1, const double *C1, int n2, const double *C2, int n3, const double *C3, int n4, const double *C4,
@@ -2115,7 +2151,6 @@ int tf_ao_to_mo(tf_ctx *ctx, int n1, const double *C1, int n2, const double *C2,
 {
     if (!ctx) return TF_EINVAL;
     if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_ao_to_mo: call tf_build_eri first");
-    if (ctx->world != 1) TF_FAIL(ctx, TF_EINVAL, "tf_ao_to_mo: the tensor must be on one GPU (world = 1) in this build");
     if (n1 < 1 || n2 < 1 || n3 < 1 || n4 < 1 || !C1 || !C2 || !C3 || !C4 || !out) TF_FAIL(ctx, TF_EINVAL, "tf_ao_to_mo: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     double *d_out = nullptr;
@@ -2131,7 +2166,6 @@ int tf_mp2_rhf(tf_ctx *ctx, int n_occ, int n_frozen, const double *C, const doub
 {
     if (!ctx) return TF_EINVAL;
     if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_mp2_rhf: call tf_build_eri first");
-    if (ctx->world != 1) TF_FAIL(ctx, TF_EINVAL, "tf_mp2_rhf: the tensor must be on one GPU (world = 1) in this build");
     const int N = ctx->N;
     if (!C || !eps || !e_os || !e_ss || n_frozen < 0 || n_occ <= n_frozen || n_occ >= N) TF_FAIL(ctx, TF_EINVAL, "tf_mp2_rhf: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));

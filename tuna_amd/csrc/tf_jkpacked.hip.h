@@ -901,6 +901,50 @@ __global__ void sample_packed_kernel(const double *__restrict__ eri, const int *
     out[q] = packed_element(eri, rowmap, rowoff, rowsec, L, idx[4 * q], idx[4 * q + 1], idx[4 * q + 2], idx[4 * q + 3]);
 }
 
+// The stored part of local rows as symmetric matrices, for the GEMM-shaped consumers (AO->MO).  With L the tensor restricted to the
+// pairs (kl) <= (ij) (its diagonal (kl) == (ij) halved), (ij|kl) = L + L^T in the pair indices: every stored value is read once, from
+// its own row, and a rank needs nothing but its own rows.  out[r - r0][k][l] = out[r - r0][l][k] = L[(ij), (kl)] for the pairs the row
+// holds; the caller has zeroed out.  ORIGINAL indices, leading dimension ld.  Grid: (ceil(max NP / 256), rows of the slab).
+__global__ void unpack_own_rows_kernel(const double *__restrict__ eri, const long long *__restrict__ rowoff, const int *__restrict__ rowsec,
+                                       BLayout L, const int2 *__restrict__ row_ij, long long r0, int ld, double *__restrict__ out)
+{
+    const long long r = r0 + blockIdx.y;
+    const int2 ij = row_ij[r];
+    const int wi = L.ao[ij.x], wj = L.ao[ij.y];
+    const int c = ao_cls(wi) ^ ao_cls(wj), iI = ao_sigma(L, wi), lamj = ao_loc(wj);
+    const int x = blockIdx.x * 256 + threadIdx.x;                            // pair index inside a complete class-c row
+    if (x >= bl_np(L, c)) return;
+    const int kI = L.gk[bl_gbase(L, c) + x / TF_SEG_PAD];
+    const int a = L.clsI[kI];
+    const KInfo ki = L.kinfo[(size_t)c * L.N + kI];
+    const int lam = x - bl_fullsec(L, c, a) - ki.offA;
+    if (lam >= ki.cnt || kI - bl_cstart(L, a) >= L.cntA[(size_t)a * L.N + iI] || (kI == iI && lam > lamj)) return;   // padding; k > i; (kl) > (ij)
+    const int *rs = rowsec + 6 * (size_t)r;
+    const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);
+    double v = eri[rowoff[r] + (long long)rs[5] * (rs[a] + ki.offA) + (long long)rs[4] * pc + lam];
+    if (kI == iI && lam == lamj) v *= 0.5;
+    const int k = L.origI[kI], l = L.origI[bl_cstart(L, a ^ c) + lam];
+    double *__restrict__ o = out + (size_t)blockIdx.y * L.N * ld;
+    o[(size_t)k * ld + l] = v;
+    o[(size_t)l * ld + k] = v;
+}
+
+// out[x][y] = G1[x][y] + G2[y][x]   (x < A, y < B; G1 [A][B], G2 [B][A]): the two halves L and L^T of a transformed tensor
+__global__ void add_transposed_kernel(const double *__restrict__ G1, const double *__restrict__ G2, long long A, long long B, double *__restrict__ out)
+{
+    __shared__ double tile[32][33];
+    const long long x0 = (long long)blockIdx.y * 32, y0 = (long long)blockIdx.x * 32;
+    for (int t = threadIdx.y; t < 32; t += blockDim.y) {                     // tile of G2: rows y0.., columns x0..
+        const long long y = y0 + t, x = x0 + threadIdx.x;
+        tile[t][threadIdx.x] = (y < B && x < A) ? G2[y * A + x] : 0.0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.y; t < 32; t += blockDim.y) {
+        const long long x = x0 + t, y = y0 + threadIdx.x;
+        if (x < A && y < B) out[x * B + y] = G1[x * B + y] + tile[threadIdx.x][t];
+    }
+}
+
 // full rows for the GEMM-shaped consumers (AO->MO): out[r - r0][k][l] (leading dimension ld, ORIGINAL indices) for local rows
 // r0 <= r < r0 + nb; row_ij holds the original (i, j) of every local row
 __global__ void unpack_full_rows_kernel(const double *__restrict__ eri, const int *__restrict__ rowmap, const long long *__restrict__ rowoff,

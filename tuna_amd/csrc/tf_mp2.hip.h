@@ -3,10 +3,12 @@
 // GEMM through rocBLAS (MFMA f64 on gfx950).
 // Reference: transform_ERI_AO_to_MO tuna_ci.py:204-255 (four einsums over the dense N^4 tensor),
 //            build_doubles_epsilons_tensor tuna_ci.py:304-334, run_restricted_MP2 tuna_mp.py:834-906 (energy part).
-// Layout trick: the stored tensor keeps rows (mu >= nu) x full [lambda][sigma], so the ket half-transformation
+// The stored tensor keeps rows (mu >= nu), so the ket half-transformation
 //     Q[mu nu][r s] = sum_{lambda sigma} C3[lambda r] (mu nu|lambda sigma) C4[sigma s]
-// is two strided-batched GEMMs with one stored row per batch entry (each stored byte is read once), and the bra half is
-// two more GEMMs on the unpacked Q.
+// is two strided-batched GEMMs with one stored row per batch entry, and the bra half is two more GEMMs on the unpacked Q.
+// Rows layout: a row is the full [lambda][sigma] matrix.  Packed layout: a row holds the pairs (lambda sigma) <= (mu nu) only; it is
+// expanded to a symmetric matrix of that part, and the other half of the tensor comes from the transposed result (see transform()).
+// Each stored value is read once and only from its own row, so a sharded tensor transforms rank by rank (sum = all-reduce).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
@@ -77,9 +79,12 @@ __global__ void mp2_energy_kernel(const double *__restrict__ g, const double *__
 
 // out[p][q][r][s] = sum C1[mu p] C2[nu q] C3[la r] C4[si s] (mu nu|la si); C_k are [N, n_k] row-major DEVICE matrices;
 // d_out [n1,n2,n3,n4] on the device.  Rows of the stored tensor are processed in slabs to bound the scratch.
-// Packed layout (d_rowoff != nullptr): the rows of a slab are first materialised as full [N][ld] matrices (unpack_full_rows_kernel).
+// Packed layout (d_rowoff != nullptr): the STORED part of every row of a slab is materialised as a symmetric [N][ld] matrix
+// (unpack_own_rows_kernel), so d_out is the transform of L, the tensor restricted to (kl) <= (ij) with its diagonal halved; the caller
+// completes it with the transform of L^T (mo_transform_device: G(C1 C2 C3 C4)[pq][rs] + G(C3 C4 C1 C2)[rs][pq]).  Either way the
+// result is linear in the rows a rank owns: the sum over ranks is the transformed tensor.
 inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowmap, const long long *d_rowoff, const int *d_rowsec,
-                     const BLayout &BL, const int2 *d_row_ij, long long n_rows, int N, int ld, const double *dC1, int n1, const double *dC2, int n2, const double *dC3, int n3,
+                     const BLayout &BL, long long max_np, const int2 *d_row_ij, long long n_rows, int N, int ld, const double *dC1, int n1, const double *dC2, int n2, const double *dC3, int n3,
                      const double *dC4, int n4, double *d_out, double *gemm_seconds, std::string &msg)
 {
     int rc = TF_OK;
@@ -95,7 +100,7 @@ inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowm
     TFM_HIP(hipEventCreate(&e0));
     TFM_HIP(hipEventCreate(&e1));
     if (packed) {
-        slab = std::max<long long>(1, std::min<long long>(slab, (long long)((2048LL << 20) / (row_len * (long long)sizeof(double)))));
+        slab = std::max<long long>(1, std::min<long long>(std::min<long long>(slab, 65535), (long long)((2048LL << 20) / (row_len * (long long)sizeof(double)))));
         TFM_HIP(hipMalloc((void **)&dM, (size_t)slab * row_len * sizeof(double)));
     }
     TFM_HIP(hipMalloc((void **)&dR, (size_t)slab * n3 * N * sizeof(double)));
@@ -105,9 +110,9 @@ inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowm
         const int nb = (int)std::min<long long>(slab, n_rows - r0);
         const double *Mrows = d_eri + r0 * row_len;
         if (packed) {
-            const long long tot = (long long)nb * row_len;
-            hipLaunchKernelGGL(unpack_full_rows_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 1 << 20)), dim3(256), 0, 0, d_eri,
-                               d_rowmap, d_rowoff, d_rowsec, BL, d_row_ij, r0, nb, ld, dM);
+            TFM_HIP(hipMemsetAsync(dM, 0, (size_t)nb * row_len * sizeof(double), 0));
+            hipLaunchKernelGGL(unpack_own_rows_kernel, dim3((unsigned)((max_np + 255) / 256), (unsigned)nb), dim3(256), 0, 0, d_eri, d_rowoff,
+                               d_rowsec, BL, d_row_ij, r0, ld, dM);
             Mrows = dM;
         }
         // R[row] (n3 x N, row-major) = C3^T (n3 x N) * M[row] (N x N, ld)
