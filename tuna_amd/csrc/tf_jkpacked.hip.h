@@ -945,19 +945,4 @@ __global__ void add_transposed_kernel(const double *__restrict__ G1, const doubl
     }
 }
 
-// full rows for the GEMM-shaped consumers (AO->MO): out[r - r0][k][l] (leading dimension ld, ORIGINAL indices) for local rows
-// r0 <= r < r0 + nb; row_ij holds the original (i, j) of every local row
-__global__ void unpack_full_rows_kernel(const double *__restrict__ eri, const int *__restrict__ rowmap, const long long *__restrict__ rowoff,
-                                        const int *__restrict__ rowsec, BLayout L, const int2 *__restrict__ row_ij, long long r0, int nb, int ld,
-                                        double *__restrict__ out)
-{
-    const int N = L.N;
-    const long long per = (long long)N * ld, total = (long long)nb * per;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const long long rr = e / per;
-        const int rem = (int)(e - rr * per);
-        const int k = rem / ld, l = rem - k * ld;
-        const int2 ij = row_ij[r0 + rr];
-        out[e] = (l < N) ? packed_element(eri, rowmap, rowoff, rowsec, L, ij.x, ij.y, k, l) : 0.0;
-    }
 }
