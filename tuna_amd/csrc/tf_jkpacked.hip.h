@@ -944,5 +944,3 @@ __global__ void add_transposed_kernel(const double *__restrict__ G1, const doubl
         if (x < A && y < B) out[x * B + y] = G1[x * B + y] + tile[threadIdx.x][t];
     }
 }
-
-}
