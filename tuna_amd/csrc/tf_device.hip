@@ -861,7 +861,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     {
         // the tensor buffer is kept across builds (geometry scans rebuild a tensor of the same size); it is replaced when it is
         // too small or more than twice too large
+#ifdef TF_ABL_ALLVALID
+        const size_t need = std::max<size_t>(1, (size_t)ctx->n_elems * sizeof(double)) + (4u << 20);
+#else
         const size_t need = std::max<size_t>(1, (size_t)ctx->n_elems * sizeof(double));
+#endif
         if (ctx->d_eri && (ctx->eri_cap < need || ctx->eri_cap > 2 * need + (64u << 20))) {
             (void)hipFree(ctx->d_eri);
             ctx->d_eri = nullptr; ctx->eri_cap = 0;
@@ -874,7 +878,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
     if (packed) {
         if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, rowsec, &ctx->d_rowsec, false)) ||
-            (rc = build_jk_tables(TF_JKP_JBB, ctx->jkt[0])) || (rc = build_jk_tables(TF_JKP_JBB / 2, ctx->jkt[1])))
+            (rc = build_jk_tables(JKShape<1>::RB, ctx->jkt[0])) || (rc = build_jk_tables(JKShape<2>::RB, ctx->jkt[1])))
             return rc;
         ctx->db.bl = ctx->bl;
         ctx->db.RLS = H.RLS;

@@ -38,7 +38,17 @@
 #include <hip/hip_runtime.h>
 #include "tf_layout.hip.h"
 
-#define TF_JKP_JBB 8
+#define TF_JKP_JBB 8               // rows of a storage unit (and the largest row group)
+#ifndef TF_JKP_VR1
+#define TF_JKP_VR1 8               // rows of a group in a one-density pass: 8 (251 VGPRs, 2 waves per SIMD) or 4 (151 VGPRs, 3 waves per
+                                   // SIMD, twice the steps: measured the same 2.1 ms at N = 400)
+#endif
+#ifndef TF_JKP_OCC4
+#define TF_JKP_OCC4 3              // waves per SIMD the 4-row shape is compiled for (4: 128 VGPRs with 41 spilled, 2.4 ms)
+#endif
+template <int ND> struct JKShape {           // virtual rows v = d * RB + r of a pass: RB tensor rows times ND densities
+    static constexpr int VR = ND == 1 ? TF_JKP_VR1 : 8, RB = VR / ND;
+};
 #define TF_JKP_CW 64             // columns per chunk (2 per lane of a half wave)
 #define TF_JKP_SEG 16            // segments of the super-group lists in the Jt reduction
 #ifndef TF_JKP_STAGES
@@ -248,23 +258,23 @@ struct JKLane {
     int nr, lamj0, r0, g;                // rows of this half's group (0: none), loc of its first j, its first local row, its index
     unsigned xrow;                       // byte offset of X[j0][0]
     unsigned djoff, dioff;               // byte offsets of the group's row parts of this chunk from U.DJr / U.DIr
-    double ppij[TF_JKP_JBB];             // Pp_d[(i, j_r)] by virtual row
-    double2 pil[ND], pjl[TF_JKP_JBB];    // P_d[i][l];  P_d[j_r][l] by virtual row
-    double2 colI[ND], colJ[TF_JKP_JBB];  // D_d[i][l], D_d[j_r][l] accumulators
+    double ppij[JKShape<ND>::VR];             // Pp_d[(i, j_r)] by virtual row
+    double2 pil[ND], pjl[JKShape<ND>::VR];    // P_d[i][l];  P_d[j_r][l] by virtual row
+    double2 colI[ND], colJ[JKShape<ND>::VR];  // D_d[i][l], D_d[j_r][l] accumulators
 };
 
 enum { JKP_DIAG = 1, JKP_FULL = 2 };
 
 // The values a lane needs from the segment of AO k: the tensor elements of its two columns and Pp_d[kl]; cnt = stored values.
 template <int ND>
-struct JKLoad { double2 m[TF_JKP_JBB / ND], pp[ND]; int cnt; };
+struct JKLoad { double2 m[JKShape<ND>::RB], pp[ND]; int cnt; };
 
 // MODE FULL: every lane has l < k (no masks); DIAG: a pair is present iff lam < cnt (the slot after an odd count reads 0).
 // ALLR: both halves have a group with all RB rows.
 template <int ND, bool ALLR, int MODE>
 __device__ __forceinline__ void jkp_load(JKLoad<ND> &L, const JKLane<ND> &C, const JKWave &U, int kap)
 {
-    constexpr int RB = TF_JKP_JBB / ND;
+    constexpr int RB = JKShape<ND>::RB;
     const KInfo ki = U.kinfo[kap];
     const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);          // padded segment: the rows of a unit follow each other at this stride
     L.cnt = ki.cnt;
@@ -274,9 +284,19 @@ __device__ __forceinline__ void jkp_load(JKLoad<ND> &L, const JKLane<ND> &C, con
     // No branches around the loads (one basic block per step lets the compiler count the loads in flight exactly; with a branch per
     // load it waits for ALL of them at every step and nothing is prefetched): a lane without a value loads from an offset beyond the
     // descriptor's range, which the buffer unit answers with zeros without touching memory.
+#ifdef TF_ABL_ALLVALID
+    const unsigned voff = 16u * (unsigned)C.q + (C.h ? d1 : 0u);      // (timing experiment only: every lane of every row loads)
+#define TF_ABL_ROWOK(r) true
+#else
     const unsigned voff = v ? 16u * (unsigned)C.q + (C.h ? d1 : 0u) : TF_BUF_OOB;
+#define TF_ABL_ROWOK(r) (ALLR || (r) < C.nr)
+#endif
 #pragma unroll
-    for (int r = 0; r < RB; ++r) L.m[r] = buf_load2<2>(rt, (ALLR || r < C.nr) ? voff : TF_BUF_OOB, 8u * (unsigned)(r * pc));
+#ifdef TF_ABL_NOTENSOR
+    for (int r = 0; r < RB; ++r) L.m[r] = make_double2(C.ppij[r] + (double)kap, C.ppij[r] - (double)voff);
+#else
+    for (int r = 0; r < RB; ++r) L.m[r] = buf_load2<2>(rt, TF_ABL_ROWOK(r) ? voff : TF_BUF_OOB, 8u * (unsigned)(r * pc));
+#endif
     const long long bk = (long long)ki.offA + U.lam0;
 #pragma unroll
     for (int d = 0; d < ND; ++d) L.pp[d] = buf_load2<0>(buf_rsrc(U.Pp + d * U.NPtot + bk), v ? 16u * (unsigned)C.q : TF_BUF_OOB, 0u);
@@ -285,10 +305,10 @@ __device__ __forceinline__ void jkp_load(JKLoad<ND> &L, const JKLane<ND> &C, con
 // part 1: everything that needs only the lane's own P values (Jd, Jt, the row sums); part 2: the column sums, which need
 // P[j_r][k] (per half: a broadcast vector load issued before part 1) and the wave-uniform P[i][k] (scalar unit).
 template <int ND>
-__device__ __forceinline__ void jkp_row1(const JKLane<ND> &C, const JKLoad<ND> &L, double (&jd)[TF_JKP_JBB],
-                                         double (&rJ)[TF_JKP_JBB], double (&rI)[ND], double2 (&jt)[ND])
+__device__ __forceinline__ void jkp_row1(const JKLane<ND> &C, const JKLoad<ND> &L, double (&jd)[JKShape<ND>::VR],
+                                         double (&rJ)[JKShape<ND>::VR], double (&rI)[ND], double2 (&jt)[ND])
 {
-    constexpr int RB = TF_JKP_JBB / ND;
+    constexpr int RB = JKShape<ND>::RB;
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
         jt[d] = make_double2(0.0, 0.0);
@@ -307,9 +327,9 @@ __device__ __forceinline__ void jkp_row1(const JKLane<ND> &C, const JKLoad<ND> &
 }
 
 template <int ND, int MODE>
-__device__ __forceinline__ void jkp_row2(JKLane<ND> &C, const JKLoad<ND> &L, const JKWave &U, const double (&pjk)[TF_JKP_JBB], const double (&pik)[ND])
+__device__ __forceinline__ void jkp_row2(JKLane<ND> &C, const JKLoad<ND> &L, const JKWave &U, const double (&pjk)[JKShape<ND>::VR], const double (&pik)[ND])
 {
-    constexpr int RB = TF_JKP_JBB / ND;
+    constexpr int RB = JKShape<ND>::RB;
     const int lim = L.cnt - U.cm;                           // columns strictly below k (the pair (k,k) has no column term)
     const double o0 = (MODE == JKP_FULL || C.lam < lim) ? 1.0 : 0.0, o1 = (MODE == JKP_FULL || C.lam + 1 < lim) ? 1.0 : 0.0;
 #pragma unroll
@@ -326,15 +346,19 @@ __device__ __forceinline__ void jkp_row2(JKLane<ND> &C, const JKLoad<ND> &L, con
 
 // P_d[j_r][k] of the lane's half (one 8-byte broadcast load per virtual row) and the wave-uniform P_d[i][k]
 template <int ND, bool ALLR>
-__device__ __forceinline__ void jkp_p_k(const JKLane<ND> &C, const JKWave &U, int kI, double (&pjk)[TF_JKP_JBB], double (&pik)[ND])
+__device__ __forceinline__ void jkp_p_k(const JKLane<ND> &C, const JKWave &U, int kI, double (&pjk)[JKShape<ND>::VR], double (&pik)[ND])
 {
-    constexpr int RB = TF_JKP_JBB / ND;
+    constexpr int RB = JKShape<ND>::RB;
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
         const double *Pd = U.X + (size_t)d * U.N * U.N;
         const __amdgpu_buffer_rsrc_t rx = buf_rsrc(Pd);
 #pragma unroll
+#ifdef TF_ABL_NOPJK
+        for (int r = 0; r < RB; ++r) pjk[d * RB + r] = C.ppij[d * RB + r];
+#else
         for (int r = 0; r < RB; ++r) pjk[d * RB + r] = buf_load1<0>(rx, (ALLR || r < C.nr) ? C.xrow : TF_BUF_OOB, 8u * (unsigned)(r * U.N + kI));
+#endif
         pik[d] = Pd[(size_t)U.i * U.N + kI];
     }
 }
@@ -342,10 +366,10 @@ __device__ __forceinline__ void jkp_p_k(const JKLane<ND> &C, const JKWave &U, in
 // The segment of k == i (tasks whose k class is that of i): row r ends at l == j_r, where the element (ij|ij) counts half in K
 // and not at all in Jt.
 template <int ND>
-__device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const double (&pjk)[TF_JKP_JBB], const double (&pik)[ND],
-                                         double (&jd)[TF_JKP_JBB], double (&rJ)[TF_JKP_JBB], double (&rI)[ND], double2 (&jt2)[ND])
+__device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const double (&pjk)[JKShape<ND>::VR], const double (&pik)[ND],
+                                         double (&jd)[JKShape<ND>::VR], double (&rJ)[JKShape<ND>::VR], double (&rI)[ND], double2 (&jt2)[ND])
 {
-    constexpr int RB = TF_JKP_JBB / ND;
+    constexpr int RB = JKShape<ND>::RB;
     const int i = U.i, lamlast = C.lamj0 + C.nr - 1;
     const KInfo kiL = U.kinfo[i - U.kI0];
     const long long bk = kiL.offA;
@@ -355,7 +379,7 @@ __device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const d
 #pragma unroll
     for (int d = 0; d < ND; ++d) { rI[d] = 0.0; jt2[d] = make_double2(0.0, 0.0); }
 #pragma unroll
-    for (int v = 0; v < TF_JKP_JBB; ++v) rJ[v] = 0.0;
+    for (int v = 0; v < JKShape<ND>::VR; ++v) rJ[v] = 0.0;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int lam = C.lam + e;
@@ -388,17 +412,27 @@ __device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const d
 }
 
 template <int ND, bool ALLR>
-__device__ __forceinline__ void jkp_row_sums(const JKLane<ND> &C, const JKWave &U, int kap, double (&rJ)[TF_JKP_JBB], const double (&rI)[ND])
+__device__ __forceinline__ void jkp_row_sums(const JKLane<ND> &C, const JKWave &U, int kap, double (&rJ)[JKShape<ND>::VR], const double (&rI)[ND])
 {
-    constexpr int RB = TF_JKP_JBB / ND;
-    const double tJ = half_sum8(rJ);
-    const int v = (C.q >> 2) & 7, d = v / RB, r = v - d * RB;
+    constexpr int VR = JKShape<ND>::VR, RB = JKShape<ND>::RB;
+    const int v = (C.q >> 2) & 7;
     // (stores without branches as well: lanes that have nothing to store use an out-of-range offset)
-    buf_store1<0>(buf_rsrc(U.DJr + kap), ((C.q & 3) == 0 && r < C.nr) ? C.djoff + 8u * (unsigned)(d * U.dstrideJ + (size_t)r * U.RS) : TF_BUF_OOB, 0u, tJ);
+    if constexpr (VR == 8) {
+        const double tJ = half_sum8(rJ);
+        const int d = v / RB, r = v - d * RB;
+        buf_store1<0>(buf_rsrc(U.DJr + kap), ((C.q & 3) == 0 && r < C.nr) ? C.djoff + 8u * (unsigned)(d * U.dstrideJ + (size_t)r * U.RS) : TF_BUF_OOB, 0u, tJ);
 #pragma unroll
-    for (int dd = 0; dd < ND; ++dd) {
-        const double tI = half_sum1(rI[dd]);
-        buf_store1<0>(buf_rsrc(U.DIr + dd * U.dstrideI + kap), (C.q == 0 && C.nr > 0) ? C.dioff : TF_BUF_OOB, 0u, tI);
+        for (int dd = 0; dd < ND; ++dd) {
+            const double tI = half_sum1(rI[dd]);
+            buf_store1<0>(buf_rsrc(U.DIr + dd * U.dstrideI + kap), (C.q == 0 && C.nr > 0) ? C.dioff : TF_BUF_OOB, 0u, tI);
+        }
+    } else {
+        // four rows, one density: the row sums and the sum of the first index share one butterfly (values 0-3: rows, 4: the first index)
+        static_assert(ND == 1 && VR == 4, "shapes: 8 virtual rows, or 4 rows of one density");
+        const double vals[8] = {rJ[0], rJ[1], rJ[2], rJ[3], rI[0], 0.0, 0.0, 0.0};
+        const double t = half_sum8(vals);
+        buf_store1<0>(buf_rsrc(U.DJr + kap), ((C.q & 3) == 0 && v < C.nr) ? C.djoff + 8u * (unsigned)((size_t)v * U.RS) : TF_BUF_OOB, 0u, t);
+        buf_store1<0>(buf_rsrc(U.DIr + kap), ((C.q & 3) == 0 && v == 4 && C.nr > 0) ? C.dioff : TF_BUF_OOB, 0u, t);
     }
 }
 
@@ -435,10 +469,10 @@ __device__ __forceinline__ void jkp_merge_jt(const JKWave &U, double2 *slots, in
 // must match.
 
 template <int ND, bool ALLR, int MODE>
-__device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane<ND> &C, double (&jd)[TF_JKP_JBB], int k0, int k1, int lane, bool active,
+__device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane<ND> &C, double (&jd)[JKShape<ND>::VR], int k0, int k1, int lane, bool active,
                                             double2 *slots, int nw, int w)
 {
-    constexpr int JBB = TF_JKP_JBB, S = TF_JKP_STAGES;
+    constexpr int JBB = JKShape<ND>::VR, S = TF_JKP_STAGES;
     static_assert(TF_JKP_KB % S == 0, "the ring position of a step must be a compile-time constant");
     if (k0 >= k1) return;
     // ring of S register buffers: step kk of a merge block uses R[kk % S] and issues the loads of step kk + S - 1 into R[(kk + S - 1) % S].
@@ -459,15 +493,37 @@ __device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane<ND> &C, doub
                     // P[j_r][k] first: vector memory operations complete in order, and part 2 must not wait for the prefetched tensor loads
                     jkp_p_k<ND, ALLR>(C, U, U.kI0 + k, pjk, pik);
                     jkp_load<ND, ALLR, MODE>(R[(kk + S - 1) % S], C, U, min(k + S - 1, k1 - 1));
+#ifdef TF_ABL_LOADSONLY
+                    {
+#pragma unroll
+                        for (int r = 0; r < JBB / ND; ++r) jd[r] += R[kk % S].m[r].x + R[kk % S].m[r].y;
+                        jd[0] += R[kk % S].pp[0].x + pjk[0] + pik[0];
+                    }
+                    continue;
+#endif
                     jkp_row1<ND>(C, R[kk % S], jd, rJ, rI, jt);
+#ifdef TF_ABL_NOMERGE
+                    {
+                        const KInfo ki = U.kinfo[k];
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) {
+                            double2 t = jt[d];
+                            t.x = pair_step32(t.x, t.x); t.y = pair_step32(t.y, t.y);
+                            buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), (lane < 32 && (MODE == JKP_FULL || U.lam0 + 2 * lane < ki.cnt)) ? 16u * (unsigned)lane : TF_BUF_OOB, 0u, t);
+                        }
+                    }
+#else
 #pragma unroll
                     for (int d = 0; d < ND; ++d) slots[((kk * TF_JKP_W + w) * ND + d) * 64 + lane] = jt[d];
+#endif
                     jkp_row_sums<ND, ALLR>(C, U, k, rJ, rI);
                     jkp_row2<ND, MODE>(C, R[kk % S], U, pjk, pik);
                 }
             }
         }
+#ifndef TF_ABL_NOMERGE
         jkp_merge_jt<ND, MODE>(U, slots, nw, w, lane, kb, k1);
+#endif
     }
 }
 
@@ -477,7 +533,7 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, JKLane<ND> &C, int NW,
                                          int w, int kap0, int kd1, int klim, bool last, double *__restrict__ Jd, size_t strideJd,
                                          double *__restrict__ DIc, size_t strideDIc, double *__restrict__ DJc, size_t strideDJc)
 {
-    constexpr int JBB = TF_JKP_JBB, RB = JBB / ND;
+    constexpr int JBB = JKShape<ND>::VR, RB = JBB / ND;
     const int N = U.N, i = U.i;
     const bool in0 = 2 * C.q < U.width, in1 = 2 * C.q + 1 < U.width;
     {
@@ -542,9 +598,12 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, JKLane<ND> &C, int NW,
         }
     }
     {
-        const double t = half_sum8(jd);
+        double vals[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) vals[v] = v < JBB ? jd[v < JBB ? v : 0] : 0.0;
+        const double t = half_sum8(vals);
         const int v = (C.q >> 2) & 7, d = v / RB, r = v - d * RB;
-        if ((C.q & 3) == 0 && r < C.nr) Jd[d * strideJd + (size_t)(C.r0 + r) * NW + wchunk] = t;
+        if ((C.q & 3) == 0 && v < JBB && r < C.nr) Jd[d * strideJd + (size_t)(C.r0 + r) * NW + wchunk] = t;
     }
 }
 
@@ -558,7 +617,7 @@ struct JKStrides { size_t P, Pp, y, Jd, DIc, DIr, DJc, DJr;      // between the 
 // Outputs: Jd [n_rows][NW] per-task partials; ypart: Jt partials per super-group; DIc [G][N], DJc [n_rows][N]: column parts
 // (l-indexed); DIr [G][RS], DJr [n_rows][RS]: row parts per task (k-indexed: entry rpoff[c][w] + kappa, written for every step).
 template <int ND>
-__global__ __launch_bounds__(64 * TF_JKP_W, TF_JKP_STAGES > 2 ? 1 : 2) void jk_packed_kernel(const double *__restrict__ T, const JKGroup *__restrict__ groups,
+__global__ __launch_bounds__(64 * TF_JKP_W, TF_JKP_STAGES > 2 ? 1 : (JKShape<ND>::VR == 4 ? TF_JKP_OCC4 : 2)) void jk_packed_kernel(const double *__restrict__ T, const JKGroup *__restrict__ groups,
                                                                   const JKSuper *__restrict__ supers,
                                                                   const JKTask *__restrict__ tasks, BLayout L,
                                                                   const KInfo *__restrict__ kinfo /* = L.kinfo: a __restrict__ kernel
@@ -568,7 +627,7 @@ __global__ __launch_bounds__(64 * TF_JKP_W, TF_JKP_STAGES > 2 ? 1 : 2) void jk_p
                                                                   double *__restrict__ DIc, double *__restrict__ DIr,
                                                                   double *__restrict__ DJc, double *__restrict__ DJr, JKStrides S)
 {
-    constexpr int JBB = TF_JKP_JBB, RB = JBB / ND;
+    constexpr int JBB = JKShape<ND>::VR, RB = JBB / ND;
     __shared__ double2 slots[TF_JKP_KB * TF_JKP_W * ND * 64];
     const JKTask t = tasks[blockIdx.x];
     const JKSuper sg = supers[t.super];
