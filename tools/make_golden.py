@@ -463,6 +463,65 @@ def make_uhf_golden(scf, blocks, ortho):
     np.savez_compressed(os.path.join(GOLD, "uhf_systems.npz"), **{f"{t}__{k}": v for t, d in out.items() for k, v in d.items()})
 
 
+# Closed-shell systems across H .. Ar and every basis set the reference ships (symbols, bond length in Angstrom or None, basis,
+# doubly occupied orbitals -- the charge follows from it).  One reference RHF run each (core guess, EXTREME, dynamic damping).
+SWEEP = {
+    "h2_augccpvtz": (["H", "H"], 0.74, "aug-cc-pVTZ", 1),
+    "heh+_augccpvdz": (["HE", "H"], 0.77, "aug-cc-pVDZ", 1),
+    "heh+_ccpvtz": (["HE", "H"], 0.77, "cc-pVTZ", 1),
+    "lih_ccpvdz": (["LI", "H"], 1.595, "cc-pVDZ", 2),
+    "beh+_6311gss": (["BE", "H"], 1.31, "6-311G**", 2),
+    "bh_def2svp": (["B", "H"], 1.232, "def2-SVP", 3),
+    "hf_631gs": (["F", "H"], 0.917, "6-31G*", 5),
+    "lif_631g": (["LI", "F"], 1.564, "6-31G", 6),
+    "co_sto6g": (["C", "O"], 1.128, "STO-6G", 7),
+    "n2_321g": (["N", "N"], 1.0977, "3-21G", 7),
+    "f2_6311g": (["F", "F"], 1.412, "6-311G", 9),
+    "nah_def2svp": (["NA", "H"], 1.887, "def2-SVP", 6),
+    "hcl_631gs": (["CL", "H"], 1.275, "6-31G*", 9),
+    "alh_631g": (["AL", "H"], 1.648, "6-31G", 7),
+    "sio_sto3g": (["SI", "O"], 1.51, "STO-3G", 11),
+    "pn_321g": (["P", "N"], 1.491, "3-21G", 11),
+    "cl2_631g": (["CL", "CL"], 1.988, "6-31G", 17),
+    "nacl_sto6g": (["NA", "CL"], 2.361, "STO-6G", 14),
+    "mgh+_631g": (["MG", "H"], 1.65, "6-31G", 6),
+    "ne2_augccpvdz": (["NE", "NE"], 3.1, "aug-cc-pVDZ", 10),
+    "ar2_def2svp": (["AR", "AR"], 3.76, "def2-SVP", 18),
+    "he_ccpv5z": (["HE"], None, "cc-pV5Z", 1),
+    "he_augccpvqz": (["HE"], None, "aug-cc-pVQZ", 1),
+    "h2_ccpvqz": (["H", "H"], 0.74, "cc-pVQZ", 1),
+    "h2_def2qzvp": (["H", "H"], 0.74, "def2-QZVP", 1),
+    "h2_def2tzvp": (["H", "H"], 0.74, "def2-TZVP", 1),
+    "oh-_def2tzvpp": (["O", "H"], 0.97, "def2-TZVPP", 5),
+    "cn-_ccpvdz": (["C", "N"], 1.177, "cc-pVDZ", 7),
+    "no+_6311gss": (["N", "O"], 1.063, "6-311G**", 7),
+    "be_ccpvtz": (["BE"], None, "cc-pVTZ", 2),
+}
+
+
+def make_sweep_golden(scf, blocks, ortho):
+    """tests/golden/sweep_systems.json: per system the reference's RHF energy, iteration count, orbital energies and norms of its
+    integral matrices (data only)."""
+    import json
+    out = {}
+    for tag, (sym, R_ang, basis, nocc) in SWEEP.items():
+        R = None if R_ang is None else mol.angstrom_to_bohr(R_ang)
+        atoms, shells, aos = system(sym, R, basis)
+        S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
+        U = reference_U(shells, blocks)
+        Ss, Ts_, Vs, Es = to_spherical(U, S), to_spherical(U, T), to_spherical(U, V), eri_to_spherical(U, E)
+        r = run_reference_scf(scf, ortho, atoms, shells, Ss, Ts_, Vs, Es, nocc, "extreme", True)
+        idx = sample_indices(U.shape[0], 64, 7)
+        out[tag] = dict(symbols=sym, R_angstrom=R_ang, basis=basis, n_occ=nocc, n_ao=int(U.shape[0]),
+                        energy=float(r["energy"]), V_NN=float(r["V_NN"]), E0=float(r["E0"]), n_iter=int(len(r["table"])),
+                        epsilons=[float(x) for x in r["epsilons"]], components=[float(x) for x in r["components"]],
+                        S_fro=float(np.linalg.norm(Ss)), T_fro=float(np.linalg.norm(Ts_)), V_fro=float(np.linalg.norm(Vs)),
+                        eri_fro=float(np.sqrt(np.sum(Es * Es))), eri_idx=idx.tolist(),
+                        eri_val=[float(x) for x in Es[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]]])
+        print(tag, U.shape[0], "E =", out[tag]["energy"], "iters", out[tag]["n_iter"], flush=True)
+    json.dump(out, open(os.path.join(GOLD, "sweep_systems.json"), "w"), indent=0)
+
+
 def run_reference_scf(scf, ortho, atoms, shells, S, T, V, ERI, n_occ, conv="extreme", damping=True):
     """Core-Hamiltonian guess (tuna_guess.py calculate_core_guess: diagonalise H_core, fill n_occ) + reference loop."""
     X, smallest, S_inv = ortho(S, None, True)
@@ -507,6 +566,9 @@ def main():
         return
     if "--mp2-only" in sys.argv:
         make_mp2_golden(scf, blocks, ortho)
+        return
+    if "--sweep-only" in sys.argv:
+        make_sweep_golden(scf, blocks, ortho)
         return
     np.savez(os.path.join(GOLD, "sph_blocks.npz"), **{f"L{L}": b for L, b in blocks.items()})
 

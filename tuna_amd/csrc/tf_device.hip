@@ -1060,6 +1060,19 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         double *d_out_slab = d_T2;                               // fused kernels write the half-transformed slab directly
         const int *d_ket = d_kets + ket_off[kcls];
         hipStream_t st = streams[launch_count++ % NSTREAM];
+        // TF_ERI_CLASS_TIMES=1 (diagnostic): every class launch alone on the device, its time printed with the class
+        static const bool class_times = getenv("TF_ERI_CLASS_TIMES") != nullptr;
+        struct ClassTimer {
+            bool on; const QClass &q; unsigned nb; std::chrono::steady_clock::time_point t0;
+            ClassTimer(bool o, const QClass &qq, unsigned n) : on(o), q(qq), nb(n) { if (on) { (void)hipDeviceSynchronize(); t0 = std::chrono::steady_clock::now(); } }
+            ~ClassTimer() {
+                if (!on) return;
+                (void)hipDeviceSynchronize();
+                const double ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                fprintf(stderr, "[tf eri class] (%d %d|%d %d) npq %d bra %u ket %d quartets %.0f: %.3f ms, %.1f ns per quartet\n", q.La, q.Lb, q.Lc, q.Ld,
+                        q.npq, nb, q.n_ket, (double)nb * q.n_ket, ms, 1e6 * ms / ((double)nb * q.n_ket));
+            }
+        } class_timer(class_times, q, n_bra);
         if (q.npq == 1 && q.ncomp <= 128) {
             // several uncontracted shell quartets per workgroup
             int ncp = 1;
