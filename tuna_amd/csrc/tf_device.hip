@@ -1115,7 +1115,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             const int nG = (q.Lc + 1) * (q.Ld + 1) * (q.La + q.Lb + 1) * nM;
             q.offBlk = o; o += std::max((int)TF_BLK_DOUBLES, nG);   // the ket half of the z tables lives here until the components start
             q.offG = q.offBlk;
-            q.offTab = o; o += 3 * (q.nca * q.ncb + q.ncc * q.ncd + 1) / 2 + 1;
+            q.offTab = o; o += 2 * (q.nca * q.ncb + q.ncc * q.ncd) + 2;
             if (tables_end >= TF_CSR_DOUBLES) q.offCsr = 0;      // staged over the dead tables (after the X/Z barrier)
             else { q.offCsr = o; o += TF_CSR_DOUBLES; }
             q.lds_doubles = o;

@@ -25,7 +25,7 @@ struct QClass {
     int n_ket;             // ket pairs in this launch
     int fused, spherical, nsc, nsd, Nout, ld, offBlk;   // fused ket transform: output dims of shells C, D; T2 geometry; LDS block buffer
     int offG;              // factorised kernel: ket half of the z tables, (Lc+1)(Ld+1)(La+Lb+1) nM doubles
-    int offTab;            // factorised kernel: per-pair component tables, (nab + ncc*ncd) * 3/2 doubles
+    int offTab;            // factorised kernel: per-pair component tables, (nab + ncc*ncd) * 2 doubles (scale, two offset words)
     int offCsr;            // fused spherical ket transform: LDS copy of the two shells' Cartesian->spherical CSR rows (TF_CSR_DOUBLES)
     int tri;               // packed layout: only kets with first shell <= the bra's first shell are needed ((kl) <= (ij))
     int tupG_off, tupXZ_off;   // factorised kernel: index words of its table entries in DBasis::tup (LRec of the class)
@@ -632,35 +632,41 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     // Per bra component pair and per ket component pair (class constants, tabulated once per workgroup): the pair's part of the three
     // table indices, the parities of its x and y exponent sums, and its normalisation ratio.  A component is then two table lookups,
     // one parity test and one unrolled triple-table sum -- no integer division by runtime shell sizes, no per-component lmn decode.
+    // The tables are staged as BYTE OFFSETS into the X / Z tables (16-bit fields, the class constants (Lc+1)(Ld+1) and nM multiplied in
+    // once per entry) and the scale of a bra pair carries the quartet's prefactor: the component loop itself has no integer
+    // multiplication (quarter rate on this hardware: nine of them cost as much as the 35 multiply-adds of an (ff|ff) component).
     const double pref = sPref[0];
     double *sBlk = smem + qc.offBlk;
     const int nsubc = qc.ncc * qc.ncd, nab = qc.nca * qc.ncb;
     double *sScAB = smem + qc.offTab, *sScCD = sScAB + nab;
-    int *sIxAB = reinterpret_cast<int *>(sScCD + nsubc), *sIxCD = sIxAB + nab;
+    int2 *sOfAB = reinterpret_cast<int2 *>(sScCD + nsubc), *sOfCD = sOfAB + nab;
+    const int LcLd = Lc1 * Ld1;
     for (int e = tid; e < nab + nsubc; e += TF_ERI_THREADS) {         // host-tabulated per shell pair (DBasis::ct_*)
         const bool bra = e < nab;
         const int f = bra ? e : e - nab, g = (bra ? ab.tab_off : cd.tab_off) + f;
-        if (bra) { sIxAB[f] = B.ct_ix[g]; sScAB[f] = B.ct_sc[g]; }
-        else { sIxCD[f] = B.ct_ix[g]; sScCD[f] = B.ct_sc[g]; }
+        const int w = B.ct_ix[g], unit = (bra ? LcLd : 1) * nM * (int)sizeof(double);
+        const int2 o = make_int2(((w & 255) * unit) | ((((w >> 8) & 255) * unit) << 16), (((w >> 16) & 255) * unit) | (((w >> 24) & 3) << 16));
+        if (bra) { sOfAB[f] = o; sScAB[f] = pref * B.ct_sc[g]; }
+        else { sOfCD[f] = o; sScCD[f] = B.ct_sc[g]; }
     }
     __syncthreads();
-    const int LcLd = Lc1 * Ld1;
-    const float inv_nsubc = 1.0f / (float)nsubc;
+    const char *bX = reinterpret_cast<const char *>(sX), *bZ = reinterpret_cast<const char *>(sZ);
     const int GB = qc.fused ? max(1, min(nab, TF_BLK_DOUBLES / nsubc)) : nab;
+    // component cl = abl * nsubc + icd of a block; a thread's components advance by the workgroup size: (abl, icd) incrementally
+    const int step_a = TF_ERI_THREADS / nsubc, step_c = TF_ERI_THREADS - step_a * nsubc;
+    const int abl_first = tid / nsubc, icd_first = tid - abl_first * nsubc;
     for (int blk0 = 0; blk0 < nab; blk0 += GB) {
         const int nblk = min(GB, nab - blk0), ncg = nblk * nsubc;
+        int abl = abl_first, icd = icd_first;
         for (int cl = tid; cl < ncg; cl += TF_ERI_THREADS) {
-            int abl = (int)((float)cl * inv_nsubc);                     // cl / nsubc without an integer division
-            if ((abl + 1) * nsubc <= cl) ++abl;
-            if (abl * nsubc > cl) --abl;
-            const int icd = cl - abl * nsubc, iab = blk0 + abl;
-            const int pa = sIxAB[iab], pc = sIxCD[icd];
+            const int iab = blk0 + abl;
+            const int2 oa = sOfAB[iab], oc = sOfCD[icd];
             double val = 0.0;
-            if ((((pa ^ pc) >> 24) & 3) == 0) {                          // x and y exponent sums both even, pyx:1324-1327
-                const double *X = sX + ((pa & 255) * LcLd + (pc & 255)) * nM;
-                const double *Y = sX + (((pa >> 8) & 255) * LcLd + ((pc >> 8) & 255)) * nM;
-                const double *Z = sZ + (((pa >> 16) & 255) * LcLd + ((pc >> 16) & 255)) * nM;
-                val = pref * fact_sum_any(nM, X, Y, Z) * (sScAB[iab] * sScCD[icd]);
+            if ((((oa.y ^ oc.y) >> 16) & 3) == 0) {                      // x and y exponent sums both even, pyx:1324-1327
+                const double *X = reinterpret_cast<const double *>(bX + ((oa.x & 0xffff) + (oc.x & 0xffff)));
+                const double *Y = reinterpret_cast<const double *>(bX + (((unsigned)oa.x >> 16) + ((unsigned)oc.x >> 16)));
+                const double *Z = reinterpret_cast<const double *>(bZ + ((oa.y & 0xffff) + (oc.y & 0xffff)));
+                val = fact_sum_any(nM, X, Y, Z) * (sScAB[iab] * sScCD[icd]);
             }
             if (qc.fused)
                 sBlk[cl] = val;
@@ -671,6 +677,8 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
                 Cslab[row * NcNc + (size_t)k * Nc + l] = val;
                 if (cd.A != cd.B && !qc.tri) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
             }
+            abl += step_a; icd += step_c;
+            if (icd >= nsubc) { icd -= nsubc; ++abl; }
         }
         if (qc.fused) {
             __syncthreads();
