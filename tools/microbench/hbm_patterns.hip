@@ -5,6 +5,7 @@
 //            four different unit pairs; chunk-major task order (the other chunks of a unit are read much later)
 //   pieces_near : the same, chunk-minor task order (the four chunks of a unit pair are four consecutive workgroups)
 //   rows   : a workgroup owns (two units), wave w reads chunk w: the workgroup reads contiguous 2 x 16 KB per step
+//   pieces256 / pieces1k : four units per wave on 32 columns each (256-byte pieces) / one unit per wave on 128 columns (1 KB pieces)
 //   masked : as pieces, through buffer loads with the lanes beyond a per-step limit out of range (the staircase of the packed rows:
 //            the limit grows from 0 to the chunk width over the steps, half of the lanes load nothing) -- is a load instruction
 //            with idle lanes cheaper?
@@ -38,7 +39,26 @@ __global__ __launch_bounds__(256, 2) void read_kernel(const double *__restrict__
     const int h = lane >> 5, q = lane & 31;
     const long long npairs = units / 2;
     double acc = 0.0;
-    if (MODE == 4) {
+    if (MODE == 5 || MODE == 6) {
+        // 5: four units per wave, 16 lanes x 16 B = 256-byte pieces; 6: one unit per wave, 64 lanes x 16 B = 1 KB pieces
+        constexpr int G = MODE == 5 ? 4 : 1, LG = 64 / G, NCH = W / (2 * LG);          // groups per wave, lanes per group, chunks per unit
+        const long long t = (long long)blockIdx.x * 4 + w;                              // units / G * NCH tasks
+        const long long ngrp = units / G;
+        const int chunk = (int)(t / ngrp); const long long grp = t % ngrp;
+        if (chunk < NCH) {
+        const double *base = T + (G * grp + lane / LG) * UNIT + chunk * (2 * LG) + 2 * (lane % LG);
+        v2d a[2][8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[0][r] = ldg(base + r * W);
+        for (int s = 0; s < K; ++s) {
+            const double *nx = base + (long long)min(s + 1, K - 1) * (R * W);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[(s + 1) & 1][r] = ldg(nx + r * W);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc += a[s & 1][r].x + a[s & 1][r].y;
+        }
+        }
+    } else if (MODE == 4) {
         const long long t = (long long)blockIdx.x * 4 + w;
         const int chunk = (int)(t / npairs); const long long pair = t % npairs;
         const double *base = T + 2 * pair * UNIT + chunk * CW;
@@ -108,9 +128,9 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const long long npairs = units / 2;
-    const char *names[5] = {"stream", "pieces", "pieces_near", "rows", "masked"};
+    const char *names[7] = {"stream", "pieces", "pieces_near", "rows", "masked", "pieces256", "pieces1k"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 5; ++mode) {
+        for (int mode = 0; mode < 7; ++mode) {
             const unsigned grid = (unsigned)npairs;      // every mode: npairs workgroups of 4 waves, a wave reads K steps x 8 KB
             float best = 1e30f;
             for (int it = 0; it < 5; ++it) {
@@ -120,6 +140,8 @@ int main(int argc, char **argv)
                 if (mode == 2) hipLaunchKernelGGL(read_kernel<2>, dim3(grid), dim3(256), 0, 0, T, units, out);
                 if (mode == 3) hipLaunchKernelGGL(read_kernel<3>, dim3(grid), dim3(256), 0, 0, T, units, out);
                 if (mode == 4) hipLaunchKernelGGL(read_kernel<4>, dim3(grid), dim3(256), 0, 0, T, units, out);
+                if (mode == 5) hipLaunchKernelGGL(read_kernel<5>, dim3(grid), dim3(256), 0, 0, T, units, out);
+                if (mode == 6) hipLaunchKernelGGL(read_kernel<6>, dim3(grid), dim3(256), 0, 0, T, units, out);
                 CHECK(hipEventRecord(e1));
                 CHECK(hipEventSynchronize(e1));
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));

@@ -789,12 +789,12 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             if (gfirst[N + a] == gfirst[a]) gfirst[a] = (int)gi;
             gfirst[N + a] = (int)gi + 1;
         }
-        // super-groups: up to 2 TF_JKP_W adjacent groups (two per wave) with the same i and class share a workgroup and one Jt partial.  The kernel's
+        // super-groups: up to TF_JKP_GPW * TF_JKP_W adjacent groups (TF_JKP_GPW per wave) with the same i and class share a workgroup and one Jt partial.  The kernel's
         // groups index into `groups`, so the super list may be reordered freely: by class, then by descending original i (the Jt
         // reduction needs those that reach an AO k to be a prefix of their class's list)
         for (size_t gi = 0; gi < groups.size();) {
             size_t ge = gi + 1;
-            while (ge < groups.size() && groups[ge].i == groups[gi].i && groups[ge].c == groups[gi].c && ge - gi < 2 * TF_JKP_W) ++ge;
+            while (ge < groups.size() && groups[ge].i == groups[gi].i && groups[ge].c == groups[gi].c && ge - gi < TF_JKP_GPW * TF_JKP_W) ++ge;
             JKSuper sg{};
             sg.g0 = (int)gi; sg.ng = (int)(ge - gi); sg.c = groups[gi].c; sg.i = groups[gi].i;
             for (int a = 0; a < 4; ++a) sg.ke[a] = H.ke(a, sg.i);
@@ -829,7 +829,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             // workgroups of 4, 2 or 1 waves (two groups per wave): a rank of several holds few groups per (i, class), and a wave without
             // a group would only sit in the barriers of its workgroup and occupy a SIMD slot.  One launch per workgroup size; inside
             // a launch longest first.
-            auto waves = [&](int t) { const int nwv = (supers[tasks[t].super].ng + 1) / 2; return nwv > 2 ? 4 : nwv; };
+            auto waves = [&](int t) {                                  // workgroup sizes TF_JKP_W, TF_JKP_W / 2, TF_JKP_W / 4 waves (at least one)
+                const int nwv = (supers[tasks[t].super].ng + TF_JKP_GPW - 1) / TF_JKP_GPW;
+                for (int b = 2; b >= 0; --b) if ((TF_JKP_W >> b) >= 1 && nwv <= (TF_JKP_W >> b)) return TF_JKP_W >> b;
+                return TF_JKP_W;
+            };
             std::vector<int> ord(tasks.size());
             std::iota(ord.begin(), ord.end(), 0);
             std::stable_sort(ord.begin(), ord.end(), [&](int u, int v) { return waves(u) != waves(v) ? waves(u) > waves(v) : steps[u] > steps[v]; });
@@ -838,8 +842,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             for (size_t t = 0; t < ord.size(); ++t) {
                 sorted[t] = tasks[ord[t]];
                 const int wv = waves(ord[t]);
-                if (wv <= 2 && T.bucket[1] == (int)tasks.size()) T.bucket[1] = (int)t;
-                if (wv <= 1 && T.bucket[2] == (int)tasks.size()) T.bucket[2] = (int)t;
+                if (wv <= TF_JKP_W / 2 && T.bucket[1] == (int)tasks.size()) T.bucket[1] = (int)t;
+                if (wv <= TF_JKP_W / 4 && T.bucket[2] == (int)tasks.size()) T.bucket[2] = (int)t;
             }
             if (T.bucket[2] < T.bucket[1]) T.bucket[1] = T.bucket[2];
             tasks.swap(sorted);
@@ -1693,7 +1697,7 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
         }
         for (int b = 0; b < 3; ++b) {
             const int t0 = T.bucket[b], t1 = T.bucket[b + 1];
-            if (t1 > t0)
+            if (t1 > t0 && (TF_JKP_W >> b) >= 1)
                 hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)(t1 - t0)), dim3(64 * (TF_JKP_W >> b)), 0, st, ctx->d_eri, T.d_groups,
                                    T.d_supers, T.d_tasks + t0, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
         }

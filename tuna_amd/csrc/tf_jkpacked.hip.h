@@ -49,7 +49,12 @@
 template <int ND> struct JKShape {           // virtual rows v = d * RB + r of a pass: RB tensor rows times ND densities
     static constexpr int VR = ND == 1 ? TF_JKP_VR1 : 8, RB = VR / ND;
 };
-#define TF_JKP_CW 64             // columns per chunk (2 per lane of a half wave)
+#ifndef TF_JKP_GPW
+#define TF_JKP_GPW 2               // row groups a wave works on at once: 2 (half waves on 64 columns) or 4 (quarter waves on 32 columns:
+                                   // 20 % fewer wave steps at N = 400, but measured 8-15 % SLOWER -- DESIGN.md section 4.1)
+#endif
+#define TF_JKP_LG (64 / TF_JKP_GPW)   // lanes per group
+#define TF_JKP_CW (2 * TF_JKP_LG)  // columns per chunk (2 per lane of a group's lanes)
 #define TF_JKP_SEG 16            // segments of the super-group lists in the Jt reduction
 #ifndef TF_JKP_STAGES
 #define TF_JKP_STAGES 2           // register buffers of the load ring: the loads of STAGES - 1 steps are in flight (2 or 4)
@@ -75,7 +80,9 @@ struct JKGroup {
     long long ub;                // base of the unit in the tensor
     int secoff[4];               // start of section a inside a row of this group
 };
-#define TF_JKP_W 4                // waves per workgroup, two groups each: their Jt partials are merged in LDS before they are written
+#ifndef TF_JKP_W
+#define TF_JKP_W 4                // waves per workgroup (TF_JKP_GPW groups each): their Jt partials are merged in LDS before they are written
+#endif
 #define TF_JKP_KB 4               // k steps per merge block
 // up to 2 TF_JKP_W adjacent groups with the same i and class share one Jt partial (complete-row shape: NP[c] doubles at yoff)
 struct JKSuper { int g0, ng, c, i; long long yoff; int ke[4]; };   // ke[a] = cntA[a][i]: the rows reach the members kappa < ke[a] of class a
@@ -222,6 +229,41 @@ __device__ __forceinline__ double half_sum1(double t)                   // every
     return sum8(t);
 }
 
+// 16-lane versions: the four quarters of a wave reduce independently
+// (DPP bank masks select groups of four lanes, not lanes inside a quad: the step across lane bit 1 takes a lane predicate)
+__device__ __forceinline__ double pair_step2(double a, double b, bool bit1)   // lanes with bit 1 clear: a[l] + a[l + 2]; set: b[l - 2] + b[l]
+{
+    const double keep = bit1 ? b : a, give = bit1 ? a : b;
+    return keep + dpp_merge<TF_DPP_QUAD_XOR2, 0xF>(give, give);
+}
+// eight per-lane values -> lane q of a quarter holds that quarter's total of value (q >> 1) & 7
+__device__ __forceinline__ double quarter_sum8(const double (&v)[8])
+{
+    const double w0 = pair_step8(v[0], v[4]), w1 = pair_step8(v[1], v[5]), w2 = pair_step8(v[2], v[6]), w3 = pair_step8(v[3], v[7]);
+    const double u0 = pair_step4(w0, w2), u1 = pair_step4(w1, w3);
+    double t = pair_step2(u0, u1, (__lane_id() & 2u) != 0u);
+    t += dpp_merge<TF_DPP_QUAD_XOR1, 0xF>(t, t);
+    return t;
+}
+__device__ __forceinline__ double quarter_sum1(double t)                // every lane gets the total of its quarter
+{
+    t += dpp_merge<TF_DPP_ROR8, 0xF>(t, t);
+    return sum8(t);
+}
+// the sums over the lanes of a group; lane q of a group holds value (q >> TF_JKP_VSH) & 7 in the lanes with (q & TF_JKP_VMASK) == 0 (and its copies)
+#if TF_JKP_GPW == 4
+#define TF_JKP_VSH 1
+__device__ __forceinline__ double group_sum8(const double (&v)[8]) { return quarter_sum8(v); }
+__device__ __forceinline__ double group_sum1(double t) { return quarter_sum1(t); }
+__device__ __forceinline__ double across_groups(double t) { t = pair_step32(t, t); return pair_step16(t, t); }   // same lane of every group
+#else
+#define TF_JKP_VSH 2
+__device__ __forceinline__ double group_sum8(const double (&v)[8]) { return half_sum8(v); }
+__device__ __forceinline__ double group_sum1(double t) { return half_sum1(t); }
+__device__ __forceinline__ double across_groups(double t) { return pair_step32(t, t); }
+#endif
+#define TF_JKP_VMASK ((1 << TF_JKP_VSH) - 1)
+
 #define TF_BUF_OOB 0x80000000u       // lane offset beyond num_records (0x7fffffff) of buf_rsrc: loads return 0, stores are dropped
 template <int AUX>
 __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, unsigned uniform_off, double v)
@@ -237,15 +279,15 @@ __device__ __forceinline__ double buf_load1(__amdgpu_buffer_rsrc_t rs, unsigned 
 
 // Wave-uniform description of a task (lives in SGPRs).
 struct JKWave {
-    const double *Tb, *X, *Pp;           // section a of the unit of half 0; densities [ND][N][N] (internal); packed densities (class
+    const double *Tb, *X, *Pp;           // the lowest storage unit of the wave's groups; densities [ND][N][N] (internal); packed densities (class
                                          // base + section a) [ND][NPtot]
     const KInfo *kinfo;                  // kinfo[c] + cstart[a]: indexed by kappa
     long long NPtot;
     int N, i;                            // AOs; internal first index of the rows
     int kI0, c0, lam0, width, cm;        // first internal AO of the k class; first internal column, its loc, columns of the chunk;
                                          // cm = 1 when k and l are of the same class (the pair (k,k) exists)
-    int unr0, p00, dub, dunr, dp0, sec;  // storage unit of half 0 (rows, position of its group) and half 1 minus half 0 (unit base in
-                                         // doubles, rows, position); sec = start of section a in a row
+    int sec;                             // start of section a in a row of these groups (same i and class: same shape)
+    __amdgpu_buffer_rsrc_t rt;           // the tensor from the lowest storage unit of the wave's groups + the chunk's first column
     int rp;                              // row parts of this chunk inside a row part vector
     double *yg, *DIr, *DJr;              // Jt partial; row parts of the workgroup's first group / row (density d: + d * ystride / dstrideI / dstrideJ)
     size_t RS, ystride, dstrideI, dstrideJ;
@@ -257,6 +299,7 @@ struct JKLane {
     int h, q, lam, lI;
     int nr, lamj0, r0, g;                // rows of this half's group (0: none), loc of its first j, its first local row, its index
     unsigned xrow;                       // byte offset of X[j0][0]
+    unsigned gb, unr, p0;                // the group's storage unit: base (doubles from U.Tb), rows, position of the group in it
     unsigned djoff, dioff;               // byte offsets of the group's row parts of this chunk from U.DJr / U.DIr
     double ppij[JKShape<ND>::VR];             // Pp_d[(i, j_r)] by virtual row
     double2 pil[ND], pjl[JKShape<ND>::VR];    // P_d[i][l];  P_d[j_r][l] by virtual row
@@ -279,16 +322,16 @@ __device__ __forceinline__ void jkp_load(JKLoad<ND> &L, const JKLane<ND> &C, con
     const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);          // padded segment: the rows of a unit follow each other at this stride
     L.cnt = ki.cnt;
     const bool v = (MODE == JKP_FULL) || C.lam < ki.cnt;
-    const __amdgpu_buffer_rsrc_t rt = buf_rsrc(U.Tb + (long long)U.unr0 * ki.offA + (long long)U.p00 * pc + U.lam0);
-    const unsigned d1 = 8u * (unsigned)(U.dub + U.dunr * (U.sec + ki.offA) + U.dp0 * pc);   // half 1's unit relative to half 0's
-    // No branches around the loads (one basic block per step lets the compiler count the loads in flight exactly; with a branch per
-    // load it waits for ALL of them at every step and nothing is prefetched): a lane without a value loads from an offset beyond the
-    // descriptor's range, which the buffer unit answers with zeros without touching memory.
+    // lane offset of the group's segment of k: unit base + rows of the unit * (section + segment offset) + position * padded length,
+    // 24-bit multiply-adds (full rate); the descriptor is the same for the whole task
+    const __amdgpu_buffer_rsrc_t rt = U.rt;
+    const unsigned seg = __umul24(C.p0, (unsigned)pc) + __umul24(C.unr, (unsigned)(U.sec + ki.offA)) + C.gb;
+    const unsigned dsel = 8u * seg;
 #ifdef TF_ABL_ALLVALID
-    const unsigned voff = 16u * (unsigned)C.q + (C.h ? d1 : 0u);      // (timing experiment only: every lane of every row loads)
+    const unsigned voff = 16u * (unsigned)C.q + dsel;      // (timing experiment only: every lane of every row loads)
 #define TF_ABL_ROWOK(r) true
 #else
-    const unsigned voff = v ? 16u * (unsigned)C.q + (C.h ? d1 : 0u) : TF_BUF_OOB;
+    const unsigned voff = v ? 16u * (unsigned)C.q + dsel : TF_BUF_OOB;
 #define TF_ABL_ROWOK(r) (ALLR || (r) < C.nr)
 #endif
 #pragma unroll
@@ -374,8 +417,7 @@ __device__ __forceinline__ void jkp_last(JKLane<ND> &C, const JKWave &U, const d
     const KInfo kiL = U.kinfo[i - U.kI0];
     const long long bk = kiL.offA;
     const int pc = (kiL.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);
-    const long long d1 = (long long)U.dub + (long long)U.dunr * (U.sec + kiL.offA) + (long long)U.dp0 * pc;
-    const double *Tk = U.Tb + (long long)U.unr0 * kiL.offA + (long long)U.p00 * pc + (C.h ? d1 : 0);   // segment of k == i, first row of the lane's group
+    const double *Tk = U.Tb + ((long long)C.gb + (long long)C.unr * (U.sec + kiL.offA) + (long long)C.p0 * pc);   // segment of k == i, first row of the lane's group
 #pragma unroll
     for (int d = 0; d < ND; ++d) { rI[d] = 0.0; jt2[d] = make_double2(0.0, 0.0); }
 #pragma unroll
@@ -415,24 +457,25 @@ template <int ND, bool ALLR>
 __device__ __forceinline__ void jkp_row_sums(const JKLane<ND> &C, const JKWave &U, int kap, double (&rJ)[JKShape<ND>::VR], const double (&rI)[ND])
 {
     constexpr int VR = JKShape<ND>::VR, RB = JKShape<ND>::RB;
-    const int v = (C.q >> 2) & 7;
+    const int v = (C.q >> TF_JKP_VSH) & 7;
+    const bool first = (C.q & TF_JKP_VMASK) == 0;
     // (stores without branches as well: lanes that have nothing to store use an out-of-range offset)
     if constexpr (VR == 8) {
-        const double tJ = half_sum8(rJ);
+        const double tJ = group_sum8(rJ);
         const int d = v / RB, r = v - d * RB;
-        buf_store1<0>(buf_rsrc(U.DJr + kap), ((C.q & 3) == 0 && r < C.nr) ? C.djoff + 8u * (unsigned)(d * U.dstrideJ + (size_t)r * U.RS) : TF_BUF_OOB, 0u, tJ);
+        buf_store1<0>(buf_rsrc(U.DJr + kap), (first && r < C.nr) ? C.djoff + 8u * (unsigned)(d * U.dstrideJ + (size_t)r * U.RS) : TF_BUF_OOB, 0u, tJ);
 #pragma unroll
         for (int dd = 0; dd < ND; ++dd) {
-            const double tI = half_sum1(rI[dd]);
+            const double tI = group_sum1(rI[dd]);
             buf_store1<0>(buf_rsrc(U.DIr + dd * U.dstrideI + kap), (C.q == 0 && C.nr > 0) ? C.dioff : TF_BUF_OOB, 0u, tI);
         }
     } else {
         // four rows, one density: the row sums and the sum of the first index share one butterfly (values 0-3: rows, 4: the first index)
         static_assert(ND == 1 && VR == 4, "shapes: 8 virtual rows, or 4 rows of one density");
         const double vals[8] = {rJ[0], rJ[1], rJ[2], rJ[3], rI[0], 0.0, 0.0, 0.0};
-        const double t = half_sum8(vals);
-        buf_store1<0>(buf_rsrc(U.DJr + kap), ((C.q & 3) == 0 && v < C.nr) ? C.djoff + 8u * (unsigned)((size_t)v * U.RS) : TF_BUF_OOB, 0u, t);
-        buf_store1<0>(buf_rsrc(U.DIr + kap), ((C.q & 3) == 0 && v == 4 && C.nr > 0) ? C.dioff : TF_BUF_OOB, 0u, t);
+        const double t = group_sum8(vals);
+        buf_store1<0>(buf_rsrc(U.DJr + kap), (first && v < C.nr) ? C.djoff + 8u * (unsigned)((size_t)v * U.RS) : TF_BUF_OOB, 0u, t);
+        buf_store1<0>(buf_rsrc(U.DIr + kap), (first && v == 4 && C.nr > 0) ? C.dioff : TF_BUF_OOB, 0u, t);
     }
 }
 
@@ -454,8 +497,8 @@ __device__ __forceinline__ void jkp_merge_jt(const JKWave &U, double2 *slots, in
         for (int d = 0; d < ND; ++d) {
             double2 t = slots[((kk * TF_JKP_W) * ND + d) * 64 + lane];
             for (int u = 1; u < nw; ++u) { const double2 x = slots[((kk * TF_JKP_W + u) * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
-            t.x = pair_step32(t.x, t.x); t.y = pair_step32(t.y, t.y);           // half 0 + half 1 (the same columns)
-            if (lane < 32 && (MODE == JKP_FULL || U.lam0 + 2 * lane < ki.cnt))
+            t.x = across_groups(t.x); t.y = across_groups(t.y);                   // the groups of the wave hold the same columns
+            if (lane < TF_JKP_LG && (MODE == JKP_FULL || U.lam0 + 2 * lane < ki.cnt))
                 buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), 16u * (unsigned)lane, 0u, t);
         }
     }
@@ -508,8 +551,8 @@ __device__ __forceinline__ void jkp_segment(const JKWave &U, JKLane<ND> &C, doub
 #pragma unroll
                         for (int d = 0; d < ND; ++d) {
                             double2 t = jt[d];
-                            t.x = pair_step32(t.x, t.x); t.y = pair_step32(t.y, t.y);
-                            buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), (lane < 32 && (MODE == JKP_FULL || U.lam0 + 2 * lane < ki.cnt)) ? 16u * (unsigned)lane : TF_BUF_OOB, 0u, t);
+                            t.x = across_groups(t.x); t.y = across_groups(t.y);
+                            buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), (lane < TF_JKP_LG && (MODE == JKP_FULL || U.lam0 + 2 * lane < ki.cnt)) ? 16u * (unsigned)lane : TF_BUF_OOB, 0u, t);
                         }
                     }
 #else
@@ -577,8 +620,8 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, JKLane<ND> &C, int NW,
             for (int d = 0; d < ND; ++d) {
                 double2 t = slots[d * 64 + lane];
                 for (int u = 1; u < nw; ++u) { const double2 x = slots[(u * ND + d) * 64 + lane]; t.x += x.x; t.y += x.y; }
-                t.x = pair_step32(t.x, t.x); t.y = pair_step32(t.y, t.y);
-                if (lane < 32 && U.lam0 + 2 * lane < ki.cnt) buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), 16u * (unsigned)lane, 0u, t);
+                t.x = across_groups(t.x); t.y = across_groups(t.y);
+                if (lane < TF_JKP_LG && U.lam0 + 2 * lane < ki.cnt) buf_store2<2>(buf_rsrc(U.yg + d * U.ystride + ki.offA + U.lam0), 16u * (unsigned)lane, 0u, t);
             }
         }
     }
@@ -601,9 +644,9 @@ __device__ __forceinline__ void jkp_task(const JKWave &U, JKLane<ND> &C, int NW,
         double vals[8];
 #pragma unroll
         for (int v = 0; v < 8; ++v) vals[v] = v < JBB ? jd[v < JBB ? v : 0] : 0.0;
-        const double t = half_sum8(vals);
-        const int v = (C.q >> 2) & 7, d = v / RB, r = v - d * RB;
-        if ((C.q & 3) == 0 && v < JBB && r < C.nr) Jd[d * strideJd + (size_t)(C.r0 + r) * NW + wchunk] = t;
+        const double t = group_sum8(vals);
+        const int v = (C.q >> TF_JKP_VSH) & 7, d = v / RB, r = v - d * RB;
+        if ((C.q & TF_JKP_VMASK) == 0 && v < JBB && r < C.nr) Jd[d * strideJd + (size_t)(C.r0 + r) * NW + wchunk] = t;
     }
 }
 
@@ -632,47 +675,70 @@ __global__ __launch_bounds__(64 * TF_JKP_W, TF_JKP_STAGES > 2 ? 1 : (JKShape<ND>
     const JKTask t = tasks[blockIdx.x];
     const JKSuper sg = supers[t.super];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nw = (sg.ng + 1) >> 1;                                   // waves with at least one group
+    constexpr int GPW = TF_JKP_GPW;
+    const int nw = (sg.ng + GPW - 1) / GPW;                            // waves with at least one group
     const bool active = w < nw;
-    const int ga = sg.g0 + (active ? 2 * w : 0);
-    const bool hasB = active && 2 * w + 1 < sg.ng;
-    // half 0 takes the group that lies lower in memory (the lane offsets of half 1 are unsigned): a lower unit, or -- two-density
-    // passes, whose groups of 4 are halves of one storage unit -- the lower position in the unit
-    int ia = ga, ib = hasB ? ga + 1 : ga;
-    {
-        const long long ua = groups[ia].ub, ub = groups[ib].ub;
-        if (ub < ua || (ub == ua && groups[ib].p0 < groups[ia].p0)) { const int tswap = ia; ia = ib; ib = tswap; }
-        ia = __builtin_amdgcn_readfirstlane(ia); ib = __builtin_amdgcn_readfirstlane(ib);   // (wave-uniform: keeps the group records in SGPRs)
+    // the wave's groups, the one that lies lowest in memory first (the lane offsets of the others are unsigned): a lower unit, or -- groups
+    // that are parts of one storage unit -- the lower position in the unit.  Missing groups repeat group 0 with no rows.
+    int ids[GPW], ngw = 0;
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int gi = sg.g0 + (active ? GPW * w : 0) + g;
+        const bool have = active && GPW * w + g < sg.ng;
+        ids[g] = have ? gi : sg.g0 + (active ? GPW * w : 0);
+        ngw += have ? 1 : 0;
     }
-    const JKGroup gA = groups[ia], gB = groups[ib];
+    {
+        auto below = [&](int x, int y) {                               // group x lies below group y
+            const long long ux = groups[x].ub, uy = groups[y].ub;
+            return ux < uy || (ux == uy && groups[x].p0 < groups[y].p0);
+        };
+        // selection of the lowest into ids[0] is all the kernel needs; the present groups stay in front of the repeats
+        int lowest = 0;
+#pragma unroll
+        for (int g = 1; g < GPW; ++g) if (g < ngw && below(ids[g], ids[lowest])) lowest = g;
+        const int tswap = ids[0]; ids[0] = ids[lowest]; ids[lowest] = tswap;
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) ids[g] = __builtin_amdgcn_readfirstlane(ids[g]);   // (wave-uniform: keeps the group records in SGPRs)
+    }
+    const JKGroup gA = groups[ids[0]];
     const int N = L.N, NW = L.NW, c = sg.c;
     const int b = L.chunk_cls[t.w], a = b ^ c;
     JKWave U;
     U.N = N; U.i = __builtin_amdgcn_readfirstlane(gA.i);
     U.kI0 = bl_cstart(L, a); U.c0 = L.chunk_c0[t.w]; U.lam0 = U.c0 - bl_cstart(L, b); U.width = L.chunk_width[t.w]; U.cm = (c == 0) ? 1 : 0;
-    U.sec = groups[ia].secoff[a];                                       // (table read from memory: a is a run-time index)
-    U.unr0 = gA.unr; U.p00 = gA.p0;
-    U.dub = (int)(gB.ub - gA.ub); U.dunr = gB.unr - gA.unr; U.dp0 = gB.p0 - gA.p0;
-    U.Tb = T + gA.ub + (long long)gA.unr * U.sec; U.X = X; U.NPtot = (long long)S.Pp;
+    U.sec = groups[ids[0]].secoff[a];                                   // (table read from memory: a is a run-time index)
+    U.Tb = T + gA.ub; U.X = X; U.NPtot = (long long)S.Pp;
+    U.rt = buf_rsrc(U.Tb + U.lam0);
     const long long pbase = bl_cbase(L, c) + bl_fullsec(L, c, a);
     U.Pp = Pp + pbase;
     U.kinfo = kinfo + (size_t)c * N + U.kI0;
     U.yg = ypart + sg.yoff + bl_fullsec(L, c, a); U.ystride = S.y;
     U.RS = (size_t)L.RS;
     U.rp = L.rpoff[c * NW + t.w];
-    // row parts: uniform bases at the lower of the two groups / rows, small per-lane offsets
-    const int gmin = min(ia, ib), rmin = min(gA.r0, gB.r0);
+    JKLane<ND> C;
+    C.h = lane / TF_JKP_LG; C.q = lane % TF_JKP_LG;
+    C.lam = U.lam0 + 2 * C.q; C.lI = U.c0 + 2 * C.q;
+    // per-lane copy of the lane's group; row parts: uniform bases at the lowest group / row of the wave, small per-lane offsets
+    int gmin = ids[0], rmin = gA.r0;
+    C.nr = active ? gA.nr : 0; C.lamj0 = gA.lamj0; C.r0 = gA.r0; C.g = ids[0];
+    C.gb = 0u; C.unr = (unsigned)gA.unr; C.p0 = (unsigned)gA.p0;
+    int j0 = gA.j0;
+    bool all_full = active && gA.nr == RB;
+#pragma unroll
+    for (int g = 1; g < GPW; ++g) {
+        const JKGroup gG = groups[ids[g]];
+        const bool have = g < ngw;
+        gmin = min(gmin, ids[g]); rmin = min(rmin, gG.r0);
+        all_full = all_full && have && gG.nr == RB;
+        if (C.h == g) {
+            C.nr = have ? gG.nr : 0; C.lamj0 = gG.lamj0; C.r0 = gG.r0; C.g = ids[g]; j0 = gG.j0;
+            C.gb = (unsigned)(gG.ub - gA.ub); C.unr = (unsigned)gG.unr; C.p0 = (unsigned)gG.p0;
+        }
+    }
     U.DIr = DIr + (size_t)gmin * L.RS + U.rp; U.dstrideI = S.DIr;
     U.DJr = DJr + (size_t)rmin * L.RS + U.rp; U.dstrideJ = S.DJr;
-    JKLane<ND> C;
-    C.h = lane >> 5; C.q = lane & 31;
-    C.lam = U.lam0 + 2 * C.q; C.lI = U.c0 + 2 * C.q;
-    const bool mine = C.h ? hasB : active;
-    C.nr = mine ? (C.h ? gB.nr : gA.nr) : 0;
-    C.lamj0 = C.h ? gB.lamj0 : gA.lamj0;
-    C.r0 = C.h ? gB.r0 : gA.r0;
-    C.g = C.h ? ib : ia;
-    C.xrow = 8u * (unsigned)((C.h ? gB.j0 : gA.j0) * N);
+    C.xrow = 8u * (unsigned)(j0 * N);
     C.dioff = 8u * (unsigned)((C.g - gmin) * L.RS);
     C.djoff = 8u * (unsigned)((C.r0 - rmin) * L.RS);
     {
@@ -691,7 +757,7 @@ __global__ __launch_bounds__(64 * TF_JKP_W, TF_JKP_STAGES > 2 ? 1 : (JKShape<ND>
     const int klim = kend - (last ? 1 : 0);
     const int kd1 = min(max(L.kapF[c * NW + t.w], kap0), klim);
     Jd += (size_t)t.part * S.planeJd; DIc += (size_t)t.part * S.planeI; DJc += (size_t)t.part * S.planeJ;   // column parts and Jd: one plane per part
-    if (hasB && gA.nr == RB && gB.nr == RB)
+    if (all_full)
         jkp_task<ND, true>(U, C, NW, t.w, lane, active, slots, nw, w, kap0, kd1, klim, last, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
     else
         jkp_task<ND, false>(U, C, NW, t.w, lane, active, slots, nw, w, kap0, kd1, klim, last, Jd, S.Jd, DIc, S.DIc, DJc, S.DJc);
