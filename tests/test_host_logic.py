@@ -184,3 +184,21 @@ def test_host_blas_pool_is_capped():
     tuna_amd.limit_host_threads(2)
     assert all(p["num_threads"] <= 2 for p in threadpool_info() if p.get("user_api") == "blas")
     tuna_amd.limit_host_threads()
+
+
+def test_finite_difference_formulas_against_the_reference_values():
+    """tuna_amd/properties.py's stencils on the reference's own field energies give the reference's derivatives
+    (tests/golden/field_systems.json: tuna_util.py:581-680 evaluated from the source text)."""
+    import json
+    import os
+    from conftest import GOLD
+    from tuna_amd import properties as props
+    for tag, g in json.load(open(os.path.join(GOLD, "field_systems.json"))).items():
+        h1, h2, h3 = g["steps"]
+        assert (h1, h2, h3) == (props.FIRST_ELEC_DERIVATIVE_STEP, props.SECOND_ELEC_DERIVATIVE_STEP, props.THIRD_ELEC_DERIVATIVE_STEP)
+        d, p, y = g["dipole_energies"], g["polarisability_energies"], g["hyperpolarisability_energies"]
+        assert -props.calculate_first_derivative(d["-z"], d["+z"], h1) == g["electronic_dipole"]
+        assert -props.calculate_second_derivative(p["-2z"], p["-z"], g["energy"], p["+z"], p["+2z"], h2) == g["polarisability_parallel"]
+        assert -props.calculate_second_derivative(p["-2x"], p["-x"], g["energy"], p["+x"], p["+2x"], h2) == g["polarisability_perpendicular"]
+        assert -props.calculate_third_derivative(y["-4z"], y["-3z"], y["-2z"], y["-z"], y["+z"], y["+2z"], y["+3z"], y["+4z"], h3) == \
+            g["hyperpolarisability_parallel"]

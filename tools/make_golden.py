@@ -522,7 +522,67 @@ def make_sweep_golden(scf, blocks, ortho):
     json.dump(out, open(os.path.join(GOLD, "sweep_systems.json"), "w"), indent=0)
 
 
-def run_reference_scf(scf, ortho, atoms, shells, S, T, V, ERI, n_occ, conv="extreme", damping=True):
+FIELD_SYSTEMS = {
+    "hf_631g": (["F", "H"], 0.917, "6-31G", 5),
+    "lih_sto3g": (["LI", "H"], 1.595, "STO-3G", 2),
+    "co_ccpvdz": (["C", "O"], 1.128, "cc-pVDZ", 7),
+}
+
+
+def make_field_golden(scf, blocks, ortho):
+    """tests/golden/field_systems.json: the reference's RHF energies in the finite electric fields of its dipole / polarisability /
+    hyperpolarisability drivers (tuna_energy.py:315-650: field term F = sum_i E_i D_i, kernel:660-677; core guess, EXTREME, dynamic
+    damping) and the derivatives its own formulas (tuna_util.py:581-680, evaluated from the source text) make of them.  Data only."""
+    import ast
+    import json
+    util_src = open(os.path.join(REF, "TUNA", "tuna_util.py")).read()
+    lines, _ = _parseable_lines(os.path.join(REF, "TUNA", "tuna_util.py"))
+    tree = ast.parse("\n".join(lines))
+    ns = {}
+    steps = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in ("calculate_first_derivative", "calculate_second_derivative", "calculate_third_derivative"):
+            node.returns = None
+            for a in node.args.args:
+                a.annotation = None
+            exec(compile(ast.Module([node], []), "tuna_util.py", "exec"), ns)
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name) and \
+                node.targets[0].id in ("FIRST_ELEC_DERIVATIVE_STEP", "SECOND_ELEC_DERIVATIVE_STEP", "THIRD_ELEC_DERIVATIVE_STEP"):
+            steps[node.targets[0].id] = float(ast.literal_eval(node.value))
+    h1, h2, h3 = steps["FIRST_ELEC_DERIVATIVE_STEP"], steps["SECOND_ELEC_DERIVATIVE_STEP"], steps["THIRD_ELEC_DERIVATIVE_STEP"]
+    out = {}
+    for tag, (sym, R_ang, basis, nocc) in FIELD_SYSTEMS.items():
+        atoms, shells, aos = system(sym, mol.angstrom_to_bohr(R_ang), basis)
+        S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
+        U = reference_U(shells, blocks)
+        Ss, Ts_, Vs, Es = to_spherical(U, S), to_spherical(U, T), to_spherical(U, V), eri_to_spherical(U, E)
+        Ds = np.array([to_spherical(U, D[k]) for k in range(3)])
+
+        def energy(field):
+            F = np.einsum("i,ijk->jk", np.asarray(field, dtype=float), Ds, optimize=True)      # kernel:675
+            return float(run_reference_scf(scf, ortho, atoms, shells, Ss, Ts_, Vs, Es, nocc, "extreme", True, F_fld=F)["energy"])
+        x, z = np.array([1.0, 0.0, 0.0]), np.array([0.0, 0.0, 1.0])
+        E0 = energy(0 * z)
+        dip = {"+z": energy(h1 * z), "-z": energy(-h1 * z)}
+        pol = {k: energy(h2 * f) for k, f in {"+2z": 2 * z, "+z": z, "-z": -z, "-2z": -2 * z, "+2x": 2 * x, "+x": x, "-x": -x, "-2x": -2 * x}.items()}
+        hyp = {k: energy(h3 * f) for k, f in {"+3z": 3 * z, "+2z": 2 * z, "+z": z, "-z": -z, "-2z": -2 * z, "-3z": -3 * z, "-4z": -4 * z,
+                                                "+4z": 4 * z, "+x+z": x + z, "-x+z": -x + z, "+x-z": x - z, "-x-z": -x - z}.items()}
+        d1, d2, d3 = ns["calculate_first_derivative"], ns["calculate_second_derivative"], ns["calculate_third_derivative"]
+        out[tag] = dict(symbols=sym, R_angstrom=R_ang, basis=basis, n_occ=nocc, n_ao=int(U.shape[0]), dipole_origin_z=float(com_z(atoms)),
+                        steps=[h1, h2, h3], energy=E0, dipole_energies=dip, polarisability_energies=pol, hyperpolarisability_energies=hyp,
+                        electronic_dipole=-1 * d1(dip["-z"], dip["+z"], h1),
+                        polarisability_parallel=-1 * d2(pol["-2z"], pol["-z"], E0, pol["+z"], pol["+2z"], h2),
+                        polarisability_perpendicular=-1 * d2(pol["-2x"], pol["-x"], E0, pol["+x"], pol["+2x"], h2),
+                        hyperpolarisability_parallel=-1 * d3(hyp["-4z"], hyp["-3z"], hyp["-2z"], hyp["-z"], hyp["+z"], hyp["+2z"], hyp["+3z"],
+                                                             hyp["+4z"], h3),
+                        hyperpolarisability_perpendicular=-(hyp["-x+z"] - 2 * hyp["+z"] + hyp["+x+z"] - hyp["-x-z"] + 2 * hyp["-z"]
+                                                            - hyp["+x-z"]) / (2 * h3 ** 3))        # energy:541
+        print(tag, U.shape[0], "E0 =", E0, "alpha", out[tag]["polarisability_parallel"], out[tag]["polarisability_perpendicular"],
+              "beta", out[tag]["hyperpolarisability_parallel"], out[tag]["hyperpolarisability_perpendicular"], flush=True)
+    json.dump(out, open(os.path.join(GOLD, "field_systems.json"), "w"), indent=0)
+
+
+def run_reference_scf(scf, ortho, atoms, shells, S, T, V, ERI, n_occ, conv="extreme", damping=True, F_fld=None):
     """Core-Hamiltonian guess (tuna_guess.py calculate_core_guess: diagonalise H_core, fill n_occ) + reference loop."""
     X, smallest, S_inv = ortho(S, None, True)
     eps0, C0 = scf.diagonalise_Fock_matrix(T + V, X)
@@ -539,7 +599,10 @@ def run_reference_scf(scf, ortho, atoms, shells, S, T, V, ERI, n_occ, conv="extr
     scf.format_output_line = rec
     try:
         V_NN = mol.nuclear_repulsion(atoms)
-        out = scf.run_self_consistent_field_cycle(molecule, Calc(CONV[conv], damping=damping), Ints(S, T, V, ERI), V_NN, X,
+        ints = Ints(S, T, V, ERI)
+        if F_fld is not None:
+            ints.F = F_fld                                   # energy:915 (set after the guess: the core guess does not see the field)
+        out = scf.run_self_consistent_field_cycle(molecule, Calc(CONV[conv], damping=damping), ints, V_NN, X,
                                                   (P0, P0 / 2, P0 / 2, E0), (None, None, None, None), True)
     finally:
         scf.format_output_line = orig
@@ -566,6 +629,9 @@ def main():
         return
     if "--mp2-only" in sys.argv:
         make_mp2_golden(scf, blocks, ortho)
+        return
+    if "--field-only" in sys.argv:
+        make_field_golden(scf, blocks, ortho)
         return
     if "--sweep-only" in sys.argv:
         make_sweep_golden(scf, blocks, ortho)

@@ -46,6 +46,10 @@ class Calculation:
     functional: str | None = None       # Kohn-Sham functional name (tuna_amd.dft.FUNCTIONALS) or None for Hartree-Fock
     grid_conv: str = "medium"           # LOOSEGRID/MEDIUMGRID/TIGHTGRID..., util:129-137
     X_alpha: float = 2 / 3              # XA, calc:156
+    dipole: bool = False                # DIPOLE, calc:137: finite-field electric properties (tuna_amd/properties.py)
+    polarisability: bool = False        # POLAR, calc:139
+    hyperpolarisability: bool = False   # HYPER, calc:140
+    electric_field: tuple = (0.0, 0.0, 0.0)
 
 
 @dataclass
@@ -131,6 +135,12 @@ def interpret_keywords(params, calc: Calculation) -> Calculation:
             calc.X_alpha = float(value())
         elif p == "COREGUESS":
             calc.core_guess = True
+        elif p == "DIPOLE":
+            calc.dipole = True
+        elif p in ("POLAR", "POLARISABILITY", "POLARIZABILITY"):
+            calc.polarisability = True
+        elif p in ("HYPER", "HYPERPOLARISABILITY", "HYPERPOLARIZABILITY"):
+            calc.hyperpolarisability = True
         elif p in ("SADGUESS", "T", "P", "DEBUG"):
             pass
         else:
@@ -239,6 +249,21 @@ def calculate_energy(symbols, R_bohr, calc: Calculation, engine: Engine | None =
                 log(f"\n  MP2 correlation energy:             {r['E_MP2']:13.10f}")
         if not silent:
             log(" Final single point energy:        " + f"{out.energy:16.10f}")        # kernel:1305
+        if calc.dipole or calc.polarisability or calc.hyperpolarisability:
+            # finite-field properties (energy:941-957): the cycles of a property run in lockstep on the resident tensor
+            from . import properties as props
+            if calc.method == "MP2":
+                raise TunaError("finite-field properties are available for Hartree-Fock energies in this build")
+            t0 = time.perf_counter()
+            fe = props.FieldEnergies(molecule, calc, integrals, V_NN, X, guess)
+            out.properties = {}
+            if calc.dipole:
+                out.properties["dipole_moment"] = props.calculate_numerical_dipole_moment(fe, silent, log)
+            if calc.polarisability:
+                out.properties["polarisability"] = props.calculate_polarisability(fe, out.energy, silent, log)
+            if calc.hyperpolarisability:
+                out.properties["hyperpolarisability"] = props.calculate_hyperpolarisability(fe, silent, log)
+            out.timings["Electric properties"] = time.perf_counter() - t0
         out.integrals = integrals if not own else None      # the device tensor dies with an engine we own
         return out
     finally:
@@ -259,4 +284,9 @@ def run(input_line: str, silent: bool = True, engine: Engine | None = None, log=
         calc.reference = "UHF"
     if method in dft_mod.FUNCTIONALS:
         calc.functional = method
+    if not any(p in params for p in ("LOOSE", "MEDIUM", "TIGHT", "EXTREME")):      # calc:473-485: derivative requests tighten the SCF
+        if calc.polarisability or calc.hyperpolarisability:
+            calc.SCF_conv = SCF_CONVERGENCE["extreme"]
+        elif calc.dipole:
+            calc.SCF_conv = SCF_CONVERGENCE["tight"]
     return calculate_energy(symbols, R, calc, engine, silent, log)

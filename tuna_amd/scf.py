@@ -300,11 +300,47 @@ def _python_level_cycle(molecule, calculation, integrals, V_NN, X, P, E, o):
     """The iteration order of scf:1072-1154 with device Fock builds (sharded tensor + all-reduce) and rocSOLVER
     diagonalisations, orchestrated from the host: the cross-check of the native cycle (TUNA_AMD_HOST_SCF=1 selects it for a
     sharded tensor).  Hartree-Fock only.  Every rank runs it redundantly."""
-    import time
     if getattr(calculation, "DFT_calculation", False):
         raise TunaError("the host-orchestrated cycle is Hartree-Fock only: Kohn-Sham runs in the native cycle (tf_scf_rhf)")
+    gen = _cycle_steps(molecule, integrals, V_NN, X, P, E, o, integrals.F + integrals.G)
+    try:
+        D = next(gen)
+        while True:
+            D = gen.send(integrals.ERI_AO.jk(D))
+    except StopIteration as done:
+        return done.value
+
+
+def run_cycles_in_lockstep(molecule, calculation, integrals, V_NN, X, guess_objects, external_terms):
+    """Several restricted Hartree-Fock cycles on the SAME tensor, one per external one-electron term (the finite-field evaluations of
+    tuna_energy.py:355-396, 483-540 differ in nothing but F_fld), advanced together: every iteration builds the Fock matrices of all
+    cycles still running in ONE call -- their densities go through the tensor as a batch (n_dens = cycles: pairs of densities per
+    pass) instead of one pass each.  Each cycle follows exactly the iteration order of a run on its own (scf:1072-1154) and stops by
+    its own criteria.  Returns the result dictionaries in the order of `external_terms`."""
+    if getattr(calculation, "DFT_calculation", False) or getattr(calculation, "reference", "RHF") == "UHF":
+        raise TunaError("finite-field batches run restricted Hartree-Fock cycles in this build")
+    P, _, _, E = guess_objects
+    o = _opts(calculation)
+    gens = [_cycle_steps(molecule, integrals, V_NN, X, P, E, o, integrals.G + term) for term in external_terms]
+    wanted = {k: next(g) for k, g in enumerate(gens)}        # cycle -> the density it needs J and K for
+    results = [None] * len(gens)
+    while wanted:
+        keys = sorted(wanted)
+        J, K = integrals.ERI_AO.jk(np.stack([wanted[k] for k in keys]))
+        for n, k in enumerate(keys):
+            try:
+                wanted[k] = gens[k].send((J[n], K[n]))
+            except StopIteration as done:
+                results[k] = done.value
+                del wanted[k]
+    return results
+
+
+def _cycle_steps(molecule, integrals, V_NN, X, P, E, o, Fext):
+    """One restricted Hartree-Fock cycle as a generator: yields the density whose J and K it needs next, receives (J, K), returns
+    the result dictionary (scf:1072-1154; DIIS scf:960-1061, damping scf:1110-1154)."""
+    import time
     S, T, V = integrals.S, integrals.T, integrals.V_NE
-    Fext = integrals.F + integrals.G
     eng = integrals.ERI_AO.engine
     thr = o["conv"]
     n_occ = molecule.n_doubly_occ
@@ -320,7 +356,7 @@ def _python_level_cycle(molecule, calculation, integrals, V_NN, X, P, E, o):
 
     for step in range(1, o["max_iter"] + 1):
         E_old, P_very_old, P_old = E, P_old, P
-        J, K = integrals.ERI_AO.jk(P)
+        J, K = yield P
         F = symmetrise(T + V + Fext + J - (1 / 2) * K * o["hfx"])
         e = X.T @ (F @ P @ S - S @ P @ F) @ X
         commutator = np.mean(e * e) ** (1 / 2)
