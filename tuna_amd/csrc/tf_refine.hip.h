@@ -10,6 +10,10 @@
 
 namespace tfref {
 
+// pairs inside the occupied or inside the virtual space closer than this are one cluster: not rotated (the projector does not care)
+#ifndef TF_REF_CLUSTER
+#define TF_REF_CLUSTER 1e-5
+#endif
 #define TFR_THREADS 1024
 #define TFR_NMAX 64
 
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
                 const double sij = 0.5 * (sT2[i * ns + j] + sT2[j * ns + i]);
                 const double dl = sLam[j] - sLam[i];
                 const bool ov = sOcc[i] != sOcc[j];
-                if (ov || (fabs(sij) <= 0.05 * fabs(dl) && fabs(dl) > 1e-5)) v = sij / dl;
+                if (ov || (fabs(sij) <= 0.05 * fabs(dl) && fabs(dl) > TF_REF_CLUSTER)) v = sij / dl;
                 emax = fmax(emax, fabs(v));
                 if (ov) eov = fmax(eov, fabs(v));
             }
