@@ -147,7 +147,11 @@ def pmc_traffic(workload: str, world: int, layout: str):
         try:
             d = json.load(open(path))
             k = [v for name, v in d.items() if JK_KERNEL[layout] in name][0]
-            return (k["FETCH_SIZE"]["mean_KB"] * 1024.0 * 2.0 + k["WRITE_SIZE"]["mean_KB"] * 1024.0), os.path.relpath(path, ROOT)
+            # a build may take several launches of the kernel (one per workgroup size: 4, 2, 1 waves): bytes per BUILD = the sum over the
+            # dispatches of the profiled run / its builds (jk_reduce_kernel runs once per build)
+            red = [v for name, v in d.items() if "jk_reduce_kernel" in name]
+            per_build = lambda c: (k[c]["sum"] / red[0][c]["dispatches"]) if red and red[0][c]["dispatches"] else k[c]["mean_KB"]
+            return (per_build("FETCH_SIZE") * 1024.0 * 2.0 + per_build("WRITE_SIZE") * 1024.0), os.path.relpath(path, ROOT)
         except Exception:
             continue
     return None, None
