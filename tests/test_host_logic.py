@@ -202,3 +202,62 @@ def test_finite_difference_formulas_against_the_reference_values():
         assert -props.calculate_second_derivative(p["-2x"], p["-x"], g["energy"], p["+x"], p["+2x"], h2) == g["polarisability_perpendicular"]
         assert -props.calculate_third_derivative(y["-4z"], y["-3z"], y["-2z"], y["-z"], y["+z"], y["+2z"], y["+3z"], y["+4z"], h3) == \
             g["hyperpolarisability_parallel"]
+
+
+def test_lockstep_cycles_on_a_cpu_stand_in():
+    """tuna_amd.scf.run_cycles_in_lockstep (the finite-field batch driver) with a stand-in for the device tensor: J/K from the
+    oracle's dense tensor for a whole batch of densities, NumPy diagonalisation.  Every cycle must follow the oracle's own RHF loop
+    (scf_oracle.run_rhf with the same external term) and the batch must ask for fewer Fock builds than the cycles have iterations."""
+    import types
+    from conftest import atom_arrays
+    from oracle import oracle as orc
+    from oracle import scf_oracle as so
+    from tuna_amd import molecule as mol, properties as props, scf, spherical
+    atoms = mol.make_atoms(["LI", "H"], mol.angstrom_to_bohr(1.595))
+    shells = mol.build_shells(atoms, "STO-3G")
+    aos = mol.expand_cartesian_aos(shells)
+    U = spherical.transformation_matrix([s.L for s in shells])
+    xyz, chg, org = atom_arrays(atoms)
+    S, T, V, D, Q = orc.one_electron(aos, xyz, chg, org)
+    S, T, V = (U @ M @ U.T for M in (S, T, V))
+    D = np.array([U @ D[k] @ U.T for k in range(3)])
+    E = so.eri_to_spherical(U, orc.eri(aos))
+    X, _, _ = so.orthogonaliser(S)
+    P0, E0 = so.core_guess(T, V, X, 2)
+    ranges = [sum(s.n_sph for s in shells if s.atom == a) for a in range(2)]
+
+    class FakeEngine:
+        world = 1
+
+        def diagonalise(self, F, Xm):
+            return so.diagonalise(F, Xm)
+
+    class FakeERI:
+        engine = FakeEngine()
+        n_builds = 0
+
+        def jk(self, P):
+            self.n_builds += 1
+            P = np.asarray(P)
+            if P.ndim == 2:
+                return so.coulomb(P, E), so.exchange(P, E)
+            return np.array([so.coulomb(p, E) for p in P]), np.array([so.exchange(p, E) for p in P])
+
+    eri = FakeERI()
+    integrals = types.SimpleNamespace(S=S, T=T, V_NE=V, D=D, F=np.zeros_like(S), G=np.zeros_like(S), ERI_AO=eri)
+    molecule = types.SimpleNamespace(atoms=atoms, n_doubly_occ=2, partition_ranges=ranges)
+    from tuna_amd.engine import SCF_CONVERGENCE
+    calc = types.SimpleNamespace(reference="RHF", DFT_calculation=False, SCF_conv=SCF_CONVERGENCE["tight"], max_iter=100, DIIS=True,
+                                 max_DIIS_matrices=6, damping=True, damping_factor=None, max_damping=0.7, HFX_prop=1.0)
+    h = props.SECOND_ELEC_DERIVATIVE_STEP
+    fields = [[0, 0, 2 * h], [0, 0, h], [0, 0, -h], [0, 0, -2 * h], [h, 0, 0]]
+    terms = [props.apply_electric_field(D, f) for f in fields]
+    V_NN = mol.nuclear_repulsion(atoms)
+    res = scf.run_cycles_in_lockstep(molecule, calc, integrals, V_NN, X, (P0, P0 / 2, P0 / 2, E0), terms)
+    total_iterations = 0
+    for r, term in zip(res, terms):
+        ref = so.run_rhf(S, T, V, E, X, P0, E0, 2, V_NN, ranges, conv="tight", damping="dynamic", Fext=term)
+        assert abs(r["energy"] - ref["energy"]) < 1e-10 and r["n_iter"] == ref["n_iter"]
+        np.testing.assert_allclose(r["table"][:, 1], ref["table"][:, 1], atol=1e-10)
+        total_iterations += r["n_iter"]
+    assert eri.n_builds == max(r["n_iter"] for r in res) < total_iterations

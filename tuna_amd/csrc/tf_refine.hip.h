@@ -14,6 +14,9 @@ namespace tfref {
 #ifndef TF_REF_CLUSTER
 #define TF_REF_CLUSTER 1e-5
 #endif
+#ifndef TF_REF_INTRA
+#define TF_REF_INTRA 0.05             // largest rotation applied inside the occupied or the virtual space
+#endif
 #define TFR_THREADS 1024
 #define TFR_NMAX 64
 
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
                 const double sij = 0.5 * (sT2[i * ns + j] + sT2[j * ns + i]);
                 const double dl = sLam[j] - sLam[i];
                 const bool ov = sOcc[i] != sOcc[j];
-                if (ov || (fabs(sij) <= 0.05 * fabs(dl) && fabs(dl) > TF_REF_CLUSTER)) v = sij / dl;
+                if (ov || (fabs(sij) <= TF_REF_INTRA * fabs(dl) && fabs(dl) > TF_REF_CLUSTER)) v = sij / dl;
                 emax = fmax(emax, fabs(v));
                 if (ov) eov = fmax(eov, fabs(v));
             }

@@ -387,7 +387,7 @@ __global__ void k_ref_E(const double *__restrict__ S, const double *__restrict__
             const double sij = 0.5 * (S[e] + S[(size_t)j * n + i]);
             const double dl = lam[j] - lam[i];
             ov = wocc[i] != wocc[j];
-            if (ov || (fabs(sij) <= 0.05 * fabs(dl) && fabs(dl) > TF_REF_CLUSTER)) v = sij / dl;
+            if (ov || (fabs(sij) <= TF_REF_INTRA * fabs(dl) && fabs(dl) > TF_REF_CLUSTER)) v = sij / dl;
         }
         E[e] = v;
     }
