@@ -29,7 +29,15 @@ if wl.isdigit():
 names = args or ["base"]
 for rep in range(2):
     for name in names:
-        lib = os.path.join(ROOT, "tuna_amd", "libtunafock.so" if name == "base" else f"libtunafock_{name}.so")
-        out = subprocess.run([sys.executable, "-c", CHILD, ROOT, wl], env=dict(os.environ, TUNAFOCK_LIB=lib), capture_output=True, text=True)
+        # name = library variant, or VAR=value to run the base library with that environment variable (e.g. TF_ERI_FACT_THREADS=256)
+        env = dict(os.environ)
+        if "=" in name:
+            k, v = name.split("=", 1)
+            env[k] = v
+            lib = os.path.join(ROOT, "tuna_amd", "libtunafock.so")
+        else:
+            lib = os.path.join(ROOT, "tuna_amd", "libtunafock.so" if name == "base" else f"libtunafock_{name}.so")
+        env["TUNAFOCK_LIB"] = lib
+        out = subprocess.run([sys.executable, "-c", CHILD, ROOT, wl], env=env, capture_output=True, text=True)
         line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-600:]
         print(name, rep, line, flush=True)

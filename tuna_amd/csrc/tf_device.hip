@@ -1123,7 +1123,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             if (tables_end >= TF_CSR_DOUBLES) q.offCsr = 0;      // staged over the dead tables (after the X/Z barrier)
             else { q.offCsr = o; o += TF_CSR_DOUBLES; }
             q.lds_doubles = o;
-            hipLaunchKernelGGL(eri_fact_kernel, dim3(q.n_ket, n_bra), dim3(TF_ERI_THREADS), (size_t)o * sizeof(double), st, ctx->db, q, d_bra,
+            // (TF_ERI_FACT_THREADS=64|128: smaller workgroups for experiments -- measured slower at N = 400, 127 / 159 ms against 113-127 ms:
+            // the LDS of a quartet limits the workgroups per CU, so fewer waves per workgroup are fewer waves per CU)
+            static const int force_thr = getenv("TF_ERI_FACT_THREADS") ? atoi(getenv("TF_ERI_FACT_THREADS")) : 0;
+            const int fact_threads = (force_thr == 64 || force_thr == 128) ? force_thr : TF_ERI_THREADS;
+            hipLaunchKernelGGL(eri_fact_kernel, dim3(q.n_ket, n_bra), dim3(fact_threads), (size_t)o * sizeof(double), st, ctx->db, q, d_bra,
                                d_braoff, d_ket, Nc, d_out_slab);
         } else {
             const int RB = 3584, EB = 3072;                     // LDS doubles for R tables / staged E tables

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     double *sEab = smem + qc.offEab, *sEcd = smem + qc.offEcd, *sScale = smem + qc.offScale;
     double *sX = smem + qc.offRed;                               // [nT][nM]
     int *sLmn = reinterpret_cast<int *>(smem + qc.offLmn);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;     // 64, 128 or 256 threads: small classes run one wave per quartet (host: fact_threads)
     const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
     const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
     if (qc.tri && cd.A > ab.A) return;
@@ -574,15 +574,15 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     {
         const double *__restrict__ gEab = B.epool + ab.e_off;
         const double *__restrict__ gEcd = B.epool + cd.e_off;
-        for (int k = tid; k < 2 * nEab; k += TF_ERI_THREADS) sEab[k] = gEab[k];
-        for (int k = tid; k < 2 * nEcd; k += TF_ERI_THREADS) sEcd[k] = gEcd[k];
+        for (int k = tid; k < 2 * nEab; k += nthr) sEab[k] = gEab[k];
+        for (int k = tid; k < 2 * nEcd; k += nthr) sEcd[k] = gEcd[k];
     }
     coop_tables(B, L, 1, 1, sR, sPref, sPQ, [&](int, int &ppab, int &ppcd) { ppab = ab.pp_off; ppcd = cd.pp_off; }, tid);
     __syncthreads();
     // ---- ket half of the z tables: G[c,d][v][n], v <= La + Lb, n <= L - v - (c + d) (zero beyond) ----
     double *sG = smem + qc.offG;
     const unsigned short *__restrict__ tupG = B.tup + qc.tupG_off, *__restrict__ tupXZ = B.tup + qc.tupXZ_off;   // entry index words (host)
-    for (int e = tid; e < Lc1 * Ld1 * Lab1 * nM; e += TF_ERI_THREADS) {
+    for (int e = tid; e < Lc1 * Ld1 * Lab1 * nM; e += nthr) {
         const int w = tupG[e];
         const int n = w & 15, v = (w >> 4) & 15, d = (w >> 8) & 7, c = (w >> 11) & 7;
         const int l34 = c + d;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     }
     __syncthreads();
     // ---- per-axis tables ----
-    for (int e = tid; e < nT * nM; e += TF_ERI_THREADS) {
+    for (int e = tid; e < nT * nM; e += nthr) {
         const int w = tupXZ[e];
         const int m = w & 15, a = (w >> 4) & 7, b = (w >> 7) & 7, c = (w >> 10) & 7, d = (w >> 13) & 7;
         const int l12 = a + b, l34 = c + d;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     __syncthreads();
     // the R / E tables are dead from here on: the spherical CSR rows of the ket shells may be staged over them (host: offCsr)
     KetCsr kcsr{};
-    if (qc.fused && qc.spherical) kcsr = stage_ket_csr(B, qc, smem + qc.offCsr, tid, TF_ERI_THREADS);
+    if (qc.fused && qc.spherical) kcsr = stage_ket_csr(B, qc, smem + qc.offCsr, tid, nthr);
     // ---- components, in groups of complete (cc,cd) sub-blocks ----
     // Per bra component pair and per ket component pair (class constants, tabulated once per workgroup): the pair's part of the three
     // table indices, the parities of its x and y exponent sums, and its normalisation ratio.  A component is then two table lookups,
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     double *sScAB = smem + qc.offTab, *sScCD = sScAB + nab;
     int2 *sOfAB = reinterpret_cast<int2 *>(sScCD + nsubc), *sOfCD = sOfAB + nab;
     const int LcLd = Lc1 * Ld1;
-    for (int e = tid; e < nab + nsubc; e += TF_ERI_THREADS) {         // host-tabulated per shell pair (DBasis::ct_*)
+    for (int e = tid; e < nab + nsubc; e += nthr) {         // host-tabulated per shell pair (DBasis::ct_*)
         const bool bra = e < nab;
         const int f = bra ? e : e - nab, g = (bra ? ab.tab_off : cd.tab_off) + f;
         const int w = B.ct_ix[g], unit = (bra ? LcLd : 1) * nM * (int)sizeof(double);
@@ -653,12 +653,12 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
     const char *bX = reinterpret_cast<const char *>(sX), *bZ = reinterpret_cast<const char *>(sZ);
     const int GB = qc.fused ? max(1, min(nab, TF_BLK_DOUBLES / nsubc)) : nab;
     // component cl = abl * nsubc + icd of a block; a thread's components advance by the workgroup size: (abl, icd) incrementally
-    const int step_a = TF_ERI_THREADS / nsubc, step_c = TF_ERI_THREADS - step_a * nsubc;
+    const int step_a = nthr / nsubc, step_c = nthr - step_a * nsubc;
     const int abl_first = tid / nsubc, icd_first = tid - abl_first * nsubc;
     for (int blk0 = 0; blk0 < nab; blk0 += GB) {
         const int nblk = min(GB, nab - blk0), ncg = nblk * nsubc;
         int abl = abl_first, icd = icd_first;
-        for (int cl = tid; cl < ncg; cl += TF_ERI_THREADS) {
+        for (int cl = tid; cl < ncg; cl += nthr) {
             const int iab = blk0 + abl;
             const int2 oa = sOfAB[iab], oc = sOfCD[icd];
             double val = 0.0;
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS) void eri_fact_kernel(DBasis B, QCla
         }
         if (qc.fused) {
             __syncthreads();
-            ket_epilogue(B, qc, kcsr, sBlk, nblk, row0 + blk0, ab, blk0, cd, Cslab, tid, TF_ERI_THREADS);
+            ket_epilogue(B, qc, kcsr, sBlk, nblk, row0 + blk0, ab, blk0, cd, Cslab, tid, nthr);
             __syncthreads();
         }
     }
