@@ -74,3 +74,44 @@ def test_hip_path_against_the_reference(engine, tag):
     assert abs(r["n_iter"] - g["n_iter"]) <= 2
     np.testing.assert_allclose(r["epsilons"], np.array(g["epsilons"]), atol=1e-6)
     np.testing.assert_allclose(r["components"][:4], np.array(g["components"]), atol=1e-6)
+
+
+UHF_SWEEP = json.load(open(os.path.join(GOLD, "uhf_sweep.json")))
+MP2_SWEEP = json.load(open(os.path.join(GOLD, "mp2_sweep.json")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(UHF_SWEEP))
+def test_open_shell_sweep_against_the_reference(engine, tag):
+    """GPU: the native unrestricted cycle (tf_scf_uhf: both spin densities in one pass over the tensor) on atoms and diatomic radicals
+    / cations across the basis sets, against one run of the reference's own UHF cycle each (core guess, EXTREME, no damping)."""
+    from tuna_amd import scf
+    from tuna_amd.energy import Calculation, build_molecule_and_integrals
+    from tuna_amd.engine import SCF_CONVERGENCE
+    g = UHF_SWEEP[tag]
+    na, nb = g["n_alpha"], g["n_beta"]
+    R = None if g["R_angstrom"] is None else mol.angstrom_to_bohr(g["R_angstrom"])
+    charge = sum(a.charge for a in mol.make_atoms(g["symbols"], R)) - (na + nb)
+    calc = Calculation(basis=g["basis"], SCF_conv=SCF_CONVERGENCE["extreme"], multiplicity=na - nb + 1, damping=False, core_guess=True,
+                       charge=int(charge))
+    molecule, integrals, X, guess, _ = build_molecule_and_integrals(g["symbols"], R, calc, engine)
+    assert calc.reference == "UHF" and (molecule.n_alpha, molecule.n_beta) == (na, nb) and engine.N == g["n_ao"]
+    assert abs(guess[3] - g["E0"]) < 1e-8
+    out = scf.run_self_consistent_field_cycle(molecule, calc, integrals, g["V_NN"], X, guess)
+    assert abs(out.energy - g["energy"]) < 1e-8
+    assert abs(out.n_iterations - g["n_iter"]) <= 3          # (the last iterations of an EXTREME run sit at the rounding floor: see above)
+    np.testing.assert_allclose(out.epsilons_alpha, np.array(g["eps_alpha"]), atol=1e-6)
+    if nb > 0:
+        np.testing.assert_allclose(out.epsilons_beta, np.array(g["eps_beta"]), atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(MP2_SWEEP))
+def test_mp2_sweep_against_the_reference(engine, tag):
+    """GPU: RMP2 (AO->MO of the (ia|jb) block on the packed rows + the energy sums) on the reference's converged orbitals of twelve
+    members of the sweep, against the reference's own transformation and energy expressions: 1e-10 Eh per component."""
+    g = MP2_SWEEP[tag]
+    atoms, shells, aos = _system(g)
+    engine.set_basis(aos).build_eri(True)
+    r = engine.mp2_rhf(np.array(g["C"]), np.array(g["eps"]), g["n_occ"])
+    assert abs(r["E_OS"] - g["E_OS"]) < 1e-10 and abs(r["E_SS"] - g["E_SS"]) < 1e-10

@@ -529,6 +529,77 @@ FIELD_SYSTEMS = {
 }
 
 
+# Open-shell systems for the unrestricted path (symbols, bond length in Angstrom or None, basis, alpha and beta electrons)
+UHF_SWEEP = {
+    "h_atom_augccpvtz": (["H"], None, "aug-cc-pVTZ", 1, 0),
+    "b_atom_631gs": (["B"], None, "6-31G*", 3, 2),
+    "c_triplet_ccpvdz": (["C"], None, "cc-pVDZ", 4, 2),
+    "n_quartet_def2svp": (["N"], None, "def2-SVP", 5, 2),
+    "f_atom_6311g": (["F"], None, "6-311G", 5, 4),
+    "na_atom_321g": (["NA"], None, "3-21G", 6, 5),
+    "p_quartet_sto6g": (["P"], None, "STO-6G", 9, 6),
+    "cl_atom_631g": (["CL"], None, "6-31G", 9, 8),
+    "h2+_def2tzvp": (["H", "H"], 1.06, "def2-TZVP", 1, 0),
+    "lih+_ccpvdz": (["LI", "H"], 2.2, "cc-pVDZ", 2, 1),
+    "beh_6311gss": (["BE", "H"], 1.343, "6-311G**", 3, 2),
+    "ch_doublet_ccpvdz": (["C", "H"], 1.12, "cc-pVDZ", 4, 3),
+    "nh_triplet_631gs": (["N", "H"], 1.036, "6-31G*", 5, 3),
+    "cn_doublet_sto3g": (["C", "N"], 1.172, "STO-3G", 7, 6),
+    "o2+_doublet_321g": (["O", "O"], 1.116, "3-21G", 8, 7),
+    "b2_triplet_sto3g": (["B", "B"], 1.59, "STO-3G", 6, 4),
+}
+# members of SWEEP whose RMP2 correlation energy is stored as well (the reference's own AO->MO transformation, tuna_ci.py:204-255)
+MP2_SWEEP = ["lih_ccpvdz", "bh_def2svp", "hf_631gs", "lif_631g", "co_sto6g", "n2_321g", "f2_6311g", "hcl_631gs", "alh_631g", "pn_321g",
+             "nah_def2svp", "heh+_ccpvtz"]
+
+
+def make_open_shell_sweep(scf, blocks, ortho):
+    """tests/golden/uhf_sweep.json: one reference UHF run per open-shell system (core guess, EXTREME, no damping)."""
+    import json
+    out = {}
+    for tag, (sym, R_ang, basis, na, nb) in UHF_SWEEP.items():
+        atoms, shells, aos = system(sym, None if R_ang is None else mol.angstrom_to_bohr(R_ang), basis)
+        S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
+        U = reference_U(shells, blocks)
+        Ss, Ts_, Vs, Es = to_spherical(U, S), to_spherical(U, T), to_spherical(U, V), eri_to_spherical(U, E)
+        try:
+            r = run_reference_uhf(scf, ortho, atoms, shells, Ss, Ts_, Vs, Es, na, nb, "extreme", False)
+        except RuntimeError as e:                            # the reference's own cycle does not converge without damping: not a fixture
+            print("UHF", tag, "skipped:", e, flush=True)
+            continue
+        out[tag] = dict(symbols=sym, R_angstrom=R_ang, basis=basis, n_alpha=na, n_beta=nb, n_ao=int(U.shape[0]), energy=float(r["energy"]),
+                        V_NN=float(r["V_NN"]), E0=float(r["E0"]), n_iter=int(len(r["table"])),
+                        eps_alpha=[float(x) for x in r["epsilons_alpha"]], eps_beta=[float(x) for x in r["epsilons_beta"]])
+        print("UHF", tag, U.shape[0], "E =", out[tag]["energy"], "iters", out[tag]["n_iter"], flush=True)
+    json.dump(out, open(os.path.join(GOLD, "uhf_sweep.json"), "w"), indent=0)
+
+
+def make_mp2_sweep(scf, blocks, ortho):
+    """tests/golden/mp2_sweep.json: RMP2 on the converged reference orbitals of some members of SWEEP (C and eps stored: the
+    correlation energy is checked on the SAME orbitals, independent of the SCF's last digits)."""
+    import json
+    ao_to_mo, doubles_eps = load_reference_ao_to_mo()
+    out = {}
+    for tag in MP2_SWEEP:
+        sym, R_ang, basis, nocc = SWEEP[tag]
+        atoms, shells, aos = system(sym, None if R_ang is None else mol.angstrom_to_bohr(R_ang), basis)
+        S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
+        U = reference_U(shells, blocks)
+        Ss, Ts_, Vs, Es = to_spherical(U, S), to_spherical(U, T), to_spherical(U, V), eri_to_spherical(U, E)
+        r = run_reference_scf(scf, ortho, atoms, shells, Ss, Ts_, Vs, Es, nocc, "extreme", True)
+        C, eps = r["C"], r["epsilons"]
+        ERI_MO = ao_to_mo(Es, C, None, True)
+        o, v = slice(0, nocc), slice(nocc, len(eps))
+        e_ijab = doubles_eps(eps, eps, o, o, v, v)
+        g = ERI_MO.transpose(0, 2, 1, 3)[o, o, v, v]
+        E_OS = float(np.einsum("ijab,ijab,ijab->", g, g, e_ijab, optimize=True))
+        E_SS = float(np.einsum("ijab,ijab,ijab->", g, g - g.swapaxes(2, 3), e_ijab, optimize=True))
+        out[tag] = dict(symbols=sym, R_angstrom=R_ang, basis=basis, n_occ=nocc, E_SCF=float(r["energy"]), E_OS=E_OS, E_SS=E_SS,
+                        C=[[float(x) for x in row] for row in C], eps=[float(x) for x in eps])
+        print("MP2", tag, len(eps), "E_MP2 =", E_OS + E_SS, flush=True)
+    json.dump(out, open(os.path.join(GOLD, "mp2_sweep.json"), "w"), indent=0)
+
+
 def make_field_golden(scf, blocks, ortho):
     """tests/golden/field_systems.json: the reference's RHF energies in the finite electric fields of its dipole / polarisability /
     hyperpolarisability drivers (tuna_energy.py:315-650: field term F = sum_i E_i D_i, kernel:660-677; core guess, EXTREME, dynamic
@@ -629,6 +700,12 @@ def main():
         return
     if "--mp2-only" in sys.argv:
         make_mp2_golden(scf, blocks, ortho)
+        return
+    if "--uhf-sweep-only" in sys.argv:
+        make_open_shell_sweep(scf, blocks, ortho)
+        return
+    if "--mp2-sweep-only" in sys.argv:
+        make_mp2_sweep(scf, blocks, ortho)
         return
     if "--field-only" in sys.argv:
         make_field_golden(scf, blocks, ortho)
