@@ -307,8 +307,15 @@ def main():
         if world > 1:
             from tuna_amd import distributed as tdist
             tdist.attach_allreduce(eng)
-        scf_w = scf_on_workload(eng, atoms, shells, nocc, desc)       # the tensor of the timed builds is still resident
-        scf_c = scf_leg(eng, args, rank, world)
+        # (an exception in a leg must not cost the headline line: it is reported in the leg's place)
+        try:
+            scf_w = scf_on_workload(eng, atoms, shells, nocc, desc)   # the tensor of the timed builds is still resident
+        except Exception as e:
+            scf_w = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            scf_c = scf_leg(eng, args, rank, world)
+        except Exception as e:
+            scf_c = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             out["scf_on_workload"], out["scf"] = scf_w, scf_c
     if rank == 0:
