@@ -179,11 +179,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: tuna_amd has no CPU fallback")
+    # TUNA_BENCH_BACKEND=gloo: rehearsal of the multi-rank flow on a box with fewer GPUs than ranks (RCCL refuses two ranks on one
+    # device): the ranks share the cards round-robin and the all-reduce of [J;K] is staged through the host.  Not a measurement.
+    backend = os.environ.get("TUNA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from tuna_amd.engine import Engine
     atoms, shells, aos, nocc, desc = build_workload(args.workload)
@@ -212,10 +220,19 @@ def main():
     dJK = torch.zeros((2, nd, N, N), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    def allreduce(t, op=None):
+        kw = {} if op is None else {"op": op}
+        if backend == "nccl":
+            dist.all_reduce(t, **kw)
+        else:                                                 # rehearsal: through the host
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
+
     def step():
         eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), nd, stream)
         if world > 1:
-            dist.all_reduce(dJK)
+            allreduce(dJK)
 
     for _ in range(args.warmup):
         step()
@@ -238,8 +255,8 @@ def main():
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     k_max = torch.tensor([kern_s / max(kern_n, 1)], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
+        allreduce(t_max, dist.ReduceOp.MAX)
+        allreduce(k_max, dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
     kernel_avg_s = float(k_max.item())
 
@@ -264,7 +281,7 @@ def main():
             "metric": "Fock builds/sec (J+K from the HBM-resident ERI tensor, one density) + SCF wall time",
             "value": args.steps / elapsed, "unit": "Fock builds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL: gloo, ranks sharing cards -- not a measurement)",
             "config": {"workload": f"{args.workload}: {desc}", "n_ao_spherical": N, "n_ao_cartesian": eng.n_cart,
                        "n_shells": eng.n_shell, "n_densities": nd, "layout": layout, "storage": storage,
                        "stored_bytes_per_gpu": stored_bytes, "parallelism": f"ij-row shards x{world} + RCCL all-reduce of [J;K]" if world > 1 else "1 GPU",
