@@ -33,8 +33,12 @@ if args and args[0].isdigit():
 names = args or ["base"]
 for rep in range(2):
     for name in names:
-        lib = os.path.join(ROOT, "tuna_amd", "libtunafock.so" if name == "base" else f"libtunafock_{name}.so")
-        env = dict(os.environ, TUNAFOCK_LIB=lib)
+        env = dict(os.environ)                               # name = a library variant, or VAR=value for the base library with that variable
+        if "=" in name:
+            k, v = name.split("=", 1)
+            env[k] = v
+        lib = os.path.join(ROOT, "tuna_amd", "libtunafock.so" if (name == "base" or "=" in name) else f"libtunafock_{name}.so")
+        env["TUNAFOCK_LIB"] = lib
         out = subprocess.run([sys.executable, "-c", CHILD, ROOT, str(n)], env=env, capture_output=True, text=True)
         line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-400:]
         print(name, rep, line, flush=True)

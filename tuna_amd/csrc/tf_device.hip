@@ -1699,11 +1699,31 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
                 ctx->prof_used += 2;
             }
         }
+        // one launch per workgroup size; the launches are independent (disjoint tasks): the smaller ones go to side streams so that
+        // their ramp-up and tail overlap the big one (fork / join on events; TF_JK_SERIAL=1: all on the caller's stream)
+        static const bool serial = getenv("TF_JK_SERIAL") != nullptr;
+        int n_launch = 0;
+        for (int b = 0; b < 3; ++b) n_launch += (T.bucket[b + 1] > T.bucket[b] && (TF_JKP_W >> b) >= 1) ? 1 : 0;
+        const bool fork = !serial && ctx->have_streams && n_launch > 1;
+        if (fork) (void)hipEventRecord(ctx->sev[0], st);
+        int side = 0;
+        bool first = true;
         for (int b = 0; b < 3; ++b) {
             const int t0 = T.bucket[b], t1 = T.bucket[b + 1];
-            if (t1 > t0 && (TF_JKP_W >> b) >= 1)
-                hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)(t1 - t0)), dim3(64 * (TF_JKP_W >> b)), 0, st, ctx->d_eri, T.d_groups,
-                                   T.d_supers, T.d_tasks + t0, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+            if (!(t1 > t0 && (TF_JKP_W >> b) >= 1)) continue;
+            hipStream_t ls = st;
+            if (fork && !first) {
+                ++side;
+                ls = ctx->streams[side];
+                (void)hipStreamWaitEvent(ls, ctx->sev[0], 0);
+            }
+            first = false;
+            hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)(t1 - t0)), dim3(64 * (TF_JKP_W >> b)), 0, ls, ctx->d_eri, T.d_groups,
+                               T.d_supers, T.d_tasks + t0, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+            if (ls != st) {
+                (void)hipEventRecord(ctx->sev[side], ls);
+                (void)hipStreamWaitEvent(st, ctx->sev[side], 0);
+            }
         }
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
