@@ -132,14 +132,24 @@ DFT_SYSTEMS = {
     "co_b3lyp_631g": (["C", "O"], R_CO, "6-31G", 7, "B3LYP", "medium"),
     "co_b3lypg_ccpvdz": (["C", "O"], R_CO, "cc-pVDZ", 7, "B3LYP/G", "loose"),
     "c4_co_b3lyp_def2tzvp": (["C", "O"], R_CO, "def2-TZVP", 7, "B3LYP", "medium"),
+    # one small system per remaining functional of tuna_amd.dft.FUNCTIONALS (tests/golden/dft_functionals.npz, --dft-sweep-only)
+    "lih_hfs_sto3g": (["LI", "H"], mol.angstrom_to_bohr(1.595), "STO-3G", 2, "HFS", "loose"),
+    "lih_svwn3_sto3g": (["LI", "H"], mol.angstrom_to_bohr(1.595), "STO-3G", 2, "SVWN3", "loose"),
+    "hf_hfb_631g": (["F", "H"], mol.angstrom_to_bohr(0.917), "6-31G", 5, "HFB", "loose"),
+    "hf_bvwn_631g": (["F", "H"], mol.angstrom_to_bohr(0.917), "6-31G", 5, "BVWN", "loose"),
+    "lih_bvwn3_sto3g": (["LI", "H"], mol.angstrom_to_bohr(1.595), "STO-3G", 2, "BVWN3", "loose"),
+    "hf_bhlyp_631g": (["F", "H"], mol.angstrom_to_bohr(0.917), "6-31G", 5, "BHLYP", "loose"),
+    "hf_b1lyp_631g": (["F", "H"], mol.angstrom_to_bohr(0.917), "6-31G", 5, "B1LYP", "loose"),
+    "lih_slyp_sto3g": (["LI", "H"], mol.angstrom_to_bohr(1.595), "STO-3G", 2, "SLYP", "loose"),
 }
 
 
 @pytest.fixture(scope="session")
 def dft_golden(golden):
-    z = golden("dft_systems")
     out = {}
-    for key in z.files:
-        tag, name = key.split("__", 1)
-        out.setdefault(tag, {})[name] = z[key]
+    for name_ in ("dft_systems", "dft_functionals"):
+        z = golden(name_)
+        for key in z.files:
+            tag, name = key.split("__", 1)
+            out.setdefault(tag, {})[name] = z[key]
     return out

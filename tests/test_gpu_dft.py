@@ -1,4 +1,5 @@
-"""GPU: restricted Kohn-Sham (BASELINE config 4: CO B3LYP/def2-TZVP, plus LDA / BLYP / B3LYP-G cases) -- AOs on the grid, density,
+"""GPU: restricted Kohn-Sham (BASELINE config 4: CO B3LYP/def2-TZVP, plus one case for every other functional of the table: LDA, BLYP,
+B3LYP/G, HFS, SVWN3, HFB, BVWN, BVWN3, BHLYP, B1LYP, SLYP) -- AOs on the grid, density,
 functional derivatives, V_XC and the whole KS-SCF on the device, against the reference's own tuna_dft.py / tuna_xc.py / tuna_scf.py
 run (tests/golden/dft_systems.npz)."""
 import numpy as np
@@ -50,7 +51,16 @@ def test_kohn_sham_scf_matches_reference(engine, dft_golden, tag):
     assert abs(r["energy"] - float(g["energy"])) < 1e-8                       # north-star bar: 1e-8 Eh
     assert abs(r["n_iter"] - len(ref)) <= 1
     n = min(r["n_iter"], len(ref))
-    np.testing.assert_allclose(r["table"][:n, 1], ref[:n, 1], atol=5e-8)
+    if tag in ("hf_hfb_631g", "hf_bvwn_631g"):
+        # HF / 6-31G from the core guess with a pure functional: the first Fock matrix has an exactly degenerate pi pair AT the Fermi level
+        # (orbitals 5 and 6: gap 6e-16, tools/gpu_dft_trace.py), so the five occupied orbitals take an arbitrary member of the pair -- the
+        # eigensolver's choice.  The quadrature grid is not invariant under rotations about the axis, so that choice moves the next
+        # energies by ~1e-7..1e-5 Eh (in the reference as well) until the occupation is closed-shell again: only the damping factors,
+        # the first energy and the converged state compare.
+        assert abs(r["table"][0, 1] - ref[0, 1]) < 5e-8
+        np.testing.assert_allclose(r["table"][:n, 1], ref[:n, 1], atol=1e-4)
+    else:
+        np.testing.assert_allclose(r["table"][:n, 1], ref[:n, 1], atol=5e-8)
     np.testing.assert_allclose(r["table"][:n, 6], ref[:n, 6], atol=1e-6)
     np.testing.assert_allclose(r["components"][:5], g["components"], atol=1e-7)
     np.testing.assert_allclose(r["epsilons"], g["eps"], atol=1e-6)

@@ -351,25 +351,43 @@ def load_reference_dft():
     return xc, dft, patched
 
 
-def make_dft_golden(scf, blocks, ortho):
+DFT_FUNCTIONAL_SWEEP = {        # one small system per functional of tuna_amd.dft.FUNCTIONALS that dft_systems.npz does not exercise
+    "lih_hfs_sto3g": (["LI", "H"], 1.595, "STO-3G", 2, "HFS", "loose"),
+    "lih_svwn3_sto3g": (["LI", "H"], 1.595, "STO-3G", 2, "SVWN3", "loose"),
+    "hf_hfb_631g": (["F", "H"], 0.917, "6-31G", 5, "HFB", "loose"),
+    "hf_bvwn_631g": (["F", "H"], 0.917, "6-31G", 5, "BVWN", "loose"),
+    "lih_bvwn3_sto3g": (["LI", "H"], 1.595, "STO-3G", 2, "BVWN3", "loose"),
+    "hf_bhlyp_631g": (["F", "H"], 0.917, "6-31G", 5, "BHLYP", "loose"),
+    "hf_b1lyp_631g": (["F", "H"], 0.917, "6-31G", 5, "B1LYP", "loose"),
+    "lih_slyp_sto3g": (["LI", "H"], 1.595, "STO-3G", 2, "SLYP", "loose"),
+}
+
+
+def make_dft_golden(scf, blocks, ortho, systems=None, outfile="dft_systems.npz"):
     """BASELINE config 4 (CO B3LYP/def2-TZVP, "medium" grid) and smaller Kohn-Sham cases with the reference's own grid, basis-on-grid,
-    density, functional and V_XC code, and its SCF loop with DFT switched on."""
+    density, functional and V_XC code, and its SCF loop with DFT switched on.  `systems` (tag -> (symbols, R in bohr, basis, n_occ,
+    method, grid)) and `outfile` select another set (--dft-sweep-only: DFT_FUNCTIONAL_SWEEP -> dft_functionals.npz)."""
     import json
     xc, dft, patched = load_reference_dft()
     print("tuna_dft.py lines patched:", patched)
     scf.dft, scf.xc = dft, xc                                       # tuna_scf.py does `import tuna_dft as dft`, `import tuna_xc as xc`
     adata = json.load(open(os.path.join(ROOT, "tuna_amd", "data", "atomic_data.json")))
     GRID = {"loose": (3, 0.7), "medium": (4, 0.9), "tight": (5, 1.0)}            # tuna_util.py:129-137
+    # (x functional, c functional, DFX, HFX, DFC, class): the rows of the reference's table, tuna_util.py:1445-1475
     FUN = {"B3LYP": ("B3", "3P", 0.80, 0.20, 1.0, "GGA"), "BLYP": ("B", "LYP", 1.0, 0.0, 1.0, "GGA"), "LDA": ("S", "VWN5", 1.0, 0.0, 1.0, "LDA"),
-           "B3LYP/G": ("B3", "3P", 0.80, 0.20, 1.0, "GGA")}
+           "B3LYP/G": ("B3", "3P", 0.80, 0.20, 1.0, "GGA"), "HFS": ("S", None, 1.0, 0.0, 0.0, "LDA"), "SVWN3": ("S", "VWN3", 1.0, 0.0, 1.0, "LDA"),
+           "HFB": ("B", None, 1.0, 0.0, 0.0, "GGA"), "BVWN": ("B", "VWN5", 1.0, 0.0, 1.0, "GGA"), "BVWN3": ("B", "VWN3", 1.0, 0.0, 1.0, "GGA"),
+           "BHLYP": ("B", "LYP", 0.50, 0.50, 1.0, "GGA"), "B1LYP": ("B", "LYP", 0.75, 0.25, 1.0, "GGA"), "SLYP": ("S", "LYP", 1.0, 0.0, 1.0, "GGA")}
     out = {}
-    for tag, (sym, R, basis, nocc, method, grid) in {
-        "h2_lda_sto3g": (["H", "H"], mol.angstrom_to_bohr(0.74), "STO-3G", 1, "LDA", "loose"),
-        "n2_blyp_631g": (["N", "N"], mol.angstrom_to_bohr(1.0977), "6-31G", 7, "BLYP", "loose"),
-        "co_b3lyp_631g": (["C", "O"], mol.angstrom_to_bohr(1.128), "6-31G", 7, "B3LYP", "medium"),
-        "co_b3lypg_ccpvdz": (["C", "O"], mol.angstrom_to_bohr(1.128), "cc-pVDZ", 7, "B3LYP/G", "loose"),
-        "c4_co_b3lyp_def2tzvp": (["C", "O"], mol.angstrom_to_bohr(1.128), "def2-TZVP", 7, "B3LYP", "medium"),
-    }.items():
+    if systems is None:
+        systems = {
+            "h2_lda_sto3g": (["H", "H"], mol.angstrom_to_bohr(0.74), "STO-3G", 1, "LDA", "loose"),
+            "n2_blyp_631g": (["N", "N"], mol.angstrom_to_bohr(1.0977), "6-31G", 7, "BLYP", "loose"),
+            "co_b3lyp_631g": (["C", "O"], mol.angstrom_to_bohr(1.128), "6-31G", 7, "B3LYP", "medium"),
+            "co_b3lypg_ccpvdz": (["C", "O"], mol.angstrom_to_bohr(1.128), "cc-pVDZ", 7, "B3LYP/G", "loose"),
+            "c4_co_b3lyp_def2tzvp": (["C", "O"], mol.angstrom_to_bohr(1.128), "def2-TZVP", 7, "B3LYP", "medium"),
+        }
+    for tag, (sym, R, basis, nocc, method, grid) in systems.items():
         atoms, shells, aos = system(sym, R, basis)
         S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
         U = reference_U(shells, blocks)
@@ -434,7 +452,7 @@ def make_dft_golden(scf, blocks, ortho):
             d["grad_pick"] = grads.reshape(3, grads.shape[1], -1)[:, :, pick]
         out[tag] = d
         print("DFT", tag, method, basis, "grid", n_radial, "x", weights.shape[1], "=", G, "pts  n_el", n_el, "E", o.energy, "iters", len(table))
-    np.savez_compressed(os.path.join(GOLD, "dft_systems.npz"), **{f"{t}__{k}": v for t, d in out.items() for k, v in d.items()})
+    np.savez_compressed(os.path.join(GOLD, outfile), **{f"{t}__{k}": v for t, d in out.items() for k, v in d.items()})
 
 
 def make_uhf_golden(scf, blocks, ortho):
@@ -694,6 +712,10 @@ def main():
         return
     if "--dft-only" in sys.argv:
         make_dft_golden(scf, blocks, ortho)
+        return
+    if "--dft-sweep-only" in sys.argv:
+        make_dft_golden(scf, blocks, ortho, {t: (sym, mol.angstrom_to_bohr(R), basis, nocc, m, g)
+                                             for t, (sym, R, basis, nocc, m, g) in DFT_FUNCTIONAL_SWEEP.items()}, "dft_functionals.npz")
         return
     if "--sad-only" in sys.argv:
         make_sad_golden(scf, blocks, ortho)
