@@ -2,11 +2,16 @@
 (tuna_energy.py:565-650), calculate_polarisability (energy:315-425) and calculate_hyperpolarisability (energy:430-560).
 
 The reference evaluates the molecular energy once per field value, one self-consistent field cycle after the other, each
-building its Fock matrices from the same dense tensor.  Here the 2, 8 or 12 cycles of a property run in LOCKSTEP
-(tuna_amd.scf.run_cycles_in_lockstep): the densities of all cycles still iterating go through the tensor as one batch per
-iteration, so the tensor is streamed once per pair of cycles instead of once per cycle.  Every cycle follows the reference's own
-iteration order and stops by its own convergence test, so the energies -- and the finite-difference formulas copied by meaning
-from tuna_util.py:581-680 -- give the reference's numbers.  Restricted Hartree-Fock only.
+building its Fock matrices from the same dense tensor.  Two ways to run the 2, 8 or 12 cycles of a property here:
+  * batched=False (the default): the native cycle (tf_scf_rhf, everything on the device) once per field value on the resident
+    tensor -- the fastest path measured (tools/gpu_field_timing.py: eight cycles at N = 400 in 1.17 s);
+  * batched=True: the cycles in LOCKSTEP (tuna_amd.scf.run_cycles_in_lockstep): the densities of all cycles still iterating go
+    through the tensor as one batch per iteration (pairs of densities per pass).  The Fock builds are then as cheap as they can be,
+    but these cycles are orchestrated from the host (NumPy algebra, one eigensolve per iteration), which costs more than the
+    batching saves (4.0 s for the same eight cycles): the mechanism the batching needs, kept for the native lockstep cycle that
+    would make it pay.
+Every cycle follows the reference's own iteration order and stops by its own convergence test, so the energies -- and the
+finite-difference formulas restated from tuna_util.py:581-680 -- give the reference's numbers.  Restricted Hartree-Fock only.
 """
 from __future__ import annotations
 
@@ -44,7 +49,7 @@ class FieldEnergies:
     """Energies of a list of electric fields for one molecule: `energies(fields)` runs the cycles in lockstep (batched=True) or one
     after the other through the native cycle (batched=False, the reference's order of work); counts the tensor passes either way."""
 
-    def __init__(self, molecule, calculation, integrals, V_NN, X, guess_objects, batched=True, dipole_origin=None):
+    def __init__(self, molecule, calculation, integrals, V_NN, X, guess_objects, batched=False, dipole_origin=None):
         if getattr(calculation, "reference", "RHF") == "UHF" or getattr(calculation, "DFT_calculation", False):
             raise TunaError("finite-field properties are available for restricted Hartree-Fock in this build")
         self.molecule, self.calculation, self.integrals = molecule, calculation, integrals
