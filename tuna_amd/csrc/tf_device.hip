@@ -47,6 +47,8 @@ struct tf_ctx {
     double *d_eri = nullptr;
     size_t eri_cap = 0;                  // bytes allocated behind d_eri: kept across builds (freeing and reallocating 27 GB costs ~1.4 s)
     int2 *d_row_ij = nullptr;
+    int *d_class_rows = nullptr, *d_row_pos = nullptr;   // packed layout: local rows listed class by class; position of a row in that order
+    long long class_row_off[5] = {0, 0, 0, 0, 0};         // rows of class c: d_class_rows[class_row_off[c] .. class_row_off[c + 1])
     int *d_rowmap = nullptr;
     std::vector<int> my_pairs;          // bra shell pairs owned by this rank
     std::vector<DPair> host_pairs;      // host mirror of db.pairs (output offsets are filled in by tf_build_eri)
@@ -160,7 +162,7 @@ static int upload(tf_ctx *ctx, const std::vector<T> &h, T **d, bool track = true
 
 static void free_eri(tf_ctx *ctx)
 {
-    for (void *p : {(void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
+    for (void *p : {(void *)ctx->d_class_rows, (void *)ctx->d_row_pos, (void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
                     (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_Psym,
                     (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ, (void *)ctx->d_Jt, (void *)ctx->d_D})
         if (p) (void)hipFree(p);
@@ -176,7 +178,7 @@ static void free_eri(tf_ctx *ctx)
     ctx->layout_allocs.clear();
     if (ctx->d_rowsec) { (void)hipFree(ctx->d_rowsec); ctx->d_rowsec = nullptr; }
     ctx->bl = BLayout{};
-    ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
+    ctx->d_class_rows = nullptr; ctx->d_row_pos = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
     ctx->d_Ppad = nullptr; ctx->d_J = nullptr; ctx->d_K = nullptr; ctx->d_P = nullptr;
     ctx->d_rowoff = nullptr; ctx->d_Psym = nullptr; ctx->d_Pp = nullptr;
     ctx->d_ypart = nullptr; ctx->d_DI = nullptr; ctx->d_DJ = nullptr; ctx->d_Jt = nullptr; ctx->d_D = nullptr;
@@ -881,6 +883,19 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     }
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
     if (packed) {
+        {
+            // rows listed class by class (the AO->MO transformation works on one class at a time: a row of class c is nonzero only in
+            // the blocks (k of class a) x (l of class a ^ c))
+            std::vector<int> class_rows, row_pos(row_ij.size(), 0);
+            class_rows.reserve(row_ij.size());
+            for (int c = 0; c < 4; ++c) {
+                ctx->class_row_off[c] = (long long)class_rows.size();
+                for (size_t r = 0; r < row_ij.size(); ++r)
+                    if ((H.cls[row_ij[r].x] ^ H.cls[row_ij[r].y]) == c) { row_pos[r] = (int)class_rows.size(); class_rows.push_back((int)r); }
+            }
+            ctx->class_row_off[4] = (long long)class_rows.size();
+            if ((rc = upload(ctx, class_rows, &ctx->d_class_rows, false)) || (rc = upload(ctx, row_pos, &ctx->d_row_pos, false))) return rc;
+        }
         if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, rowsec, &ctx->d_rowsec, false)) ||
             (rc = build_jk_tables(JKShape<1>::RB, ctx->jkt[0])) || (rc = build_jk_tables(JKShape<2>::RB, ctx->jkt[1])))
             return rc;
@@ -2161,7 +2176,13 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     if (hipMalloc((void **)d_out, total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
     auto run = [&](int a, int b, int c, int d, double *dst) {
         double s1 = 0.0;
-        int r = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, packed ? ctx->d_rowoff : nullptr, ctx->d_rowsec, ctx->bl, ctx->hl.RLS,
+        tfmp2::PackedRows pr{};
+        if (packed) {
+            for (int q = 0; q < 4; ++q) { pr.csize[q] = ctx->hl.csize[q]; pr.cstart[q] = ctx->hl.cstart[q]; pr.NP[q] = ctx->hl.NP[q]; }
+            for (int q = 0; q < 5; ++q) pr.class_row_off[q] = ctx->class_row_off[q];
+            pr.d_class_rows = ctx->d_class_rows; pr.d_row_pos = ctx->d_row_pos;
+        }
+        int r = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, packed ? ctx->d_rowoff : nullptr, ctx->d_rowsec, ctx->bl, pr,
                                  ctx->d_row_ij, ctx->n_rows, N, ctx->ld, dC[a], nk[a], dC[b], nk[b], dC[c], nk[c], dC[d], nk[d], dst, &s1, msg);
         secs += s1;
         return r;

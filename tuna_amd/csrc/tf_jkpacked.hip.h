@@ -1054,6 +1054,35 @@ __global__ void unpack_own_rows_kernel(const double *__restrict__ eri, const lon
     o[(size_t)l * ld + k] = v;
 }
 
+// The same in class-blocked form, for the rows of ONE class c (the list `rows`): a row of class c is nonzero only in the four blocks
+// (k of class a) x (l of class a ^ c), so only those are materialised -- a quarter of the N x N matrix.  Block a of a row: |a| x ldb[a]
+// doubles at boff[a] (ldb[a] >= |a ^ c|), INTERNAL class-local indices (loc); row stride rstride.  The caller has zeroed out.
+struct RowBlocks { int boff[4], ldb[4]; long long rstride; };
+__global__ void unpack_own_rows_blocked_kernel(const double *__restrict__ eri, const long long *__restrict__ rowoff, const int *__restrict__ rowsec,
+                                               BLayout L, const int2 *__restrict__ row_ij, const int *__restrict__ rows, int c, RowBlocks RBk,
+                                               double *__restrict__ out)
+{
+    const long long r = rows[blockIdx.y];
+    const int2 ij = row_ij[r];
+    const int wi = L.ao[ij.x], wj = L.ao[ij.y];
+    const int iI = ao_sigma(L, wi), lamj = ao_loc(wj);
+    const int x = blockIdx.x * 256 + threadIdx.x;                            // pair index inside a complete class-c row
+    if (x >= bl_np(L, c)) return;
+    const int kI = L.gk[bl_gbase(L, c) + x / TF_SEG_PAD];
+    const int a = L.clsI[kI], b = a ^ c;
+    const KInfo ki = L.kinfo[(size_t)c * L.N + kI];
+    const int lam = x - bl_fullsec(L, c, a) - ki.offA;
+    const int kl = kI - bl_cstart(L, a);                                     // loc of k
+    if (lam >= ki.cnt || kl >= L.cntA[(size_t)a * L.N + iI] || (kI == iI && lam > lamj)) return;   // padding; k > i; (kl) > (ij)
+    const int *rs = rowsec + 6 * (size_t)r;
+    const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);
+    double v = eri[rowoff[r] + (long long)rs[5] * (rs[a] + ki.offA) + (long long)rs[4] * pc + lam];
+    if (kI == iI && lam == lamj) v *= 0.5;
+    double *__restrict__ o = out + (size_t)blockIdx.y * RBk.rstride;
+    o[RBk.boff[a] + (size_t)kl * RBk.ldb[a] + lam] = v;                      // [k][l] in block a
+    o[RBk.boff[b] + (size_t)lam * RBk.ldb[b] + kl] = v;                      // [l][k] in block b (the same slot when k == l)
+}
+
 // out[x][y] = G1[x][y] + G2[y][x]   (x < A, y < B; G1 [A][B], G2 [B][A]): the two halves L and L^T of a transformed tensor
 __global__ void add_transposed_kernel(const double *__restrict__ G1, const double *__restrict__ G2, long long A, long long B, double *__restrict__ out)
 {

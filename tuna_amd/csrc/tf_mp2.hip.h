@@ -35,7 +35,7 @@ namespace tfmp2 {
 // Qfull[mu][nu][x] = Q[row(max,min)][x]; the row table of the packed layout is keyed by internal AO indices (ao: class | loc << 2
 // of every original AO, nullptr for the rows layout)
 __global__ void unpack_rows_kernel(const double *__restrict__ Q, const int *__restrict__ rowmap, int N, long long width,
-                                   double *__restrict__ Qfull, BLayout L, int packed)
+                                   double *__restrict__ Qfull, BLayout L, int packed, const int *__restrict__ row_pos /* packed: where Q keeps row r */)
 {
     const long long total = (long long)N * N * width;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -44,7 +44,8 @@ __global__ void unpack_rows_kernel(const double *__restrict__ Q, const int *__re
         int mu = (int)(mn / N), nu = (int)(mn - (long long)mu * N);
         if (packed) { mu = ao_sigma(L, L.ao[mu]); nu = ao_sigma(L, L.ao[nu]); }
         const int hi = max(mu, nu), lo = min(mu, nu);
-        const int r = rowmap[hi * (hi + 1) / 2 + lo];
+        int r = rowmap[hi * (hi + 1) / 2 + lo];
+        if (r >= 0 && packed) r = row_pos[r];
         Qfull[e] = (r >= 0) ? Q[(long long)r * width + x] : 0.0;
     }
 }
@@ -77,6 +78,22 @@ __global__ void mp2_energy_kernel(const double *__restrict__ g, const double *__
     if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s_os[0]; partial[2 * blockIdx.x + 1] = s_ss[0]; }
 }
 
+// Ci[x][:] = C[origI[x]][:]: coefficient rows in the internal (class-sorted) AO order of the packed layout
+__global__ void permute_rows_kernel(const double *__restrict__ C, const int *__restrict__ origI, int N, int n, double *__restrict__ Ci)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * n) return;
+    const int x = e / n, p = e - x * n;
+    Ci[e] = C[(size_t)origI[x] * n + p];
+}
+
+// host view of the packed layout for the transformation: class sizes / starts (internal order), pair spaces, rows listed by class
+struct PackedRows {
+    int csize[4], cstart[4];
+    long long NP[4], class_row_off[5];
+    const int *d_class_rows, *d_row_pos;
+};
+
 // out[p][q][r][s] = sum C1[mu p] C2[nu q] C3[la r] C4[si s] (mu nu|la si); C_k are [N, n_k] row-major DEVICE matrices;
 // d_out [n1,n2,n3,n4] on the device.  Rows of the stored tensor are processed in slabs to bound the scratch.
 // Packed layout (d_rowoff != nullptr): the STORED part of every row of a slab is materialised as a symmetric [N][ld] matrix
@@ -84,43 +101,77 @@ __global__ void mp2_energy_kernel(const double *__restrict__ g, const double *__
 // completes it with the transform of L^T (mo_transform_device: G(C1 C2 C3 C4)[pq][rs] + G(C3 C4 C1 C2)[rs][pq]).  Either way the
 // result is linear in the rows a rank owns: the sum over ranks is the transformed tensor.
 inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowmap, const long long *d_rowoff, const int *d_rowsec,
-                     const BLayout &BL, long long max_np, const int2 *d_row_ij, long long n_rows, int N, int ld, const double *dC1, int n1, const double *dC2, int n2, const double *dC3, int n3,
+                     const BLayout &BL, const PackedRows &PR, const int2 *d_row_ij, long long n_rows, int N, int ld, const double *dC1, int n1, const double *dC2, int n2, const double *dC3, int n3,
                      const double *dC4, int n4, double *d_out, double *gemm_seconds, std::string &msg)
 {
     int rc = TF_OK;
     const long long n34 = (long long)n3 * n4;
     const long long row_len = (long long)N * ld;
-    double *dR = nullptr, *dQ = nullptr, *dQfull = nullptr, *dW = nullptr, *dM = nullptr;
+    double *dR = nullptr, *dQ = nullptr, *dQfull = nullptr, *dW = nullptr, *dM = nullptr, *dC3i = nullptr, *dC4i = nullptr;
     const bool packed = d_rowoff != nullptr;
     const double one = 1.0, zero = 0.0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    RowBlocks RBc[4];
+    long long max_rs = 1;
     // slab of rows for the first quarter transformation: R = C3^T M needs n3*N doubles per row
     long long slab = std::max<long long>(1, std::min<long long>(n_rows, (long long)((2048LL << 20) / ((long long)n3 * N * sizeof(double)))));
     if (n34 * N > 0x7fffffffLL || n34 > 0x7fffffffLL) { msg = "AO->MO transformation: dimension overflow"; return TF_EINVAL; }
     TFM_HIP(hipEventCreate(&e0));
     TFM_HIP(hipEventCreate(&e1));
+    // packed: the largest class-blocked row (doubles) bounds the slab as well
     if (packed) {
-        slab = std::max<long long>(1, std::min<long long>(std::min<long long>(slab, 65535), (long long)((2048LL << 20) / (row_len * (long long)sizeof(double)))));
-        TFM_HIP(hipMalloc((void **)&dM, (size_t)slab * row_len * sizeof(double)));
+        for (int c = 0; c < 4; ++c) {
+            long long o = 0;
+            for (int a = 0; a < 4; ++a) { RBc[c].boff[a] = (int)o; RBc[c].ldb[a] = std::max(1, PR.csize[a ^ c]); o += (long long)PR.csize[a] * RBc[c].ldb[a]; }
+            RBc[c].rstride = (o + 1) & ~1LL;
+            max_rs = std::max(max_rs, RBc[c].rstride);
+        }
+        slab = std::max<long long>(1, std::min<long long>(std::min<long long>(slab, 65535), (long long)((2048LL << 20) / (max_rs * (long long)sizeof(double)))));
+        TFM_HIP(hipMalloc((void **)&dM, (size_t)slab * max_rs * sizeof(double)));
+        TFM_HIP(hipMalloc((void **)&dC3i, (size_t)N * n3 * sizeof(double)));
+        TFM_HIP(hipMalloc((void **)&dC4i, (size_t)N * n4 * sizeof(double)));
+        hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)((N * n3 + 255) / 256)), dim3(256), 0, 0, dC3, BL.origI, N, n3, dC3i);
+        hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)((N * n4 + 255) / 256)), dim3(256), 0, 0, dC4, BL.origI, N, n4, dC4i);
     }
     TFM_HIP(hipMalloc((void **)&dR, (size_t)slab * n3 * N * sizeof(double)));
     TFM_HIP(hipMalloc((void **)&dQ, (size_t)std::max<long long>(1, n_rows) * n34 * sizeof(double)));
     TFM_HIP(hipEventRecord(e0, 0));
-    for (long long r0 = 0; r0 < n_rows; r0 += slab) {
-        const int nb = (int)std::min<long long>(slab, n_rows - r0);
-        const double *Mrows = d_eri + r0 * row_len;
-        if (packed) {
-            TFM_HIP(hipMemsetAsync(dM, 0, (size_t)nb * row_len * sizeof(double), 0));
-            hipLaunchKernelGGL(unpack_own_rows_kernel, dim3((unsigned)((max_np + 255) / 256), (unsigned)nb), dim3(256), 0, 0, d_eri, d_rowoff,
-                               d_rowsec, BL, d_row_ij, r0, ld, dM);
-            Mrows = dM;
+    if (!packed) {
+        for (long long r0 = 0; r0 < n_rows; r0 += slab) {
+            const int nb = (int)std::min<long long>(slab, n_rows - r0);
+            const double *Mrows = d_eri + r0 * row_len;
+            // R[row] (n3 x N, row-major) = C3^T (n3 x N) * M[row] (N x N, ld)
+            TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, N, n3, N, &one, Mrows, ld, row_len,
+                                                   dC3, n3, 0, &zero, dR, N, (rocblas_stride)n3 * N, nb));
+            // Q[row] (n3 x n4) = R[row] (n3 x N) * C4 (N x n4)
+            TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, n4, n3, N, &one, dC4, n4, 0, dR, N,
+                                                   (rocblas_stride)n3 * N, &zero, dQ + r0 * n34, n4, (rocblas_stride)n34, nb));
         }
-        // R[row] (n3 x N, row-major) = C3^T (n3 x N) * M[row] (N x N, ld)
-        TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, N, n3, N, &one, Mrows, ld, row_len,
-                                               dC3, n3, 0, &zero, dR, N, (rocblas_stride)n3 * N, nb));
-        // Q[row] (n3 x n4) = R[row] (n3 x N) * C4 (N x n4)
-        TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, n4, n3, N, &one, dC4, n4, 0, dR, N,
-                                               (rocblas_stride)n3 * N, &zero, dQ + r0 * n34, n4, (rocblas_stride)n34, nb));
+    } else {
+        // class by class: the stored part of a class-c row is nonzero only in the blocks (k of class a) x (l of class a ^ c), a quarter of
+        // the N x N matrix; Q is kept in class order (row_pos).  Internal AO order throughout the ket half.
+        for (int c = 0; c < 4; ++c) {
+            const long long nrc = PR.class_row_off[c + 1] - PR.class_row_off[c];
+            const RowBlocks &RB = RBc[c];
+            for (long long t0 = 0; t0 < nrc; t0 += slab) {
+                const int nb = (int)std::min<long long>(slab, nrc - t0);
+                const long long q0 = PR.class_row_off[c] + t0;
+                TFM_HIP(hipMemsetAsync(dM, 0, (size_t)nb * RB.rstride * sizeof(double), 0));
+                TFM_HIP(hipMemsetAsync(dR, 0, (size_t)nb * n3 * N * sizeof(double), 0));      // (a class without members leaves its columns untouched)
+                hipLaunchKernelGGL(unpack_own_rows_blocked_kernel, dim3((unsigned)((PR.NP[c] + 255) / 256), (unsigned)nb), dim3(256), 0, 0, d_eri,
+                                   d_rowoff, d_rowsec, BL, d_row_ij, PR.d_class_rows + q0, c, RB, dM);
+                for (int b = 0; b < 4; ++b) {
+                    const int a = b ^ c;
+                    if (PR.csize[b] == 0 || PR.csize[a] == 0) continue;
+                    // R[row][p][cstart[b] + l] = sum_{k in a} C3i[cstart[a] + k][p] M_a[k][l]   (column-major: (|b| x |a|) (|a| x n3))
+                    TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, PR.csize[b], n3, PR.csize[a], &one,
+                                                           dM + RB.boff[a], RB.ldb[a], (rocblas_stride)RB.rstride, dC3i + (size_t)PR.cstart[a] * n3, n3, 0,
+                                                           &zero, dR + PR.cstart[b], N, (rocblas_stride)n3 * N, nb));
+                }
+                TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, n4, n3, N, &one, dC4i, n4, 0, dR, N,
+                                                       (rocblas_stride)n3 * N, &zero, dQ + q0 * n34, n4, (rocblas_stride)n34, nb));
+            }
+        }
     }
     (void)hipFree(dR); dR = nullptr;
     if (dM) { (void)hipFree(dM); dM = nullptr; }
@@ -128,7 +179,7 @@ inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowm
     {
         const long long tot = (long long)N * N * n34;
         hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 1 << 20)), dim3(256), 0, 0, dQ, d_rowmap, N,
-                           n34, dQfull, BL, packed ? 1 : 0);
+                           n34, dQfull, BL, packed ? 1 : 0, PR.d_row_pos);
     }
     TFM_HIP(hipDeviceSynchronize());
     (void)hipFree(dQ); dQ = nullptr;
@@ -146,6 +197,8 @@ inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowm
 done:
     if (dR) (void)hipFree(dR);
     if (dM) (void)hipFree(dM);
+    if (dC3i) (void)hipFree(dC3i);
+    if (dC4i) (void)hipFree(dC4i);
     if (dQ) (void)hipFree(dQ);
     if (dQfull) (void)hipFree(dQfull);
     if (dW) (void)hipFree(dW);
