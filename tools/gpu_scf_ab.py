@@ -6,8 +6,11 @@ args = sys.argv[1:]
 n = args.pop(0) if args and args[0].isdigit() else "400"
 for rep in range(2):
     for name in args or ["base"]:
-        lib = os.path.join(ROOT, "tuna_amd", "libtunafock.so" if name == "base" else f"libtunafock_{name}.so")
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_scf_synth.py"), n, "2"], env=dict(os.environ, TUNAFOCK_LIB=lib),
-                             capture_output=True, text=True)
+        env = dict(os.environ)                               # name = a library variant, or VAR=value for the base library with that variable
+        if "=" in name:
+            k, v = name.split("=", 1)
+            env[k] = v
+        env["TUNAFOCK_LIB"] = os.path.join(ROOT, "tuna_amd", "libtunafock.so" if (name == "base" or "=" in name) else f"libtunafock_{name}.so")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_scf_synth.py"), n, "2"], env=env, capture_output=True, text=True)
         lines = [l for l in out.stdout.splitlines() if l.startswith("synth-")]
         print(name, rep, lines[-1][:300] if lines else out.stderr[-400:], flush=True)

@@ -17,6 +17,11 @@ namespace tfref {
 #ifndef TF_REF_INTRA
 #define TF_REF_INTRA 0.05             // largest rotation applied inside the occupied or the virtual space
 #endif
+#ifndef TF_REF_INNER
+#define TF_REF_INNER 0                // fixed-point sweeps of the occupied-virtual equations per step (0: the diagonal first-order formula
+                                      // alone).  2-4 sweeps halve the steps of a solve (3.8 -> 1.9 on N2/cc-pVTZ) but not its time: a solve is
+                                      // ~150 us of launch, load, projection and status read-back around ~10 us steps
+#endif
 #define TFR_THREADS 1024
 #define TFR_NMAX 64
 
@@ -137,6 +142,63 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
             }
             sT1[i * ns + j] = v;
         }
+#if TF_REF_INNER > 0
+        // The formula above divides s_ia by (lambda_a - lambda_i): exact to first order only while the occupied-occupied and the
+        // virtual-virtual blocks of S are diagonal.  They are not after a few Fock builds (the clusters inside a space are left
+        // alone on purpose), and the iteration then converges linearly, a digit per step.  The occupied-virtual rotations that
+        // annihilate s_ia to first order solve   sum_b e_ib s_ba - sum_j s_ij e_ja = s_ia   (b virtual, j occupied): a few Jacobi
+        // sweeps with the diagonal as the preconditioner cost O(n_occ n_virt n) each -- nothing beside the five n^3 products of a
+        // step.  16 lanes per entry (i, a) share the sum over m; new values go through a compact [n_occ][n_virt] buffer.
+        {
+            double *eNew = sRed;                                               // [n_occ x n_virt] <= 1024 doubles
+            int *oList = reinterpret_cast<int *>(sRed + TFR_THREADS), *vList = oList + TFR_NMAX;
+            __syncthreads();                                                   // E (first order) complete in T1
+            if (tid < np) {                                                    // the occupied / virtual vectors, in index order
+                int ro = 0, rv = 0;
+                for (int j = 0; j < tid; ++j) { if (sOcc[j] == 1.0) ++ro; else ++rv; }
+                if (sOcc[tid] == 1.0) oList[ro] = tid; else vList[rv] = tid;
+            }
+            for (int e = tid; e < np * np; e += TFR_THREADS) {                 // S <- sym(S) in place (pairs i < j)
+                const int i = e / np, j = e - i * np;
+                if (i < j) { const double m2 = 0.5 * (sT2[i * ns + j] + sT2[j * ns + i]); sT2[i * ns + j] = m2; sT2[j * ns + i] = m2; }
+            }
+            __syncthreads();
+            const int no = n_occ, nv = np - n_occ, npair = no * nv;
+            const int grp = tid >> 4, t16 = tid & 15;
+            bool mocc[TFR_NMAX / 16];
+#pragma unroll
+            for (int u = 0; u < TFR_NMAX / 16; ++u) mocc[u] = (t16 + 16 * u < np) && sOcc[t16 + 16 * u] == 1.0;
+            for (int sweep = 0; sweep < TF_REF_INNER; ++sweep) {
+                for (int q = grp; q < npair; q += TFR_THREADS / 16) {
+                    const int qo = q / nv, i = oList[qo], a2 = vList[q - qo * nv];
+                    double r = 0.0;
+#pragma unroll
+                    for (int u = 0; u < TFR_NMAX / 16; ++u) {
+                        const int m = t16 + 16 * u;
+                        if (m < np && m != i && m != a2)
+                            r += mocc[u] ? sT2[i * ns + m] * sT1[m * ns + a2] : -sT1[i * ns + m] * sT2[m * ns + a2];
+                    }
+                    r += __shfl_xor(r, 8, 16); r += __shfl_xor(r, 4, 16); r += __shfl_xor(r, 2, 16); r += __shfl_xor(r, 1, 16);
+                    if (t16 == 0) eNew[q] = (sT2[i * ns + a2] + r) / (sLam[a2] - sLam[i]);
+                }
+                __syncthreads();
+                for (int q = tid; q < npair; q += TFR_THREADS) {
+                    const int qo = q / nv, i = oList[qo], a2 = vList[q - qo * nv];
+                    const double v = eNew[q];
+                    sT1[i * ns + a2] = v; sT1[a2 * ns + i] = -v;
+                }
+                __syncthreads();
+            }
+            emax = 0.0; eov = 0.0;
+            for (int e = tid; e < np * np; e += TFR_THREADS) {
+                const int i = e / np, j = e - i * np;
+                const double v = fabs(sT1[i * ns + j]);
+                emax = fmax(emax, v);
+                if (sOcc[i] != sOcc[j]) eov = fmax(eov, v);
+            }
+            __syncthreads();                                                   // (sRed is reused by the reduction below)
+        }
+#endif
         sRed[tid] = emax; sRed[TFR_THREADS + tid] = eov;
         __syncthreads();
         for (int st = TFR_THREADS / 2; st > 0; st >>= 1) {
