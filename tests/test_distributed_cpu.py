@@ -131,3 +131,51 @@ def test_generic_lpt_plan():
     assert _lib.lib().tf_shard_plan(len(w), _lib.ptr(w), 3, _lib.ptr(owner)) == 0
     loads = np.array([w[owner == r].sum() for r in range(3)])
     assert loads.sum() == w.sum() and loads.max() - loads.min() <= w.max()
+
+
+def _mo_worker(rank, world, port, tag, ret):
+    """The algebra of the sharded AO->MO transformation (tf_ao_to_mo on a packed, sharded tensor) in NumPy: a rank holds, for the rows
+    (ij) it owns, the pairs (kl) <= (ij) (diagonal pair halved) -- L restricted to its rows; it transforms that with (C1 C2 | C3 C4) and
+    with (C3 C4 | C1 C2); the sum over ranks of G1 + G2^T is the transformed tensor."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        atoms, shells, aos, nocc = make_system(tag)
+        from tuna_amd import spherical
+        U = spherical.transformation_matrix([s.L for s in shells])
+        Es = so.eri_to_spherical(U, orc.eri(aos, 2))
+        N = Es.shape[0]
+        owner = tdist.row_owner_matrix(shells, world, layout="packed")
+        Lr = np.zeros_like(Es)                                   # this rank's part of L, as a dense tensor with both AO orders of each pair
+        for i in range(N):
+            for j in range(i + 1):
+                if owner[i, j] != rank:
+                    continue
+                for k in range(i + 1):
+                    for l in range(k + 1):
+                        if (k, l) > (i, j):
+                            continue
+                        v = Es[i, j, k, l] * (0.5 if (k, l) == (i, j) else 1.0)
+                        for (p, q) in {(i, j), (j, i)}:
+                            for (r, s) in {(k, l), (l, k)}:
+                                Lr[p, q, r, s] = v
+        rng = np.random.default_rng(4)
+        C1, C2, C3, C4 = (rng.standard_normal((N, n)) for n in (2, 3, 3, 2))
+        G1 = np.einsum("mnls,mp,nq,lr,st->pqrt", Lr, C1, C2, C3, C4, optimize=True)
+        G2 = np.einsum("mnls,mp,nq,lr,st->pqrt", Lr, C3, C4, C1, C2, optimize=True)
+        part = torch.from_numpy(np.ascontiguousarray(G1 + G2.transpose(2, 3, 0, 1)))
+        dist.all_reduce(part)
+        ref = np.einsum("mnls,mp,nq,lr,st->pqrt", Es, C1, C2, C3, C4, optimize=True)
+        ret[rank] = float(np.abs(part.numpy() - ref).max())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_ao_to_mo_algebra():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_mo_worker, args=(world, port, "n2_sto3g", ret), nprocs=world, join=True)
+        res = dict(ret)
+    assert set(res) == {0, 1} and all(v < 1e-11 for v in res.values())
