@@ -28,8 +28,12 @@ print(json.dumps({"energy_Eh": r["energy"], "iterations": r["n_iter"], "scf_wall
 """
 for rep in range(2):
     for name in sys.argv[1:] or ["base"]:
-        lib = os.path.join(ROOT, "tuna_amd", "libtunafock.so" if name == "base" else f"libtunafock_{name}.so")
-        out = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=dict(os.environ, TUNAFOCK_LIB=lib, TF_DEBUG="1"), capture_output=True, text=True)
+        env = dict(os.environ, TF_DEBUG="1")                  # name = a library variant, or VAR=value for the base library with that variable
+        if "=" in name:
+            k, v = name.split("=", 1)
+            env[k] = v
+        env["TUNAFOCK_LIB"] = os.path.join(ROOT, "tuna_amd", "libtunafock.so" if (name == "base" or "=" in name) else f"libtunafock_{name}.so")
+        out = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, capture_output=True, text=True)
         steps = [int(l.split("after")[1].split()[0]) for l in out.stderr.splitlines() if "tf refine/lds" in l and "after" in l]
         line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:]
         print(name, rep, line, "refine solves", len(steps), "mean steps %.2f" % (sum(steps) / max(1, len(steps))), flush=True)

@@ -153,10 +153,11 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
             double *eNew = sRed;                                               // [n_occ x n_virt] <= 1024 doubles
             int *oList = reinterpret_cast<int *>(sRed + TFR_THREADS), *vList = oList + TFR_NMAX;
             __syncthreads();                                                   // E (first order) complete in T1
-            if (tid < np) {                                                    // the occupied / virtual vectors, in index order
-                int ro = 0, rv = 0;
-                for (int j = 0; j < tid; ++j) { if (sOcc[j] == 1.0) ++ro; else ++rv; }
-                if (sOcc[tid] == 1.0) oList[ro] = tid; else vList[rv] = tid;
+            if (tid < 64) {                                                    // the occupied / virtual vectors, in index order (np <= 64: wave 0)
+                const bool in = tid < np, occ = in && sOcc[tid] == 1.0;
+                const unsigned long long mo = __ballot(occ), below = (tid == 0) ? 0ull : (~0ull >> (64 - tid));
+                const int ro = __popcll(mo & below);
+                if (in) { if (occ) oList[ro] = tid; else vList[tid - ro] = tid; }
             }
             for (int e = tid; e < np * np; e += TFR_THREADS) {                 // S <- sym(S) in place (pairs i < j)
                 const int i = e / np, j = e - i * np;
