@@ -120,11 +120,15 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
         __syncthreads();
         if (tid < np) sLam[tid] = sT2[tid * ns + tid];
         __syncthreads();
-        if (tid < np) {                                        // the n_occ lowest are occupied (ties by index, like a stable sort)
-            const double li = sLam[tid];
+        {                                                      // the n_occ lowest are occupied (ties by index, like a stable sort):
+            const int i = tid >> 4, t16 = tid & 15;            // 16 lanes share the rank count of vector i
             int rank = 0;
-            for (int j = 0; j < np; ++j) { const double lj = sLam[j]; rank += (lj < li || (lj == li && j < tid)) ? 1 : 0; }
-            sOcc[tid] = rank < n_occ ? 1.0 : 0.0;
+            if (i < np) {
+                const double li = sLam[i];
+                for (int j = t16; j < np; j += 16) { const double lj = sLam[j]; rank += (lj < li || (lj == li && j < i)) ? 1 : 0; }
+            }
+            rank += __shfl_xor(rank, 8, 16); rank += __shfl_xor(rank, 4, 16); rank += __shfl_xor(rank, 2, 16); rank += __shfl_xor(rank, 1, 16);
+            if (i < np && t16 == 0) sOcc[i] = rank < n_occ ? 1.0 : 0.0;
         }
         __syncthreads();
         // E (antisymmetric) into T1; largest rotation overall and between occupied and virtual vectors
@@ -200,13 +204,14 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
             __syncthreads();                                                   // (sRed is reused by the reduction below)
         }
 #endif
-        sRed[tid] = emax; sRed[TFR_THREADS + tid] = eov;
+        // block maxima: inside a wave by shuffles, across the 16 waves through LDS (two barriers instead of a ten-level tree)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { emax = fmax(emax, __shfl_xor(emax, d, 64)); eov = fmax(eov, __shfl_xor(eov, d, 64)); }
+        if (lane == 0) { sRed[w] = emax; sRed[TFR_THREADS + w] = eov; }
         __syncthreads();
-        for (int st = TFR_THREADS / 2; st > 0; st >>= 1) {
-            if (tid < st) { sRed[tid] = fmax(sRed[tid], sRed[tid + st]); sRed[TFR_THREADS + tid] = fmax(sRed[TFR_THREADS + tid], sRed[TFR_THREADS + tid + st]); }
-            __syncthreads();
-        }
         emax = sRed[0]; eov = sRed[TFR_THREADS];
+#pragma unroll
+        for (int u = 1; u < TFR_THREADS / 64; ++u) { emax = fmax(emax, sRed[u]); eov = fmax(eov, sRed[TFR_THREADS + u]); }
         __syncthreads();
         if (!(emax <= 0.3)) break;                             // NaN, or not in the quadratic regime: the caller diagonalises
         // X <- X + E^T X = X - E X
@@ -237,6 +242,75 @@ __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_oc
         }
     }
     if (tid == 0) { status[0] = sFlag; status[1] = steps; }
+}
+
+// n <= 64: the Fock matrix and the DIIS error of an SCF iteration in ONE launch (everything in LDS, products on the FP64 matrix core):
+//     F = sym(H + J - hfx/2 K [+ V_XC])                                   (scf:497-531)
+//     e = X^T (F P S - S P F) X,  with G = F P S and S P F = G^T            (scf:906-920; F, P, S symmetric)
+// F goes to Fout and to the DIIS history slot Fhist, e to Eout.  Replaces nine launches (two element-wise kernels, six rocBLAS GEMMs, a
+// copy) whose host side, not their arithmetic, is what an iteration at this size consists of.
+__global__ __launch_bounds__(TFR_THREADS) void fock_diis_lds_kernel(int n, const double *__restrict__ H, const double *__restrict__ J,
+                                                                    const double *__restrict__ K, double hfx, const double *__restrict__ Vxc,
+                                                                    const double *__restrict__ P, const double *__restrict__ S,
+                                                                    const double *__restrict__ X, double *__restrict__ Fout,
+                                                                    double *__restrict__ Fhist, double *__restrict__ Eout)
+{
+    extern __shared__ double sm[];
+    const int np = tfr_np(n), ns = tfr_stride(np);
+    double *sA = sm, *sB = sA + np * ns, *sT1 = sB + np * ns, *sT2 = sT1 + np * ns;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = np / 16;
+    const bool on = w < nt * nt;
+    const int I = on ? w / nt : 0, Jt = on ? w - I * nt : 0;
+    auto fock = [&](int i, int j) {
+        const size_t e = (size_t)i * n + j;
+        double f = H[e] + J[e] - (1.0 / 2.0) * K[e] * hfx;
+        if (Vxc) f += Vxc[e];
+        return f;
+    };
+    for (int e = tid; e < np * np; e += TFR_THREADS) {
+        const int i = e / np, j = e - i * np;
+        const bool in = i < n && j < n;
+        const double f = in ? 0.5 * (fock(i, j) + fock(j, i)) : 0.0;
+        sA[i * ns + j] = f;
+        sB[i * ns + j] = in ? P[(size_t)i * n + j] : 0.0;
+        if (in) { Fout[(size_t)i * n + j] = f; Fhist[(size_t)i * n + j] = f; }
+    }
+    __syncthreads();
+    mm_tile<false>(sT1, sA, sB, 1.0, 0.0, sA, np, ns, I, Jt, lane, on);              // F P
+    __syncthreads();
+    for (int e = tid; e < np * np; e += TFR_THREADS) { const int i = e / np, j = e - i * np; sB[i * ns + j] = (i < n && j < n) ? S[(size_t)i * n + j] : 0.0; }
+    __syncthreads();
+    mm_tile<false>(sT2, sT1, sB, 1.0, 0.0, sA, np, ns, I, Jt, lane, on);             // G = F P S
+    __syncthreads();
+    for (int e = tid; e < np * np; e += TFR_THREADS) {
+        const int i = e / np, j = e - i * np;
+        sT1[i * ns + j] = sT2[i * ns + j] - sT2[j * ns + i];                          // F P S - S P F
+        sB[i * ns + j] = (i < n && j < n) ? X[(size_t)i * n + j] : 0.0;
+    }
+    __syncthreads();
+    mm_tile<false, true>(sT2, sB, sT1, 1.0, 0.0, sA, np, ns, I, Jt, lane, on);       // X^T (.)
+    __syncthreads();
+    mm_tile<false>(sT1, sT2, sB, 1.0, 0.0, sA, np, ns, I, Jt, lane, on);             // (.) X
+    __syncthreads();
+    for (int e = tid; e < n * n; e += TFR_THREADS) { const int i = e / n, j = e - i * n; Eout[e] = sT1[i * ns + j]; }
+}
+
+inline bool launch_fock_diis(int n, const double *H, const double *J, const double *K, double hfx, const double *Vxc, const double *P,
+                             const double *S, const double *X, double *Fout, double *Fhist, double *Eout, hipStream_t st, hipError_t *err)
+{
+    static bool attr_set = false;
+    if (n < 2 || n > TFR_NMAX) return false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)fock_diis_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        attr_set = true;
+    }
+    const int np = tfr_np(n);
+    hipLaunchKernelGGL(fock_diis_lds_kernel, dim3(1), dim3(TFR_THREADS), (size_t)4 * np * tfr_stride(np) * sizeof(double), st, n, H, J, K, hfx, Vxc, P,
+                       S, X, Fout, Fhist, Eout);
+    *err = hipGetLastError();
+    return *err == hipSuccess;
 }
 
 inline bool launch(int n, int n_occ, const double *A, double *X, double *lam, double *wocc, int *status, hipStream_t st, hipError_t *err,

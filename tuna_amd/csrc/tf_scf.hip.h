@@ -853,24 +853,32 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         rc = jk(dP, dJ, dK, 0);
         if (rc) { msg.clear(); return rc; }                          // (the hook has left its message in the context)
         span_end(tf);
-        hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, 0, dH, dJ, dK, o.hfx, t1, (int)nn);
-        if (xc) hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, t1, 1.0, dVxc, t1, (int)nn);        // + V_XC, scf:525
-        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, dF, n);
-        // DIIS error e = X^T (F P S - S P F) X   (scf:906-920)
-        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dF, dP, 0.0, t1));        // F P
-        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dS, 0.0, t2));        // F P S
-        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dS, dP, 0.0, t1));        // S P
-        TFS_BLAS(gemm_rm(w.blas, false, false, n, -1.0, t1, dF, 1.0, t2));       // F P S - S P F
-        TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, t2, 0.0, t1));         // X^T e
-        // push into the history (trim to max_diis, scf:943-946)
+        // push into the history: trim to max_diis first (scf:943-946), so that the slot of the new entry is known
         if (n_hist == max_diis) {
             std::rotate(slot.begin(), slot.begin() + 1, slot.end());     // the oldest entry's slot becomes the newest
             for (int r = 0; r + 1 < n_hist; ++r)
                 for (int c = 0; c + 1 < n_hist; ++c) B[r * max_diis + c] = B[(r + 1) * max_diis + c + 1];
             --n_hist;
         }
-        TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, histE(n_hist)));   // (X^T e) X
-        TFS_HIP(hipMemcpyAsync(histF(n_hist), dF, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        static const bool no_fused_fock = getenv("TF_FOCK_UNFUSED") != nullptr;
+        hipError_t ferr = hipSuccess;
+        if (!no_fused_fock && n <= TFR_NMAX &&
+            tfref::launch_fock_diis(n, dH, dJ, dK, o.hfx, xc ? dVxc : nullptr, dP, dS, dX, dF, histF(n_hist), histE(n_hist), 0, &ferr)) {
+            // n <= 64: Fock matrix, DIIS error and the history entry in one launch (tf_refine.hip.h)
+        } else {
+            if (ferr != hipSuccess) { msg = std::string("Fock / DIIS kernel launch failed: ") + hipGetErrorString(ferr); return TF_ENODEVICE; }
+            hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, 0, dH, dJ, dK, o.hfx, t1, (int)nn);
+            if (xc) hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, t1, 1.0, dVxc, t1, (int)nn);        // + V_XC, scf:525
+            hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, dF, n);
+            // DIIS error e = X^T (F P S - S P F) X   (scf:906-920)
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dF, dP, 0.0, t1));        // F P
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dS, 0.0, t2));        // F P S
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dS, dP, 0.0, t1));        // S P
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, -1.0, t1, dF, 1.0, t2));       // F P S - S P F
+            TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, t2, 0.0, t1));         // X^T e
+            TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, histE(n_hist)));   // (X^T e) X
+            TFS_HIP(hipMemcpyAsync(histF(n_hist), dF, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        }
         ++n_hist;
         double ee = 0.0;
         {
