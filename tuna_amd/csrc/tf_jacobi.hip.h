@@ -10,7 +10,9 @@
 
 namespace tfjac {
 
+#ifndef TFJ_THREADS
 #define TFJ_THREADS 1024
+#endif
 #define TFJ_NMAX 140
 
 // round-robin tournament: pair k of round r among m (even) players
