@@ -54,7 +54,7 @@ def build_library(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(HERE, "csrc")
     # force: `make -B` recompiles every object (a library newer than its sources is not trusted: the driver's build check)
-    subprocess.check_call(["make", "-C", src_dir, "--no-print-directory"] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-j4", "-C", src_dir, "--no-print-directory"] + (["-B"] if force else []))
     return LIB_PATH
 
 

@@ -18,6 +18,8 @@
 #include "tf_kernels.hip.h"
 #include "tf_jkpacked.hip.h"
 #include "tf_eri.hip.h"
+#include "tf_eri_team.hip.h"
+#include "tf_eri_team_api.h"
 #include "tf_oneel.hip.h"
 #include "tf_scf.hip.h"
 #include "tf_mp2.hip.h"
@@ -54,6 +56,8 @@ struct tf_ctx {
     std::vector<DPair> host_pairs;      // host mirror of db.pairs (output offsets are filled in by tf_build_eri)
     DPair *d_pairs = nullptr;
     std::vector<int> pair_class;        // class id of every shell pair
+    std::vector<int> h_ct_ix, h_ct_ord;  // host mirrors of DBasis::ct_ix / ct_ord / ct_sc (the team kernels' transform tables are built from them)
+    std::vector<double> h_ct_sc;
     std::vector<std::vector<int>> class_pairs;   // pairs of each class, ascending
     // J/K scratch
     double *d_Jrow = nullptr, *d_Kp = nullptr, *d_Ppad = nullptr, *d_J = nullptr, *d_K = nullptr, *d_P = nullptr;
@@ -567,6 +571,7 @@ int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t
         return rc;
     ctx->db = DBasis{d_sh, d_pr, d_lx, d_ly, d_lz, d_sc, d_p, d_Pz, d_K, d_E, d_boys, d_sb, d_sp, d_si, d_sv, d_cti, d_ctp, d_cto, d_cts, nullptr, nullptr};
     ctx->host_pairs = hp;
+    ctx->h_ct_ix = ct_ix; ctx->h_ct_ord = ct_ord; ctx->h_ct_sc = ct_sc;
     ctx->d_pairs = d_pr;
     ctx->have_basis = true;
     return TF_OK;
@@ -1053,6 +1058,13 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     DBG("streams created");
 
     std::vector<LRec> lrecs_host;                              // per (La, Lb | Lc, Ld), filled by make_lrecs below
+    hipError_t team_error = hipSuccess;                        // first failed launch of a team kernel
+    static const bool team_off = getenv("TF_ERI_TEAM") && getenv("TF_ERI_TEAM")[0] == '0';
+    const bool use_team = per_class && packed && !team_off;
+    struct KClassTab { int pS[5] = {0, 0, 0, 0, 0}; int nkap = 0, nnzT = 0, tp_off = 0, te_off = 0; };
+    std::vector<KClassTab> kct(ncls);
+    int *d_kq_ptr = nullptr, *d_kq_off = nullptr, *d_kt_ptr = nullptr, *d_kt_k = nullptr;
+    double *d_kt_c = nullptr;
     // bra_Amax: largest first shell among the bra pairs of the run -- in the packed layout only kets with first shell <= it are needed
     // (the class ket lists ascend in the first shell, so that is a prefix: workgroups beyond it are not even launched)
     auto class_launch = [&](int bcls, int kcls, int max_npp_bra, unsigned n_bra, const int *d_bra, const long long *d_braoff, int bra_Amax) {
@@ -1092,6 +1104,47 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                         q.npq, nb, q.n_ket, (double)nb * q.n_ket, ms, 1e6 * ms / ((double)nb * q.n_ket));
             }
         } class_timer(class_times, q, n_bra);
+        if (use_team && q.npq == 1 && q.La + q.Lb <= TF_TEAM_LMAX && q.Lc + q.Ld <= TF_TEAM_LMAX) {
+            // one shell quartet per team of lanes, tables private to the team (tf_eri_team.hip.h)
+            const DPair &hb = ctx->host_pairs[ctx->class_pairs[bcls][0]], &hk = ctx->host_pairs[ctx->class_pairs[kcls][0]];
+            const KClassTab &kt = kct[kcls];
+            TClass t{};
+            t.La = q.La; t.Lb = q.Lb; t.Lc = q.Lc; t.Ld = q.Ld;
+            t.nTab = (q.La + 1) * (q.Lb + 1); t.nTcd = (q.Lc + 1) * (q.Ld + 1); t.nT = t.nTab * t.nTcd;
+            t.inv_nTcd = 1.0f / (float)t.nTcd;
+            t.nab = q.nca * q.ncb; t.ncd = q.ncc * q.ncd;
+            int maxblk = 1, maxK = 1;
+            for (int i = 0; i < 5; ++i) { t.pA[i] = hb.pcls[i]; t.pK[i] = hk.pcls[i]; t.pS[i] = kt.pS[i]; }
+            for (int i = 0; i < 4; ++i) {
+                maxK = std::max(maxK, t.pK[i + 1] - t.pK[i]);
+                maxblk = std::max(maxblk, (t.pA[i + 1] - t.pA[i]) * (t.pK[i + 1] - t.pK[i]));
+            }
+            t.nkap = kt.nkap; t.nnzT = kt.nnzT; t.tabA = hb.tab_off; t.tabK = hk.tab_off; t.ktp_off = kt.tp_off; t.kte_off = kt.te_off;
+            t.n_ket = q.n_ket; t.nEab = q.nEab; t.nEcd = q.nEcd; t.RLS = H.RLS;
+            const int LAB = q.La + q.Lb, LCD = q.Lc + q.Ld, NM = q.L / 2 + 1, XS = NM | 1, RSr = q.L + 2;
+            const int team = eri_team_size(t.nT), NT = 256 / team;
+            auto even = [](int x) { return (x + 1) & ~1; };
+            int o = 0;
+            t.oE12 = o; o += even(2 * t.nEab);
+            t.oOffA = o; o += 2 * t.nab;
+            t.oScA = o; o += even(t.nab);
+            t.oOffK = o; o += 2 * t.ncd;
+            t.oTp = o; o += even((t.nkap + 2) / 2);
+            t.oTk = o; o += even((t.nnzT + 1) / 2);
+            t.oTc = o; o += even(t.nnzT);
+            t.shared_doubles = o;
+            const int nG = t.nTcd * (LAB + 1) * NM, scr1 = 2 * t.nEcd + (q.L + 1) * RSr + nG;
+            const int vmax = team == 256 ? 2048 : (team == 64 ? 512 : 96);
+            t.vcap = even(std::max(scr1, std::max(maxK, std::min(maxblk, vmax))));
+            t.team_doubles = 2 * t.nT * XS + t.vcap + even((t.nkap + 1) / 2);
+            const size_t bytes = ((size_t)t.shared_doubles + (size_t)NT * t.team_doubles) * sizeof(double);
+            if (bytes <= 160 * 1024 - 256) {
+                TeamLaunch a{LAB, LCD, team, dim3((unsigned)((q.n_ket + NT - 1) / NT), n_bra), bytes, st, &ctx->db, &t, d_bra, d_braoff, d_ket, d_out_slab};
+                const hipError_t e = eri_team_launch(a);
+                if (e != hipSuccess) { team_error = e; }
+                return;
+            }
+        }
         if (q.npq == 1 && q.ncomp <= 128) {
             // several uncontracted shell quartets per workgroup
             int ncp = 1;
@@ -1392,6 +1445,73 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     };
     if (!per_class) make_caps();
     if ((rc = make_lrecs(!per_class))) return rc;
+    // ---- team kernels (tf_eri_team.hip.h): the uncontracted classes of the per-class mode, packed layout.  Per pair class the ket
+    // pair transform (Cartesian component pairs -> output pairs inside each x/y parity class, normalisation ratios folded in), per
+    // shell pair the slab offsets of its output pairs.
+    if (use_team) {
+        std::vector<int> kt_ptr, kt_k, kq_ptr(npairs, 0), kq_off;
+        std::vector<double> kt_c, blkC, blkD;
+        std::vector<std::vector<int>> kap_list(ncls);               // output pairs (sc << 8 | sd) of a pair class, sorted by parity class
+        auto rows_of = [&](const tf::Shell &sh, std::vector<double> &U) {   // transformation rows of a shell (identity: Cartesian output)
+            if (spherical) { tf::sph_block(sh.L, U); return; }
+            U.assign((size_t)sh.ncomp * sh.ncomp, 0.0);
+            for (int i = 0; i < sh.ncomp; ++i) U[(size_t)i * sh.ncomp + i] = 1.0;
+        };
+        auto cls_of = [&](const tf::Shell &sh, const std::vector<double> &U, int r) {   // parity class of an output function: its first component's
+            int cc = 0;
+            while (cc + 1 < sh.ncomp && U[(size_t)r * sh.ncomp + cc] == 0.0) ++cc;
+            const int a = sh.comp_off + cc;
+            return (bs.c_lx[a] & 1) | ((bs.c_ly[a] & 1) << 1);
+        };
+        for (int c = 0; c < ncls; ++c) {
+            const DPair &pr = ctx->host_pairs[ctx->class_pairs[c][0]];
+            const tf::Shell &sC = bs.shells[pr.A], &sD = bs.shells[pr.B];
+            const int nsc = out_dim(sC), nsd = out_dim(sD), ncc = sC.ncomp, ncd = sD.ncomp;
+            rows_of(sC, blkC); rows_of(sD, blkD);
+            std::vector<int> loc((size_t)ncc * ncd, 0);              // position of a component pair inside its parity class (inverse of ct_ord)
+            for (int cl = 0; cl < 4; ++cl)
+                for (int s2 = pr.pcls[cl]; s2 < pr.pcls[cl + 1]; ++s2) loc[ctx->h_ct_ord[pr.tab_off + s2]] = s2 - pr.pcls[cl];
+            KClassTab &kt = kct[c];
+            kt.tp_off = (int)kt_ptr.size(); kt.te_off = (int)kt_k.size();
+            for (int cl = 0; cl < 4; ++cl) {
+                kt.pS[cl] = (int)kap_list[c].size();
+                for (int sc = 0; sc < nsc; ++sc)
+                    for (int sd = 0; sd < nsd; ++sd) {
+                        if ((cls_of(sC, blkC, sc) ^ cls_of(sD, blkD, sd)) != cl) continue;
+                        kap_list[c].push_back((sc << 8) | sd);
+                        kt_ptr.push_back((int)kt_k.size() - kt.te_off);
+                        for (int cc = 0; cc < ncc; ++cc) {
+                            const double uc = blkC[(size_t)sc * ncc + cc];
+                            if (uc == 0.0) continue;
+                            for (int cd2 = 0; cd2 < ncd; ++cd2) {
+                                const double ud = blkD[(size_t)sd * ncd + cd2];
+                                if (ud == 0.0) continue;
+                                const int f = cc * ncd + cd2;
+                                kt_k.push_back(loc[f]);
+                                kt_c.push_back(uc * ud * ctx->h_ct_sc[pr.tab_off + f]);
+                            }
+                        }
+                    }
+            }
+            kt.pS[4] = kt.nkap = (int)kap_list[c].size();
+            kt_ptr.push_back((int)kt_k.size() - kt.te_off);
+            kt.nnzT = (int)kt_k.size() - kt.te_off;
+        }
+        for (int p = 0; p < npairs; ++p) {
+            const DPair &pr = ctx->host_pairs[p];
+            kq_ptr[p] = (int)kq_off.size();
+            for (int word : kap_list[ctx->pair_class[p]]) {
+                const int k = pr.outoff_a + (word >> 8), l = pr.outoff_b + (word & 255);
+                if (l > k) { kq_off.push_back(-1); continue; }
+                const int cb = H.cls[k] ^ H.cls[l];
+                kq_off.push_back(H.fullsec[cb][H.cls[k]] + H.kinfo[(size_t)cb * N + H.sigma[k]].offA + H.loc[l]);
+            }
+        }
+        if ((rc = upload(ctx, kq_ptr, &d_kq_ptr, false)) || (rc = upload(ctx, kq_off, &d_kq_off, false)) || (rc = upload(ctx, kt_ptr, &d_kt_ptr, false)) ||
+            (rc = upload(ctx, kt_k, &d_kt_k, false)) || (rc = upload(ctx, kt_c, &d_kt_c, false)))
+            return rc;
+        ctx->db.kq_ptr = d_kq_ptr; ctx->db.kq_off = d_kq_off; ctx->db.kt_ptr = d_kt_ptr; ctx->db.kt_k = d_kt_k; ctx->db.kt_c = d_kt_c;
+    }
     if (!per_class)
         std::stable_sort(mine_sorted.begin(), mine_sorted.end(), [&](int x, int y) {
             const int gx = pair_group(x), gy = pair_group(y);
@@ -1542,6 +1662,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out);
     if (d_rowcls) (void)hipFree(d_rowcls);
     (void)hipFree(d_kets); (void)hipFree(d_kets_all);
+    for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c})
+        if (pt) (void)hipFree(pt);
+    ctx->db.kq_ptr = ctx->db.kq_off = ctx->db.kt_ptr = ctx->db.kt_k = nullptr; ctx->db.kt_c = nullptr;
+    if (team_error != hipSuccess) TF_FAIL(ctx, TF_ENODEVICE, "launch of a team ERI kernel failed: %s", hipGetErrorString(team_error));
     t_stage[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall0).count();
     std::copy(t_stage, t_stage + 4, ctx->eri_seconds);
     ctx->eri_counts[0] = n_quart; ctx->eri_counts[1] = n_primq; ctx->eri_counts[2] = n_compq;
