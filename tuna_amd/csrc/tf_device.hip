@@ -1060,11 +1060,14 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     std::vector<LRec> lrecs_host;                              // per (La, Lb | Lc, Ld), filled by make_lrecs below
     hipError_t team_error = hipSuccess;                        // first failed launch of a team kernel
     static const bool team_off = getenv("TF_ERI_TEAM") && getenv("TF_ERI_TEAM")[0] == '0';
-    const bool use_team = per_class && packed && !team_off;
+    const bool use_team = per_class && packed && !team_off && bs.epool.size() < 0xffffffffull;
     struct KClassTab { int pS[5] = {0, 0, 0, 0, 0}; int nkap = 0, nnzT = 0, tp_off = 0, te_off = 0; };
     std::vector<KClassTab> kct(ncls);
-    int *d_kq_ptr = nullptr, *d_kq_off = nullptr, *d_kt_ptr = nullptr, *d_kt_k = nullptr;
+    int *d_kq_ptr = nullptr, *d_kq_off = nullptr, *d_kt_ptr = nullptr, *d_kt_k = nullptr, *d_kcnt = nullptr;
     double *d_kt_c = nullptr;
+    KetRec *d_ketrec = nullptr;                                // parallel to d_kets (class-sorted ket list)
+    BraRec *d_brarec = nullptr;                                // parallel to the slab's bra list d_bra
+    const int *d_bra_base = nullptr;
     // bra_Amax: largest first shell among the bra pairs of the run -- in the packed layout only kets with first shell <= it are needed
     // (the class ket lists ascend in the first shell, so that is a prefix: workgroups beyond it are not even launched)
     auto class_launch = [&](int bcls, int kcls, int max_npp_bra, unsigned n_bra, const int *d_bra, const long long *d_braoff, int bra_Amax) {
@@ -1113,16 +1116,16 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             t.nTab = (q.La + 1) * (q.Lb + 1); t.nTcd = (q.Lc + 1) * (q.Ld + 1); t.nT = t.nTab * t.nTcd;
             t.inv_nTcd = 1.0f / (float)t.nTcd;
             t.nab = q.nca * q.ncb; t.ncd = q.ncc * q.ncd;
-            int maxblk = 1, maxK = 1;
+            int maxblk = 1, maxK = 1, nnzc = 0;
             for (int i = 0; i < 5; ++i) { t.pA[i] = hb.pcls[i]; t.pK[i] = hk.pcls[i]; t.pS[i] = kt.pS[i]; }
             for (int i = 0; i < 4; ++i) {
                 maxK = std::max(maxK, t.pK[i + 1] - t.pK[i]);
                 maxblk = std::max(maxblk, (t.pA[i + 1] - t.pA[i]) * (t.pK[i + 1] - t.pK[i]));
+                nnzc += (t.pA[i + 1] - t.pA[i]) * (t.pK[i + 1] - t.pK[i]);
             }
             t.nkap = kt.nkap; t.nnzT = kt.nnzT; t.tabA = hb.tab_off; t.tabK = hk.tab_off; t.ktp_off = kt.tp_off; t.kte_off = kt.te_off;
             t.n_ket = q.n_ket; t.nEab = q.nEab; t.nEcd = q.nEcd; t.RLS = H.RLS;
             const int LAB = q.La + q.Lb, LCD = q.Lc + q.Ld, NM = q.L / 2 + 1, XS = NM | 1, RSr = q.L + 2;
-            const int team = eri_team_size(t.nT), NT = 256 / team;
             auto even = [](int x) { return (x + 1) & ~1; };
             int o = 0;
             t.oE12 = o; o += even(2 * t.nEab);
@@ -1134,12 +1137,26 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             t.oTc = o; o += even(t.nnzT);
             t.shared_doubles = o;
             const int nG = t.nTcd * (LAB + 1) * NM, scr1 = 2 * t.nEcd + (q.L + 1) * RSr + nG;
-            const int vmax = team == 256 ? 2048 : (team == 64 ? 512 : 96);
-            t.vcap = even(std::max(scr1, std::max(maxK, std::min(maxblk, vmax))));
-            t.team_doubles = 2 * t.nT * XS + t.vcap + even((t.nkap + 1) / 2);
-            const size_t bytes = ((size_t)t.shared_doubles + (size_t)NT * t.team_doubles) * sizeof(double);
-            if (bytes <= 160 * 1024 - 256) {
-                TeamLaunch a{LAB, LCD, team, dim3((unsigned)((q.n_ket + NT - 1) / NT), n_bra), bytes, st, &ctx->db, &t, d_bra, d_braoff, d_ket, d_out_slab};
+            auto vcap_of = [&](int tm) { return even(std::max(scr1, std::max(maxK, std::min(maxblk, tm == 256 ? 2048 : (tm == 64 ? 512 : 96))))); };
+            auto team_doubles_of = [&](int tm) { return 2 * t.nT * XS + vcap_of(tm) + even((t.nkap + 1) / 2); };
+            auto bytes_of = [&](int tm) { return ((size_t)t.shared_doubles + (size_t)(256 / tm) * team_doubles_of(tm)) * sizeof(double); };
+            // lanes per quartet: 16 for the smallest classes; a wave while four quartets' tables fit a third of the LDS (three workgroups per
+            // CU); the whole workgroup beyond
+            static const int force_team = getenv("TF_ERI_TEAM_SIZE") ? atoi(getenv("TF_ERI_TEAM_SIZE")) : 0;
+            int team = 0;
+            if (t.nT <= 16 && nnzc <= 96 && eri_team_available(LAB, LCD, 16)) team = 16;
+            else if (eri_team_available(LAB, LCD, 64) && bytes_of(64) <= 52 * 1024) team = 64;
+            else if (eri_team_available(LAB, LCD, 256) && bytes_of(256) <= 160 * 1024 - 256) team = 256;
+            else if (eri_team_available(LAB, LCD, 64) && bytes_of(64) <= 160 * 1024 - 256) team = 64;
+            if (force_team && eri_team_available(LAB, LCD, force_team) && bytes_of(force_team) <= 160 * 1024 - 256) team = force_team;
+            if (team) {
+                const int NT = 256 / team;
+                t.vcap = vcap_of(team); t.team_doubles = team_doubles_of(team);
+                // a workgroup walks over several ket groups (shared staging once): enough workgroups to fill the chip, at most 8 groups each
+                const long long groups = (q.n_ket + NT - 1) / NT;
+                const long long kpw = std::max<long long>(1, std::min<long long>(8, groups * n_bra / 16384));
+                TeamLaunch a{LAB, LCD, team, dim3((unsigned)((groups + kpw - 1) / kpw), n_bra), bytes_of(team), st, &ctx->db, &t,
+                             d_brarec + (d_bra - d_bra_base), d_ketrec + ket_off[kcls], d_kcnt + (size_t)kcls * nsh, d_out_slab};
                 const hipError_t e = eri_team_launch(a);
                 if (e != hipSuccess) { team_error = e; }
                 return;
@@ -1511,6 +1528,19 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             (rc = upload(ctx, kt_k, &d_kt_k, false)) || (rc = upload(ctx, kt_c, &d_kt_c, false)))
             return rc;
         ctx->db.kq_ptr = d_kq_ptr; ctx->db.kq_off = d_kq_off; ctx->db.kt_ptr = d_kt_ptr; ctx->db.kt_k = d_kt_k; ctx->db.kt_c = d_kt_c;
+        // flat records of the class-sorted ket list (uncontracted pairs) and, per class and shell A, the kets with first shell <= A
+        std::vector<KetRec> krec(ket_sorted.size());
+        for (size_t k = 0; k < ket_sorted.size(); ++k) {
+            const tf::Pair &pr = bs.pairs[ket_sorted[k]];
+            const double qq = bs.pp_p[pr.pp_off];
+            krec[k] = KetRec{qq, bs.pp_Pz[pr.pp_off], bs.pp_K[pr.pp_off] / qq, (unsigned)pr.e_off, kq_ptr[ket_sorted[k]]};
+        }
+        std::vector<int> kcnt((size_t)ncls * nsh, 0);
+        for (int c = 0; c < ncls; ++c) {
+            for (int p2 : ctx->class_pairs[c]) ++kcnt[(size_t)c * nsh + bs.pairs[p2].A];
+            for (int a = 1; a < nsh; ++a) kcnt[(size_t)c * nsh + a] += kcnt[(size_t)c * nsh + a - 1];
+        }
+        if ((rc = upload(ctx, krec, &d_ketrec, false)) || (rc = upload(ctx, kcnt, &d_kcnt, false))) return rc;
     }
     if (!per_class)
         std::stable_sort(mine_sorted.begin(), mine_sorted.end(), [&](int x, int y) {
@@ -1527,6 +1557,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     signed char *d_rowcls = nullptr;                               // parity class of every slab row (small-problem mode, packed layout)
     HIPCHK(ctx, hipMalloc((void **)&d_bra, cap_bra * sizeof(int)));
     HIPCHK(ctx, hipMalloc((void **)&d_braoff, cap_bra * sizeof(long long)));
+    if (use_team) HIPCHK(ctx, hipMalloc((void **)&d_brarec, cap_bra * sizeof(BraRec)));
+    d_bra_base = d_bra;
     HIPCHK(ctx, hipMalloc((void **)&d_out, cap_out * std::max(sizeof(OutRow), sizeof(OutRowP))));
     if (packed && !per_class) HIPCHK(ctx, hipMalloc((void **)&d_rowcls, (size_t)max_rows_c + 1));
     std::vector<hipEvent_t> tev;                                   // 4 timing events per slab, read at the end
@@ -1584,6 +1616,15 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         HIPCHK(ctx, hipDeviceSynchronize());
         HIPCHK(ctx, hipMemcpy(d_bra, bra.data(), bra.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(d_braoff, braoff.data(), braoff.size() * sizeof(long long), hipMemcpyHostToDevice));
+        if (use_team) {
+            std::vector<BraRec> brec(bra.size());
+            for (size_t k = 0; k < bra.size(); ++k) {
+                const tf::Pair &pr = bs.pairs[bra[k]];
+                const double pp = bs.pp_p[pr.pp_off];
+                brec[k] = BraRec{pp, bs.pp_Pz[pr.pp_off], bs.pp_K[pr.pp_off] / pp, (unsigned)pr.e_off, pr.A, braoff[k], 0};
+            }
+            HIPCHK(ctx, hipMemcpy(d_brarec, brec.data(), brec.size() * sizeof(BraRec), hipMemcpyHostToDevice));
+        }
         if (!outs.empty()) HIPCHK(ctx, hipMemcpy(d_out, outs.data(), outs.size() * sizeof(OutRow), hipMemcpyHostToDevice));
         if (!outsP.empty()) HIPCHK(ctx, hipMemcpy(d_out, outsP.data(), outsP.size() * sizeof(OutRowP), hipMemcpyHostToDevice));
         if (!rowcls.empty()) HIPCHK(ctx, hipMemcpy(d_rowcls, rowcls.data(), rowcls.size(), hipMemcpyHostToDevice));
@@ -1662,7 +1703,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out);
     if (d_rowcls) (void)hipFree(d_rowcls);
     (void)hipFree(d_kets); (void)hipFree(d_kets_all);
-    for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c})
+    for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c, (void *)d_ketrec, (void *)d_brarec, (void *)d_kcnt})
         if (pt) (void)hipFree(pt);
     ctx->db.kq_ptr = ctx->db.kq_off = ctx->db.kt_ptr = ctx->db.kt_k = nullptr; ctx->db.kt_c = nullptr;
     if (team_error != hipSuccess) TF_FAIL(ctx, TF_ENODEVICE, "launch of a team ERI kernel failed: %s", hipGetErrorString(team_error));

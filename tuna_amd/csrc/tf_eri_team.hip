@@ -6,15 +6,20 @@
 
 namespace tfk {
 
-// team size by the number of exponent tuple pairs (the rows of the X / Z tables: one lane each)
-int eri_team_size(int nT) { return nT <= 16 ? 16 : (nT <= 64 ? 64 : 256); }
+bool eri_team_available(int LAB, int LCD, int team)
+{
+    const int mn = (LAB + 1) * (LCD + 1);
+    const int mx = (LAB / 2 + 1) * ((LAB + 1) / 2 + 1) * (LCD / 2 + 1) * ((LCD + 1) / 2 + 1);
+    if (LAB > TF_TEAM_LMAX || LCD > TF_TEAM_LMAX) return false;
+    return team == 16 ? mn <= 16 : (team == 64 ? mn <= 256 : (team == 256 && mx > 32));
+}
 
 template <int LAB, int LCD, int TEAM>
 constexpr bool team_combo_possible()
 {
     constexpr int mn = (LAB + 1) * (LCD + 1);                                       // one shell of each pair is an s shell
     constexpr int mx = (LAB / 2 + 1) * ((LAB + 1) / 2 + 1) * (LCD / 2 + 1) * ((LCD + 1) / 2 + 1);
-    return TEAM == 16 ? mn <= 16 : (TEAM == 64 ? (mn <= 64 && mx > 16) : mx > 64);
+    return TEAM == 16 ? mn <= 16 : (TEAM == 64 ? mn <= 256 : mx > 32);
 }
 
 template <int LAB, int LCD, int TEAM>
@@ -27,8 +32,7 @@ static hipError_t launch_one(const TeamLaunch &a)
             if (e != hipSuccess) return e;
             lds_set = 160 * 1024;
         }
-        hipLaunchKernelGGL((eri_team_kernel<LAB, LCD, TEAM>), a.grid, dim3(256), a.lds_bytes, a.stream, *a.B, *a.tc, a.bra_pairs, a.bra_rowoff,
-                           a.ket_pairs, a.T2);
+        hipLaunchKernelGGL((eri_team_kernel<LAB, LCD, TEAM>), a.grid, dim3(256), a.lds_bytes, a.stream, *a.B, *a.tc, a.bras, a.kets, a.kcnt, a.T2);
         return hipGetLastError();
     } else
         return hipErrorInvalidValue;

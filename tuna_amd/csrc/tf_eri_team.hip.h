@@ -40,6 +40,11 @@ struct TClass {
     long long RLS;                // stride of a slab row
 };
 
+// What a team needs of a ket / bra shell pair (uncontracted: one primitive pair), parallel to the launch's pair lists: no pointer chasing
+// through DBasis::pairs.  Kq = weight product / exponent sum (the 1 / (p q) of the prefactor folded in on the host).
+struct KetRec { double q, Qz, Kq; unsigned e_off; int kq; };                                  // kq: first entry of the pair's slab offsets in kq_off
+struct BraRec { double p, Pz, Kp; unsigned e_off; int A; long long row_first; long long pad; };   // row_first: slab row of the pair's first component pair
+
 template <int TEAM>
 __device__ __forceinline__ void wave_lds_order()
 {
@@ -76,9 +81,8 @@ __device__ __forceinline__ double team_fact_sum(const double *__restrict__ X, co
 }
 
 template <int LAB, int LCD, int TEAM>
-__global__ __launch_bounds__(256) void eri_team_kernel(DBasis B, TClass tc, const int *__restrict__ bra_pairs,
-                                                       const long long *__restrict__ bra_rowoff, const int *__restrict__ ket_pairs,
-                                                       double *__restrict__ T2)
+__global__ __launch_bounds__(256) void eri_team_kernel(DBasis B, TClass tc, const BraRec *__restrict__ bras, const KetRec *__restrict__ kets,
+                                                       const int *__restrict__ kcnt, double *__restrict__ T2)
 {
     constexpr int NT = 256 / TEAM, L = LAB + LCD, NM = L / 2 + 1, XS = NM | 1, Lab1 = LAB + 1, Lcd1 = LCD + 1, RS = L + 2;
     constexpr double DF[11] = {1.0, 1.0, 3.0, 15.0, 105.0, 945.0, 10395.0, 135135.0, 2027025.0, 34459425.0, 654729075.0};
@@ -86,10 +90,10 @@ __global__ __launch_bounds__(256) void eri_team_kernel(DBasis B, TClass tc, cons
     extern __shared__ double smem[];
     const int tid = threadIdx.x;
     const int team = TEAM >= 256 ? 0 : tid / TEAM, tl = TEAM >= 256 ? tid : tid % TEAM;
-    const DPair *__restrict__ ab = B.pairs + bra_pairs[blockIdx.y];
-    const int ket0 = blockIdx.x * NT, abA = ab->A;
-    // the class list ascends in the first shell: if the group's first ket lies above the bra's first shell, all of them do
-    if (B.pairs[ket_pairs[ket0]].A > abA) return;
+    const BraRec *__restrict__ ab = bras + blockIdx.y;
+    // kets of the class list this bra pair needs: those whose first shell does not lie above the bra's (the list ascends in it)
+    const int nket_b = min(tc.n_ket, kcnt[ab->A]);
+    if ((int)blockIdx.x * NT >= nket_b) return;
 
     // ---- shared staging: bra Hermite tables, component-pair tables of both shell pairs, the ket pair transform ----
     double *sE12 = smem + tc.oE12, *sScA = smem + tc.oScA, *sTc = smem + tc.oTc;
@@ -114,24 +118,26 @@ __global__ __launch_bounds__(256) void eri_team_kernel(DBasis B, TClass tc, cons
     }
     __syncthreads();
 
-    // ---- the team's quartet ----
-    const int kq = ket0 + team;
-    if (kq >= tc.n_ket) return;
-    const int pcd = ket_pairs[kq];
-    const DPair *__restrict__ cd = B.pairs + pcd;
-    if (cd->A > abA) return;
+    const double p = ab->p, Pz = ab->Pz, Kp = ab->Kp;
+    const long long row_first = ab->row_first;
     double *tm = smem + tc.shared_doubles + team * tc.team_doubles;
     double *sX = tm, *sZ = sX + tc.nT * XS, *scr = sZ + tc.nT * XS;
     double *sE34 = scr, *sR = sE34 + 2 * nEcd, *sG = sR + (L + 1) * RS;
     double *sV = scr;                                                     // the component block lives over E34 / R / G once X and Z exist
     int *sDoff = reinterpret_cast<int *>(scr + tc.vcap);
+    const char *bX = reinterpret_cast<const char *>(sX), *bZ = reinterpret_cast<const char *>(sZ);
 
-    const double p = B.pp_p[ab->pp_off], q = B.pp_p[cd->pp_off];
-    const double s = p + q, alpha = p * q / s;
-    const double PQ = B.pp_Pz[ab->pp_off] - B.pp_Pz[cd->pp_off];
+    // ---- the workgroup's ket groups: a team takes ket g NT + team of every group g = blockIdx.x, blockIdx.x + gridDim.x, ... ----
+    for (int g = blockIdx.x; g * NT < nket_b; g += gridDim.x) {
+    const int kq = g * NT + team;
+    if (TEAM >= 256 || kq < nket_b) {
+    const KetRec *__restrict__ cd = kets + kq;
+    const double q = cd->q;
+    const double s = p + q, rs = rsqrt(s), pq = p * q, alpha = pq * (rs * rs);
+    const double PQ = Pz - cd->Qz;
     const double T = alpha * PQ * PQ;
-    // 2 pi^(5/2) / (p q sqrt(p+q)) * coefficient product, pyx:1219-1221
-    const double pref = B.pp_K[ab->pp_off] * B.pp_K[cd->pp_off] * (34.986836655249725 / (p * q * sqrt(s)));
+    // 2 pi^(5/2) / (p q sqrt(p+q)) * coefficient product, pyx:1219-1221 (1 / p and 1 / q are folded into Kp, Kq)
+    const double pref = Kp * cd->Kq * (34.986836655249725 * rs);
 
     // ---- phase 0: ket Hermite tables with (-1)^tau, (-1)^phi folded in; R zeroed; slab offsets of the output pairs ----
     {
@@ -171,10 +177,12 @@ __global__ __launch_bounds__(256) void eri_team_kernel(DBasis B, TClass tc, cons
                 if (m + 1 == n) f = g;
             }
         }
-        double pw = 1.0;
-        const double fac = -2.0 * alpha;
+        double pw = 1.0, fac = -2.0 * alpha;                               // (-2 alpha)^n by binary powering (n <= 12)
 #pragma unroll
-        for (int k = 0; k < L; ++k) pw = (k < n) ? pw * fac : pw;
+        for (int bit = 0; (1 << bit) <= L; ++bit) {
+            pw = ((n >> bit) & 1) ? pw * fac : pw;
+            fac *= fac;
+        }
         sR[n] = f * pw;                                                    // R[0][n] = (-2 alpha)^n F_n
     }
 #pragma unroll
@@ -226,12 +234,10 @@ __global__ __launch_bounds__(256) void eri_team_kernel(DBasis B, TClass tc, cons
         }
     }
     // slab offsets of the output pairs (the scratch area behind the component block)
-    for (int k = tl; k < tc.nkap; k += TEAM) sDoff[k] = B.kq_off[B.kq_ptr[pcd] + k];
+    for (int k = tl; k < tc.nkap; k += TEAM) sDoff[k] = B.kq_off[cd->kq + k];
     team_sync<TEAM>();
 
     // ---- phases 4 and 5, parity class by parity class, in chunks of complete bra rows ----
-    const long long row_first = bra_rowoff[blockIdx.y];
-    const char *bX = reinterpret_cast<const char *>(sX), *bZ = reinterpret_cast<const char *>(sZ);
     for (int c = 0; c < 4; ++c) {
         const int nA = tc.pA[c + 1] - tc.pA[c], nK = tc.pK[c + 1] - tc.pK[c], nS = tc.pS[c + 1] - tc.pS[c];
         if (nA == 0 || nK == 0 || nS == 0) continue;
@@ -262,6 +268,8 @@ __global__ __launch_bounds__(256) void eri_team_kernel(DBasis B, TClass tc, cons
             team_sync<TEAM>();
         }
     }
+    }   // this team's ket
+    }   // ket groups
 }
 
 }  // namespace tfk

@@ -8,6 +8,8 @@ namespace tfk {
 #define TF_TEAM_LMAX 6           // pair sums La + Lb, Lc + Ld the team kernels are instantiated for (up to two f shells)
 
 struct TClass;                    // tf_eri_team.hip.h
+struct BraRec;
+struct KetRec;
 
 struct TeamLaunch {
     int LAB, LCD, team;           // pair sums; lanes per shell quartet (eri_team_size)
@@ -16,13 +18,13 @@ struct TeamLaunch {
     hipStream_t stream;
     const DBasis *B;
     const TClass *tc;
-    const int *bra_pairs;
-    const long long *bra_rowoff;
-    const int *ket_pairs;
+    const BraRec *bras;           // one record per bra pair of the launch (grid.y)
+    const KetRec *kets;           // the ket class list
+    const int *kcnt;              // [shell A]: kets of the class list whose first shell is <= A
     double *T2;
 };
 
-int eri_team_size(int nT);
+bool eri_team_available(int LAB, int LCD, int team);   // is this combination instantiated
 hipError_t eri_team_launch(const TeamLaunch &a);
 
 }  // namespace tfk
