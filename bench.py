@@ -133,28 +133,31 @@ def cpu_baseline_eri(aos, limit_s: float = 20.0):
 JK_KERNEL = {"packed": "jk_packed_kernel", "rows": "tfk::jk_rows_kernel"}
 
 
-def pmc_traffic(workload: str, world: int, layout: str):
-    """HBM bytes per launch of the J/K kernel from the committed rocprofv3 PMC passes (profiles/), corrected as
-    MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KB) x 1024 x 2 for 16-byte coalesced streaming reads, plus
-    WRITE_SIZE (KB) x 1024.  Counters cannot be collected from inside an un-profiled run, so this is the figure of the
-    profiled run of the same workload; null when no such profile is committed."""
+def pmc_traffic(workload: str, world: int, layout: str, stored_bytes: float):
+    """HBM bytes per BUILD of the J/K kernel from the committed rocprofv3 PMC passes (profiles/), corrected as
+    MI355X_MICROARCH.md (section HBM) prescribes for gfx950: FETCH_SIZE (KB) x 1024 x 2 -- the counter tallies the 128-byte requests
+    of 16-byte-per-lane streaming reads at 64 bytes -- plus WRITE_SIZE (KB) x 1024 (exact for 16-byte-per-lane streaming stores).
+    Counters cannot be collected from inside an un-profiled run, so this is the figure of the profiled run of the same workload.
+    The profile carries `_meta` (commit and stored bytes of the run it was taken from); a profile whose stored bytes differ from this
+    run's (another layout or padding) is not used.  Returns (bytes, file, meta) or (None, None, None)."""
     if world != 1:
-        return None, None
-    for rnd in ("r02", "r01"):
-        if rnd == "r01" and layout == "packed":
-            break                                                    # (round 1's packed layout was a different one)
+        return None, None, None
+    for rnd in ("r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload.replace('-', '')}_{layout}.json")
         try:
             d = json.load(open(path))
+            meta = d.get("_meta", {})
+            if meta.get("stored_bytes") not in (None, stored_bytes):
+                continue
             k = [v for name, v in d.items() if JK_KERNEL[layout] in name][0]
-            # a build may take several launches of the kernel (one per workgroup size: 4, 2, 1 waves): bytes per BUILD = the sum over the
+            # a build takes several launches of the kernel (one per workgroup size: 4, 2, 1 waves): bytes per BUILD = the sum over the
             # dispatches of the profiled run / its builds (jk_reduce_kernel runs once per build)
             red = [v for name, v in d.items() if "jk_reduce_kernel" in name]
             per_build = lambda c: (k[c]["sum"] / red[0][c]["dispatches"]) if red and red[0][c]["dispatches"] else k[c]["mean_KB"]
-            return (per_build("FETCH_SIZE") * 1024.0 * 2.0 + per_build("WRITE_SIZE") * 1024.0), os.path.relpath(path, ROOT)
+            return (per_build("FETCH_SIZE") * 1024.0 * 2.0 + per_build("WRITE_SIZE") * 1024.0), os.path.relpath(path, ROOT), meta
         except Exception:
             continue
-    return None, None
+    return None, None, None
 
 
 def main():
@@ -266,13 +269,12 @@ def main():
 
     if rank == 0:
         layout = st["layout"]
-        traffic, traffic_src = pmc_traffic(args.workload, world, layout)
         alg_bytes = 8.0 * N ** 4 / world                    # 8 N^4 bytes per build, per GPU 8 N^4 / G
         stored_bytes = float(st["bytes"])
-        # physical bytes of one launch of the J/K kernel: the PMC counters of the profiled run of this workload when committed,
-        # else the stored tensor (read once; the partial sums it writes come on top)
-        phys_bytes = traffic if traffic is not None else stored_bytes
-        achieved = phys_bytes / kernel_avg_s / 1e9
+        traffic, traffic_src, traffic_meta = pmc_traffic(args.workload, world, layout, stored_bytes) if nd == 1 else (None, None, None)
+        # roofline of the dominant kernel on the bytes it HAS to read: the stored tensor, once per build.  What the kernel moves on top
+        # (density re-reads, partial sums) is waste and shows up as traffic_ratio > 1, not as achievement.
+        achieved = stored_bytes / kernel_avg_s / 1e9
         storage = {"packed": "parity-blocked 8-fold symmetry-unique values of the spherical tensor: row (i>=j) keeps the pairs (k>=l) <= (i,j) "
                              "whose x/y reflection parity class equals that of (i,j) -- the others are exact zeros (pyx:1324-1327) -- f64, "
                              "units of 8 interleaved rows, sharded by (ij) shell pair over ranks",
@@ -289,18 +291,20 @@ def main():
             # roofline of the dominant kernel on PHYSICAL bytes (a fraction of the 8 TB/s HBM peak, <= 1); the reference's dense 8 N^4
             # bytes per build that the same launch stands for are reported separately
             "roofline": {"bound": "hbm", "kernel": JK_KERNEL[layout], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_avg_ms": 1e3 * kernel_avg_s, "stored_bytes_per_launch": stored_bytes,
-                         "achieved_on_stored_bytes": stored_bytes / kernel_avg_s / 1e9,
-                         "frac_on_stored_bytes": stored_bytes / kernel_avg_s / 1e9 / HBM_PEAK_GBS,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_ratio": (traffic / stored_bytes) if traffic else None, "traffic_source": traffic_src,
+                         "traffic_profile": traffic_meta,
+                         "kernel_avg_ms": 1e3 * kernel_avg_s, "necessary_bytes_per_launch": stored_bytes,
+                         "frac_on_ms_per_step": stored_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_equivalent": {"bytes_per_launch": alg_bytes, "GBs": alg_bytes / kernel_avg_s / 1e9,
                                                     "reduction_vs_dense": alg_bytes / stored_bytes,
                                                     "permutational_symmetry": 8.0 if layout == "packed" else 2.0,
                                                     "parity_zeros_and_padding": alg_bytes / stored_bytes / (8.0 if layout == "packed" else 2.0),
                                                     "note": "SURVEY 8d prices a build at the reference's dense 8 N^4 bytes; the kernel streams "
                                                             "1/reduction_vs_dense of them (8-fold permutational symmetry x the x/y parity rule, less padding)"},
-                         "note": "achieved = physical HBM bytes per launch (traffic when a PMC profile of this workload is committed, else the "
-                                 "stored tensor) / average kernel time from HIP events on the launch stream"},
+                         "note": "achieved = stored tensor bytes (each read once per build: the bytes the build cannot avoid) / average kernel time "
+                                 "from HIP events on the launch stream; traffic = HBM bytes per build from the PMC counters of the committed profile "
+                                 "(FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md section HBM); traffic_ratio = traffic / stored bytes"},
             "eri_build": {"wall_s": eri_wall, "cold_wall_s": eri_wall_cold, "device_s": {k: float(v) for k, v in eri_t.items() if k.endswith("_s")},
                           "shell_quartets": eri_t["shell_quartets"], "primitive_shell_quartets": eri_t["primitive_shell_quartets"],
                           "component_quartets": eri_t["component_quartets"],
@@ -324,15 +328,22 @@ def main():
         if world > 1:
             from tuna_amd import distributed as tdist
             tdist.attach_allreduce(eng)
-        # (an exception in a leg must not cost the headline line: it is reported in the leg's place)
-        try:
-            scf_w = scf_on_workload(eng, atoms, shells, nocc, desc)   # the tensor of the timed builds is still resident
-        except Exception as e:
-            scf_w = {"error": f"{type(e).__name__}: {e}"}
-        try:
-            scf_c = scf_leg(eng, args, rank, world)
-        except Exception as e:
-            scf_c = {"error": f"{type(e).__name__}: {e}"}
+        # (an exception in a leg must not cost the headline line: it is reported in the leg's place.  With several ranks a leg that
+        # fails on one rank fails on all of them -- the flag is all-reduced -- so that no rank is left waiting in a collective)
+        def run_leg(fn):
+            try:
+                res = fn()
+                ok_leg = 1.0 if "error" not in res else 0.0
+            except Exception as e:
+                res, ok_leg = {"error": f"{type(e).__name__}: {e}"}, 0.0
+            if world > 1:
+                flag = torch.tensor([ok_leg], dtype=torch.float64, device=dev)
+                allreduce(flag, dist.ReduceOp.MIN)
+                if float(flag.item()) == 0.0 and "error" not in res:
+                    res = {"error": "the leg failed on another rank"}
+            return res
+        scf_w = run_leg(lambda: scf_on_workload(eng, atoms, shells, nocc, desc))   # the tensor of the timed builds is still resident
+        scf_c = run_leg(lambda: scf_leg(eng, args, rank, world, allreduce))
         if rank == 0:
             out["scf_on_workload"], out["scf"] = scf_w, scf_c
     if rank == 0:
@@ -409,7 +420,7 @@ def eng_aos_lmn(eng):
     return eng.aos.lmn
 
 
-def scf_leg(eng, args, rank=0, world=1):
+def scf_leg(eng, args, rank=0, world=1, allreduce=None):
     """SCF wall time on BASELINE.json configs[1] (N2 RHF/cc-pVTZ): ERI build + native RHF (EXTREME thresholds, core guess,
     DIIS 6, no damping) on the GPU, energy checked against the reference anchor; CPU ERI build beside it."""
     from tuna_amd import molecule as mol
@@ -437,12 +448,11 @@ def scf_leg(eng, args, rank=0, world=1):
     dP = torch.from_numpy(r["P"]).to(dev)
     dJK = torch.zeros((2, eng.N, eng.N), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    import torch.distributed as dist
 
     def one_build():
         eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, stream)
         if world > 1:
-            dist.all_reduce(dJK)
+            allreduce(dJK)
     for _ in range(5):
         one_build()
     torch.cuda.synchronize()
@@ -455,11 +465,38 @@ def scf_leg(eng, args, rank=0, world=1):
            "iterations": r["n_iter"], "eri_build_wall_s": t_eri, "scf_wall_s": t_scf, "total_wall_s": t_eri + t_scf,
            "cold_first_call": {"eri_build_wall_s": cold_eri, "scf_wall_s": cold_scf, "total_wall_s": cold_eri + cold_scf},
            "note": "wall times of the 3rd repetition in this process (1e integrals + orthogonaliser + core guess + EXTREME RHF in scf_wall_s)",
-           "fock_kernel_s": r["fock_seconds"], "eigensolver_s": r["eig_seconds"], "fock_builds_per_s": fps,
-           "cpu_reference_fock_builds_per_s_8core_container": 23.4}
+           "fock_kernel_s": r["fock_seconds"], "eigensolver_s": r["eig_seconds"], "fock_builds_per_s": fps}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_eri_build"] = cpu_baseline_eri(aos)
+        out.update(cpu_baseline_scf(aos, shells, atoms, nocc, S, T, V, X, P0, E0, r["energy"], r["n_iter"]))
     return out
+
+
+def cpu_baseline_scf(aos, shells, atoms, nocc, S, T, V, X, P0, E0, gpu_energy, gpu_iters):
+    """The CPU path timed on this box for the same input (N2 RHF/cc-pVTZ, EXTREME, core guess, DIIS 6, no damping): the C port's ERI build
+    (OpenMP over AO pairs, all CPUs of the process), the dense Cartesian -> spherical transform and the NumPy restatement of the
+    reference's RHF cycle with its einsum Fock builds (oracle/scf_oracle.py; scf:1072-1154, 1292-1435)."""
+    from oracle import oracle as orc
+    from oracle import scf_oracle as so
+    from tuna_amd import molecule as mol
+    from tuna_amd import spherical
+    import tuna_amd
+    cores = tuna_amd.cpu_quota()
+    t0 = time.perf_counter()
+    E_cart = orc.eri(aos, cores)
+    t_eri = time.perf_counter() - t0
+    U = spherical.transformation_matrix([sh.L for sh in shells])
+    t0 = time.perf_counter()
+    E_sph = so.eri_to_spherical(U, E_cart)
+    t_sph = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    o = so.run_rhf(S, T, V, E_sph, X, P0, E0, nocc, mol.nuclear_repulsion(atoms), [30, 30], conv="extreme", damping=False)
+    t_scf = time.perf_counter() - t0
+    return {"cpu_scf_wall_s": t_scf, "cpu_scf": {"kind": "port", "cores": int(cores), "eri_build_s": t_eri, "spherical_transform_s": t_sph,
+                                                 "scf_loop_s": t_scf, "total_s": t_eri + t_sph + t_scf, "iterations": o["n_iter"],
+                                                 "fock_builds_per_s": o["n_iter"] / t_scf if t_scf > 0 else None,
+                                                 "energy_Eh": o["energy"], "abs_diff_to_gpu_energy_Eh": abs(o["energy"] - gpu_energy),
+                                                 "gpu_iterations": gpu_iters}}
 
 
 if __name__ == "__main__":

@@ -179,3 +179,38 @@ def test_two_rank_sharded_ao_to_mo_algebra():
         mp.spawn(_mo_worker, args=(world, port, "n2_sto3g", ret), nprocs=world, join=True)
         res = dict(ret)
     assert set(res) == {0, 1} and all(v < 1e-11 for v in res.values())
+
+
+def _status_worker(rank, world, port, failing_rank, ret):
+    """The exchange step with its status word (tuna_amd.distributed.allreduce_with_status, what the registered hook runs): a rank whose
+    staging fails still takes part in the collective, with the status word set."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        buf = torch.cat([torch.full((10,), float(rank + 1), dtype=torch.float64), torch.zeros(1, dtype=torch.float64)])
+
+        def to_host(x):
+            if rank == failing_rank:
+                raise RuntimeError("simulated staging failure on this rank")
+            return x.clone()
+        rc = tdist.allreduce_with_status(buf, backend="gloo", to_host=to_host)
+        ret[rank] = (rc, float(buf[-1]), float(buf[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing_rank", [-1, 1])
+def test_exchange_step_reports_a_failing_rank_on_every_rank(failing_rank):
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_status_worker, args=(world, port, failing_rank, ret), nprocs=world, join=True)       # (returns: nobody waits for ever)
+        res = dict(ret)
+    assert set(res) == {0, 1}
+    for rank, (rc, status, first) in res.items():
+        assert rc == 0
+        if failing_rank < 0:
+            assert status == 0.0 and first == 3.0              # 1 + 2: the payload summed over the ranks
+        else:
+            assert status == 1.0                               # what the library turns into an error on EVERY rank (tf_device.hip: allreduce_jk)

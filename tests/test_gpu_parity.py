@@ -198,6 +198,43 @@ def test_synthetic_series_properties(engine, n_sph):
     assert abs(J1[i, j] - np.sum(M * P1)) < 1e-10 * scale
 
 
+def test_multi_chunk_contraction_against_the_reference_einsums(engine):
+    """The contraction itself where a parity class is wider than one 64-column chunk (N = 200: 81 / 48 / 48 / 23 AOs per class, so the
+    tasks of jk_packed_kernel come in several chunks per class -- no golden system reaches that): the dense copy of the GPU tensor (pinned
+    block-wise to the oracle by test_bench_workload_tensor_against_oracle / test_synthetic_series_properties) goes through the
+    reference's own einsum strings (scf:70, scf:42) in NumPy; J and K of the one-density pass, of the fused two-density pass and of a
+    non-symmetric density (two passes) must agree to 1e-10 relative."""
+    n_sph = 200
+    counts = mol.synthetic_counts(n_sph)
+    atoms = mol.make_atoms(["AR", "AR"], 7.1)
+    aos = mol.expand_cartesian_aos(mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)}))
+    engine.set_basis(aos).build_eri(True, layout="packed")
+    N = engine.N
+    assert N == n_sph
+    ERI = engine.copy_eri()                                               # dense [N,N,N,N], all images and the parity zeros
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((3, N, N))
+    P = np.stack([A[0] + A[0].T, A[1] + A[1].T])
+    M2 = ERI.reshape(N * N, N * N)
+
+    def ref_jk(D):
+        J = (M2 @ D.reshape(-1)).reshape(N, N)                            # np.einsum("ijkl,kl->ij", ERI, D)
+        K = np.einsum("ilkj,kl->ij", ERI, D, optimize=True)
+        return J, K
+    refs = [ref_jk(P[0]), ref_jk(P[1]), ref_jk(A[2])]
+    assert np.abs(refs[0][0] - so.coulomb(P[0], ERI)).max() < 1e-9 * np.abs(refs[0][0]).max()    # (the GEMV is the reference string "ijkl,kl->ij")
+    J1, K1 = engine.fock_jk(P[0])                                         # jk_packed_kernel<1>
+    J2, K2 = engine.fock_jk(P)                                            # jk_packed_kernel<2>: both densities in one pass
+    J3, K3 = engine.fock_jk(A[2])                                         # non-symmetric: two passes, K = D(P^T) + D(P)^T
+    for got, ref in ((J1, refs[0][0]), (K1, refs[0][1]), (J2[0], refs[0][0]), (K2[0], refs[0][1]), (J2[1], refs[1][0]), (K2[1], refs[1][1]),
+                     (J3, refs[2][0]), (K3, refs[2][1])):
+        assert np.abs(got - ref).max() < 1e-10 * np.abs(ref).max()
+    # the pass variants share partial-sum buffers whose never-written entries must stay zero (the reductions read them): after the
+    # two-density and the two-pass builds, the one-density build still gives bitwise what it gave on the fresh buffers
+    J1b, K1b = engine.fock_jk(P[0])
+    assert np.array_equal(J1, J1b) and np.array_equal(K1, K1b)
+
+
 def test_packed_and_rows_layouts_agree(engine):
     """The 8-fold packed tensor + jk_packed_kernel against the (i >= j) x [k][l] rows layout + jk_rows_kernel: same tensor values,
     same J and K for one and for two densities (the fused two-density pass included)."""

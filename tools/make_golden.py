@@ -671,6 +671,82 @@ def make_field_golden(scf, blocks, ortho):
     json.dump(out, open(os.path.join(GOLD, "field_systems.json"), "w"), indent=0)
 
 
+
+KEYWORD_CASES = {
+    # tag: (keywords of the input line, fields of the reference Calculation they set)
+    "base": ("", {}),
+    "ez": ("EZ 0.01", {"field": [0.0, 0.0, 0.01]}),
+    "ex_ez": ("EX 0.005 EZ -0.002", {"field": [0.005, 0.0, -0.002]}),
+    "egz": ("EGZ 0.01", {"gradient": [0.0, 0.0, 0.01]}),
+    "egx_egy": ("EGX 0.004 EGY 0.002", {"gradient": [0.004, 0.002, 0.0]}),
+    "conv": ("ECONV 1e-4 RMSDP 1e-3 MAXDP 1e-3 DIISERR 1e-2", {"conv": {"delta_E": 1e-4, "RMS_DP": 1e-3, "max_DP": 1e-3, "commutator": 1e-2}}),
+    "diis10": ("EXTREME DIIS 10 NODAMP", {"max_diis": 10, "conv_name": "extreme", "damping": False}),
+    "diis12_damp": ("EXTREME DIIS 12", {"max_diis": 12, "conv_name": "extreme"}),
+}
+
+
+def make_keyword_golden(scf, blocks, ortho):
+    """tests/golden/keyword_runs.json: the reference's RHF cycle (core guess) under the SCF keywords of tuna_calc.py:153-165,187-190
+    (EX/EY/EZ, EGX/EGY/EGZ through kernel:660-707 executed from the source text; ECONV/RMSDP/MAXDP/DIISERR through calc:491-494;
+    DIIS n with n > 8) for two small systems: energies and iteration tables.  Data only."""
+    import ast
+    import json
+    lines, _ = _parseable_lines(os.path.join(REF, "TUNA", "tuna_kernel.py"))
+    tree = ast.parse("\n".join(lines))
+    ns = {"np": np}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in ("apply_electric_field", "apply_electric_field_gradient"):
+            node.returns = None
+            for a in node.args.args:
+                a.annotation = None
+            exec(compile(ast.Module([node], []), "tuna_kernel.py", "exec"), ns)
+    out = {}
+    for sysname, (sym, R_ang, basis, nocc) in {"hf_631g": (["F", "H"], 0.917, "6-31G", 5), "co_ccpvdz": (["C", "O"], 1.128, "cc-pVDZ", 7)}.items():
+        atoms, shells, aos = system(sym, mol.angstrom_to_bohr(R_ang), basis)
+        S, T, V, D, Q, E = one_e_and_eri(atoms, aos)
+        # dipole / quadrupole integrals about the centre of mass, as the input line has them (kernel:312; the masses are the reference's table)
+        from tuna_amd import guess as guess_mod
+        com = guess_mod.centre_of_mass(atoms)
+        _, _, _, D, Q = orc.ref_one_electron(aos, [a.origin for a in atoms], [float(a.charge) for a in atoms], [0.0, 0.0, com])
+        U = reference_U(shells, blocks)
+        Ss, Ts_, Vs, Es = to_spherical(U, S), to_spherical(U, T), to_spherical(U, V), eri_to_spherical(U, E)
+        Ds = np.array([to_spherical(U, D[k]) for k in range(3)])
+        Qs = np.array([to_spherical(U, Q[k]) for k in range(len(Q))])
+        X, smallest, S_inv = ortho(Ss, None, True)
+        eps0, C0 = scf.diagonalise_Fock_matrix(Ts_ + Vs, X)
+        P0 = scf.construct_density_matrix(C0, nocc, 2)
+        E0 = float(np.einsum("mn,mn->", Ts_ + Vs, P0))
+        n_sph = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
+        molecule = types.SimpleNamespace(n_doubly_occ=nocc, partition_ranges=n_sph, atoms=atoms, n_electrons=2 * nocc, n_alpha=nocc, n_beta=nocc)
+        cases = {}
+        for tag, (kw, f) in KEYWORD_CASES.items():
+            conv = dict(CONV[f.get("conv_name", "medium")])
+            conv.update(f.get("conv", {}))                                   # calc:491-494
+            calc = Calc(conv, damping=f.get("damping", True))
+            calc.max_DIIS_matrices = f.get("max_diis", 6)
+            ints = Ints(Ss, Ts_, Vs, Es)
+            if "field" in f:
+                ints.F = ns["apply_electric_field"](Ds, np.array(f["field"]))                  # energy:915
+            if "gradient" in f:
+                ints.G = ns["apply_electric_field_gradient"](Qs, np.array(f["gradient"]))      # energy:919
+            table = []
+            orig = scf.format_output_line
+
+            def rec(E_total, delta_E, max_DP, RMS_DP, damping_factor, step, commutator, calculation, silent=False):
+                table.append([step, E_total, delta_E, RMS_DP, max_DP, commutator, float(damping_factor)])
+            scf.format_output_line = rec
+            try:
+                o = scf.run_self_consistent_field_cycle(molecule, calc, ints, mol.nuclear_repulsion(atoms), X, (P0, P0 / 2, P0 / 2, E0),
+                                                        (None, None, None, None), True)
+            finally:
+                scf.format_output_line = orig
+            cases[tag] = dict(keywords=kw, energy=float(o.energy), iterations=len(table), table=[[float(x) for x in row] for row in table],
+                              field_energy=float(o.electric_field_energy), field_gradient_energy=float(o.electric_field_gradient_energy))
+            print(sysname, tag, kw, "E =", o.energy, "iterations", len(table), flush=True)
+        out[sysname] = dict(symbols=sym, R_angstrom=R_ang, basis=basis, n_occ=nocc, smallest_overlap_eigenvalue=float(smallest), dipole_origin_z=float(com), cases=cases)
+    json.dump(out, open(os.path.join(GOLD, "keyword_runs.json"), "w"), indent=0)
+
+
 def run_reference_scf(scf, ortho, atoms, shells, S, T, V, ERI, n_occ, conv="extreme", damping=True, F_fld=None):
     """Core-Hamiltonian guess (tuna_guess.py calculate_core_guess: diagonalise H_core, fill n_occ) + reference loop."""
     X, smallest, S_inv = ortho(S, None, True)
@@ -731,6 +807,9 @@ def main():
         return
     if "--field-only" in sys.argv:
         make_field_golden(scf, blocks, ortho)
+        return
+    if "--keywords-only" in sys.argv:
+        make_keyword_golden(scf, blocks, ortho)
         return
     if "--sweep-only" in sys.argv:
         make_sweep_golden(scf, blocks, ortho)

@@ -107,6 +107,7 @@ struct tf_ctx {
     tf_allreduce_fn allreduce = nullptr;  // completes partial [J;K] over the ranks of a sharded tensor (tf_set_allreduce)
     void *allreduce_user = nullptr;
     double *d_jkstage = nullptr;          // [2][nd][N][N] staging buffer of that exchange step
+    double *d_agree = nullptr;            // 16 doubles: per-iteration decision values summed over the ranks (agree_over_ranks)
     size_t jkstage_doubles = 0;
     double eri_seconds[4] = {0, 0, 0, 0};
     long long eri_counts[3] = {0, 0, 0};
@@ -463,6 +464,7 @@ void tf_destroy(tf_ctx *ctx)
     for (int k = 0; k < 3; ++k)
         if (ctx->scr[k]) (void)hipFree(ctx->scr[k]);
     if (ctx->d_jkstage) (void)hipFree(ctx->d_jkstage);
+    if (ctx->d_agree) (void)hipFree(ctx->d_agree);
     if (ctx->d_lrec) (void)hipFree(ctx->d_lrec);
     if (ctx->d_tup) (void)hipFree(ctx->d_tup);
     if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
@@ -2032,21 +2034,55 @@ static int allreduce_jk(tf_ctx *ctx, int nd, double *const *dJ, double *const *d
     if (!ctx->allreduce)
         TF_FAIL(ctx, TF_EINVAL, "the tensor is sharded over %d ranks: register the all-reduce of the partial [J;K] with tf_set_allreduce", ctx->world);
     const size_t nn = (size_t)ctx->N * ctx->N, need = 2 * (size_t)nd * nn;
-    if (ctx->jkstage_doubles < need) {
+    // one slot beyond the payload carries a status word through the same collective: a rank whose exchange step failed locally (the
+    // hook sets it) makes the sum non-zero on EVERY rank, so that all of them return an error instead of some waiting in a collective
+    if (ctx->jkstage_doubles < need + 1) {
         if (ctx->d_jkstage) (void)hipFree(ctx->d_jkstage);
         ctx->d_jkstage = nullptr; ctx->jkstage_doubles = 0;
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_jkstage, need * sizeof(double)));
-        ctx->jkstage_doubles = need;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_jkstage, (need + 1) * sizeof(double)));
+        ctx->jkstage_doubles = need + 1;
     }
     for (int d = 0; d < nd; ++d) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_jkstage + (size_t)d * nn, dJ[d], nn * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_jkstage + (size_t)(nd + d) * nn, dK[d], nn * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
-    const int rc = ctx->allreduce(ctx->allreduce_user, ctx->d_jkstage, (int64_t)need, (void *)st);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_jkstage + need, 0, sizeof(double), st));
+    const int rc = ctx->allreduce(ctx->allreduce_user, ctx->d_jkstage, (int64_t)(need + 1), (void *)st);
     if (rc) TF_FAIL(ctx, TF_ENODEVICE, "the registered all-reduce failed (code %d)", rc);
+    double status = 0.0;
+    HIPCHK(ctx, hipMemcpyAsync(&status, ctx->d_jkstage + need, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (status != 0.0) TF_FAIL(ctx, TF_ENODEVICE, "the exchange step of the sharded Fock build failed on %g rank(s): every rank stops", status);
     for (int d = 0; d < nd; ++d) {
         HIPCHK(ctx, hipMemcpyAsync(dJ[d], ctx->d_jkstage + (size_t)d * nn, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIPCHK(ctx, hipMemcpyAsync(dK[d], ctx->d_jkstage + (size_t)(nd + d) * nn, nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    return TF_OK;
+}
+
+// Collective control flow of the native cycles on a sharded tensor (tfscf::Workspace::agree): the values are summed over the ranks
+// through the registered all-reduce; a rank whose values differ from the mean makes EVERY rank fail instead of leaving some of them
+// waiting in the next collective.
+static int agree_over_ranks(tf_ctx *ctx, const double *vals, int n, std::string &msg)
+{
+    if (ctx->world == 1 || !ctx->allreduce) return TF_OK;
+    if (n > 7) n = 7;
+    double h[16] = {0};
+    h[0] = 1.0;
+    for (int k = 0; k < n; ++k) { h[1 + k] = vals[k]; h[8 + k] = vals[k] * vals[k]; }
+    if (!ctx->d_agree && hipMalloc((void **)&ctx->d_agree, 16 * sizeof(double)) != hipSuccess) { msg = "hipMalloc failed (agree buffer)"; return TF_ENOMEM; }
+    if (hipMemcpy(ctx->d_agree, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { msg = "hipMemcpy failed (agree buffer)"; return TF_ENODEVICE; }
+    const int rc = ctx->allreduce(ctx->allreduce_user, ctx->d_agree, 16, nullptr);
+    if (rc) { msg = "the registered all-reduce failed (code " + std::to_string(rc) + ")"; return TF_ENODEVICE; }
+    double s[16];
+    if (hipMemcpy(s, ctx->d_agree, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) { msg = "hipMemcpy failed (agree buffer)"; return TF_ENODEVICE; }
+    const double w = (double)ctx->world;
+    bool same = s[0] == w;
+    // all equal <=> sum of squares == (sum)^2 / world (small integers and flags: exact in double precision)
+    for (int k = 0; k < n && same; ++k) same = (s[1 + k] == w * vals[k]) && (s[8 + k] == w * vals[k] * vals[k]);
+    if (!same) {
+        msg = "the ranks of the sharded SCF cycle disagree on a control decision (convergence / DIIS history / step): every rank stops";
+        return TF_ELINALG;
     }
     return TF_OK;
 }
@@ -2437,6 +2473,25 @@ int tf_eigh_probe(tf_ctx *ctx, int n, int variant, int reps, double *seconds)
     return rc;
 }
 
+extern "C++" {
+// A native cycle on a sharded tensor: every rank must take the same decisions from the same data.  For the duration of the cycle the
+// control decisions are agreed over the ranks (agree_over_ranks) and rocBLAS runs without atomics (bitwise reproducible GEMMs; not
+// otherwise: its split-K kernels need them -- the skinny GEMMs of the AO->MO transformation are ten times slower without).
+struct ShardedCycleGuard {
+    tf_ctx *ctx;
+    bool on;
+    explicit ShardedCycleGuard(tf_ctx *c) : ctx(c), on(c->world > 1 && c->allreduce) {
+        if (!on) { ctx->scf.agree = nullptr; return; }
+        ctx->scf.agree = [c](const double *v, int nv, std::string &m) { return agree_over_ranks(c, v, nv, m); };
+        if (ctx->scf.blas) (void)rocblas_set_atomics_mode(ctx->scf.blas, rocblas_atomics_not_allowed);
+    }
+    ~ShardedCycleGuard() {
+        ctx->scf.agree = nullptr;
+        if (on && ctx->scf.blas) (void)rocblas_set_atomics_mode(ctx->scf.blas, rocblas_atomics_allowed);
+    }
+};
+}
+
 int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const double *T, const double *V, const double *Fext,
                const double *X, const double *P0, double E0, int n_occ, double V_NN, tf_scf_result *out)
 {
@@ -2456,6 +2511,7 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
         if (ctx->grid.N != ctx->N) TF_FAIL(ctx, TF_EINVAL, "tf_scf_rhf: the DFT grid was set up for a different AO dimension");
         xc = [&](const double *dP, double *dV, double *o3) { return tfdft::vxc(ctx->scf.blas, ctx->grid, dP, dV, o3, msg); };
     }
+    ShardedCycleGuard guard(ctx);
     int rc = tfscf::run_rhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0, E0, n_occ, V_NN, jk, ctx->world, *out, msg, xc);
     if (rc && !msg.empty()) ctx->err = msg;
     return rc;
@@ -2480,6 +2536,7 @@ int tf_scf_uhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
     };
     tfscf::UhfOut uo;
     for (int sp = 0; sp < 2; ++sp) { uo.P[sp] = out->P_spin[sp]; uo.C[sp] = out->C_spin[sp]; uo.eps[sp] = out->eps_spin[sp]; uo.F[sp] = out->F_spin[sp]; }
+    ShardedCycleGuard guard(ctx);
     int rc = tfscf::run_uhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0_alpha, P0_beta, E0, n_alpha, n_beta, V_NN, jk2, ctx->world,
                             out->common, uo, msg);
     if (rc && !msg.empty()) ctx->err = msg;

@@ -80,8 +80,11 @@ __device__ __forceinline__ double team_fact_sum(const double *__restrict__ X, co
     return sum;
 }
 
+#ifndef TF_TEAM_OCC
+#define TF_TEAM_OCC 1            // minimum waves per SIMD the team kernels are compiled for (register budget)
+#endif
 template <int LAB, int LCD, int TEAM>
-__global__ __launch_bounds__(256) void eri_team_kernel(DBasis B, TClass tc, const BraRec *__restrict__ bras, const KetRec *__restrict__ kets,
+__global__ __launch_bounds__(256, TF_TEAM_OCC) void eri_team_kernel(DBasis B, TClass tc, const BraRec *__restrict__ bras, const KetRec *__restrict__ kets,
                                                        const int *__restrict__ kcnt, double *__restrict__ T2)
 {
     constexpr int NT = 256 / TEAM, L = LAB + LCD, NM = L / 2 + 1, XS = NM | 1, Lab1 = LAB + 1, Lcd1 = LCD + 1, RS = L + 2;

@@ -27,6 +27,10 @@
 namespace tfscf {
 
 struct Workspace {
+    // Sharded tensors (world > 1): every rank runs the cycle redundantly on identical data, and a last-bit difference must not let one
+    // rank leave the loop (or take another branch) while the others wait in the next all-reduce.  `agree` sums a few per-iteration
+    // decision values over the ranks (tf_device.hip: through the registered all-reduce) and fails on EVERY rank when they differ.
+    std::function<int(const double *vals, int n, std::string &msg)> agree;
     rocblas_handle blas = nullptr;
     int n = 0;
     double *pool = nullptr;      // all N x N device matrices live in one allocation
@@ -89,7 +93,7 @@ inline int ensure(Workspace &w, int n, int n_mats, std::string &msg)
 {
     if (!w.blas) {
         TFS_BLAS(rocblas_create_handle(&w.blas));
-        TFS_HIP(hipMalloc((void **)&w.d_scal, 128 * sizeof(double)));
+        TFS_HIP(hipMalloc((void **)&w.d_scal, 256 * sizeof(double)));   // [128, 256): scalar products of the DIIS history (64 per spin)
         TFS_HIP(hipMalloc((void **)&w.d_part, 256 * 8 * sizeof(double)));
         TFS_HIP(hipMalloc((void **)&w.d_info, sizeof(rocblas_int)));
         TFS_HIP(hipEventCreate(&w.ev0));
@@ -140,11 +144,12 @@ __global__ void k_scale_cols(const double *__restrict__ V, const double *__restr
 }
 
 struct Ptr8 { const double *p[8]; double c[8]; };
-__global__ void k_lincomb(Ptr8 a, int m, double *__restrict__ out, int nn)     // F_DIIS = sum_k c_k F_k (scf:1025)
+#define TF_MAX_DIIS 64           // history entries the native cycles hold (the reference keeps any `DIIS n`, scf:943-946; 8 per launch here)
+__global__ void k_lincomb(Ptr8 a, int m, double *__restrict__ out, int nn, int accumulate)     // F_DIIS = sum_k c_k F_k (scf:1025)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nn) return;
-    double s = 0.0;
+    double s = accumulate ? out[e] : 0.0;
     for (int k = 0; k < m; ++k) s += a.c[k] * a.p[k][e];
     out[e] = s;
 }
@@ -706,7 +711,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     // world > 1: the J/K hook completes the partial sums of this rank's tensor rows with the registered all-reduce (tf_set_allreduce);
     // every rank then runs the O(N^3) steps redundantly on identical data
     (void)world;
-    if (o.max_diis > 8) { msg = "tf_scf_rhf: at most 8 DIIS matrices are supported by the native cycle (the reference keeps any `DIIS n`)"; return TF_EINVAL; }
+    if (o.max_diis > TF_MAX_DIIS) { msg = "tf_scf_rhf: at most 64 DIIS matrices are held by the native cycle"; return TF_EINVAL; }
     const int max_diis = std::max(1, (int)o.max_diis);
     const int n_mats = 22 + 2 * max_diis;
     int rc = ensure(w, n, n_mats, msg);
@@ -882,12 +887,15 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         ++n_hist;
         double ee = 0.0;
         {
-            Ptr8 a;
-            for (int k = 0; k < 8; ++k) { a.p[k] = histE(0); a.c[k] = 0.0; }
-            for (int k = 0; k < n_hist; ++k) a.p[k] = histE(k);
-            double hd[8];
-            launch_multi_dot(w, histE(n_hist - 1), a, n_hist, (int)nn, w.d_scal + 48);
-            TFS_HIP(hipMemcpy(hd, w.d_scal + 48, n_hist * sizeof(double), hipMemcpyDeviceToHost));
+            double hd[TF_MAX_DIIS];
+            for (int k0 = 0; k0 < n_hist; k0 += 8) {               // eight scalar products per launch
+                Ptr8 a;
+                const int mk = std::min(8, n_hist - k0);
+                for (int k = 0; k < 8; ++k) { a.p[k] = histE(0); a.c[k] = 0.0; }
+                for (int k = 0; k < mk; ++k) a.p[k] = histE(k0 + k);
+                launch_multi_dot(w, histE(n_hist - 1), a, mk, (int)nn, w.d_scal + 128 + k0);
+            }
+            TFS_HIP(hipMemcpy(hd, w.d_scal + 128, n_hist * sizeof(double), hipMemcpyDeviceToHost));
             for (int k = 0; k < n_hist; ++k) {
                 // the reference stores the error twice (alpha and beta copies, scf:934), hence the factor 2
                 B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = 2.0 * hd[k];
@@ -920,10 +928,13 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             }
             rhs[n_hist] = -1.0;
             if (small_solve(m, A, rhs, x)) {
-                Ptr8 a;
-                for (int k = 0; k < 8; ++k) { a.p[k] = histF(0); a.c[k] = 0.0; }
-                for (int k = 0; k < n_hist; ++k) { a.p[k] = histF(k); a.c[k] = x[k]; }
-                hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, 0, a, n_hist, scr, (int)nn);
+                for (int k0 = 0; k0 < n_hist; k0 += 8) {
+                    Ptr8 a;
+                    const int mk = std::min(8, n_hist - k0);
+                    for (int k = 0; k < 8; ++k) { a.p[k] = histF(0); a.c[k] = 0.0; }
+                    for (int k = 0; k < mk; ++k) { a.p[k] = histF(k0 + k); a.c[k] = x[k0 + k]; }
+                    hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, 0, a, mk, scr, (int)nn, k0 > 0 ? 1 : 0);
+                }
                 rc = diag_density(scr, dPn);     // overwrites dC/vals: results were copied out above
                 if (rc) return rc;
             } else {
@@ -970,8 +981,14 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             double *row = out.table + (size_t)(step - 1) * 7;
             row[0] = step; row[1] = E + V_NN; row[2] = dE; row[3] = rmsDP; row[4] = maxDP; row[5] = commutator; row[6] = damp;
         }
-        if (std::fabs(dE) < o.conv_delta_E && std::fabs(maxDP) < o.conv_max_DP && std::fabs(rmsDP) < o.conv_rms_DP &&
-            std::fabs(commutator) < o.conv_commutator) {
+        const bool conv_now = std::fabs(dE) < o.conv_delta_E && std::fabs(maxDP) < o.conv_max_DP && std::fabs(rmsDP) < o.conv_rms_DP &&
+                              std::fabs(commutator) < o.conv_commutator;
+        if (w.agree) {                                               // collective control flow on a sharded tensor
+            const double vals[3] = {conv_now ? 1.0 : 0.0, (double)n_hist, (double)step};
+            rc = w.agree(vals, 3, msg);
+            if (rc) return rc;
+        }
+        if (conv_now) {
             out.converged = 1;
             break;
         }
@@ -1025,7 +1042,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                    int world, tf_scf_result &out, const UhfOut &uo, std::string &msg)
 {
     (void)world;                                                    // (sharded tensors: see run_rhf)
-    if (o.max_diis > 8) { msg = "tf_scf_uhf: at most 8 DIIS matrices are supported by the native cycle (the reference keeps any `DIIS n`)"; return TF_EINVAL; }
+    if (o.max_diis > TF_MAX_DIIS) { msg = "tf_scf_uhf: at most 64 DIIS matrices are held by the native cycle"; return TF_EINVAL; }
     const int max_diis = std::max(1, (int)o.max_diis);
     const int n_fixed = 30;
     const int n_mats = n_fixed + 4 * max_diis;
@@ -1175,16 +1192,18 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         ++n_hist;
         double ee[2] = {0.0, 0.0};
         {
-            double hd[16];
-            for (int sp = 0; sp < 2; ++sp) {
-                Ptr8 a;
-                for (int k = 0; k < 8; ++k) { a.p[k] = histE(0, sp); a.c[k] = 0.0; }
-                for (int k = 0; k < n_hist; ++k) a.p[k] = histE(k, sp);
-                launch_multi_dot(w, histE(n_hist - 1, sp), a, n_hist, (int)nn, w.d_scal + 64 + 8 * sp);
-            }
-            TFS_HIP(hipMemcpy(hd, w.d_scal + 64, 16 * sizeof(double), hipMemcpyDeviceToHost));
-            for (int k = 0; k < n_hist; ++k) B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = hd[k] + hd[8 + k];
-            ee[0] = hd[n_hist - 1]; ee[1] = hd[8 + n_hist - 1];
+            double hd[2 * TF_MAX_DIIS];
+            for (int sp = 0; sp < 2; ++sp)
+                for (int k0 = 0; k0 < n_hist; k0 += 8) {            // eight scalar products per launch
+                    Ptr8 a;
+                    const int mk = std::min(8, n_hist - k0);
+                    for (int k = 0; k < 8; ++k) { a.p[k] = histE(0, sp); a.c[k] = 0.0; }
+                    for (int k = 0; k < mk; ++k) a.p[k] = histE(k0 + k, sp);
+                    launch_multi_dot(w, histE(n_hist - 1, sp), a, mk, (int)nn, w.d_scal + 128 + TF_MAX_DIIS * sp + k0);
+                }
+            TFS_HIP(hipMemcpy(hd, w.d_scal + 128, 2 * TF_MAX_DIIS * sizeof(double), hipMemcpyDeviceToHost));
+            for (int k = 0; k < n_hist; ++k) B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = hd[k] + hd[TF_MAX_DIIS + k];
+            ee[0] = hd[n_hist - 1]; ee[1] = hd[TF_MAX_DIIS + n_hist - 1];
         }
         const double comm_s[2] = {std::sqrt(ee[0] / (double)nn), std::sqrt(ee[1] / (double)nn)};
         commutator = std::max(comm_s[0], comm_s[1]);                  // scf:1211
@@ -1215,10 +1234,13 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             rhs[n_hist] = -1.0;
             if (small_solve(m, A, rhs, x)) {
                 for (int sp = 0; sp < 2; ++sp) {
-                    Ptr8 a;
-                    for (int k = 0; k < 8; ++k) { a.p[k] = histF(0, sp); a.c[k] = 0.0; }
-                    for (int k = 0; k < n_hist; ++k) { a.p[k] = histF(k, sp); a.c[k] = x[k]; }
-                    hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, 0, a, n_hist, scr, (int)nn);
+                    for (int k0 = 0; k0 < n_hist; k0 += 8) {
+                        Ptr8 a;
+                        const int mk = std::min(8, n_hist - k0);
+                        for (int k = 0; k < 8; ++k) { a.p[k] = histF(0, sp); a.c[k] = 0.0; }
+                        for (int k = 0; k < mk; ++k) { a.p[k] = histF(k0 + k, sp); a.c[k] = x[k0 + k]; }
+                        hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, 0, a, mk, scr, (int)nn, k0 > 0 ? 1 : 0);
+                    }
                     rc = diag_density(sp, scr, dPn[sp]);
                     if (rc) return rc;
                 }
@@ -1271,8 +1293,14 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             double *row = out.table + (size_t)(step - 1) * 7;
             row[0] = step; row[1] = E + V_NN; row[2] = dE; row[3] = rmsDP; row[4] = maxDP; row[5] = commutator; row[6] = std::max(damp[0], damp[1]);
         }
-        if (std::fabs(dE) < o.conv_delta_E && std::fabs(maxDP) < o.conv_max_DP && std::fabs(rmsDP) < o.conv_rms_DP &&
-            std::fabs(commutator) < o.conv_commutator) {
+        const bool conv_now = std::fabs(dE) < o.conv_delta_E && std::fabs(maxDP) < o.conv_max_DP && std::fabs(rmsDP) < o.conv_rms_DP &&
+                              std::fabs(commutator) < o.conv_commutator;
+        if (w.agree) {                                               // collective control flow on a sharded tensor
+            const double vals[3] = {conv_now ? 1.0 : 0.0, (double)n_hist, (double)step};
+            rc = w.agree(vals, 3, msg);
+            if (rc) return rc;
+        }
+        if (conv_now) {
             out.converged = 1;
             break;
         }

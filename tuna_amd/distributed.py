@@ -90,12 +90,41 @@ class _DeviceBuffer:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
+def allreduce_with_status(t, group=None, backend=None, to_host=None, from_host=None):
+    """The exchange step on a buffer whose LAST element is a status word (0 on entry): sum-all-reduce of the whole buffer.  `to_host` /
+    `from_host` stage the buffer through the host (gloo).  A staging failure on this rank does not skip the collective -- the other
+    ranks would wait in it for ever -- but sends zeros with the status word set, so that every rank sees a non-zero status afterwards.
+    Returns 0, or 1 when this rank could not even take part (nothing to be done about that here)."""
+    import torch
+    import torch.distributed as dist
+    backend = backend or dist.get_backend(group)
+    if backend == "nccl":
+        dist.all_reduce(t, group=group)                      # on the current stream: the caller selects the library's stream
+        return 0
+    try:
+        h = (to_host or (lambda x: x.cpu()))(t)
+    except Exception:
+        import traceback
+        traceback.print_exc()
+        h = torch.zeros(t.numel(), dtype=torch.float64)
+        h[-1] = 1.0
+    dist.all_reduce(h, group=group)
+    try:
+        (from_host or (lambda x, y: x.copy_(y)))(t, h)
+    except Exception:
+        import traceback
+        traceback.print_exc()
+        return 1
+    return 0
+
+
 def attach_allreduce(engine, group=None):
     """Registers the exchange step of a sharded Fock build with the library (tf_set_allreduce): the native SCF cycles then run
-    on a tensor spread over the ranks of `group` -- per iteration ONE sum-all-reduce of the stacked partial [J;K], on the device
-    buffer the library hands over.  Backend "nccl" (= RCCL over xGMI): torch.distributed orders the collective after the
-    library's work (the legacy default stream, which is torch's current stream) and the library's next launch after it.  Backend
-    "gloo" (CPU tests, several ranks sharing one card): the buffer is staged through the host."""
+    on a tensor spread over the ranks of `group` -- per iteration ONE sum-all-reduce of the stacked partial [J;K] (plus a status word,
+    and a 16-double agreement vector per iteration), on the device buffer the library hands over.  Backend "nccl" (= RCCL over xGMI):
+    the collective is issued on the stream the library passes (`torch.cuda.ExternalStream`; the legacy default stream when it passes
+    NULL), i.e. ordered after the library's copies into the buffer and before its copies out of it, whatever torch's current stream
+    is.  Backend "gloo" (CPU tests, several ranks sharing one card): the buffer is staged through the host."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -107,14 +136,18 @@ def attach_allreduce(engine, group=None):
         try:
             t = torch.as_tensor(_DeviceBuffer(buf, count), device=device)
             if backend == "nccl":
-                dist.all_reduce(t, group=group)
-            else:
+                s = torch.cuda.ExternalStream(int(stream), device=device) if stream else torch.cuda.default_stream(device)
+                with torch.cuda.stream(s):
+                    return allreduce_with_status(t, group, backend)
+
+            def to_host(x):
                 torch.cuda.synchronize(device)
-                h = t.cpu()
-                dist.all_reduce(h, group=group)
-                t.copy_(h)
+                return x.cpu()
+
+            def from_host(x, h):
+                x.copy_(h)
                 torch.cuda.synchronize(device)
-            return 0
+            return allreduce_with_status(t, group, backend, to_host, from_host)
         except Exception:                                   # no exception may cross the C ABI
             import traceback
             traceback.print_exc()

@@ -49,7 +49,10 @@ class Calculation:
     dipole: bool = False                # DIPOLE, calc:137: finite-field electric properties (tuna_amd/properties.py)
     polarisability: bool = False        # POLAR, calc:139
     hyperpolarisability: bool = False   # HYPER, calc:140
-    electric_field: tuple = (0.0, 0.0, 0.0)
+    electric_field: tuple = (0.0, 0.0, 0.0)            # EX, EY, EZ, calc:160-162, 431
+    electric_field_gradient: tuple = (0.0, 0.0, 0.0)   # EGX, EGY, EGZ, calc:163-165, 432
+    S_eigenvalue_threshold: float = 1e-7               # STHRESH, calc:157
+    number_of_threads: int = 4                         # THREADS, calc:153 (host threads of the reference's OpenMP loops: no meaning here)
 
 
 @dataclass
@@ -91,6 +94,7 @@ def parse_input(input_line: str):
 def interpret_keywords(params, calc: Calculation) -> Calculation:
     """The SCF subset of tuna_calc.py:83-217, 357-521."""
     it = iter(range(len(params)))
+    custom = {}
     for k in it:
         p = params[k]
 
@@ -141,10 +145,26 @@ def interpret_keywords(params, calc: Calculation) -> Calculation:
             calc.polarisability = True
         elif p in ("HYPER", "HYPERPOLARISABILITY", "HYPERPOLARIZABILITY"):
             calc.hyperpolarisability = True
-        elif p in ("SADGUESS", "T", "P", "DEBUG"):
-            pass
+        elif p == "THREADS":
+            calc.number_of_threads = int(value())           # accepted and ignored: the integrals run on the GPU
+        elif p == "STHRESH":
+            calc.S_eigenvalue_threshold = float(value())
+        elif p in ("EX", "EY", "EZ"):
+            f = list(calc.electric_field)
+            f["XYZ".index(p[1])] = float(value())
+            calc.electric_field = tuple(f)
+        elif p in ("EGX", "EGY", "EGZ"):
+            f = list(calc.electric_field_gradient)
+            f["XYZ".index(p[2])] = float(value())
+            calc.electric_field_gradient = tuple(f)
+        elif p in ("ECONV", "RMSDP", "MAXDP", "DIISERR"):      # calc:187-190, applied over the named criteria at calc:491-494
+            custom[{"ECONV": "delta_E", "RMSDP": "RMS_DP", "MAXDP": "max_DP", "DIISERR": "commutator"}[p]] = float(value())
+        elif p in ("SADGUESS", "SCFGUESS", "T", "P", "DEBUG"):
+            pass                                             # (SCFGUESS: the reference's default guess path, calc:405-421 -- reproduced by default)
         else:
             raise TunaError(f"Keyword \"{p}\" is not supported on the GPU hot path (SCF keywords only)")
+    if custom:
+        calc.SCF_conv = dict(calc.SCF_conv, **custom)
     return calc
 
 
@@ -193,7 +213,7 @@ def build_molecule_and_integrals(symbols, R_bohr, calc: Calculation, engine: Eng
     t0 = time.perf_counter()
     X, smallest, S_inv = engine.orthogonaliser(S)
     timings["Fock orthogonalisation matrix"] = time.perf_counter() - t0
-    if smallest < 1e-7:                                   # STHRESH, kernel:887
+    if smallest < calc.S_eigenvalue_threshold:            # STHRESH, kernel:887
         raise TunaError("An overlap matrix eigenvalue is too small! Change the basis set or decrease the threshold with STHRESH.")
     t0 = time.perf_counter()
     use_core = calc.core_guess or calc.cartesian_harmonics or any(a.charge == 0 for a in atoms)
@@ -218,6 +238,13 @@ def calculate_energy(symbols, R_bohr, calc: Calculation, engine: Engine | None =
     try:
         molecule, integrals, X, guess, timings = build_molecule_and_integrals(symbols, R_bohr, calc, engine)
         V_NN = mol.nuclear_repulsion(molecule.atoms)
+        # field terms of the Hamiltonian, set after the guess as the reference does (energy:915-919; kernel:660-707: only two
+        # independent components of the quadrupole tensor are used, [Q0, Q0, Q1])
+        if np.linalg.norm(calc.electric_field) > 0:
+            integrals.F = np.einsum("i,ijk->jk", np.asarray(calc.electric_field, dtype=float), integrals.D, optimize=True)
+        if np.linalg.norm(calc.electric_field_gradient) > 0:
+            Q3 = np.array([integrals.Q[0], integrals.Q[0], integrals.Q[1]])
+            integrals.G = np.einsum("i,ijk->jk", np.asarray(calc.electric_field_gradient, dtype=float), Q3, optimize=True)
         if not silent:
             log(f" Nuclear repulsion energy: {V_NN:.10f}\n")
         t0 = time.perf_counter()
