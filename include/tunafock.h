@@ -192,7 +192,17 @@ typedef struct {
     double *P_spin[2];          /* [N,N]                                           */
     double *C_spin[2];          /* [N,N]                                           */
     double *eps_spin[2];        /* [N]                                             */
-    double *F_spin[2];          /* [N,N]                                           */
+    double *F_spin[2];          /* Several restricted cycles on the SAME tensor advanced in lockstep: what the reference's finite-field drivers run one after the other
+ * (tuna_energy.py:315-540: 2, 8 or 12 energy evaluations that differ only in the field term F_fld, kernel:660-677).  Arguments as
+ * tf_scf_rhf, with one Fext (may be NULL, or entries NULL), P0, E0 and result per cycle; every cycle follows the iteration order of
+ * a run on its own (scf:1072-1154) and stops by its own criteria, but the Fock builds of an iteration go through the tensor together
+ * (two densities per pass).  rc_out[c] (may be NULL): return code of cycle c; passes_out (may be NULL): {passes over the tensor,
+ * Fock builds}.  Returns 0 or the first non-zero cycle code.  Unsharded tensors, Hartree-Fock only. */
+int tf_scf_rhf_batch(tf_ctx *ctx, int n_cycles, const tf_scf_opts *opts, const double *S, const double *T, const double *V,
+                     const double *const *Fext, const double *X, const double *const *P0, const double *E0, int n_occ, double V_NN,
+                     tf_scf_result *out, int32_t *rc_out, int64_t *passes_out);
+
+/* [N,N]                                           */
 } tf_scf_uhf_result;
 int tf_scf_uhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const double *T, const double *V,
                const double *Fext, const double *X, const double *P0_alpha, const double *P0_beta, double E0,

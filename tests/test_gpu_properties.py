@@ -85,6 +85,19 @@ def test_lockstep_cycles_equal_cycles_run_one_by_one(engine):
     assert abs(together.iterations - one_by_one.iterations) <= len(fields)          # same trajectories, cycle by cycle
     # a field along x mixes AOs of different x parity: the density leaves the block structure of the zero-field problem
     assert abs(Ea[4] - Ea[7]) < 1e-9 and abs(Ea[5] - Ea[6]) < 1e-9                  # E(+x) = E(-x) by symmetry
+    # the same batch inside the library (tf_scf_rhf_batch: the native cycle per field on its own host thread and workspace, the Fock
+    # builds of an iteration together -- two densities per pass over the tensor)
+    native = props.FieldEnergies(molecule, calc, integrals, V_NN, X, guess, batched="native")
+    b0 = integrals.ERI_AO.n_builds
+    Ec = native.energies(fields)
+    assert np.abs(np.array(Ec) - np.array(Eb)).max() < 1e-9
+    assert abs(native.iterations - one_by_one.iterations) <= len(fields)            # the same native cycle, only scheduled together
+    assert integrals.ERI_AO.n_builds - b0 <= (one_by_one.iterations + 1) // 2 + len(fields)   # passes over the tensor: two densities each
+    # an odd number of cycles (the last pass of an iteration carries one density) and a single one
+    Ed = props.FieldEnergies(molecule, calc, integrals, V_NN, X, guess, batched="native").energies(fields[:3])
+    assert np.abs(np.array(Ed) - np.array(Eb[:3])).max() < 1e-9
+    Ee = props.FieldEnergies(molecule, calc, integrals, V_NN, X, guess, batched="native").energies(fields[:1])
+    assert abs(Ee[0] - Eb[0]) < 1e-9
 
 
 def test_polarisability_input_line(engine):

@@ -54,6 +54,22 @@ def _rank_main(rank, world, port, tag, mode, layout, ret):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world,tag,mode,layout", [(2, "c3_ar2_ccpvqz", "", "packed"), (4, "c3_ar2_ccpvqz", "", "packed"), (4, "n2_ccpvdz", "class", "packed")])
+def test_config3_ar2_ccpvqz_sharded_and_four_ranks(world, tag, mode, layout):
+    """BASELINE config 3 verbatim (Ar2 RHF/cc-pVQZ, shell-pair shards) on two and on four ranks sharing the card; four ranks also with the
+    per-class ERI kernels on a small system (ranks whose row share of a class is empty)."""
+    import torch.multiprocessing as mp
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rank_main, args=(world, _free_port(), tag, mode, layout, ret), nprocs=world, join=True)
+        res = dict(ret)
+    assert set(res) == set(range(world))
+    for eJ, eK, eV, nbytes in res.values():
+        assert eJ < 1e-9 and eK < 1e-9 and eV < 1e-12
+    n_total = sum(v[3] for v in res.values())
+    assert max(v[3] for v in res.values()) - min(v[3] for v in res.values()) <= 0.08 * n_total
+
+
 @pytest.mark.parametrize("layout", ["packed", "rows"])
 @pytest.mark.parametrize("tag,mode", [("n2_ccpvdz", ""), ("c2_n2_ccpvtz", "class"), ("c4_co_def2tzvp", "generic")])
 def test_two_ranks_on_one_card(tag, mode, layout):

@@ -24,11 +24,11 @@ def case(eng, atoms, shells, aos, nocc, label, conv):
     V_NN = mol.nuclear_repulsion(atoms)
     h = props.SECOND_ELEC_DERIVATIVE_STEP
     fields = [[0, 0, 2 * h], [0, 0, h], [0, 0, -h], [0, 0, -2 * h], [2 * h, 0, 0], [h, 0, 0], [-h, 0, 0], [-2 * h, 0, 0]]
-    for batched in (True, False, True, False):
+    for batched in ("native", True, False, "native", False):
         fe = props.FieldEnergies(molecule, calc, integrals, V_NN, X, (P0, P0 / 2, P0 / 2, E0), batched=batched)
         b0 = integrals.ERI_AO.n_builds
         t0 = time.perf_counter(); E = fe.energies(fields); dt = time.perf_counter() - t0
-        print(f"{label} N={eng.N} {'lockstep/batched' if batched else 'native, one by one'}: {dt * 1e3:8.1f} ms, {fe.iterations} iterations, "
+        print(f"{label} N={eng.N} {('native lockstep (tf_scf_rhf_batch)' if batched == 'native' else 'host-orchestrated lockstep') if batched else 'native, one by one'}: {dt * 1e3:8.1f} ms, {fe.iterations} iterations, "
               f"{integrals.ERI_AO.n_builds - b0} host-level Fock calls, E(+2z) = {E[0]:.10f}", flush=True)
 
 with Engine(0) as eng:

@@ -45,7 +45,7 @@ EXPORTS = ["tf_create", "tf_destroy", "tf_last_error", "tf_version", "tf_normali
            "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf", "tf_scf_uhf",
            "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts", "tf_shard_plan", "tf_jk_profile",
            "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_ao_to_mo", "tf_mp2_rhf", "tf_dft_setup", "tf_dft_vxc",
-           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs", "tf_packed_pad", "tf_eri_flops", "tf_segment_pad", "tf_set_allreduce"]
+           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs", "tf_packed_pad", "tf_eri_flops", "tf_segment_pad", "tf_set_allreduce", "tf_scf_rhf_batch"]
 
 _lib = None
 
@@ -94,6 +94,7 @@ def lib():
     L.tf_fock_jk_device.restype = ci; L.tf_fock_jk_device.argtypes = [vp, ci, vp, vp, vp, vp]
     L.tf_scf_rhf.restype = ci
     L.tf_scf_rhf.argtypes = [vp, C.POINTER(ScfOpts), vp, vp, vp, vp, vp, vp, cd, ci, cd, C.POINTER(ScfResult)]
+    L.tf_scf_rhf_batch.restype = ci; L.tf_scf_rhf_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, cd, vp, vp, vp]
     L.tf_scf_uhf.restype = ci
     L.tf_scf_uhf.argtypes = [vp, C.POINTER(ScfOpts), vp, vp, vp, vp, vp, vp, vp, cd, ci, ci, cd, C.POINTER(ScfUhfResult)]
     L.tf_orthogonaliser.restype = ci; L.tf_orthogonaliser.argtypes = [vp, ci, vp, vp, vp, dp]

@@ -8,7 +8,11 @@
 #include <cstdlib>
 #include <array>
 #include <cstring>
+#include <condition_variable>
 #include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -113,6 +117,7 @@ struct tf_ctx {
     long long eri_counts[3] = {0, 0, 0};
     double eri_nominal_flops = 0.0;      // the reference algorithm's operation count for the quartets of the last build
     tfscf::Workspace scf;
+    std::vector<std::unique_ptr<tfscf::Workspace>> scf_batch;   // one workspace per cycle of a lockstep batch (tf_scf_rhf_batch), kept across calls
     tfdft::Grid grid;                    // Kohn-Sham integration grid with the AOs evaluated on it (tf_dft_setup)
     // persistent helpers of tf_build_eri (creating streams / freeing GiB-sized buffers costs tens of ms per call)
     static const int NSTREAM_MAX = 8;
@@ -457,6 +462,8 @@ void tf_destroy(tf_ctx *ctx)
     if (ctx->d_eri) { (void)hipFree(ctx->d_eri); ctx->d_eri = nullptr; ctx->eri_cap = 0; }
     free_basis(ctx);
     tfscf::release(ctx->scf);
+    for (auto &wsp : ctx->scf_batch) if (wsp) tfscf::release(*wsp);
+    ctx->scf_batch.clear();
     tfdft::release(ctx->grid);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->have_streams)
@@ -2514,6 +2521,110 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
     ShardedCycleGuard guard(ctx);
     int rc = tfscf::run_rhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0, E0, n_occ, V_NN, jk, ctx->world, *out, msg, xc);
     if (rc && !msg.empty()) ctx->err = msg;
+    return rc;
+}
+
+extern "C++" {
+// Rendezvous of the cycles of a lockstep batch in their Fock builds (tf_scf_rhf_batch): every cycle runs the unmodified native cycle
+// (tfscf::run_rhf) on a host thread of its own and asks for J and K of its density once per iteration; the last cycle to arrive sends
+// the densities of all cycles still iterating through the tensor together (two per pass, jk_packed_kernel<2>).
+struct LockstepJK {
+    struct Req { const double *dP; double *dJ, *dK; };
+    tf_ctx *ctx;
+    std::mutex mu;
+    std::condition_variable cv;
+    int active = 0, waiting = 0, last_rc = TF_OK;
+    long long generation = 0, passes = 0, builds = 0;
+    std::vector<Req> req;
+    hipEvent_t ev[2] = {nullptr, nullptr};          // "the builds of generation g are queued", alternating
+    LockstepJK(tf_ctx *c, int n) : ctx(c), active(n), req((size_t)n)
+    {
+        (void)hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+    }
+    ~LockstepJK() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+    void build_locked(hipStream_t st)               // on the stream of the cycle that arrived last; the others wait for its event
+    {
+        int rc = TF_OK;
+        for (int q = 0; q < waiting && rc == TF_OK; q += 2) {
+            const int nd = (q + 1 < waiting) ? 2 : 1;
+            const double *p[2] = {req[q].dP, req[q + nd - 1].dP};
+            double *j[2] = {req[q].dJ, req[q + nd - 1].dJ}, *k[2] = {req[q].dK, req[q + nd - 1].dK};
+            rc = launch_jk(ctx, nd, p, j, k, st, nullptr);
+            ++passes; builds += nd;
+        }
+        if (hipEventRecord(ev[generation & 1], st) != hipSuccess && rc == TF_OK) rc = TF_ENODEVICE;
+        last_rc = rc;
+        waiting = 0;
+        ++generation;
+        cv.notify_all();
+    }
+    int fock(const double *dP, double *dJ, double *dK, hipStream_t st)
+    {
+        if (hipStreamSynchronize(st) != hipSuccess) return TF_ENODEVICE;   // this cycle's density is complete before another stream reads it
+        hipEvent_t done;
+        int rc;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            req[(size_t)waiting++] = Req{dP, dJ, dK};
+            const long long g = generation;
+            if (waiting == active) build_locked(st);
+            else cv.wait(lk, [&] { return generation != g; });
+            done = ev[g & 1];
+            rc = last_rc;
+        }
+        if (hipStreamWaitEvent(st, done, 0) != hipSuccess && rc == TF_OK) rc = TF_ENODEVICE;
+        return rc;
+    }
+    void finish(hipStream_t st)                     // a cycle has left its loop: those waiting may be complete now
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        --active;
+        if (active > 0 && waiting == active) build_locked(st);
+    }
+};
+}
+
+int tf_scf_rhf_batch(tf_ctx *ctx, int n_cycles, const tf_scf_opts *opts, const double *S, const double *T, const double *V,
+                     const double *const *Fext, const double *X, const double *const *P0, const double *E0, int n_occ, double V_NN,
+                     tf_scf_result *out, int32_t *rc_out, int64_t *passes_out)
+{
+    if (!ctx) return TF_EINVAL;
+    if (!ctx->have_eri) TF_FAIL(ctx, TF_EINVAL, "tf_scf_rhf_batch: call tf_build_eri first");
+    if (n_cycles < 1 || n_cycles > 64 || !opts || !S || !T || !V || !P0 || !E0 || !out || n_occ < 1 || n_occ > ctx->N)
+        TF_FAIL(ctx, TF_EINVAL, "tf_scf_rhf_batch: bad arguments");
+    if (ctx->world > 1) TF_FAIL(ctx, TF_EINVAL, "tf_scf_rhf_batch: lockstep batches run on an unsharded tensor (world = 1) in this build");
+    if (ctx->grid.G > 0) TF_FAIL(ctx, TF_EINVAL, "tf_scf_rhf_batch: lockstep batches run Hartree-Fock cycles (clear the DFT grid with tf_dft_clear)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    while ((int)ctx->scf_batch.size() < n_cycles) ctx->scf_batch.emplace_back(new tfscf::Workspace());
+    LockstepJK ls(ctx, n_cycles);
+    static const bool serial_streams = getenv("TF_BATCH_ONE_STREAM") != nullptr;      // (A/B: every cycle on the legacy default stream)
+    std::vector<int> rcs((size_t)n_cycles, TF_OK);
+    std::vector<std::string> msgs((size_t)n_cycles);
+    std::vector<std::thread> threads;
+    for (int c = 0; c < n_cycles; ++c)
+        threads.emplace_back([&, c] {
+            // a host thread and a non-blocking stream per cycle: the O(N^3) steps of different cycles overlap on the device
+            (void)hipSetDevice(ctx->device);
+            hipStream_t st = nullptr;
+            if (!serial_streams && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+            tfscf::t_stream = st;
+            auto jk = [&](const double *dP, double *dJ, double *dK, hipStream_t s2) { return ls.fock(dP, dJ, dK, s2); };
+            rcs[(size_t)c] = tfscf::run_rhf(*ctx->scf_batch[(size_t)c], ctx->N, *opts, S, T, V, Fext ? Fext[c] : nullptr, X, P0[c], E0[c], n_occ, V_NN, jk, 1,
+                                             out[c], msgs[(size_t)c], tfscf::XCFn());
+            (void)hipStreamSynchronize(st);
+            ls.finish(st);
+            (void)hipStreamSynchronize(st);
+            tfscf::t_stream = nullptr;
+            if (st) (void)hipStreamDestroy(st);
+        });
+    for (auto &t : threads) t.join();
+    int rc = TF_OK;
+    for (int c = 0; c < n_cycles; ++c) {
+        if (rc_out) rc_out[c] = rcs[(size_t)c];
+        if (rcs[(size_t)c] != TF_OK && rc == TF_OK) { rc = rcs[(size_t)c]; ctx->err = "cycle " + std::to_string(c) + ": " + msgs[(size_t)c]; }
+    }
+    if (passes_out) { passes_out[0] = ls.passes; passes_out[1] = ls.builds; }
     return rc;
 }
 

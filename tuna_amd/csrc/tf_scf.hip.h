@@ -26,6 +26,19 @@
 
 namespace tfscf {
 
+// The stream the SCF code of the calling host thread works on: the legacy default stream, except inside a lockstep batch
+// (tf_scf_rhf_batch), where every cycle runs on a host thread and a non-blocking stream of its own so that the O(N^3) steps of different
+// cycles overlap on the device.
+inline thread_local hipStream_t t_stream = nullptr;
+#define TFS_ST (tfscf::t_stream)
+inline hipError_t tfs_memcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    if (!t_stream) return hipMemcpy(dst, src, bytes, kind);
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, t_stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(t_stream);
+}
+inline hipError_t tfs_sync() { return t_stream ? hipStreamSynchronize(t_stream) : hipDeviceSynchronize(); }
+
 struct Workspace {
     // Sharded tensors (world > 1): every rank runs the cycle redundantly on identical data, and a last-bit difference must not let one
     // rank leave the loop (or take another branch) while the others wait in the next all-reduce.  `agree` sums a few per-iteration
@@ -283,17 +296,17 @@ __global__ void k_mulliken(const double *__restrict__ P, const double *__restric
 // row-major C = alpha * op(A) * op(B) + beta * C, all n x n (k = inner dimension, default n)
 inline void launch_multi_dot(Workspace &w, const double *x, const Ptr8 &a, int m, int nn, double *out)
 {
-    if (nn <= 8192) { hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, 0, x, a, m, nn, out); return; }
+    if (nn <= 8192) { hipLaunchKernelGGL(k_multi_dot, dim3(1), dim3(256), 0, TFS_ST, x, a, m, nn, out); return; }
     const int nblk = std::min(256, (nn + 2047) / 2048);
-    hipLaunchKernelGGL(k_multi_dot_part, dim3(nblk), dim3(256), 0, 0, x, a, m, nn, w.d_part);
-    hipLaunchKernelGGL(k_multi_dot_fin, dim3(1), dim3(64), 0, 0, w.d_part, nblk, m, out);
+    hipLaunchKernelGGL(k_multi_dot_part, dim3(nblk), dim3(256), 0, TFS_ST, x, a, m, nn, w.d_part);
+    hipLaunchKernelGGL(k_multi_dot_fin, dim3(1), dim3(64), 0, TFS_ST, w.d_part, nblk, m, out);
 }
 inline void launch_delta_norms(Workspace &w, const double *a, const double *b, int nn, double *res)
 {
-    if (nn <= 8192) { hipLaunchKernelGGL(k_delta_norms, dim3(1), dim3(256), 0, 0, a, b, nn, res); return; }
+    if (nn <= 8192) { hipLaunchKernelGGL(k_delta_norms, dim3(1), dim3(256), 0, TFS_ST, a, b, nn, res); return; }
     const int nblk = std::min(256, (nn + 2047) / 2048);
-    hipLaunchKernelGGL(k_delta_norms_part, dim3(nblk), dim3(256), 0, 0, a, b, nn, w.d_part);
-    hipLaunchKernelGGL(k_delta_norms_fin, dim3(1), dim3(64), 0, 0, w.d_part, nblk, res);
+    hipLaunchKernelGGL(k_delta_norms_part, dim3(nblk), dim3(256), 0, TFS_ST, a, b, nn, w.d_part);
+    hipLaunchKernelGGL(k_delta_norms_fin, dim3(1), dim3(64), 0, TFS_ST, w.d_part, nblk, res);
 }
 
 inline rocblas_status gemm_rm(rocblas_handle h, bool tA, bool tB, int n, double alpha, const double *A, const double *B, double beta,
@@ -326,7 +339,7 @@ inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, st
         static const bool no_warm = getenv("TF_EIGH_COLD") != nullptr;
         const double *V0 = (w.warm_ok && !no_warm && w.jac_prev_n == n) ? w.jac_prev : nullptr;
         hipError_t e = hipSuccess;
-        if (tfjac::launch(n, W, vals, w.jac_scratch, (int *)w.d_info, 0, &e, V0, w.warm_ok ? w.jac_prev : nullptr)) {
+        if (tfjac::launch(n, W, vals, w.jac_scratch, (int *)w.d_info, TFS_ST, &e, V0, w.warm_ok ? w.jac_prev : nullptr)) {
             if (w.warm_ok) w.jac_prev_n = n;
             return TF_OK;
         }
@@ -445,7 +458,7 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
     // X <- (3/2 I - 1/2 G) X with G = X X^T (rows are the vectors)
     auto orthonormalise = [&]() -> int {
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, X, X, 0.0, G));
-        TFS_HIP(hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        TFS_HIP(hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
         TFS_BLAS(gemm_rm(w.blas, false, false, n, -0.5, G, X, 1.5, Xn));
         std::swap(X, Xn);
         return TF_OK;
@@ -461,11 +474,11 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
     for (int step = 0; step < 16 && !ok; ++step) {
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, X, A, 0.0, Y));         // rows A x_i
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Y, X, 0.0, S));          // S = X^T A X
-        hipLaunchKernelGGL(k_ref_diag, dim3(1), dim3(1024), 0, 0, S, n, n_occ, lam, wocc, bmax + 2 * (size_t)g);
-        hipLaunchKernelGGL(k_ref_E, dim3(g), dim3(256), 0, 0, S, lam, wocc, n, E, bmax);
-        TFS_HIP(hipMemcpyAsync(w.h_pin, bmax, npin * sizeof(double), hipMemcpyDeviceToHost, 0));
-        TFS_HIP(hipEventRecord(w.ev_pin, 0));
-        TFS_HIP(hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        hipLaunchKernelGGL(k_ref_diag, dim3(1), dim3(1024), 0, TFS_ST, S, n, n_occ, lam, wocc, bmax + 2 * (size_t)g);
+        hipLaunchKernelGGL(k_ref_E, dim3(g), dim3(256), 0, TFS_ST, S, lam, wocc, n, E, bmax);
+        TFS_HIP(hipMemcpyAsync(w.h_pin, bmax, npin * sizeof(double), hipMemcpyDeviceToHost, TFS_ST));
+        TFS_HIP(hipEventRecord(w.ev_pin, TFS_ST));
+        TFS_HIP(hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, E, X, 1.0, Xn));         // X + E^T X   (rows)
         std::swap(X, Xn);
         if ((rc = orthonormalise())) return rc;
@@ -481,11 +494,11 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
     }
     if (ok) {
         if (X != w.ref_buf) {                                                  // keep the vectors in the first slot for the next solve
-            TFS_HIP(hipMemcpyAsync(w.ref_buf, X, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            TFS_HIP(hipMemcpyAsync(w.ref_buf, X, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
             X = w.ref_buf;
         }
         double *Xw = w.ref_buf + 2 * nn;                                       // G's slot: free now
-        hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, 0, X, wocc, Xw, n);
+        hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, TFS_ST, X, wocc, Xw, n);
         *Xocc = Xw;
         return TF_OK;
     }
@@ -503,18 +516,18 @@ inline int ref_refine_lds(Workspace &w, int n, int n_occ, const double *A, doubl
     int *status = reinterpret_cast<int *>(w.d_scal + 62);
     hipError_t e = hipSuccess;
     ++w.ref_solves;
-    if (!tfref::launch(n, n_occ, A, X, lam, wocc, status, 0, &e)) {
+    if (!tfref::launch(n, n_occ, A, X, lam, wocc, status, TFS_ST, &e)) {
         if (e != hipSuccess) { msg = std::string("refinement kernel launch failed: ") + hipGetErrorString(e); return TF_ENODEVICE; }
         return TF_ELINALG;
     }
     int h[2] = {0, 0};
-    TFS_HIP(hipMemcpy(h, status, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    TFS_HIP(tfs_memcpy(h, status, 2 * sizeof(int), hipMemcpyDeviceToHost));
     static const bool dbg = getenv("TF_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[tf refine/lds] n %d: %s after %d steps\n", n, h[0] ? "converged" : "NOT converged", h[1]);
     if (!h[0]) { ++w.ref_fallbacks; w.ref_n = 0; return TF_ELINALG; }
     w.ref_steps += h[1];
     const int g = (int)((nn + 255) / 256);
-    hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, 0, X, wocc, Xw, n);
+    hipLaunchKernelGGL(k_scale_rows, dim3(g), dim3(256), 0, TFS_ST, X, wocc, Xw, n);
     *Xocc = Xw;
     return TF_OK;
 }
@@ -529,12 +542,12 @@ inline int ref_density_lds(Workspace &w, int n, int n_occ, const double *Fao, co
     int *status = reinterpret_cast<int *>(w.d_scal + 62);
     hipError_t e = hipSuccess;
     ++w.ref_solves;
-    if (!tfref::launch(n, n_occ, nullptr, X, lam, wocc, status, 0, &e, Fao, Xo, Pout, occ)) {
+    if (!tfref::launch(n, n_occ, nullptr, X, lam, wocc, status, TFS_ST, &e, Fao, Xo, Pout, occ)) {
         if (e != hipSuccess) { msg = std::string("refinement kernel launch failed: ") + hipGetErrorString(e); return TF_ENODEVICE; }
         return TF_ELINALG;
     }
     int h[2] = {0, 0};
-    TFS_HIP(hipMemcpy(h, status, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    TFS_HIP(tfs_memcpy(h, status, 2 * sizeof(int), hipMemcpyDeviceToHost));
     static const bool dbg = getenv("TF_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[tf refine/lds fused] n %d: %s after %d steps\n", n, h[0] ? "converged" : "NOT converged", h[1]);
     if (!h[0]) { ++w.ref_fallbacks; w.ref_n = 0; return TF_ELINALG; }
@@ -547,7 +560,7 @@ inline int ref_store(Workspace &w, int n, const double *V, std::string &msg)
 {
     int rc = ref_ensure(w, n, msg);
     if (rc) return rc;
-    TFS_HIP(hipMemcpyAsync(w.ref_buf, V, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, 0));
+    TFS_HIP(hipMemcpyAsync(w.ref_buf, V, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
     w.ref_n = n;
     return TF_OK;
 }
@@ -586,11 +599,11 @@ inline int orthogonaliser_device(Workspace &w, int n, const double *dS, double *
 {
     const int nn = n * n, g = (nn + 255) / 256;
     double *W = scratch, *Vs = scratch + nn, *vals = scratch + 2 * (size_t)nn, *e = vals + n;
-    hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, dS, W, n);
+    hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, dS, W, n);
     int rc = eigh(w, n, W, vals, e, msg);
     if (rc) return rc;
     std::vector<double> hv(n);
-    TFS_HIP(hipMemcpy(hv.data(), vals, n * sizeof(double), hipMemcpyDeviceToHost));
+    TFS_HIP(tfs_memcpy(hv.data(), vals, n * sizeof(double), hipMemcpyDeviceToHost));
     double mn = hv[0];
     for (double v : hv) mn = std::min(mn, v);
     if (smallest) *smallest = mn;
@@ -605,7 +618,7 @@ inline int orthogonaliser_device(Workspace &w, int n, const double *dS, double *
         // form Wt = W^T, scale columns, then X = Wt_scaled * W
         double one = 1.0, zero = 0.0;
         TFS_BLAS(rocblas_dgeam(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, &one, W, n, &zero, W, n, Vs, n));
-        hipLaunchKernelGGL(k_scale_cols, dim3(g), dim3(256), 0, 0, Vs, vals, mode, Vs, n);
+        hipLaunchKernelGGL(k_scale_cols, dim3(g), dim3(256), 0, TFS_ST, Vs, vals, mode, Vs, n);
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, Vs, W, 0.0, out));
     }
     return TF_OK;
@@ -617,11 +630,11 @@ inline int orthogonaliser(Workspace &w, int n, const double *S, double *X, doubl
     if (rc) return rc;
     const size_t nn = (size_t)n * n;
     double *dS = w.pool, *dX = dS + nn, *dSi = dX + nn, *scr = dSi + nn;
-    TFS_HIP(hipMemcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
     rc = orthogonaliser_device(w, n, dS, dX, S_inv ? dSi : nullptr, smallest, scr, msg);
     if (rc) return rc;
-    TFS_HIP(hipMemcpy(X, dX, nn * sizeof(double), hipMemcpyDeviceToHost));
-    if (S_inv) TFS_HIP(hipMemcpy(S_inv, dSi, nn * sizeof(double), hipMemcpyDeviceToHost));
+    TFS_HIP(tfs_memcpy(X, dX, nn * sizeof(double), hipMemcpyDeviceToHost));
+    if (S_inv) TFS_HIP(tfs_memcpy(S_inv, dSi, nn * sizeof(double), hipMemcpyDeviceToHost));
     return TF_OK;
 }
 
@@ -633,16 +646,16 @@ inline int diagonalise(Workspace &w, int n, const double *F, const double *X, do
     const size_t nn = (size_t)n * n;
     const int g = (int)((nn + 255) / 256);
     double *dF = w.pool, *dX = dF + nn, *t1 = dX + nn, *t2 = t1 + nn, *dW = t2 + nn, *vals = dW + nn, *e = vals + n;
-    TFS_HIP(hipMemcpy(dF, F, nn * sizeof(double), hipMemcpyHostToDevice));
-    TFS_HIP(hipMemcpy(dX, X, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dF, F, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dX, X, nn * sizeof(double), hipMemcpyHostToDevice));
     TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, dF, 0.0, t1));
     TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
-    hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+    hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t2, dW, n);
     rc = eigh(w, n, dW, vals, e, msg);
     if (rc) return rc;
     TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, t1));
-    TFS_HIP(hipMemcpy(eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
-    TFS_HIP(hipMemcpy(C, t1, nn * sizeof(double), hipMemcpyDeviceToHost));
+    TFS_HIP(tfs_memcpy(eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
+    TFS_HIP(tfs_memcpy(C, t1, nn * sizeof(double), hipMemcpyDeviceToHost));
     return TF_OK;
 }
 
@@ -663,11 +676,11 @@ inline int eigh_probe(Workspace &w, int n, int variant, int reps, double *second
             h[(size_t)i * n + j] = h[(size_t)j * n + i] = v;
         }
     double *A0 = w.pool, *A = A0 + nn, *V = A + nn, *vals = V + nn, *e = vals + n;
-    TFS_HIP(hipMemcpy(A0, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(A0, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
     double tot = 0.0;
     for (int r = 0; r < reps + 1; ++r) {
-        TFS_HIP(hipMemcpy(A, A0, nn * sizeof(double), hipMemcpyDeviceToDevice));
-        TFS_HIP(hipDeviceSynchronize());
+        TFS_HIP(tfs_memcpy(A, A0, nn * sizeof(double), hipMemcpyDeviceToDevice));
+        TFS_HIP(tfs_sync());
         auto t0 = std::chrono::steady_clock::now();
         if (variant == 0) TFS_BLAS(rocsolver_dsyevd(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, e, w.d_info));
         else if (variant == 3) { int rc3 = eigh(w, n, A, vals, e, msg); if (rc3) return rc3; }
@@ -693,7 +706,7 @@ inline int eigh_probe(Workspace &w, int n, int variant, int reps, double *second
             TFS_BLAS(rocsolver_dsyevj(w.blas, rocblas_esort_ascending, rocblas_evect_original, rocblas_fill_upper, n, A, n, 1e-14, resid, 100,
                                       nsweeps, vals, w.d_info));
         }
-        TFS_HIP(hipDeviceSynchronize());
+        TFS_HIP(tfs_sync());
         if (r > 0) tot += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     *seconds = tot / reps;
@@ -716,6 +729,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     const int n_mats = 22 + 2 * max_diis;
     int rc = ensure(w, n, n_mats, msg);
     if (rc) return rc;
+    TFS_BLAS(rocblas_set_stream(w.blas, TFS_ST));
     const size_t nn = (size_t)n * n;
     const int g = (int)((nn + 255) / 256);
     auto t_wall = std::chrono::steady_clock::now();
@@ -732,24 +746,24 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     auto histF = [&](int k) { return hist + (size_t)(2 * slot[k]) * nn; };
     auto histE = [&](int k) { return hist + (size_t)(2 * slot[k] + 1) * nn; };
 
-    TFS_HIP(hipMemcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
-    TFS_HIP(hipMemcpy(dT, T, nn * sizeof(double), hipMemcpyHostToDevice));
-    TFS_HIP(hipMemcpy(dV, V, nn * sizeof(double), hipMemcpyHostToDevice));
-    if (Fext) TFS_HIP(hipMemcpy(dFx, Fext, nn * sizeof(double), hipMemcpyHostToDevice));
-    else TFS_HIP(hipMemset(dFx, 0, nn * sizeof(double)));
-    TFS_HIP(hipMemcpy(dP, P0, nn * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dT, 1.0, dV, dH, (int)nn);      // H = T + V (+ field)
-    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dH, 1.0, dFx, dH, (int)nn);
-    if (X) TFS_HIP(hipMemcpy(dX, X, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dT, T, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dV, V, nn * sizeof(double), hipMemcpyHostToDevice));
+    if (Fext) TFS_HIP(tfs_memcpy(dFx, Fext, nn * sizeof(double), hipMemcpyHostToDevice));
+    else TFS_HIP(hipMemsetAsync(dFx, 0, nn * sizeof(double), TFS_ST));
+    TFS_HIP(tfs_memcpy(dP, P0, nn * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, 1.0, dT, 1.0, dV, dH, (int)nn);      // H = T + V (+ field)
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, 1.0, dH, 1.0, dFx, dH, (int)nn);
+    if (X) TFS_HIP(tfs_memcpy(dX, X, nn * sizeof(double), hipMemcpyHostToDevice));
     else {
         double sm = 0;
         rc = orthogonaliser_device(w, n, dS, dX, nullptr, &sm, scr - 0 /*uses scr..*/, msg);
         if (rc) return rc;
     }
-    TFS_HIP(hipMemset(dPold, 0, nn * sizeof(double)));
-    TFS_HIP(hipMemset(dPbd, 0, nn * sizeof(double)));
-    TFS_HIP(hipMemset(dPvold, 0, nn * sizeof(double)));
-    TFS_HIP(hipMemset(dPoldbd, 0, nn * sizeof(double)));
+    TFS_HIP(hipMemsetAsync(dPold, 0, nn * sizeof(double), TFS_ST));
+    TFS_HIP(hipMemsetAsync(dPbd, 0, nn * sizeof(double), TFS_ST));
+    TFS_HIP(hipMemsetAsync(dPvold, 0, nn * sizeof(double), TFS_ST));
+    TFS_HIP(hipMemsetAsync(dPoldbd, 0, nn * sizeof(double), TFS_ST));
 
     TFS_BLAS(rocblas_set_pointer_mode(w.blas, rocblas_pointer_mode_host));
     // device-time spans without synchronising inside the cycle: events from a pool, read after the last iteration
@@ -762,11 +776,11 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             w.tev.push_back(e);
         }
         spans.emplace_back(tev_used, kind);
-        (void)hipEventRecord(w.tev[tev_used], 0);
+        (void)hipEventRecord(w.tev[tev_used], TFS_ST);
         tev_used += 2;
         return (int)tev_used - 1;
     };
-    auto span_end = [&](int idx) { if (idx >= 0) (void)hipEventRecord(w.tev[idx], 0); };
+    auto span_end = [&](int idx) { if (idx >= 0) (void)hipEventRecord(w.tev[idx], TFS_ST); };
 
     // diagonalise F (AO) -> eps, C ; P = 2 C_occ C_occ^T symmetrised      (scf:222-250, 183-211)
     // After the first solve of a cycle the density comes from refined eigenvectors: GEMM-based for n > 64 (where the eigensolver
@@ -787,7 +801,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         }
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, Fao, 0.0, t1));     // X^T F
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));     // (X^T F) X
-        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t2, dW, n);
         const int te = span_begin(1);
         orbitals_current = false;
         if (refining && w.ref_n == n) {
@@ -798,17 +812,17 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                 const double two = 2.0, zero = 0.0;
                 TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Xocc, dX, 0.0, t1));    // rows: occupied orbitals in the AO basis (others 0)
                 TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &two, t1, n, t1, n, &zero, t2, n));
-                hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, Pout, n);
+                hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t2, Pout, n);
                 span_end(te);
                 if (getenv("TF_REFINE_CHECK")) {                 // debugging aid: the same density from a real eigensolve
                     std::vector<double> hp(nn), hq(nn);
-                    TFS_HIP(hipMemcpy(hp.data(), Pout, nn * sizeof(double), hipMemcpyDeviceToHost));
+                    TFS_HIP(tfs_memcpy(hp.data(), Pout, nn * sizeof(double), hipMemcpyDeviceToHost));
                     int r2 = eigh(w, n, dW, vals, ework, msg);
                     if (r2) return r2;
                     TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
                     TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, n_occ, &two, dC, n, dC, n, &zero, t1, n));
-                    hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, t2, n);
-                    TFS_HIP(hipMemcpy(hq.data(), t2, nn * sizeof(double), hipMemcpyDeviceToHost));
+                    hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t1, t2, n);
+                    TFS_HIP(tfs_memcpy(hq.data(), t2, nn * sizeof(double), hipMemcpyDeviceToHost));
                     double dmax = 0.0;
                     for (size_t q = 0; q < nn; ++q) dmax = std::max(dmax, std::fabs(hp[q] - hq[q]));
                     fprintf(stderr, "[tf refine] max |P_refined - P_eigh| = %.3e\n", dmax);
@@ -825,7 +839,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         const double two = 2.0, zero = 0.0;
         // col-major view of dC is C^T: P = sum_{k<nocc} C[:,k] C[:,k]^T = M[:nocc,:]^T M[:nocc,:]
         TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, n_occ, &two, dC, n, dC, n, &zero, t1, n));
-        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, Pout, n);
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t1, Pout, n);
         orbitals_current = true;
         return TF_OK;
     };
@@ -846,7 +860,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         // iteration of the reference: run_restricted_SCF_cycle does not return P_before_damping (scf:1154), so the
         // outer loop keeps handing in its initial zeros (scf:1359,1373).  dPoldbd therefore stays zero.
         std::swap(dPvold, dPold);            // dPvold <- old P_old ; dPold free to be overwritten
-        TFS_HIP(hipMemcpyAsync(dPold, dP, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        TFS_HIP(hipMemcpyAsync(dPold, dP, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
         // Fock matrix (scf:497-531)
         // Kohn-Sham: exchange-correlation matrix and energy densities from the CURRENT (old) density (scf:1121)
         double xc3[3] = {0.0, 0.0, 0.0};
@@ -855,7 +869,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             if (rc) { msg = "exchange-correlation evaluation failed"; return rc; }
         }
         const int tf = span_begin(0);
-        rc = jk(dP, dJ, dK, 0);
+        rc = jk(dP, dJ, dK, TFS_ST);
         if (rc) { msg.clear(); return rc; }                          // (the hook has left its message in the context)
         span_end(tf);
         // push into the history: trim to max_diis first (scf:943-946), so that the slot of the new entry is known
@@ -868,13 +882,13 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         static const bool no_fused_fock = getenv("TF_FOCK_UNFUSED") != nullptr;
         hipError_t ferr = hipSuccess;
         if (!no_fused_fock && n <= TFR_NMAX &&
-            tfref::launch_fock_diis(n, dH, dJ, dK, o.hfx, xc ? dVxc : nullptr, dP, dS, dX, dF, histF(n_hist), histE(n_hist), 0, &ferr)) {
+            tfref::launch_fock_diis(n, dH, dJ, dK, o.hfx, xc ? dVxc : nullptr, dP, dS, dX, dF, histF(n_hist), histE(n_hist), TFS_ST, &ferr)) {
             // n <= 64: Fock matrix, DIIS error and the history entry in one launch (tf_refine.hip.h)
         } else {
             if (ferr != hipSuccess) { msg = std::string("Fock / DIIS kernel launch failed: ") + hipGetErrorString(ferr); return TF_ENODEVICE; }
-            hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, 0, dH, dJ, dK, o.hfx, t1, (int)nn);
-            if (xc) hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, t1, 1.0, dVxc, t1, (int)nn);        // + V_XC, scf:525
-            hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, dF, n);
+            hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, TFS_ST, dH, dJ, dK, o.hfx, t1, (int)nn);
+            if (xc) hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, 1.0, t1, 1.0, dVxc, t1, (int)nn);        // + V_XC, scf:525
+            hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t1, dF, n);
             // DIIS error e = X^T (F P S - S P F) X   (scf:906-920)
             TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dF, dP, 0.0, t1));        // F P
             TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dS, 0.0, t2));        // F P S
@@ -882,7 +896,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             TFS_BLAS(gemm_rm(w.blas, false, false, n, -1.0, t1, dF, 1.0, t2));       // F P S - S P F
             TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, t2, 0.0, t1));         // X^T e
             TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, histE(n_hist)));   // (X^T e) X
-            TFS_HIP(hipMemcpyAsync(histF(n_hist), dF, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            TFS_HIP(hipMemcpyAsync(histF(n_hist), dF, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
         }
         ++n_hist;
         double ee = 0.0;
@@ -895,7 +909,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                 for (int k = 0; k < mk; ++k) a.p[k] = histE(k0 + k);
                 launch_multi_dot(w, histE(n_hist - 1), a, mk, (int)nn, w.d_scal + 128 + k0);
             }
-            TFS_HIP(hipMemcpy(hd, w.d_scal + 128, n_hist * sizeof(double), hipMemcpyDeviceToHost));
+            TFS_HIP(tfs_memcpy(hd, w.d_scal + 128, n_hist * sizeof(double), hipMemcpyDeviceToHost));
             for (int k = 0; k < n_hist; ++k) {
                 // the reference stores the error twice (alpha and beta copies, scf:934), hence the factor 2
                 B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = 2.0 * hd[k];
@@ -914,8 +928,8 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         }
         orbitals_final = orbitals_current;                            // of THIS iteration's Fock matrix (the DIIS solve below reuses dC)
         if (orbitals_final && (out.eps || out.C)) {                  // kept on the device; copied out after the cycle
-            TFS_HIP(hipMemcpyAsync(vals_save, vals, n * sizeof(double), hipMemcpyDeviceToDevice, 0));
-            TFS_HIP(hipMemcpyAsync(dCsave, dC, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            TFS_HIP(hipMemcpyAsync(vals_save, vals, n * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
+            TFS_HIP(hipMemcpyAsync(dCsave, dC, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
         }
         // DIIS extrapolation (scf:991-1059)
         double *Pcur = dPn;
@@ -933,7 +947,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                     const int mk = std::min(8, n_hist - k0);
                     for (int k = 0; k < 8; ++k) { a.p[k] = histF(0); a.c[k] = 0.0; }
                     for (int k = 0; k < mk; ++k) { a.p[k] = histF(k0 + k); a.c[k] = x[k0 + k]; }
-                    hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, 0, a, mk, scr, (int)nn, k0 > 0 ? 1 : 0);
+                    hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, TFS_ST, a, mk, scr, (int)nn, k0 > 0 ? 1 : 0);
                 }
                 rc = diag_density(scr, dPn);     // overwrites dC/vals: results were copied out above
                 if (rc) return rc;
@@ -942,16 +956,16 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             }
         }
         // P_before_damping = P ; damping (scf:763-868)
-        TFS_HIP(hipMemcpyAsync(dPbd, Pcur, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        TFS_HIP(hipMemcpyAsync(dPbd, Pcur, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
         double damp = 0.0;
         if (o.damping == 2) damp = o.damping_factor;
         else if (o.damping == 1 && commutator > 0.01 && step > 1) {
             double pop[4][2];
             const double *dens[4] = {dPbd, dPold, dPoldbd, dPvold};   // A_n_out, A_n1_in, A_n1_out, A_n2_in
             for (int q = 0; q < 4; ++q) {
-                hipLaunchKernelGGL(k_mulliken, dim3(1), dim3(256), 0, 0, dens[q], dS, n, nA, w.d_scal + 2 * q);
+                hipLaunchKernelGGL(k_mulliken, dim3(1), dim3(256), 0, TFS_ST, dens[q], dS, n, nA, w.d_scal + 2 * q);
             }
-            TFS_HIP(hipMemcpy(&pop[0][0], w.d_scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
+            TFS_HIP(tfs_memcpy(&pop[0][0], w.d_scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
             if (o.n_atoms < 2) { for (int q = 0; q < 4; ++q) pop[q][1] = 0.0; }
             double den[2], alpha[2] = {0.0, 0.0};
             for (int a = 0; a < 2; ++a) den[a] = pop[0][a] - pop[2][a] - pop[1][a] + pop[3][a];
@@ -964,11 +978,11 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             damp = std::max(damp, 0.0);
             damp = (damp < std::min(o.max_damping, 1.0)) ? damp : o.max_damping;
         }
-        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, damp, dPold, 1.0 - damp, dPbd, dP, (int)nn);
+        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, damp, dPold, 1.0 - damp, dPbd, dP, (int)nn);
         // changes and convergence (scf:261-333)
         launch_delta_norms(w, dP, dPold, (int)nn, w.d_scal + 16);
         double res[7];
-        TFS_HIP(hipMemcpy(res, w.d_scal + 16, 7 * sizeof(double), hipMemcpyDeviceToHost));
+        TFS_HIP(tfs_memcpy(res, w.d_scal + 16, 7 * sizeof(double), hipMemcpyDeviceToHost));
         {
             const double eT = res[2], eV = res[3], eF = res[4], eJ = res[5], eK = res[6];
             comps[0] = eT; comps[1] = eV; comps[2] = (1.0 / 2.0) * eJ; comps[3] = -(1.0 / 4.0) * eK * o.hfx + xc3[1]; comps[4] = xc3[2];   // scf:380-394
@@ -994,32 +1008,32 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         }
     }
     if (orbitals_final) {
-        if (out.eps) TFS_HIP(hipMemcpy(out.eps, vals_save, n * sizeof(double), hipMemcpyDeviceToHost));
-        if (out.C) TFS_HIP(hipMemcpy(out.C, dCsave, nn * sizeof(double), hipMemcpyDeviceToHost));
+        if (out.eps) TFS_HIP(tfs_memcpy(out.eps, vals_save, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (out.C) TFS_HIP(tfs_memcpy(out.C, dCsave, nn * sizeof(double), hipMemcpyDeviceToHost));
     }
     if (!orbitals_final && (out.eps || out.C) && out.n_iter > 0) {
         // orbitals and orbital energies of the last Fock matrix (what the reference's last diagonalisation leaves, scf:1133)
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, dF, 0.0, t1));
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
-        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t2, dW, n);
         const int te = span_begin(1);
         rc = eigh(w, n, dW, vals, ework, msg);
         if (rc) return rc;
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
         span_end(te);
-        if (out.eps) TFS_HIP(hipMemcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
-        if (out.C) TFS_HIP(hipMemcpy(out.C, dC, nn * sizeof(double), hipMemcpyDeviceToHost));
+        if (out.eps) TFS_HIP(tfs_memcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (out.C) TFS_HIP(tfs_memcpy(out.C, dC, nn * sizeof(double), hipMemcpyDeviceToHost));
     }
     w.ref_n = 0;
-    TFS_HIP(hipDeviceSynchronize());
+    TFS_HIP(tfs_sync());
     for (const auto &sp : spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, w.tev[sp.first], w.tev[sp.first + 1]) == hipSuccess) (sp.second == 0 ? out.fock_seconds : out.eig_seconds) += ms * 1e-3;
     }
     out.energy = E + V_NN;
     std::memcpy(out.components, comps, sizeof(comps));
-    if (out.P) TFS_HIP(hipMemcpy(out.P, dP, nn * sizeof(double), hipMemcpyDeviceToHost));
-    if (out.F) TFS_HIP(hipMemcpy(out.F, dF, nn * sizeof(double), hipMemcpyDeviceToHost));
+    if (out.P) TFS_HIP(tfs_memcpy(out.P, dP, nn * sizeof(double), hipMemcpyDeviceToHost));
+    if (out.F) TFS_HIP(tfs_memcpy(out.F, dF, nn * sizeof(double), hipMemcpyDeviceToHost));
     out.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall).count();
     if (!out.converged) { msg = "Self-consistent field not converged in " + std::to_string(o.max_iter) + " iterations! Increase maximum iterations or give up."; return TF_ENOTCONV; }
     return TF_OK;
@@ -1048,6 +1062,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     const int n_mats = n_fixed + 4 * max_diis;
     int rc = ensure(w, n, n_mats, msg);
     if (rc) return rc;
+    TFS_BLAS(rocblas_set_stream(w.blas, TFS_ST));
     const size_t nn = (size_t)n * n;
     const int g = (int)((nn + 255) / 256);
     auto t_wall = std::chrono::steady_clock::now();
@@ -1066,17 +1081,17 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     auto histE = [&](int k, int s) { return hist + (size_t)(4 * slot[k] + 2 + s) * nn; };
     const int n_occ[2] = {n_alpha, n_beta};
 
-    TFS_HIP(hipMemcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
-    TFS_HIP(hipMemcpy(dT, T, nn * sizeof(double), hipMemcpyHostToDevice));
-    TFS_HIP(hipMemcpy(dV, V, nn * sizeof(double), hipMemcpyHostToDevice));
-    if (Fext) TFS_HIP(hipMemcpy(dFx, Fext, nn * sizeof(double), hipMemcpyHostToDevice));
-    else TFS_HIP(hipMemset(dFx, 0, nn * sizeof(double)));
-    TFS_HIP(hipMemcpy(dP[0], Pa0, nn * sizeof(double), hipMemcpyHostToDevice));
-    TFS_HIP(hipMemcpy(dP[1], Pb0, nn * sizeof(double), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dT, 1.0, dV, dH, (int)nn);
-    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dH, 1.0, dFx, dH, (int)nn);
-    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dP[0], 1.0, dP[1], dPt, (int)nn);
-    if (X) TFS_HIP(hipMemcpy(dX, X, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dS, S, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dT, T, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dV, V, nn * sizeof(double), hipMemcpyHostToDevice));
+    if (Fext) TFS_HIP(tfs_memcpy(dFx, Fext, nn * sizeof(double), hipMemcpyHostToDevice));
+    else TFS_HIP(hipMemsetAsync(dFx, 0, nn * sizeof(double), TFS_ST));
+    TFS_HIP(tfs_memcpy(dP[0], Pa0, nn * sizeof(double), hipMemcpyHostToDevice));
+    TFS_HIP(tfs_memcpy(dP[1], Pb0, nn * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, 1.0, dT, 1.0, dV, dH, (int)nn);
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, 1.0, dH, 1.0, dFx, dH, (int)nn);
+    hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, 1.0, dP[0], 1.0, dP[1], dPt, (int)nn);
+    if (X) TFS_HIP(tfs_memcpy(dX, X, nn * sizeof(double), hipMemcpyHostToDevice));
     else {
         double sm = 0;
         rc = orthogonaliser_device(w, n, dS, dX, nullptr, &sm, mat(28), msg);
@@ -1092,11 +1107,11 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             w.tev.push_back(e);
         }
         spans.emplace_back(tev_used, kind);
-        (void)hipEventRecord(w.tev[tev_used], 0);
+        (void)hipEventRecord(w.tev[tev_used], TFS_ST);
         tev_used += 2;
         return (int)tev_used - 1;
     };
-    auto span_end = [&](int idx) { if (idx >= 0) (void)hipEventRecord(w.tev[idx], 0); };
+    auto span_end = [&](int idx) { if (idx >= 0) (void)hipEventRecord(w.tev[idx], TFS_ST); };
 
     static const bool no_refine = getenv("TF_EIGH") != nullptr;
     // the refinement state of the beta spin lives in the alternate slot and is swapped in around its solves
@@ -1113,7 +1128,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     auto diag_density = [&](int sp, const double *Fao, double *Pout) -> int {
         orbitals_current[sp] = false;
         const int no = n_occ[sp];
-        if (no <= 0) { TFS_HIP(hipMemsetAsync(Pout, 0, nn * sizeof(double), 0)); return TF_OK; }
+        if (no <= 0) { TFS_HIP(hipMemsetAsync(Pout, 0, nn * sizeof(double), TFS_ST)); return TF_OK; }
         SpinSlot slot(w, sp == 1);
         const bool refining = !no_refine && n >= 2 && no < n;
         static const bool no_fused = getenv("TF_REFINE_UNFUSED") != nullptr;
@@ -1127,7 +1142,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         }
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, Fao, 0.0, t1));
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
-        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t2, dW, n);
         const int te = span_begin(1);
         const double one = 1.0, zero = 0.0;
         if (refining && w.ref_n == n) {
@@ -1137,7 +1152,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             if (rr == TF_OK) {
                 TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Xocc, dX, 0.0, t1));
                 TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, t1, n, t1, n, &zero, t2, n));
-                hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, Pout, n);
+                hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t2, Pout, n);
                 span_end(te);
                 return TF_OK;
             }
@@ -1149,7 +1164,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         span_end(te);
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
         TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, no, &one, dC, n, dC, n, &zero, t1, n));
-        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, Pout, n);
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t1, Pout, n);
         orbitals_current[sp] = true;
         return TF_OK;
     };
@@ -1163,14 +1178,14 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
 
     for (int step = 1; step <= o.max_iter; ++step) {
         E_old = E;
-        TFS_HIP(hipMemcpyAsync(dPtold, dPt, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
-        for (int sp = 0; sp < 2; ++sp) TFS_HIP(hipMemcpyAsync(dPold[sp], dP[sp], nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+        TFS_HIP(hipMemcpyAsync(dPtold, dPt, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
+        for (int sp = 0; sp < 2; ++sp) TFS_HIP(hipMemcpyAsync(dPold[sp], dP[sp], nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
         // Fock matrices (scf:542-589): F_s = H + J_alpha + J_beta - HFX K_s, symmetrised
         const int tf = span_begin(0);
-        rc = jk2(dP[0], dP[1], dJ[0], dJ[1], dK[0], dK[1], 0);
+        rc = jk2(dP[0], dP[1], dJ[0], dJ[1], dK[0], dK[1], TFS_ST);
         if (rc) { msg.clear(); return rc; }
         span_end(tf);
-        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dJ[0], 1.0, dJ[1], dJt, (int)nn);
+        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, 1.0, dJ[0], 1.0, dJ[1], dJt, (int)nn);
         if (n_hist == max_diis) {                                   // trim the history to max_diis entries (scf:1216-1219)
             std::rotate(slot.begin(), slot.begin() + 1, slot.end());
             for (int r = 0; r + 1 < n_hist; ++r)
@@ -1178,8 +1193,8 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             --n_hist;
         }
         for (int sp = 0; sp < 2; ++sp) {
-            hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, 0, dH, dJt, dK[sp], 2.0 * o.hfx, t1, (int)nn);   // k_fock: H + J - hfx/2 K
-            hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t1, dF[sp], n);
+            hipLaunchKernelGGL(k_fock, dim3(g), dim3(256), 0, TFS_ST, dH, dJt, dK[sp], 2.0 * o.hfx, t1, (int)nn);   // k_fock: H + J - hfx/2 K
+            hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t1, dF[sp], n);
             // e_s = X^T (F_s P_s S - S P_s F_s) X   (scf:906-920)
             TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, dF[sp], dP[sp], 0.0, t1));
             TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dS, 0.0, t2));
@@ -1187,7 +1202,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             TFS_BLAS(gemm_rm(w.blas, false, false, n, -1.0, t1, dF[sp], 1.0, t2));
             TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, t2, 0.0, t1));
             TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, histE(n_hist, sp)));
-            TFS_HIP(hipMemcpyAsync(histF(n_hist, sp), dF[sp], nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+            TFS_HIP(hipMemcpyAsync(histF(n_hist, sp), dF[sp], nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
         }
         ++n_hist;
         double ee[2] = {0.0, 0.0};
@@ -1201,7 +1216,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                     for (int k = 0; k < mk; ++k) a.p[k] = histE(k0 + k, sp);
                     launch_multi_dot(w, histE(n_hist - 1, sp), a, mk, (int)nn, w.d_scal + 128 + TF_MAX_DIIS * sp + k0);
                 }
-            TFS_HIP(hipMemcpy(hd, w.d_scal + 128, 2 * TF_MAX_DIIS * sizeof(double), hipMemcpyDeviceToHost));
+            TFS_HIP(tfs_memcpy(hd, w.d_scal + 128, 2 * TF_MAX_DIIS * sizeof(double), hipMemcpyDeviceToHost));
             for (int k = 0; k < n_hist; ++k) B[(n_hist - 1) * max_diis + k] = B[k * max_diis + (n_hist - 1)] = hd[k] + hd[TF_MAX_DIIS + k];
             ee[0] = hd[n_hist - 1]; ee[1] = hd[TF_MAX_DIIS + n_hist - 1];
         }
@@ -1213,8 +1228,8 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             if (rc) return rc;
             orbitals_final[sp] = orbitals_current[sp];
             if (orbitals_final[sp]) {
-                TFS_HIP(hipMemcpyAsync(vals_save[sp], vals, n * sizeof(double), hipMemcpyDeviceToDevice, 0));
-                TFS_HIP(hipMemcpyAsync(dCsave[sp], dC, nn * sizeof(double), hipMemcpyDeviceToDevice, 0));
+                TFS_HIP(hipMemcpyAsync(vals_save[sp], vals, n * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
+                TFS_HIP(hipMemcpyAsync(dCsave[sp], dC, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
             }
         }
         for (int sp = 0; sp < 2; ++sp) {     // the energy terms are read back at the end of the iteration, together with the density changes
@@ -1239,7 +1254,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                         const int mk = std::min(8, n_hist - k0);
                         for (int k = 0; k < 8; ++k) { a.p[k] = histF(0, sp); a.c[k] = 0.0; }
                         for (int k = 0; k < mk; ++k) { a.p[k] = histF(k0 + k, sp); a.c[k] = x[k0 + k]; }
-                        hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, 0, a, mk, scr, (int)nn, k0 > 0 ? 1 : 0);
+                        hipLaunchKernelGGL(k_lincomb, dim3(g), dim3(256), 0, TFS_ST, a, mk, scr, (int)nn, k0 > 0 ? 1 : 0);
                     }
                     rc = diag_density(sp, scr, dPn[sp]);
                     if (rc) return rc;
@@ -1254,8 +1269,8 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         else if (o.damping == 1 && step > 1 && (comm_s[0] > 0.01 || comm_s[1] > 0.01)) {
             double pop[4][2];
             const double *dens[4] = {dPn[0], dPold[0], dPn[1], dPold[1]};
-            for (int q = 0; q < 4; ++q) hipLaunchKernelGGL(k_mulliken, dim3(1), dim3(256), 0, 0, dens[q], dS, n, nA, w.d_scal + 2 * q);
-            TFS_HIP(hipMemcpy(&pop[0][0], w.d_scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
+            for (int q = 0; q < 4; ++q) hipLaunchKernelGGL(k_mulliken, dim3(1), dim3(256), 0, TFS_ST, dens[q], dS, n, nA, w.d_scal + 2 * q);
+            TFS_HIP(tfs_memcpy(&pop[0][0], w.d_scal, 8 * sizeof(double), hipMemcpyDeviceToHost));
             if (o.n_atoms < 2) { for (int q = 0; q < 4; ++q) pop[q][1] = 0.0; }
             for (int sp = 0; sp < 2; ++sp) {
                 if (!(comm_s[sp] > 0.01)) continue;
@@ -1274,11 +1289,11 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
             }
         }
         for (int sp = 0; sp < 2; ++sp)
-            hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, damp[sp], dPold[sp], 1.0 - damp[sp], dPn[sp], dP[sp], (int)nn);
-        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, 0, 1.0, dP[0], 1.0, dP[1], dPt, (int)nn);
+            hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, damp[sp], dPold[sp], 1.0 - damp[sp], dPn[sp], dP[sp], (int)nn);
+        hipLaunchKernelGGL(k_axpby, dim3(g), dim3(256), 0, TFS_ST, 1.0, dP[0], 1.0, dP[1], dPt, (int)nn);
         launch_delta_norms(w, dPt, dPtold, (int)nn, w.d_scal + 16);
         double res[14];
-        TFS_HIP(hipMemcpy(res, w.d_scal + 16, 14 * sizeof(double), hipMemcpyDeviceToHost));
+        TFS_HIP(tfs_memcpy(res, w.d_scal + 16, 14 * sizeof(double), hipMemcpyDeviceToHost));
         {
             const double *hd = res + 2;
             comps[0] = hd[0] + hd[6]; comps[1] = hd[1] + hd[7]; comps[5] = hd[2] + hd[8];
@@ -1309,23 +1324,23 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     for (int sp = 0; sp < 2 && out.n_iter > 0; ++sp) {
         if (!uo.eps[sp] && !uo.C[sp]) continue;
         if (orbitals_final[sp]) {
-            if (uo.eps[sp]) TFS_HIP(hipMemcpy(uo.eps[sp], vals_save[sp], n * sizeof(double), hipMemcpyDeviceToHost));
-            if (uo.C[sp]) TFS_HIP(hipMemcpy(uo.C[sp], dCsave[sp], nn * sizeof(double), hipMemcpyDeviceToHost));
+            if (uo.eps[sp]) TFS_HIP(tfs_memcpy(uo.eps[sp], vals_save[sp], n * sizeof(double), hipMemcpyDeviceToHost));
+            if (uo.C[sp]) TFS_HIP(tfs_memcpy(uo.C[sp], dCsave[sp], nn * sizeof(double), hipMemcpyDeviceToHost));
             continue;
         }
         TFS_BLAS(gemm_rm(w.blas, true, false, n, 1.0, dX, dF[sp], 0.0, t1));
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, t1, dX, 0.0, t2));
-        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, 0, t2, dW, n);
+        hipLaunchKernelGGL(k_symmetrise, dim3(g), dim3(256), 0, TFS_ST, t2, dW, n);
         const int te = span_begin(1);
         rc = eigh(w, n, dW, vals, ework, msg);
         if (rc) return rc;
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
         span_end(te);
-        if (uo.eps[sp]) TFS_HIP(hipMemcpy(uo.eps[sp], vals, n * sizeof(double), hipMemcpyDeviceToHost));
-        if (uo.C[sp]) TFS_HIP(hipMemcpy(uo.C[sp], dC, nn * sizeof(double), hipMemcpyDeviceToHost));
+        if (uo.eps[sp]) TFS_HIP(tfs_memcpy(uo.eps[sp], vals, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (uo.C[sp]) TFS_HIP(tfs_memcpy(uo.C[sp], dC, nn * sizeof(double), hipMemcpyDeviceToHost));
     }
     w.ref_n = 0; w.ref_alt_n = 0;
-    TFS_HIP(hipDeviceSynchronize());
+    TFS_HIP(tfs_sync());
     for (const auto &sp : spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, w.tev[sp.first], w.tev[sp.first + 1]) == hipSuccess) (sp.second == 0 ? out.fock_seconds : out.eig_seconds) += ms * 1e-3;
@@ -1333,10 +1348,10 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     out.energy = E + V_NN;
     std::memcpy(out.components, comps, sizeof(comps));
     for (int sp = 0; sp < 2; ++sp) {
-        if (uo.P[sp]) TFS_HIP(hipMemcpy(uo.P[sp], dP[sp], nn * sizeof(double), hipMemcpyDeviceToHost));
-        if (uo.F[sp]) TFS_HIP(hipMemcpy(uo.F[sp], dF[sp], nn * sizeof(double), hipMemcpyDeviceToHost));
+        if (uo.P[sp]) TFS_HIP(tfs_memcpy(uo.P[sp], dP[sp], nn * sizeof(double), hipMemcpyDeviceToHost));
+        if (uo.F[sp]) TFS_HIP(tfs_memcpy(uo.F[sp], dF[sp], nn * sizeof(double), hipMemcpyDeviceToHost));
     }
-    if (out.P) TFS_HIP(hipMemcpy(out.P, dPt, nn * sizeof(double), hipMemcpyDeviceToHost));
+    if (out.P) TFS_HIP(tfs_memcpy(out.P, dPt, nn * sizeof(double), hipMemcpyDeviceToHost));
     out.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall).count();
     if (!out.converged) { msg = "Self-consistent field not converged in " + std::to_string(o.max_iter) + " iterations! Increase maximum iterations or give up."; return TF_ENOTCONV; }
     return TF_OK;

@@ -274,6 +274,42 @@ class Engine:
             raise err
         return res
 
+    def scf_rhf_batch(self, S, T, V, P0s, E0s, n_occ, V_NN, *, X=None, Fexts=None, max_iter=100, **opts):
+        """tf_scf_rhf_batch: several restricted cycles on the resident tensor advanced in lockstep inside the library (the finite-field
+        evaluations of energy:315-540); the Fock builds of an iteration go through the tensor together.  Returns the result
+        dictionaries of tf_scf_rhf in order, each with "rc"; raises if any cycle failed (err.partial = the list)."""
+        N, n = self.N, len(P0s)
+        o = self._scf_opts(max_iter=max_iter, **opts)
+        res_arr = (ScfResult * n)()
+        bufs = []
+        for k in range(n):
+            P, Cm, F, eps, table = np.zeros((N, N)), np.zeros((N, N)), np.zeros((N, N)), np.zeros(N), np.zeros((max_iter, 7))
+            res_arr[k].P, res_arr[k].C, res_arr[k].F, res_arr[k].eps, res_arr[k].table = (a.ctypes.data for a in (P, Cm, F, eps, table))
+            bufs.append((P, Cm, F, eps, table))
+        P0a = [f64(p) for p in P0s]
+        Fa = [None if (Fexts is None or f is None) else f64(f) for f in (Fexts if Fexts is not None else [None] * n)]
+        p0_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in P0a])
+        f_ptrs = (C.c_void_p * n)(*[(a.ctypes.data if a is not None else None) for a in Fa])
+        E0a = f64(np.asarray(E0s, dtype=np.float64))
+        rcs = np.zeros(n, dtype=np.int32)
+        passes = np.zeros(2, dtype=np.int64)
+        arrs = [f64(S), f64(T), f64(V)]
+        Xa = None if X is None else f64(X)
+        rc = self._L.tf_scf_rhf_batch(self._ctx, n, C.byref(o), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), f_ptrs, ptr(Xa), p0_ptrs, ptr(E0a),
+                                      int(n_occ), float(V_NN), res_arr, ptr(rcs), ptr(passes))
+        out = []
+        for k in range(n):
+            r, (P, Cm, F, eps, table) = res_arr[k], bufs[k]
+            out.append({"energy": r.energy, "components": np.array(r.components[:]), "n_iter": r.n_iter, "converged": bool(r.converged),
+                        "P": P, "C": Cm, "F": F, "epsilons": eps, "table": table[:r.n_iter].copy(), "fock_seconds": r.fock_seconds,
+                        "eig_seconds": r.eig_seconds, "wall_seconds": r.wall_seconds, "rc": int(rcs[k]),
+                        "tensor_passes": int(passes[0]), "fock_builds": int(passes[1])})
+        if rc != 0:
+            err = TunaError(self._L.tf_last_error(self._ctx).decode(), rc)
+            err.partial = out
+            raise err
+        return out
+
     def scf_uhf(self, S, T, V, P0_alpha, P0_beta, E0, n_alpha, n_beta, V_NN, *, X=None, Fext=None, max_iter=100, **opts):
         """tf_scf_uhf: the unrestricted cycle (scf:1165-1281) on the device; spin quantities come back as pairs (alpha, beta)."""
         N = self.N

@@ -46,10 +46,12 @@ def calculate_nuclear_dipole_moment(dipole_origin, charges, coordinates):       
 
 
 class FieldEnergies:
-    """Energies of a list of electric fields for one molecule: `energies(fields)` runs the cycles in lockstep (batched=True) or one
-    after the other through the native cycle (batched=False, the reference's order of work); counts the tensor passes either way."""
+    """Energies of a list of electric fields for one molecule: `energies(fields)` runs the cycles in lockstep inside the library
+    (batched="native": tf_scf_rhf_batch), in lockstep orchestrated from the host (batched=True), or one after the other through the
+    native cycle (batched=False, the reference's order of work); "auto" picks the native lockstep for N >= 96.  Counts the tensor
+    passes either way."""
 
-    def __init__(self, molecule, calculation, integrals, V_NN, X, guess_objects, batched=False, dipole_origin=None):
+    def __init__(self, molecule, calculation, integrals, V_NN, X, guess_objects, batched="auto", dipole_origin=None):
         if getattr(calculation, "reference", "RHF") == "UHF" or getattr(calculation, "DFT_calculation", False):
             raise TunaError("finite-field properties are available for restricted Hartree-Fock in this build")
         self.molecule, self.calculation, self.integrals = molecule, calculation, integrals
@@ -61,8 +63,18 @@ class FieldEnergies:
 
     def energies(self, fields):
         terms = [apply_electric_field(self.integrals.D, self.base_field + np.asarray(f, dtype=float)) for f in fields]
-        if self.batched:
-            res = scf_mod.run_cycles_in_lockstep(self.molecule, self.calculation, self.integrals, self.V_NN, self.X, self.guess, terms)
+        eng = getattr(self.integrals.ERI_AO, "engine", None)
+        mode = self.batched
+        if mode == "auto":
+            # the lockstep batch pays where the O(N^3) steps of one cycle leave most of the device idle and a pass over the tensor costs
+            # something (N = 400: 0.58 s against 1.15 s for the eight cycles of a polarisability); tiny problems are launch-bound and
+            # run faster one by one (CO/cc-pVDZ: 45 ms against 68 ms)
+            mode = "native" if (eng is not None and eng.N >= 96) else False
+        if mode == "native" and (eng is None or eng.world > 1):
+            mode = False                                     # (sharded tensors: the cycles run one by one, each with its all-reduce)
+        if mode:
+            lock = scf_mod.run_cycles_in_native_lockstep if mode == "native" else scf_mod.run_cycles_in_lockstep
+            res = lock(self.molecule, self.calculation, self.integrals, self.V_NN, self.X, self.guess, terms)
             out = [r["energy"] for r in res]
             self.iterations += sum(r["n_iter"] for r in res)
         else:

@@ -336,6 +336,22 @@ def run_cycles_in_lockstep(molecule, calculation, integrals, V_NN, X, guess_obje
     return results
 
 
+def run_cycles_in_native_lockstep(molecule, calculation, integrals, V_NN, X, guess_objects, external_terms):
+    """The same batch inside the library (tf_scf_rhf_batch): every cycle is the native cycle (tf_scf.hip.h: run_rhf, on a host thread
+    and a workspace of its own -- DIIS history, eigenvector refinement state, damping), and the cycles meet once per iteration in the
+    Fock build, where the densities of all cycles still iterating go through the tensor together."""
+    if getattr(calculation, "DFT_calculation", False) or getattr(calculation, "reference", "RHF") == "UHF":
+        raise TunaError("finite-field batches run restricted Hartree-Fock cycles in this build")
+    P, _, _, E = guess_objects
+    eng = _device(integrals.ERI_AO).engine
+    o = _opts(calculation)
+    n = len(external_terms)
+    res = eng.scf_rhf_batch(integrals.S, integrals.T, integrals.V_NE, [P] * n, [E] * n, molecule.n_doubly_occ, V_NN, X=X,
+                            Fexts=[integrals.G + t for t in external_terms], n_atom_ao=molecule.partition_ranges, **o)
+    integrals.ERI_AO.n_builds += res[0]["tensor_passes"] if res else 0
+    return res
+
+
 def _cycle_steps(molecule, integrals, V_NN, X, P, E, o, Fext):
     """One restricted Hartree-Fock cycle as a generator: yields the density whose J and K it needs next, receives (J, K), returns
     the result dictionary (scf:1072-1154; DIIS scf:960-1061, damping scf:1110-1154)."""
