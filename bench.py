@@ -168,7 +168,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("TUNA_BENCH_WORKLOAD", "synth-400"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scf", action="store_true")
-    ap.add_argument("--n-dens", type=int, choices=[1, 2], default=1, help="densities per Fock build (2 = a UHF build: alpha and beta in one pass)")
+    ap.add_argument("--n-dens", type=int, choices=[1, 2, 4, 8, 16], default=1,
+                    help="densities per step (2 = a UHF build: alpha and beta in one pass; 4, 8, 16 = a finite-field batch: pairs of densities per pass)")
     ap.add_argument("--layout", choices=["packed", "rows"], default="packed", help="ERI storage layout (tunafock.h: tf_set_eri_layout)")
     args = ap.parse_args()
 
@@ -219,7 +220,12 @@ def main():
     P = A + A.T
     P *= 2 * nocc / np.trace(P @ S)
     nd = args.n_dens
-    dP = torch.from_numpy(np.stack([P, 0.5 * P + 0.25 * np.diag(np.diag(P))][:nd])).to(dev)       # [nd, N, N], symmetric
+    if nd <= 2:
+        dens = [P, 0.5 * P + 0.25 * np.diag(np.diag(P))][:nd]
+    else:                                                     # a batch: the first density and symmetric perturbations of it
+        rngd = np.random.default_rng(1)
+        dens = [P] + [P + 0.05 * (lambda B: B + B.T)(rngd.standard_normal((N, N))) for _ in range(nd - 1)]
+    dP = torch.from_numpy(np.stack(dens)).to(dev)              # [nd, N, N], symmetric
     dJK = torch.zeros((2, nd, N, N), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -288,6 +294,12 @@ def main():
                        "n_shells": eng.n_shell, "n_densities": nd, "layout": layout, "storage": storage,
                        "stored_bytes_per_gpu": stored_bytes, "parallelism": f"ij-row shards x{world} + RCCL all-reduce of [J;K]" if world > 1 else "1 GPU",
                        "result_ok": ok},
+            # all densities of a step: Fock matrices per second, and the executed FP64 rate -- six multiply-adds per stored value and
+            # density (tf_jkpacked.hip.h) -- against the FP64 peak (78.6 TFLOP/s; vector and matrix cores run FP64 at the same rate on CDNA4)
+            "per_density": {"n_densities": nd, "fock_matrices_per_s": nd * args.steps / elapsed,
+                            "executed_fp64_tflops": 12.0 * (stored_bytes / 8.0) * nd * args.steps / elapsed / 1e12,
+                            "frac_of_fp64_peak": 12.0 * (stored_bytes / 8.0) * nd * args.steps / elapsed / FP64_VECTOR_PEAK_FLOPS,
+                            "passes_over_the_tensor_per_step": (nd + 1) // 2},
             # roofline of the dominant kernel on PHYSICAL bytes (a fraction of the 8 TB/s HBM peak, <= 1); the reference's dense 8 N^4
             # bytes per build that the same launch stands for are reported separately
             "roofline": {"bound": "hbm", "kernel": JK_KERNEL[layout], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -23,6 +23,7 @@
 #include "tf_jkpacked.hip.h"
 #include "tf_eri.hip.h"
 #include "tf_eri_team.hip.h"
+#include "tf_eri_teamc.hip.h"
 #include "tf_eri_team_api.h"
 #include "tf_oneel.hip.h"
 #include "tf_scf.hip.h"
@@ -512,9 +513,19 @@ int tf_set_basis(tf_ctx *ctx, int n_ao_cart, const double *origin, const int32_t
     ctx->pair_class.assign(hp.size(), 0);
     ctx->class_pairs.clear();
     {
-        std::map<std::array<int, 5>, int> ids;
+        // (shells that are not complete -- the one-component shells of the DECONTRACT ordering -- carry their components in the key: the
+        // pairs of a class share one set of component-pair tables)
+        auto comp_code = [&](const tf::Shell &sh) {
+            if (sh.full) return 0;
+            int code = 1;
+            for (int c = 0; c < sh.ncomp && c < 2; ++c)
+                code = code * 4096 + (bs.c_lx[sh.comp_off + c] | (bs.c_ly[sh.comp_off + c] << 4) | (bs.c_lz[sh.comp_off + c] << 8));
+            return code;
+        };
+        std::map<std::array<int, 7>, int> ids;
         for (size_t i = 0; i < hp.size(); ++i) {
-            const std::array<int, 5> key{hp[i].La, hp[i].Lb, getenv("TF_ERI_EXACT_CLASS") ? hp[i].npp : (hp[i].npp == 1 ? 1 : 0), hp[i].nca, hp[i].ncb};
+            const std::array<int, 7> key{hp[i].La, hp[i].Lb, getenv("TF_ERI_EXACT_CLASS") ? hp[i].npp : (hp[i].npp == 1 ? 1 : 0), hp[i].nca, hp[i].ncb,
+                                         comp_code(bs.shells[bs.pairs[i].A]), comp_code(bs.shells[bs.pairs[i].B])};
             auto it = ids.find(key);
             if (it == ids.end()) { it = ids.emplace(key, (int)ids.size()).first; ctx->class_pairs.emplace_back(); }
             hp[i].cls = it->second;
@@ -1069,7 +1080,14 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     std::vector<LRec> lrecs_host;                              // per (La, Lb | Lc, Ld), filled by make_lrecs below
     hipError_t team_error = hipSuccess;                        // first failed launch of a team kernel
     static const bool team_off = getenv("TF_ERI_TEAM") && getenv("TF_ERI_TEAM")[0] == '0';
-    const bool use_team = per_class && packed && !team_off && bs.epool.size() < 0xffffffffull;
+    const bool use_team = packed && !team_off && bs.epool.size() < 0xffffffffull;      // tables of the team kernels (both launch modes)
+    const bool use_team_pc = use_team && per_class;                                       // per-class mode: eri_team_kernel for the uncontracted classes
+    // (off by default: on the BASELINE basis sets eri_cfact_kernel is faster -- N2/cc-pVTZ 1.2 ms against 3.3-4.2 ms, Ar2/cc-pVQZ 18 ms against
+    // 22-25 ms of ERI kernels: a team walks the primitive quartets of its shell quartet one after the other, a chain of dependent phases
+    // with nothing else on the chip to hide it; TF_ERI_TEAMC=1 switches it on for experiments and for the parity tests)
+    static const bool teamc_off = !(getenv("TF_ERI_TEAMC") && getenv("TF_ERI_TEAMC")[0] == '1');
+    const bool use_teamc = use_team && !per_class && !teamc_off;                         // small-problem mode: eri_teamc_kernel over task lists
+    static const int teamc_pqmax = getenv("TF_TEAMC_PQMAX") ? atoi(getenv("TF_TEAMC_PQMAX")) : 700;
     struct KClassTab { int pS[5] = {0, 0, 0, 0, 0}; int nkap = 0, nnzT = 0, tp_off = 0, te_off = 0; };
     std::vector<KClassTab> kct(ncls);
     int *d_kq_ptr = nullptr, *d_kq_off = nullptr, *d_kt_ptr = nullptr, *d_kt_k = nullptr, *d_kcnt = nullptr;
@@ -1077,6 +1095,26 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     KetRec *d_ketrec = nullptr;                                // parallel to d_kets (class-sorted ket list)
     BraRec *d_brarec = nullptr;                                // parallel to the slab's bra list d_bra
     const int *d_bra_base = nullptr;
+    // the class-wide part of a team kernel's class record (tf_eri_team.hip.h) for (bra pair class, ket pair class)
+    auto tclass_common = [&](int bcls, int kcls, int &maxblk, int &maxK, int &nnzc) {
+        const DPair &hb = ctx->host_pairs[ctx->class_pairs[bcls][0]], &hk = ctx->host_pairs[ctx->class_pairs[kcls][0]];
+        const KClassTab &kt = kct[kcls];
+        TClass t{};
+        t.La = hb.La; t.Lb = hb.Lb; t.Lc = hk.La; t.Ld = hk.Lb;
+        t.nTab = (t.La + 1) * (t.Lb + 1); t.nTcd = (t.Lc + 1) * (t.Ld + 1); t.nT = t.nTab * t.nTcd;
+        t.inv_nTcd = 1.0f / (float)t.nTcd;
+        t.nab = hb.nca * hb.ncb; t.ncd = hk.nca * hk.ncb;
+        maxblk = 1; maxK = 1; nnzc = 0;
+        for (int i = 0; i < 5; ++i) { t.pA[i] = hb.pcls[i]; t.pK[i] = hk.pcls[i]; t.pS[i] = kt.pS[i]; }
+        for (int i = 0; i < 4; ++i) {
+            maxK = std::max(maxK, t.pK[i + 1] - t.pK[i]);
+            maxblk = std::max(maxblk, (t.pA[i + 1] - t.pA[i]) * (t.pK[i + 1] - t.pK[i]));
+            nnzc += (t.pA[i + 1] - t.pA[i]) * (t.pK[i + 1] - t.pK[i]);
+        }
+        t.nkap = kt.nkap; t.nnzT = kt.nnzT; t.tabA = hb.tab_off; t.tabK = hk.tab_off; t.ktp_off = kt.tp_off; t.kte_off = kt.te_off;
+        t.nEab = hb.nE; t.nEcd = hk.nE; t.RLS = H.RLS; t.nacc = nnzc;
+        return t;
+    };
     // bra_Amax: largest first shell among the bra pairs of the run -- in the packed layout only kets with first shell <= it are needed
     // (the class ket lists ascend in the first shell, so that is a prefix: workgroups beyond it are not even launched)
     auto class_launch = [&](int bcls, int kcls, int max_npp_bra, unsigned n_bra, const int *d_bra, const long long *d_braoff, int bra_Amax) {
@@ -1116,24 +1154,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                         q.npq, nb, q.n_ket, (double)nb * q.n_ket, ms, 1e6 * ms / ((double)nb * q.n_ket));
             }
         } class_timer(class_times, q, n_bra);
-        if (use_team && q.npq == 1 && q.La + q.Lb <= TF_TEAM_LMAX && q.Lc + q.Ld <= TF_TEAM_LMAX) {
+        if (use_team_pc && q.npq == 1 && q.La + q.Lb <= TF_TEAM_LMAX && q.Lc + q.Ld <= TF_TEAM_LMAX) {
             // one shell quartet per team of lanes, tables private to the team (tf_eri_team.hip.h)
-            const DPair &hb = ctx->host_pairs[ctx->class_pairs[bcls][0]], &hk = ctx->host_pairs[ctx->class_pairs[kcls][0]];
-            const KClassTab &kt = kct[kcls];
-            TClass t{};
-            t.La = q.La; t.Lb = q.Lb; t.Lc = q.Lc; t.Ld = q.Ld;
-            t.nTab = (q.La + 1) * (q.Lb + 1); t.nTcd = (q.Lc + 1) * (q.Ld + 1); t.nT = t.nTab * t.nTcd;
-            t.inv_nTcd = 1.0f / (float)t.nTcd;
-            t.nab = q.nca * q.ncb; t.ncd = q.ncc * q.ncd;
             int maxblk = 1, maxK = 1, nnzc = 0;
-            for (int i = 0; i < 5; ++i) { t.pA[i] = hb.pcls[i]; t.pK[i] = hk.pcls[i]; t.pS[i] = kt.pS[i]; }
-            for (int i = 0; i < 4; ++i) {
-                maxK = std::max(maxK, t.pK[i + 1] - t.pK[i]);
-                maxblk = std::max(maxblk, (t.pA[i + 1] - t.pA[i]) * (t.pK[i + 1] - t.pK[i]));
-                nnzc += (t.pA[i + 1] - t.pA[i]) * (t.pK[i + 1] - t.pK[i]);
-            }
-            t.nkap = kt.nkap; t.nnzT = kt.nnzT; t.tabA = hb.tab_off; t.tabK = hk.tab_off; t.ktp_off = kt.tp_off; t.kte_off = kt.te_off;
-            t.n_ket = q.n_ket; t.nEab = q.nEab; t.nEcd = q.nEcd; t.RLS = H.RLS;
+            TClass t = tclass_common(bcls, kcls, maxblk, maxK, nnzc);
+            t.n_ket = q.n_ket;
             const int LAB = q.La + q.Lb, LCD = q.Lc + q.Ld, NM = q.L / 2 + 1, XS = NM | 1, RSr = q.L + 2;
             auto even = [](int x) { return (x + 1) & ~1; };
             int o = 0;
@@ -1323,6 +1348,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 c.lds_doubles = o;
                 c.tri = packed ? 1 : 0;
                 c.dbg_npq_lo = 0; c.dbg_npq_hi = 0x7fffffff;
+                c.team_lmax = use_teamc ? TF_TEAM_LMAX : -1; c.team_pqmax = teamc_pqmax;
                 if (const char *e = getenv("TF_ERI_DBG_NPQ")) (void)sscanf(e, "%d:%d", &c.dbg_npq_lo, &c.dbg_npq_hi);
                 gcaps[gb][gk] = c;
                 gcaps_fit[gb][gk] = (size_t)o * sizeof(double) <= 160 * 1024 - 256;
@@ -1566,11 +1592,55 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     signed char *d_rowcls = nullptr;                               // parity class of every slab row (small-problem mode, packed layout)
     HIPCHK(ctx, hipMalloc((void **)&d_bra, cap_bra * sizeof(int)));
     HIPCHK(ctx, hipMalloc((void **)&d_braoff, cap_bra * sizeof(long long)));
-    if (use_team) HIPCHK(ctx, hipMalloc((void **)&d_brarec, cap_bra * sizeof(BraRec)));
+    if (use_team_pc) HIPCHK(ctx, hipMalloc((void **)&d_brarec, cap_bra * sizeof(BraRec)));
     d_bra_base = d_bra;
     HIPCHK(ctx, hipMalloc((void **)&d_out, cap_out * std::max(sizeof(OutRow), sizeof(OutRowP))));
     if (packed && !per_class) HIPCHK(ctx, hipMalloc((void **)&d_rowcls, (size_t)max_rows_c + 1));
     std::vector<hipEvent_t> tev;                                   // 4 timing events per slab, read at the end
+    std::vector<hipEvent_t> tev2;                                  // 2 per slab around the task-list team kernels (they count as ERI kernels)
+    // ---- small-problem mode with team kernels (eri_teamc_kernel): class records per (bra class, ket class), created on demand; tasks
+    // per slab.  A quartet belongs to that kernel when both pair sums are <= TF_TEAM_LMAX and it has <= teamc_pqmax primitive quartets;
+    // eri_cfact_kernel skips exactly those (CFCaps::team_lmax / team_pqmax).
+    std::vector<TClass> tcs_host;
+    std::vector<int> tc_of((size_t)ncls * ncls, -2), tc_team;                // -2: not made yet, -1: not eligible
+    std::vector<size_t> tc_lds;
+    auto teamc_class = [&](int bcls, int kcls) -> int {
+        int &slot = tc_of[(size_t)bcls * ncls + kcls];
+        if (slot != -2) return slot;
+        int maxblk, maxK, nnzc;
+        TClass t = tclass_common(bcls, kcls, maxblk, maxK, nnzc);
+        const int LAB = t.La + t.Lb, LCD = t.Lc + t.Ld, L = LAB + LCD, NM = L / 2 + 1, XS = NM | 1;
+        if (LAB > TF_TEAM_LMAX || LCD > TF_TEAM_LMAX) return slot = -1;
+        auto even = [](int x) { return (x + 1) & ~1; };
+        int o = 0;
+        t.oE12 = 0;
+        t.oOffA = o; o += 2 * t.nab;
+        t.oScA = o; o += even(t.nab);
+        t.oOffK = o; o += 2 * t.ncd;
+        t.oTp = o; o += even((t.nkap + 2) / 2);
+        t.oTk = o; o += even((t.nnzT + 1) / 2);
+        t.oTc = o; o += even(t.nnzT);
+        t.shared_doubles = o;
+        t.vcap = even(2 * t.nEab + 2 * t.nEcd + (L + 1) * (L + 2) + t.nTcd * (LAB + 1) * NM);      // E12, E34, R, G of one primitive quartet
+        t.team_doubles = 2 * t.nT * XS + t.vcap + even(t.nacc) + even((t.nkap + 1) / 2);
+        auto bytes_of = [&](int tm) { return ((size_t)t.shared_doubles + (size_t)(256 / tm) * t.team_doubles) * sizeof(double); };
+        int team = 0;
+        if (t.nT <= 16 && nnzc <= 96 && eri_team_available(LAB, LCD, 16)) team = 16;
+        else if (eri_team_available(LAB, LCD, 64) && bytes_of(64) <= 52 * 1024) team = 64;
+        else if (eri_team_available(LAB, LCD, 256) && bytes_of(256) <= 160 * 1024 - 256) team = 256;
+        else if (eri_team_available(LAB, LCD, 64) && bytes_of(64) <= 160 * 1024 - 256) team = 64;
+        if (!team) return slot = -1;
+        tcs_host.push_back(t); tc_team.push_back(team); tc_lds.push_back(bytes_of(team));
+        return slot = (int)tcs_host.size() - 1;
+    };
+    bool any_wide_pair = false;                                    // a pair sum beyond the team kernels' instantiations
+    int max_npp_all = 1;
+    for (int p2 = 0; p2 < npairs; ++p2) {
+        any_wide_pair = any_wide_pair || bs.pairs[p2].La + bs.pairs[p2].Lb > TF_TEAM_LMAX;
+        max_npp_all = std::max(max_npp_all, bs.pairs[p2].npp);
+    }
+    TClass *d_tcs = nullptr; TeamTask *d_tasks = nullptr;
+    size_t d_tcs_cap = 0, d_tasks_cap = 0;
     size_t cursor = 0;
     while (cursor < mine_sorted.size()) {
         std::vector<int> bra; std::vector<long long> braoff; std::vector<OutRow> outs;
@@ -1625,7 +1695,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         HIPCHK(ctx, hipDeviceSynchronize());
         HIPCHK(ctx, hipMemcpy(d_bra, bra.data(), bra.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(ctx, hipMemcpy(d_braoff, braoff.data(), braoff.size() * sizeof(long long), hipMemcpyHostToDevice));
-        if (use_team) {
+        if (use_team_pc) {
             std::vector<BraRec> brec(bra.size());
             for (size_t k = 0; k < bra.size(); ++k) {
                 const tf::Pair &pr = bs.pairs[bra[k]];
@@ -1641,13 +1711,75 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         hipEvent_t e4[4];
         for (auto &e : e4) { HIPCHK(ctx, hipEventCreate(&e)); tev.push_back(e); }
         if (per_class && !packed && ld != N) HIPCHK(ctx, hipMemsetAsync(d_T2, 0, (size_t)rows_c * N * ld * sizeof(double), 0));   // pad columns
+        // small-problem mode with team kernels: the slab's tasks, one launch per (LAB, LCD, team, LDS size class)
+        struct TcLaunch { int LAB, LCD, team; size_t lds; std::vector<TeamTask> tasks; std::vector<double> cost; };
+        std::vector<TcLaunch> tcl;
+        bool old_needed = !use_teamc;
+        if (use_teamc) {
+            std::map<std::array<int, 4>, int> lidx;
+            int max_npp_bra = 1;
+            for (size_t b = 0; b < bra.size(); ++b) {
+                const int pb = bra[b], A = bs.pairs[pb].A, bcls = ctx->pair_class[pb];
+                max_npp_bra = std::max(max_npp_bra, bs.pairs[pb].npp);
+                for (int kc = 0; kc < ncls; ++kc) {
+                    const std::vector<int> &kl = ctx->class_pairs[kc];
+                    const int nk_all = (int)(std::upper_bound(kl.begin(), kl.end(), A, [&](int a, int p2) { return a < bs.pairs[p2].A; }) - kl.begin());
+                    if (nk_all == 0) continue;
+                    const int id = teamc_class(bcls, kc);
+                    if (id < 0) continue;
+                    const int team = tc_team[(size_t)id], NT = 256 / team;
+                    int lg = 10;
+                    while (((size_t)1 << lg) < tc_lds[(size_t)id]) ++lg;
+                    const std::array<int, 4> key{tcs_host[(size_t)id].La + tcs_host[(size_t)id].Lb, tcs_host[(size_t)id].Lc + tcs_host[(size_t)id].Ld, team, lg};
+                    auto it = lidx.find(key);
+                    if (it == lidx.end()) { it = lidx.emplace(key, (int)tcl.size()).first; tcl.push_back(TcLaunch{key[0], key[1], team, 0, {}, {}}); }
+                    TcLaunch &TL = tcl[(size_t)it->second];
+                    TL.lds = std::max(TL.lds, tc_lds[(size_t)id]);
+                    for (int g0 = 0; g0 < nk_all; g0 += NT) {
+                        const int nk = std::min(NT, nk_all - g0);
+                        int npq_max = 0, todo = 0;
+                        for (int u = 0; u < nk; ++u) {
+                            const int npq = bs.pairs[pb].npp * bs.pairs[kl[(size_t)(g0 + u)]].npp;
+                            if (npq <= teamc_pqmax) { ++todo; npq_max = std::max(npq_max, npq); }
+                        }
+                        if (!todo) continue;                       // (every quartet of the group goes to eri_cfact_kernel)
+                        TL.tasks.push_back(TeamTask{id, pb, ket_off[kc] + g0, nk, braoff[b]});
+                        TL.cost.push_back((double)npq_max * (tcs_host[(size_t)id].nT + tcs_host[(size_t)id].nacc));
+                    }
+                }
+            }
+            old_needed = any_wide_pair || (long long)max_npp_bra * max_npp_all > teamc_pqmax;
+            // heaviest tasks first inside a launch (workgroups are dispatched in index order), all tasks in one device array
+            std::vector<TeamTask> all;
+            for (TcLaunch &TL : tcl) {
+                std::vector<int> ord(TL.tasks.size());
+                std::iota(ord.begin(), ord.end(), 0);
+                std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return TL.cost[(size_t)x] > TL.cost[(size_t)y]; });
+                std::vector<TeamTask> sorted(TL.tasks.size());
+                for (size_t k = 0; k < ord.size(); ++k) sorted[k] = TL.tasks[(size_t)ord[k]];
+                TL.tasks.swap(sorted);
+                all.insert(all.end(), TL.tasks.begin(), TL.tasks.end());
+            }
+            if (tcs_host.size() > d_tcs_cap) {
+                if (d_tcs) (void)hipFree(d_tcs);
+                d_tcs_cap = tcs_host.size() + 64;
+                HIPCHK(ctx, hipMalloc((void **)&d_tcs, d_tcs_cap * sizeof(TClass)));
+            }
+            if (all.size() > d_tasks_cap) {
+                if (d_tasks) (void)hipFree(d_tasks);
+                d_tasks_cap = all.size() + 1024;
+                HIPCHK(ctx, hipMalloc((void **)&d_tasks, d_tasks_cap * sizeof(TeamTask)));
+            }
+            if (!tcs_host.empty()) HIPCHK(ctx, hipMemcpy(d_tcs, tcs_host.data(), tcs_host.size() * sizeof(TClass), hipMemcpyHostToDevice));
+            if (!all.empty()) HIPCHK(ctx, hipMemcpy(d_tasks, all.data(), all.size() * sizeof(TeamTask), hipMemcpyHostToDevice));
+        }
         // generic mode: eri_cfact_kernel stores only the components that are not zero by x/y parity
-        if (!per_class) HIPCHK(ctx, hipMemsetAsync(d_C, 0, (size_t)rows_c * Nc * Nc * sizeof(double), 0));
+        if (!per_class && old_needed) HIPCHK(ctx, hipMemsetAsync(d_C, 0, (size_t)rows_c * Nc * Nc * sizeof(double), 0));
         HIPCHK(ctx, hipEventRecord(e4[0], 0));
         for (int k = 0; k < NSTREAM; ++k) HIPCHK(ctx, hipStreamWaitEvent(streams[k], e4[0], 0));
         // runs of equal bra class inside the slab
         size_t r0 = 0;
-        if (!per_class) { if ((rc = generic_launch(bra, d_bra, d_braoff))) return rc; r0 = bra.size(); }
+        if (!per_class) { if (old_needed && (rc = generic_launch(bra, d_bra, d_braoff))) return rc; r0 = bra.size(); }
         while (r0 < bra.size()) {
             const int bcls = ctx->pair_class[bra[r0]];
             size_t r1 = r0;
@@ -1666,7 +1798,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             HIPCHK(ctx, hipStreamWaitEvent(0, sev[k], 0));
         }
         HIPCHK(ctx, hipEventRecord(e4[1], 0));
-        if (!per_class) {
+        if (!per_class && old_needed) {
             for (long long r0s = 0; r0s < rows_c; r0s += 65535) {      // both ket axes in one pass over the slab
                 const unsigned ny = (unsigned)std::min<long long>(65535, rows_c - r0s);
                 if (packed)
@@ -1677,6 +1809,37 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                     hipLaunchKernelGGL(xform_ket_both, dim3((unsigned)((N + 3) / 4), ny), dim3(256), 0, 0, d_C + (size_t)r0s * Nc * Nc,
                                        d_T2 + (size_t)r0s * N * ld, Nc, N, ld, ctx->d_csr_ptr, ctx->d_csr_idx, ctx->d_csr_val, 0);
             }
+        }
+        if (use_teamc && !tcl.empty()) {
+            // the team kernels write their quartets' part of the half-transformed slab (behind the ket transform of the others' part,
+            // which has left zeros there); heaviest launches first, spread over the streams
+            std::vector<size_t> first(tcl.size(), 0), order(tcl.size());
+            for (size_t k = 1; k < tcl.size(); ++k) first[k] = first[k - 1] + tcl[k - 1].tasks.size();
+            std::iota(order.begin(), order.end(), 0);
+            auto total = [&](size_t k) { double c = 0; for (double x : tcl[k].cost) c += x; return c; };
+            std::vector<double> tot(tcl.size());
+            for (size_t k = 0; k < tcl.size(); ++k) tot[k] = total(k);
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return tot[x] > tot[y]; });
+            hipEvent_t et[2];
+            for (auto &e : et) { HIPCHK(ctx, hipEventCreate(&e)); tev2.push_back(e); }
+            HIPCHK(ctx, hipEventRecord(et[0], 0));
+            HIPCHK(ctx, hipEventRecord(sev[0], 0));
+            for (int k = 0; k < NSTREAM; ++k) HIPCHK(ctx, hipStreamWaitEvent(streams[k], sev[0], 0));
+            int nl = 0;
+            for (size_t k : order) {
+                const TcLaunch &TL = tcl[k];
+                if (TL.tasks.empty()) continue;
+                TeamcLaunch a{TL.LAB, TL.LCD, TL.team, (unsigned)TL.tasks.size(), TL.lds, streams[nl++ % NSTREAM], &ctx->db, d_tcs, d_tasks + first[k], d_kets,
+                              teamc_pqmax, d_T2};
+                const hipError_t e = eri_teamc_launch(a);
+                if (e != hipSuccess && team_error == hipSuccess) team_error = e;
+                ++launch_count;
+            }
+            for (int k = 0; k < NSTREAM; ++k) {
+                HIPCHK(ctx, hipEventRecord(sev[k], streams[k]));
+                HIPCHK(ctx, hipStreamWaitEvent(0, sev[k], 0));
+            }
+            HIPCHK(ctx, hipEventRecord(et[1], 0));
         }
         HIPCHK(ctx, hipEventRecord(e4[2], 0));
         if (!outs.empty()) {
@@ -1708,11 +1871,17 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         t_stage[2] += seconds_between(tev[k + 1], tev[k + 2]);
         t_stage[3] += seconds_between(tev[k + 2], tev[k + 3]);
     }
+    for (size_t k = 0; k + 1 < tev2.size(); k += 2) {
+        const double dt = seconds_between(tev2[k], tev2[k + 1]);
+        t_stage[1] += dt; t_stage[2] -= dt;
+    }
     for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : tev2) (void)hipEventDestroy(e);
     (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out);
     if (d_rowcls) (void)hipFree(d_rowcls);
     (void)hipFree(d_kets); (void)hipFree(d_kets_all);
-    for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c, (void *)d_ketrec, (void *)d_brarec, (void *)d_kcnt})
+    for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c, (void *)d_ketrec, (void *)d_brarec, (void *)d_kcnt,
+                     (void *)d_tcs, (void *)d_tasks})
         if (pt) (void)hipFree(pt);
     ctx->db.kq_ptr = ctx->db.kq_off = ctx->db.kt_ptr = ctx->db.kt_k = nullptr; ctx->db.kt_c = nullptr;
     if (team_error != hipSuccess) TF_FAIL(ctx, TF_ENODEVICE, "launch of a team ERI kernel failed: %s", hipGetErrorString(team_error));

@@ -706,6 +706,7 @@ struct CFCaps {
     int offRed, lds_doubles, tri;
     int gtab_doubles;                // GTAB launches: offG / offX / offZ are relative to the workgroup's block of this many doubles in global memory
     int dbg_npq_lo, dbg_npq_hi;      // profiling aid (TF_ERI_DBG_NPQ=lo:hi): only quartets with lo <= primitive quartets <= hi are computed
+    int team_lmax, team_pqmax;       // quartets with both pair sums <= team_lmax and <= team_pqmax primitive quartets belong to eri_teamc_kernel (-1: none)
 };
 
 // GTAB: the G / X / Z tables of the workgroup live in global memory (gtab, one block of cap.gtab_doubles per workgroup, L2-resident)
@@ -722,6 +723,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
     const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
     if (cap.tri && cd.A > ab.A) return;
     if (ab.npp * cd.npp < cap.dbg_npq_lo || ab.npp * cd.npp > cap.dbg_npq_hi) return;
+    if (cap.team_lmax >= 0 && ab.La + ab.Lb <= cap.team_lmax && cd.La + cd.Lb <= cap.team_lmax && ab.npp * cd.npp <= cap.team_pqmax) return;
     const LRec lr = B.lrec[((ab.La * 6 + ab.Lb) * 6 + cd.La) * 6 + cd.Lb];
     const int Lb1 = ab.Lb + 1, Lc1 = cd.La + 1, Ld1 = cd.Lb + 1;
     const int Lab1 = ab.La + ab.Lb + 1, Lcd1 = cd.La + cd.Lb + 1;

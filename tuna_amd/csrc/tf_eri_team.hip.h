@@ -35,7 +35,8 @@ struct TClass {
     int ktp_off, kte_off;         // ket pair transform of the ket class: row pointers at kt_ptr[ktp_off ..], entries at kt_k / kt_c[kte_off ..]
     int n_ket;                    // ket pairs of the launch (class list prefix)
     int nEab, nEcd;               // doubles of one Hermite table of the bra / ket pair
-    int vcap;                     // doubles of a team's component block
+    int vcap;                     // doubles of a team's component block (eri_teamc_kernel: of its table scratch)
+    int nacc;                     // parity-allowed Cartesian components of a quartet (eri_teamc_kernel: the accumulation block)
     int oE12, oOffA, oScA, oOffK, oTp, oTk, oTc, shared_doubles, team_doubles;   // LDS carve-out, in doubles
     long long RLS;                // stride of a slab row
 };
@@ -78,6 +79,104 @@ __device__ __forceinline__ double team_fact_sum(const double *__restrict__ X, co
         sum += x[m] * t;
     }
     return sum;
+}
+
+// Phases 1-3 of a team for ONE primitive quartet: Boys values and the z-only Hermite-Coulomb table R, the ket half G of the z tables,
+// then the X and Z rows.  On entry sE34 holds the ket Hermite tables (signs folded in) and sR is zeroed; sE12 the bra tables.  Ends
+// with a team barrier: sX / sZ are complete, sE34 / sR / sG dead.
+template <int LAB, int LCD, int TEAM>
+__device__ __forceinline__ void team_tables(const DBasis &B, int tl, double alpha, double PQ, double T, const double *sE12, int nEab,
+                                            const double *sE34, int nEcd, double *sR, double *sG, double *sX, double *sZ, int nTcd, int nT,
+                                            float inv_nTcd)
+{
+    constexpr int L = LAB + LCD, NM = L / 2 + 1, XS = NM | 1, Lab1 = LAB + 1, Lcd1 = LCD + 1, RS = L + 2;
+    constexpr double DF[11] = {1.0, 1.0, 3.0, 15.0, 105.0, 945.0, 10395.0, 135135.0, 2027025.0, 34459425.0, 654729075.0};
+    team_sync<TEAM>();
+    // ---- phase 1: Boys values (reference: fill_boys_table pyx:1540-1572) and R[v][n] = PQ R[v-1][n+1] + (v-1) R[v-2][n+1] (pyx:1612-1651) ----
+    if (tl <= L) {
+        const int n = tl;
+        double f;
+        if (T < TF_BOYS_TMAX) {
+            const int i = (int)(T * (1.0 / TF_BOYS_STEP) + 0.5);
+            const double d = (double)i * TF_BOYS_STEP - T;            // F_n(T) = sum_k F_{n+k}(T0) d^k / k!
+            const double *__restrict__ row = B.boys + (size_t)i * TF_BOYS_NORD + n;
+            f = row[8];
+            f = row[7] + f * d * (1.0 / 8.0);
+            f = row[6] + f * d * (1.0 / 7.0);
+            f = row[5] + f * d * (1.0 / 6.0);
+            f = row[4] + f * d * (1.0 / 5.0);
+            f = row[3] + f * d * (1.0 / 4.0);
+            f = row[2] + f * d * (1.0 / 3.0);
+            f = row[1] + f * d * (1.0 / 2.0);
+            f = row[0] + f * d;
+        } else {
+            // T >= 36: erf(sqrt T) = 1 to double precision; the upward recursion is contracting for m < T
+            const double e = exp(-T), inv2T = 1.0 / (2.0 * T);
+            double g = 0.5 * sqrt(3.141592653589793238462643383279 / T);
+            f = g;
+#pragma unroll
+            for (int m = 0; m < L; ++m) {
+                g = ((2.0 * m + 1.0) * g - e) * inv2T;
+                if (m + 1 == n) f = g;
+            }
+        }
+        double pw = 1.0, fac = -2.0 * alpha;                               // (-2 alpha)^n by binary powering (n <= 12)
+#pragma unroll
+        for (int bit = 0; (1 << bit) <= L; ++bit) {
+            pw = ((n >> bit) & 1) ? pw * fac : pw;
+            fac *= fac;
+        }
+        sR[n] = f * pw;                                                    // R[0][n] = (-2 alpha)^n F_n
+    }
+#pragma unroll
+    for (int v = 1; v <= L; ++v) {
+        wave_lds_order<TEAM>();
+        if (tl <= L - v) {
+            double val = PQ * sR[(v - 1) * RS + tl + 1];
+            if (v > 1) val += (double)(v - 1) * sR[(v - 2) * RS + tl + 1];
+            sR[v * RS + tl] = val;
+        }
+    }
+    team_sync<TEAM>();
+    // ---- phase 2: G[cdt][v][n] = sum_phi Ez34'[phi] R[v + phi][n]   (entries beyond n + v + phi <= L meet a zero coefficient or a zero of R) ----
+    for (int e = tl; e < nTcd * Lab1; e += TEAM) {
+        const int cdt = e / Lab1, v = e - cdt * Lab1;
+        double ez[Lcd1];
+#pragma unroll
+        for (int ph = 0; ph < Lcd1; ++ph) ez[ph] = sE34[nEcd + cdt * Lcd1 + ph];
+        const double *Rv = sR + v * RS;
+#pragma unroll
+        for (int n = 0; n < NM; ++n) {
+            double g = 0.0;
+#pragma unroll
+            for (int ph = 0; ph < Lcd1; ++ph) g += ez[ph] * Rv[ph * RS + n];
+            sG[e * NM + n] = g;
+        }
+    }
+    team_sync<TEAM>();
+    // ---- phase 3: X and Z rows, one exponent tuple pair per lane ----
+    for (int tu = tl; tu < nT; tu += TEAM) {
+        const int abt = small_div(tu, inv_nTcd), cdt = tu - abt * nTcd;
+        double e12x[Lab1], e12z[Lab1], e34x[Lcd1];
+#pragma unroll
+        for (int t = 0; t < Lab1; ++t) { e12x[t] = sE12[abt * Lab1 + t]; e12z[t] = sE12[nEab + abt * Lab1 + t]; }
+#pragma unroll
+        for (int t = 0; t < Lcd1; ++t) e34x[t] = sE34[cdt * Lcd1 + t];
+        const double *Gc = sG + cdt * Lab1 * NM;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            double x = 0.0;
+#pragma unroll
+            for (int t = 0; t < Lab1; ++t)
+                if (2 * m - t >= 0 && 2 * m - t <= LCD) x += e12x[t] * e34x[2 * m - t];
+            sX[tu * XS + m] = x * DF[m];
+            double z = 0.0;
+#pragma unroll
+            for (int v = 0; v < Lab1; ++v) z += e12z[v] * Gc[v * NM + m];
+            sZ[tu * XS + m] = z;
+        }
+    }
+    team_sync<TEAM>();
 }
 
 #ifndef TF_TEAM_OCC
@@ -150,95 +249,9 @@ __global__ __launch_bounds__(256, TF_TEAM_OCC) void eri_team_kernel(DBasis B, TC
             sE34[k] = ((k % Lcd1) & 1) ? -v : v;                           // (both tables have rows of Lcd1 entries; nEcd is a multiple of Lcd1)
         }
         for (int k = tl; k < (L + 1) * RS; k += TEAM) sR[k] = 0.0;
+        for (int k = tl; k < tc.nkap; k += TEAM) sDoff[k] = B.kq_off[cd->kq + k];   // (behind the scratch area: untouched by the phases)
     }
-    team_sync<TEAM>();
-    // ---- phase 1: Boys values (reference: fill_boys_table pyx:1540-1572) and R[v][n] = PQ R[v-1][n+1] + (v-1) R[v-2][n+1] (pyx:1612-1651) ----
-    if (tl <= L) {
-        const int n = tl;
-        double f;
-        if (T < TF_BOYS_TMAX) {
-            const int i = (int)(T * (1.0 / TF_BOYS_STEP) + 0.5);
-            const double d = (double)i * TF_BOYS_STEP - T;            // F_n(T) = sum_k F_{n+k}(T0) d^k / k!
-            const double *__restrict__ row = B.boys + (size_t)i * TF_BOYS_NORD + n;
-            f = row[8];
-            f = row[7] + f * d * (1.0 / 8.0);
-            f = row[6] + f * d * (1.0 / 7.0);
-            f = row[5] + f * d * (1.0 / 6.0);
-            f = row[4] + f * d * (1.0 / 5.0);
-            f = row[3] + f * d * (1.0 / 4.0);
-            f = row[2] + f * d * (1.0 / 3.0);
-            f = row[1] + f * d * (1.0 / 2.0);
-            f = row[0] + f * d;
-        } else {
-            // T >= 36: erf(sqrt T) = 1 to double precision; the upward recursion is contracting for m < T
-            const double e = exp(-T), inv2T = 1.0 / (2.0 * T);
-            double g = 0.5 * sqrt(3.141592653589793238462643383279 / T);
-            f = g;
-#pragma unroll
-            for (int m = 0; m < L; ++m) {
-                g = ((2.0 * m + 1.0) * g - e) * inv2T;
-                if (m + 1 == n) f = g;
-            }
-        }
-        double pw = 1.0, fac = -2.0 * alpha;                               // (-2 alpha)^n by binary powering (n <= 12)
-#pragma unroll
-        for (int bit = 0; (1 << bit) <= L; ++bit) {
-            pw = ((n >> bit) & 1) ? pw * fac : pw;
-            fac *= fac;
-        }
-        sR[n] = f * pw;                                                    // R[0][n] = (-2 alpha)^n F_n
-    }
-#pragma unroll
-    for (int v = 1; v <= L; ++v) {
-        wave_lds_order<TEAM>();
-        if (tl <= L - v) {
-            double val = PQ * sR[(v - 1) * RS + tl + 1];
-            if (v > 1) val += (double)(v - 1) * sR[(v - 2) * RS + tl + 1];
-            sR[v * RS + tl] = val;
-        }
-    }
-    team_sync<TEAM>();
-    // ---- phase 2: G[cdt][v][n] = sum_phi Ez34'[phi] R[v + phi][n]   (entries beyond n + v + phi <= L meet a zero coefficient or a zero of R) ----
-    for (int e = tl; e < nTcd * Lab1; e += TEAM) {
-        const int cdt = e / Lab1, v = e - cdt * Lab1;
-        double ez[Lcd1];
-#pragma unroll
-        for (int ph = 0; ph < Lcd1; ++ph) ez[ph] = sE34[nEcd + cdt * Lcd1 + ph];
-        const double *Rv = sR + v * RS;
-#pragma unroll
-        for (int n = 0; n < NM; ++n) {
-            double g = 0.0;
-#pragma unroll
-            for (int ph = 0; ph < Lcd1; ++ph) g += ez[ph] * Rv[ph * RS + n];
-            sG[e * NM + n] = g;
-        }
-    }
-    team_sync<TEAM>();
-    // ---- phase 3: X and Z rows, one exponent tuple pair per lane ----
-    for (int tu = tl; tu < tc.nT; tu += TEAM) {
-        const int abt = small_div(tu, tc.inv_nTcd), cdt = tu - abt * nTcd;
-        double e12x[Lab1], e12z[Lab1], e34x[Lcd1];
-#pragma unroll
-        for (int t = 0; t < Lab1; ++t) { e12x[t] = sE12[abt * Lab1 + t]; e12z[t] = sE12[nEab + abt * Lab1 + t]; }
-#pragma unroll
-        for (int t = 0; t < Lcd1; ++t) e34x[t] = sE34[cdt * Lcd1 + t];
-        const double *Gc = sG + cdt * Lab1 * NM;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            double x = 0.0;
-#pragma unroll
-            for (int t = 0; t < Lab1; ++t)
-                if (2 * m - t >= 0 && 2 * m - t <= LCD) x += e12x[t] * e34x[2 * m - t];
-            sX[tu * XS + m] = x * DF[m];
-            double z = 0.0;
-#pragma unroll
-            for (int v = 0; v < Lab1; ++v) z += e12z[v] * Gc[v * NM + m];
-            sZ[tu * XS + m] = z;
-        }
-    }
-    // slab offsets of the output pairs (the scratch area behind the component block)
-    for (int k = tl; k < tc.nkap; k += TEAM) sDoff[k] = B.kq_off[cd->kq + k];
-    team_sync<TEAM>();
+    team_tables<LAB, LCD, TEAM>(B, tl, alpha, PQ, T, sE12, nEab, sE34, nEcd, sR, sG, sX, sZ, nTcd, tc.nT, tc.inv_nTcd);
 
     // ---- phases 4 and 5, parity class by parity class, in chunks of complete bra rows ----
     for (int c = 0; c < 4; ++c) {

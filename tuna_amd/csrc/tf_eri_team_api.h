@@ -24,6 +24,21 @@ struct TeamLaunch {
     double *T2;
 };
 
+struct TeamTask;                  // tf_eri_teamc.hip.h
+struct TeamcLaunch {              // eri_teamc_kernel: one launch per (LAB, LCD, team) over a task list that may mix classes
+    int LAB, LCD, team;
+    unsigned n_tasks;
+    size_t lds_bytes;             // the largest carve-out among the classes of the tasks
+    hipStream_t stream;
+    const DBasis *B;
+    const TClass *tcs;            // device: class records
+    const TeamTask *tasks;        // device: this launch's tasks
+    const int *klist;             // device: ket pair ids the tasks point into
+    int pq_max;                   // quartets with more primitive quartets are skipped (eri_cfact_kernel computes them)
+    double *T2;
+};
+hipError_t eri_teamc_launch(const TeamcLaunch &a);
+
 bool eri_team_available(int LAB, int LCD, int team);   // is this combination instantiated
 hipError_t eri_team_launch(const TeamLaunch &a);
 

@@ -85,14 +85,17 @@ __device__ inline void boys_fill(int M, double T, const double *__restrict__ tab
     }
 }
 
+// WAVE_PER_PAIR: one wave per AO pair, the lanes share the primitive pairs (a deeply contracted pair -- 13 x 13 primitives of two Ar s
+// shells -- kept one thread busy for milliseconds) and are summed in a fixed butterfly at the end.  Otherwise one LANE per AO pair
+// (uncontracted or barely contracted basis sets: 118 000 AO pairs of one primitive pair each at N = 400 -- a wave per pair left 63 of
+// 64 lanes idle, 8 ms; now 64 pairs per wave).
+template <bool WAVE_PER_PAIR>
 __global__ void oneel_kernel(DAO A, int n, int n_atoms, double zc0, double zc1, double q0, double q1, double oz,
                              const double *__restrict__ boys, double *__restrict__ S, double *__restrict__ T,
                              double *__restrict__ V, double *__restrict__ D, double *__restrict__ Q)
 {
-    // one wave per AO pair: the lanes share the primitive pairs (a deeply contracted pair -- 13 x 13 primitives of two Ar s shells --
-    // kept one thread busy for milliseconds) and are summed in a fixed butterfly at the end
-    const long long pidx = blockIdx.x;
-    const int lane = threadIdx.x;
+    const long long pidx = WAVE_PER_PAIR ? (long long)blockIdx.x : (long long)blockIdx.x * 64 + threadIdx.x;
+    const int lane = WAVE_PER_PAIR ? (int)threadIdx.x : 0;
     const long long npair = (long long)n * (n + 1) / 2;
     if (pidx >= npair) return;
     int i = (int)((sqrt(8.0 * (double)pidx + 1.0) - 1.0) * 0.5);
@@ -110,7 +113,7 @@ __global__ void oneel_kernel(DAO A, int n, int n_atoms, double zc0, double zc1, 
     const double PI = 3.141592653589793238462643383279, PI32 = 5.5683279968317078452848179821188357;
     const int Vmax = n1 + n2, Nmax = L1 + L2, stride = Nmax + 1;
     const int pa0 = A.prim_off[i], npa = A.prim_off[i + 1] - pa0, pb0 = A.prim_off[j], npb = A.prim_off[j + 1] - pb0;
-    for (int pq = lane; pq < npa * npb; pq += 64) {
+    for (int pq = lane; pq < npa * npb; pq += (WAVE_PER_PAIR ? 64 : 1)) {
         {
             const int a = pa0 + pq / npb, b = pb0 + pq % npb;
             const double ea = A.exps[a], wa = A.w[a];
@@ -162,6 +165,7 @@ __global__ void oneel_kernel(DAO A, int n, int n_atoms, double zc0, double zc1, 
             }
         }
     }
+    if (WAVE_PER_PAIR)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_xor(s, off); t += __shfl_xor(t, off); dx += __shfl_xor(dx, off); dy += __shfl_xor(dy, off); dzz += __shfl_xor(dzz, off);
@@ -305,8 +309,14 @@ inline std::string one_electron(const tf::Basis &bs, int n_atoms, const double *
     if (!err.empty()) return err;
     double *dS = d_all, *dT = d_all + nn, *dV = d_all + 2 * nn, *dD = d_all + 3 * nn, *dQ = d_all + 6 * nn;
     const long long npair = (long long)n * (n + 1) / 2;
-    hipLaunchKernelGGL(oneel_kernel, dim3((unsigned)npair), dim3(64), 0, 0, A, n, n_atoms, xyz[2],
-                       n_atoms > 1 ? xyz[5] : 0.0, charge[0], n_atoms > 1 ? charge[1] : 0.0, origin[2], d_boys, dS, dT, dV, dD, dQ);
+    int max_nprim = 1;                                          // deepest contraction of an AO
+    for (int i = 0; i < n; ++i) max_nprim = std::max(max_nprim, (int)(bs.ao_prim_off[i + 1] - bs.ao_prim_off[i]));
+    if (max_nprim <= 2)                                         // (at most four primitive pairs per AO pair: a lane per pair)
+        hipLaunchKernelGGL(oneel_kernel<false>, dim3((unsigned)((npair + 63) / 64)), dim3(64), 0, 0, A, n, n_atoms, xyz[2],
+                           n_atoms > 1 ? xyz[5] : 0.0, charge[0], n_atoms > 1 ? charge[1] : 0.0, origin[2], d_boys, dS, dT, dV, dD, dQ);
+    else
+        hipLaunchKernelGGL(oneel_kernel<true>, dim3((unsigned)npair), dim3(64), 0, 0, A, n, n_atoms, xyz[2],
+                           n_atoms > 1 ? xyz[5] : 0.0, charge[0], n_atoms > 1 ? charge[1] : 0.0, origin[2], d_boys, dS, dT, dV, dD, dQ);
     double *src = d_all;
     int m = n;
     if (spherical) {
