@@ -47,6 +47,7 @@ struct DBasis {
     // -1: not stored), per pair class the Cartesian -> output transform of its component pairs, parity class by parity class
     const int *kq_ptr, *kq_off, *kt_ptr, *kt_k;
     const double *kt_c;
+    const int *tflat;            // flat component / output lists of the class pairs (TClass::flat_off)
 };
 
 }  // namespace tfk

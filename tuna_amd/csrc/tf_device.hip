@@ -1080,19 +1080,22 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     std::vector<LRec> lrecs_host;                              // per (La, Lb | Lc, Ld), filled by make_lrecs below
     hipError_t team_error = hipSuccess;                        // first failed launch of a team kernel
     static const bool team_off = getenv("TF_ERI_TEAM") && getenv("TF_ERI_TEAM")[0] == '0';
-    const bool use_team = packed && !team_off && bs.epool.size() < 0xffffffffull;      // tables of the team kernels (both launch modes)
-    const bool use_team_pc = use_team && per_class;                                       // per-class mode: eri_team_kernel for the uncontracted classes
+    const bool team_ok = packed && !team_off && bs.epool.size() < 0xffffffffull;
+    const bool use_team_pc = team_ok && per_class;                                        // per-class mode: eri_team_kernel for the uncontracted classes
     // (off by default: on the BASELINE basis sets eri_cfact_kernel is faster -- N2/cc-pVTZ 1.2 ms against 3.3-4.2 ms, Ar2/cc-pVQZ 18 ms against
     // 22-25 ms of ERI kernels: a team walks the primitive quartets of its shell quartet one after the other, a chain of dependent phases
     // with nothing else on the chip to hide it; TF_ERI_TEAMC=1 switches it on for experiments and for the parity tests)
     static const bool teamc_off = !(getenv("TF_ERI_TEAMC") && getenv("TF_ERI_TEAMC")[0] == '1');
-    const bool use_teamc = use_team && !per_class && !teamc_off;                         // small-problem mode: eri_teamc_kernel over task lists
+    const bool use_teamc = team_ok && !per_class && !teamc_off;                          // small-problem mode: eri_teamc_kernel over task lists
+    const bool use_team = use_team_pc || use_teamc;                                       // the team kernels' tables are needed
     static const int teamc_pqmax = getenv("TF_TEAMC_PQMAX") ? atoi(getenv("TF_TEAMC_PQMAX")) : 700;
     struct KClassTab { int pS[5] = {0, 0, 0, 0, 0}; int nkap = 0, nnzT = 0, tp_off = 0, te_off = 0; };
     std::vector<KClassTab> kct(ncls);
     int *d_kq_ptr = nullptr, *d_kq_off = nullptr, *d_kt_ptr = nullptr, *d_kt_k = nullptr, *d_kcnt = nullptr;
     double *d_kt_c = nullptr;
     KetRec *d_ketrec = nullptr;                                // parallel to d_kets (class-sorted ket list)
+    int *d_tflat = nullptr;                                    // flat component / output lists of the class pairs (TClass::flat_off)
+    std::vector<int> flat_off;
     BraRec *d_brarec = nullptr;                                // parallel to the slab's bra list d_bra
     const int *d_bra_base = nullptr;
     // the class-wide part of a team kernel's class record (tf_eri_team.hip.h) for (bra pair class, ket pair class)
@@ -1113,6 +1116,12 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
         t.nkap = kt.nkap; t.nnzT = kt.nnzT; t.tabA = hb.tab_off; t.tabK = hk.tab_off; t.ktp_off = kt.tp_off; t.kte_off = kt.te_off;
         t.nEab = hb.nE; t.nEcd = hk.nE; t.RLS = H.RLS; t.nacc = nnzc;
+        t.nout = 0;
+        for (int i = 0; i < 4; ++i) {
+            t.invK[i] = 1.0f / (float)std::max(1, t.pK[i + 1] - t.pK[i]);
+            t.invS[i] = 1.0f / (float)std::max(1, t.pS[i + 1] - t.pS[i]);
+            t.nout += (t.pA[i + 1] - t.pA[i]) * (t.pS[i + 1] - t.pS[i]);
+        }
         return t;
     };
     // bra_Amax: largest first shell among the bra pairs of the run -- in the packed layout only kets with first shell <= it are needed
@@ -1169,11 +1178,20 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             t.oTp = o; o += even((t.nkap + 2) / 2);
             t.oTk = o; o += even((t.nnzT + 1) / 2);
             t.oTc = o; o += even(t.nnzT);
+            t.oRowOff = o; o += t.nab;
+            const int foff = flat_off.empty() ? -1 : flat_off[(size_t)bcls * ncls + kcls];
+            auto vmax_of = [](int tm) { return tm == 256 ? 2048 : (tm == 64 ? 512 : 96); };
+            const int nacc_pad = even(nnzc);
+            t.oCompW = o; t.oOutW = o + nacc_pad / 2; t.flat_off = std::max(0, foff); t.nflat = nacc_pad + 2 * t.nout;
+            const int flat_doubles = even((t.nflat + 1) / 2);
+            const int shared_noflat = o;
             t.shared_doubles = o;
             const int nG = t.nTcd * (LAB + 1) * NM, scr1 = 2 * t.nEcd + (q.L + 1) * RSr + nG;
-            auto vcap_of = [&](int tm) { return even(std::max(scr1, std::max(maxK, std::min(maxblk, tm == 256 ? 2048 : (tm == 64 ? 512 : 96))))); };
+            // (a class whose parity-allowed components fit the team's block runs the flat lists: one loop over all components)
+            auto flat_for = [&](int tm) { return foff >= 0 && nnzc <= vmax_of(tm); };
+            auto vcap_of = [&](int tm) { return flat_for(tm) ? even(std::max(scr1, nnzc)) : even(std::max(scr1, std::max(maxK, std::min(maxblk, vmax_of(tm))))); };
             auto team_doubles_of = [&](int tm) { return 2 * t.nT * XS + vcap_of(tm) + even((t.nkap + 1) / 2); };
-            auto bytes_of = [&](int tm) { return ((size_t)t.shared_doubles + (size_t)(256 / tm) * team_doubles_of(tm)) * sizeof(double); };
+            auto bytes_of = [&](int tm) { return ((size_t)shared_noflat + (flat_for(tm) ? flat_doubles : 0) + (size_t)(256 / tm) * team_doubles_of(tm)) * sizeof(double); };
             // lanes per quartet: 16 for the smallest classes; a wave while four quartets' tables fit a third of the LDS (three workgroups per
             // CU); the whole workgroup beyond
             static const int force_team = getenv("TF_ERI_TEAM_SIZE") ? atoi(getenv("TF_ERI_TEAM_SIZE")) : 0;
@@ -1186,6 +1204,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             if (team) {
                 const int NT = 256 / team;
                 t.vcap = vcap_of(team); t.team_doubles = team_doubles_of(team);
+                t.flat = flat_for(team) ? 1 : 0;
+                t.shared_doubles = shared_noflat + (t.flat ? flat_doubles : 0);
                 // a workgroup walks over several ket groups (shared staging once): enough workgroups to fill the chip, at most 8 groups each
                 const long long groups = (q.n_ket + NT - 1) / NT;
                 const long long kpw = std::max<long long>(1, std::min<long long>(8, groups * n_bra / 16384));
@@ -1576,6 +1596,33 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             for (int a = 1; a < nsh; ++a) kcnt[(size_t)c * nsh + a] += kcnt[(size_t)c * nsh + a - 1];
         }
         if ((rc = upload(ctx, krec, &d_ketrec, false)) || (rc = upload(ctx, kcnt, &d_kcnt, false))) return rc;
+        if (use_team_pc) {
+            // flat lists of the parity-allowed components and of the outputs of every (bra class, ket class) of uncontracted pairs
+            std::vector<int> tflat;
+            flat_off.assign((size_t)ncls * ncls, -1);
+            for (int bc = 0; bc < ncls; ++bc)
+                for (int kc = 0; kc < ncls; ++kc) {
+                    const DPair &hb = ctx->host_pairs[ctx->class_pairs[bc][0]], &hk = ctx->host_pairs[ctx->class_pairs[kc][0]];
+                    if (hb.npp != 1 || hk.npp != 1 || hb.La + hb.Lb > TF_TEAM_LMAX || hk.La + hk.Lb > TF_TEAM_LMAX) continue;
+                    int mb, mk, nz;
+                    const TClass t = tclass_common(bc, kc, mb, mk, nz);
+                    if (nz > 2048) continue;                          // (chunked classes keep the loop per parity class)
+                    flat_off[(size_t)bc * ncls + kc] = (int)tflat.size();
+                    for (int c = 0; c < 4; ++c)
+                        for (int il = 0; il < t.pA[c + 1] - t.pA[c]; ++il)
+                            for (int kl = 0; kl < t.pK[c + 1] - t.pK[c]; ++kl) tflat.push_back((t.pA[c] + il) | ((t.pK[c] + kl) << 16));
+                    if (tflat.size() & 1) tflat.push_back(0);
+                    int vbase = 0;
+                    for (int c = 0; c < 4; ++c) {
+                        const int nA = t.pA[c + 1] - t.pA[c], nK = t.pK[c + 1] - t.pK[c], nS = t.pS[c + 1] - t.pS[c];
+                        for (int il = 0; il < nA; ++il)
+                            for (int ks = 0; ks < nS; ++ks) { tflat.push_back((t.pA[c] + il) | ((t.pS[c] + ks) << 16)); tflat.push_back(vbase + il * nK); }
+                        vbase += nA * nK;
+                    }
+                }
+            if ((rc = upload(ctx, tflat, &d_tflat, false))) return rc;
+            ctx->db.tflat = d_tflat;
+        }
     }
     if (!per_class)
         std::stable_sort(mine_sorted.begin(), mine_sorted.end(), [&](int x, int y) {
@@ -1881,7 +1928,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     if (d_rowcls) (void)hipFree(d_rowcls);
     (void)hipFree(d_kets); (void)hipFree(d_kets_all);
     for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c, (void *)d_ketrec, (void *)d_brarec, (void *)d_kcnt,
-                     (void *)d_tcs, (void *)d_tasks})
+                     (void *)d_tcs, (void *)d_tasks, (void *)d_tflat})
         if (pt) (void)hipFree(pt);
     ctx->db.kq_ptr = ctx->db.kq_off = ctx->db.kt_ptr = ctx->db.kt_k = nullptr; ctx->db.kt_c = nullptr;
     if (team_error != hipSuccess) TF_FAIL(ctx, TF_ENODEVICE, "launch of a team ERI kernel failed: %s", hipGetErrorString(team_error));

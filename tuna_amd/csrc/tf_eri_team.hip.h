@@ -38,6 +38,11 @@ struct TClass {
     int vcap;                     // doubles of a team's component block (eri_teamc_kernel: of its table scratch)
     int nacc;                     // parity-allowed Cartesian components of a quartet (eri_teamc_kernel: the accumulation block)
     int oE12, oOffA, oScA, oOffK, oTp, oTk, oTc, shared_doubles, team_doubles;   // LDS carve-out, in doubles
+    // flat component / output lists (classes whose parity-allowed components fit the team's block: one loop over all of them instead
+    // of one per parity class): DBasis::tflat[flat_off ..] = nacc words (bra index | ket index << 16, class-sorted indices), then nout
+    // pairs (bra index | output pair << 16, offset of the bra row inside the block)
+    int flat, flat_off, nflat, nout, oCompW, oOutW, oRowOff;   // nflat: words to stage (components padded to an even count, then outputs)
+    float invK[4], invS[4];       // 1 / (ket component pairs of class c), 1 / (ket output pairs of class c)
     long long RLS;                // stride of a slab row
 };
 
@@ -217,11 +222,17 @@ __global__ __launch_bounds__(256, TF_TEAM_OCC) void eri_team_kernel(DBasis B, TC
         }
         for (int s = tid; s <= tc.nkap; s += 256) sTp[s] = B.kt_ptr[tc.ktp_off + s];
         for (int s = tid; s < tc.nnzT; s += 256) { sTk[s] = B.kt_k[tc.kte_off + s]; sTc[s] = B.kt_c[tc.kte_off + s]; }
+        if (tc.flat) {
+            int *sW = reinterpret_cast<int *>(smem + tc.oCompW);          // component words, then output words (contiguous)
+            for (int s = tid; s < tc.nflat; s += 256) sW[s] = B.tflat[tc.flat_off + s];
+        }
     }
+    const long long row_first = ab->row_first;
+    long long *sRowOff = reinterpret_cast<long long *>(smem + tc.oRowOff);    // slab offset of the row of bra component pair s (class-sorted index)
+    for (int s = tid; s < tc.nab; s += 256) sRowOff[s] = (row_first + B.ct_ord[tc.tabA + s]) * tc.RLS;
     __syncthreads();
 
     const double p = ab->p, Pz = ab->Pz, Kp = ab->Kp;
-    const long long row_first = ab->row_first;
     double *tm = smem + tc.shared_doubles + team * tc.team_doubles;
     double *sX = tm, *sZ = sX + tc.nT * XS, *scr = sZ + tc.nT * XS;
     double *sE34 = scr, *sR = sE34 + 2 * nEcd, *sG = sR + (L + 1) * RS;
@@ -253,11 +264,36 @@ __global__ __launch_bounds__(256, TF_TEAM_OCC) void eri_team_kernel(DBasis B, TC
     }
     team_tables<LAB, LCD, TEAM>(B, tl, alpha, PQ, T, sE12, nEab, sE34, nEcd, sR, sG, sX, sZ, nTcd, tc.nT, tc.inv_nTcd);
 
+    if (tc.flat) {
+        // ---- phases 4 and 5 over the flat lists: every parity-allowed component, then every output, in one loop each ----
+        const int *sCompW = reinterpret_cast<const int *>(smem + tc.oCompW);
+        const int2 *sOutW = reinterpret_cast<const int2 *>(smem + tc.oOutW);
+        for (int j = tl; j < tc.nacc; j += TEAM) {
+            const unsigned w = (unsigned)sCompW[j];
+            const int4 oa = sOffA[w & 0xffffu], oc = sOffK[w >> 16];
+            const double *X = reinterpret_cast<const double *>(bX + (oa.x + oc.x));
+            const double *Y = reinterpret_cast<const double *>(bX + (oa.y + oc.y));
+            const double *Z = reinterpret_cast<const double *>(bZ + (oa.z + oc.z));
+            sV[j] = team_fact_sum<NM>(X, Y, Z);
+        }
+        team_sync<TEAM>();
+        for (int o = tl; o < tc.nout; o += TEAM) {
+            const int2 w = sOutW[o];
+            const int iA = w.x & 0xffff, kap = (int)((unsigned)w.x >> 16);
+            const int doff = sDoff[kap];
+            if (doff < 0) continue;
+            const double *Vr = sV + w.y;
+            double acc = 0.0;
+            for (int e = sTp[kap]; e < sTp[kap + 1]; ++e) acc += sTc[e] * Vr[sTk[e]];
+            T2[sRowOff[iA] + doff] = acc * (pref * sScA[iA]);
+        }
+        team_sync<TEAM>();
+    } else
     // ---- phases 4 and 5, parity class by parity class, in chunks of complete bra rows ----
     for (int c = 0; c < 4; ++c) {
         const int nA = tc.pA[c + 1] - tc.pA[c], nK = tc.pK[c + 1] - tc.pK[c], nS = tc.pS[c + 1] - tc.pS[c];
         if (nA == 0 || nK == 0 || nS == 0) continue;
-        const float invK = 1.0f / (float)nK, invS = 1.0f / (float)nS;
+        const float invK = tc.invK[c], invS = tc.invS[c];
         const int rows = max(1, tc.vcap / nK);
         const int4 *offA = sOffA + tc.pA[c], *offK = sOffK + tc.pK[c];
         const double *scA = sScA + tc.pA[c];
@@ -279,7 +315,7 @@ __global__ __launch_bounds__(256, TF_TEAM_OCC) void eri_team_kernel(DBasis B, TC
                 const double *Vr = sV + il * nK;
                 double acc = 0.0;
                 for (int e = sTp[kap]; e < sTp[kap + 1]; ++e) acc += sTc[e] * Vr[sTk[e]];
-                T2[(size_t)(row_first + offA[i0 + il].w) * (size_t)tc.RLS + doff] = acc * (pref * scA[i0 + il]);
+                T2[sRowOff[tc.pA[c] + i0 + il] + doff] = acc * (pref * scA[i0 + il]);
             }
             team_sync<TEAM>();
         }

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, TF_TEAM_OCC) void eri_teamc_kernel(DBasis B, c
             for (int c = 0; c < 4; ++c) {
                 const int nA = tc.pA[c + 1] - tc.pA[c], nK = tc.pK[c + 1] - tc.pK[c];
                 if (nA == 0 || nK == 0) continue;
-                const float invK = 1.0f / (float)nK;
+                const float invK = tc.invK[c];
                 const int4 *offA = sOffA + tc.pA[c], *offK = sOffK + tc.pK[c];
                 for (int j = tl; j < nA * nK; j += TEAM) {
                     const int il = small_div(j, invK), kl = j - il * nK;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, TF_TEAM_OCC) void eri_teamc_kernel(DBasis B, c
         const int nA = tc.pA[c + 1] - tc.pA[c], nK = tc.pK[c + 1] - tc.pK[c], nS = tc.pS[c + 1] - tc.pS[c];
         if (nA == 0 || nK == 0) continue;
         if (nS > 0) {
-            const float invS = 1.0f / (float)nS;
+            const float invS = tc.invS[c];
             const int4 *offA = sOffA + tc.pA[c];
             const double *scA = sScA + tc.pA[c];
             for (int o = tl; o < nA * nS; o += TEAM) {
