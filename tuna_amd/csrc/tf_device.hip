@@ -839,7 +839,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
         for (int c = 0; c < 4; ++c) {
             jp.sfirst[c + 1] += jp.sfirst[c];
-            jp.bfirst[c + 1] = jp.bfirst[c] + (int)((H.NP[c] + 255) / 256);
+            jp.bfirst[c + 1] = jp.bfirst[c] + (int)((H.NP[c] + TF_JKR_THREADS - 1) / TF_JKR_THREADS);
         }
         // tasks (super-group, chunk) that have at least one step, longest first: the hardware dispatches workgroups in this order
         std::vector<int> steps;
@@ -2136,10 +2136,10 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
     R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.MC = ctx->hl.MC; R.MP = MP; R.planeI = S.planeI; R.planeJ = S.planeJ; R.nseg = T.nseg; R.jp = T.jp;
     R.Jt = ctx->d_Jt; R.sJt = (size_t)T.nseg * npr;
     R.DIc = DIc; R.sDIc = S.DIc; R.DIr = DIr; R.sDIr = S.DIr; R.DJc = DJc; R.sDJc = S.DJc; R.DJr = DJr; R.sDJr = S.DJr;
-    R.gfirst = T.d_gfirst; R.jptr = ctx->d_jptr; R.jrows = ctx->d_jrows;
+    R.gfirst = T.d_gfirst; R.jptr = ctx->d_jptr; R.jrows = ctx->d_jrows; R.row_ij = ctx->d_row_ij;
     for (int d = 0; d < ND; ++d) R.D[d] = dDout[d];
     const unsigned nblk = (unsigned)ND * ((unsigned)N * ((N + 127) / 128) + (unsigned)T.jp.bfirst[4] * T.nseg);
-    hipLaunchKernelGGL(jk_reduce_kernel, dim3(nblk), dim3(256), 0, st, R, L);
+    hipLaunchKernelGGL(jk_reduce_kernel, dim3(nblk), dim3(TF_JKR_THREADS), 0, st, R, L);
     return TF_OK;
 }
 }  // extern "C++"

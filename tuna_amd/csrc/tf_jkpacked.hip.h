@@ -766,13 +766,16 @@ __global__ __launch_bounds__(64 * TF_JKP_W, TF_JKP_STAGES > 2 ? 1 : (JKShape<ND>
 // Jt partial sums over the pair index q of class c: the super-groups of a class are sorted by descending original i, so those whose
 // rows reach the AO k of q are a prefix of the class's list (ke[a] is non-increasing along it).  Block (bx, by) of a
 // (sum_c ceil(NP[c] / 256), nseg) grid: segment by sums its slice of every class's list; out[by][q].
+#ifndef TF_JKR_THREADS
+#define TF_JKR_THREADS 256         // (measured: 1024-thread blocks, 16 slices, are slower: 0.41 against 0.34 ms of tail at N = 400) threads of a jk_reduce_kernel block: 64 lanes x TF_JKR_THREADS / 64 slices of the rows / groups of an index
+#endif
 struct JKJtPlan { int sfirst[5]; int bfirst[5]; };   // supers of class c: sfirst[c] .. sfirst[c + 1]; blocks of class c: bfirst[c] .. bfirst[c + 1]
 __device__ __forceinline__ void jt_reduce_block(int bx, int by, int nseg, const double *__restrict__ ypart, const JKSuper *__restrict__ supers,
                                                 const JKJtPlan &JP, const BLayout &L, double *__restrict__ out)
 {
     int c = 0;
     while (c < 3 && bx >= JP.bfirst[c + 1]) ++c;
-    const long long q = (long long)(bx - JP.bfirst[c]) * 256 + threadIdx.x;
+    const long long q = (long long)(bx - JP.bfirst[c]) * TF_JKR_THREADS + threadIdx.x;
     if (q >= bl_np(L, c)) return;
     const int kI = L.gk[bl_gbase(L, c) + (int)(q / TF_SEG_PAD)];
     const int a = L.clsI[kI], kap = kI - bl_cstart(L, a);
@@ -810,7 +813,7 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, c
                                                 const double *__restrict__ DJc, const double *__restrict__ DJr, int N, int MC, int MP,
                                                 size_t planeI, size_t planeJ,
                                                 const int *__restrict__ gfirst, const int *__restrict__ jptr, const int *__restrict__ jrows,
-                                                double *__restrict__ D)
+                                                const int *__restrict__ origI, const int2 *__restrict__ row_ij, double *__restrict__ D)
 {
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int y = bx * 128 + 2 * lane;
@@ -818,14 +821,19 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, c
     const bool two = ((N & 1) == 0) && y + 1 < N;           // 16-byte loads need even row strides
     double2 s = make_double2(0.0, 0.0);
     if (y < N) {
+        // A row (i, j) holds values (ij|kl) with k <= i, l <= k in ORIGINAL order, so its partial sums at an index above i were never
+        // written (they are the zeros of the allocation): those rows / groups are skipped -- the same sums, half of the bytes.
+        const int yo = (y + 1 < N) ? min(origI[y], origI[y + 1]) : origI[y];
+        const bool groups_reach = origI[x] >= yo;
         for (int pass = 0; pass < (two || y + 1 >= N ? 1 : 2); ++pass) {
             const int yy = y + pass;
             double2 acc = make_double2(0.0, 0.0);
-            for (int g0 = gfirst[x] + sl, ge = gfirst[N + x]; g0 < ge; g0 += 16) {
+            constexpr int NSL = TF_JKR_THREADS / 64;                   // slices
+            for (int g0 = gfirst[x] + sl, ge = groups_reach ? gfirst[N + x] : 0; g0 < ge; g0 += 4 * NSL) {
                 double2 t[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int g = g0 + 4 * u;
+                    const int g = g0 + NSL * u;
                     t[u] = (g < ge) ? kd_vec(DIc + (size_t)g * N, DIr + (size_t)g * RS, N, MC, yy, two) : make_double2(0.0, 0.0);
                     for (int pl = 1; pl < MP; ++pl)                 // column parts of the further parts of a cut walk
                         if (g < ge) { const double2 v = kd_vec(DIc + pl * planeI + (size_t)g * N, DIr, N, 0, yy, two); t[u].x += v.x; t[u].y += v.y; }
@@ -833,12 +841,13 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, c
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { acc.x += t[u].x; acc.y += t[u].y; }
             }
-            for (int p0 = jptr[x] + sl, pe = jptr[x + 1]; p0 < pe; p0 += 16) {
+            for (int p0 = jptr[x] + sl, pe = jptr[x + 1]; p0 < pe; p0 += 4 * NSL) {
                 double2 t[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int p = p0 + 4 * u;
-                    const int r = (p < pe) ? jrows[p] : -1;
+                    const int p = p0 + NSL * u;
+                    int r = (p < pe) ? jrows[p] : -1;
+                    if (r >= 0 && row_ij[r].x < yo) r = -1;              // (the row's first index lies below both columns)
                     t[u] = (r >= 0) ? kd_vec(DJc + (size_t)r * N, DJr + (size_t)r * RS, N, MC, yy, two) : make_double2(0.0, 0.0);
                     for (int pl = 1; pl < MP; ++pl)
                         if (r >= 0) { const double2 v = kd_vec(DJc + pl * planeJ + (size_t)r * N, DJr, N, 0, yy, two); t[u].x += v.x; t[u].y += v.y; }
@@ -852,9 +861,10 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, c
     sPart[threadIdx.x] = s;
     __syncthreads();
     if (sl == 0 && y < N) {
-        const double2 a0 = sPart[lane], a1 = sPart[64 + lane], a2 = sPart[128 + lane], a3 = sPart[192 + lane];
-        D[(size_t)x * N + y] = ((a0.x + a1.x) + a2.x) + a3.x;
-        if (y + 1 < N) D[(size_t)x * N + y + 1] = ((a0.y + a1.y) + a2.y) + a3.y;
+        double2 a = sPart[lane];
+        for (int q = 1; q < TF_JKR_THREADS / 64; ++q) { const double2 b = sPart[64 * q + lane]; a.x += b.x; a.y += b.y; }   // fixed order
+        D[(size_t)x * N + y] = a.x;
+        if (y + 1 < N) D[(size_t)x * N + y + 1] = a.y;
     }
 }
 
@@ -866,15 +876,16 @@ struct JKReduce {
     double *Jt, *D[2];
     const JKSuper *supers;
     const int *gfirst, *jptr, *jrows;
+    const int2 *row_ij;                                  // original (i, j) of the local rows
     int MC, MP;                                          // slots of a row part vector: most chunks of one class; parts of a walk
     size_t planeI, planeJ;                               // between the column-part planes of the parts
     JKJtPlan jp;
     size_t sy, sJt, sDIc, sDIr, sDJc, sDJr;              // strides between densities
     int nseg;
 };
-__global__ __launch_bounds__(256) void jk_reduce_kernel(JKReduce R, BLayout L)
+__global__ __launch_bounds__(TF_JKR_THREADS) void jk_reduce_kernel(JKReduce R, BLayout L)
 {
-    __shared__ double2 sPart[256];
+    __shared__ double2 sPart[TF_JKR_THREADS];
     const int gxK = (L.N + 127) / 128, nK = L.N * gxK;
     const int gxJ = R.jp.bfirst[4], nJ = gxJ * R.nseg;
     int b = blockIdx.x;
@@ -882,7 +893,7 @@ __global__ __launch_bounds__(256) void jk_reduce_kernel(JKReduce R, BLayout L)
     b -= d * (nK + nJ);
     if (b < nK)
         kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, L.N, R.MC, R.MP,
-                        R.planeI, R.planeJ, R.gfirst, R.jptr, R.jrows, R.D[d]);
+                        R.planeI, R.planeJ, R.gfirst, R.jptr, R.jrows, L.origI, R.row_ij, R.D[d]);
     else {
         b -= nK;
         jt_reduce_block(b % gxJ, b / gxJ, R.nseg, R.ypart + d * R.sy, R.supers, R.jp, L, R.Jt + d * R.sJt);
