@@ -32,8 +32,9 @@ for rep in range(2):
         # name = library variant, or VAR=value to run the base library with that environment variable (e.g. TF_ERI_FACT_THREADS=256)
         env = dict(os.environ)
         if "=" in name:
-            k, v = name.split("=", 1)
-            env[k] = v
+            for kv in name.split(","):                                  # VAR=value[,VAR2=value2...]
+                k, v = kv.split("=", 1)
+                env[k] = v
             lib = os.path.join(ROOT, "tuna_amd", "libtunafock.so")
         else:
             lib = os.path.join(ROOT, "tuna_amd", "libtunafock.so" if name == "base" else f"libtunafock_{name}.so")

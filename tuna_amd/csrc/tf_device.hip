@@ -1192,12 +1192,16 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             auto vcap_of = [&](int tm) { return flat_for(tm) ? even(std::max(scr1, nnzc)) : even(std::max(scr1, std::max(maxK, std::min(maxblk, vmax_of(tm))))); };
             auto team_doubles_of = [&](int tm) { return 2 * t.nT * XS + vcap_of(tm) + even((t.nkap + 1) / 2); };
             auto bytes_of = [&](int tm) { return ((size_t)shared_noflat + (flat_for(tm) ? flat_doubles : 0) + (size_t)(256 / tm) * team_doubles_of(tm)) * sizeof(double); };
-            // lanes per quartet: 16 for the smallest classes; a wave while four quartets' tables fit a third of the LDS (three workgroups per
-            // CU); the whole workgroup beyond
+            // lanes per quartet: 16 for the smallest classes; a wave while four quartets' tables fit about half of the LDS (two workgroups per
+            // CU); the whole workgroup beyond.  (Measured at N = 400, ERI kernels: 36 / 52 / 76 / 100 KB limit: 35.3 / 32.8 / 31.9 / 33 ms.)
             static const int force_team = getenv("TF_ERI_TEAM_SIZE") ? atoi(getenv("TF_ERI_TEAM_SIZE")) : 0;
+            static const int lds_kb = getenv("TF_TEAM_LDS_KB") ? atoi(getenv("TF_TEAM_LDS_KB")) : 76;
+            static const int t16_nnz = getenv("TF_TEAM16_NNZ") ? atoi(getenv("TF_TEAM16_NNZ")) : 96;
+            static const long long kpw_div = getenv("TF_TEAM_KPW_DIV") ? atoll(getenv("TF_TEAM_KPW_DIV")) : 2048;
+            static const long long kpw_max = getenv("TF_TEAM_KPW_MAX") ? atoll(getenv("TF_TEAM_KPW_MAX")) : 16;
             int team = 0;
-            if (t.nT <= 16 && nnzc <= 96 && eri_team_available(LAB, LCD, 16)) team = 16;
-            else if (eri_team_available(LAB, LCD, 64) && bytes_of(64) <= 52 * 1024) team = 64;
+            if (t.nT <= 16 && nnzc <= t16_nnz && eri_team_available(LAB, LCD, 16)) team = 16;
+            else if (eri_team_available(LAB, LCD, 64) && bytes_of(64) <= (size_t)lds_kb * 1024) team = 64;
             else if (eri_team_available(LAB, LCD, 256) && bytes_of(256) <= 160 * 1024 - 256) team = 256;
             else if (eri_team_available(LAB, LCD, 64) && bytes_of(64) <= 160 * 1024 - 256) team = 64;
             if (force_team && eri_team_available(LAB, LCD, force_team) && bytes_of(force_team) <= 160 * 1024 - 256) team = force_team;
@@ -1206,9 +1210,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 t.vcap = vcap_of(team); t.team_doubles = team_doubles_of(team);
                 t.flat = flat_for(team) ? 1 : 0;
                 t.shared_doubles = shared_noflat + (t.flat ? flat_doubles : 0);
-                // a workgroup walks over several ket groups (shared staging once): enough workgroups to fill the chip, at most 8 groups each
+                // a workgroup walks over several ket groups (shared staging once): enough workgroups to fill the chip, at most 16 groups each
+                // (measured at N = 400, ERI kernels: >= 65536 / 16384 / 4096 / 2048 / 1024 / 512 workgroups per launch aimed at:
+                // 36.0 / 32.8 / 28.3 / 26.8 / 26.5-27.1 / 27.9 ms)
                 const long long groups = (q.n_ket + NT - 1) / NT;
-                const long long kpw = std::max<long long>(1, std::min<long long>(8, groups * n_bra / 16384));
+                const long long kpw = std::max<long long>(1, std::min<long long>(kpw_max, groups * n_bra / kpw_div));
                 TeamLaunch a{LAB, LCD, team, dim3((unsigned)((groups + kpw - 1) / kpw), n_bra), bytes_of(team), st, &ctx->db, &t,
                              d_brarec + (d_bra - d_bra_base), d_ketrec + ket_off[kcls], d_kcnt + (size_t)kcls * nsh, d_out_slab};
                 const hipError_t e = eri_team_launch(a);
