@@ -125,6 +125,8 @@ struct tf_ctx {
     hipStream_t streams[NSTREAM_MAX] = {};
     hipEvent_t sev[NSTREAM_MAX] = {};
     bool have_streams = false;
+    hipStream_t cstream = nullptr;            // uploads of a slab's index lists (beside the kernels of the previous slab)
+    hipEvent_t slab_done[2] = {nullptr, nullptr}, slab_lists[2] = {nullptr, nullptr};
     size_t cfact_lds_set = 0;                // dynamic LDS limit requested for eri_cfact_kernel
     tfk::LRec *d_lrec = nullptr;             // per-(La,Lb|Lc,Ld) records and entry index words of eri_cfact_kernel (per build)
     unsigned short *d_tup = nullptr;
@@ -761,9 +763,16 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     if (packed) {
         // owned rows in ascending internal (sigma(i), sigma(j)): rows that share i and the class of j are adjacent (the row groups of the
         // J/K kernel); rowmap is keyed by the unordered pair of internal indices
-        std::sort(row_ij.begin(), row_ij.end(), [&](const int2 &u, const int2 &v) {
-            return H.sigma[u.x] != H.sigma[v.x] ? H.sigma[u.x] < H.sigma[v.x] : H.sigma[u.y] < H.sigma[v.y];
-        });
+        {
+            // (the keys sigma(i) N + sigma(j) are distinct: one pass over the N^2 key space instead of a comparison sort -- 3 ms at N = 400)
+            std::vector<int> slot((size_t)N * N, -1);
+            for (size_t r = 0; r < row_ij.size(); ++r) slot[(size_t)H.sigma[row_ij[r].x] * N + H.sigma[row_ij[r].y]] = (int)r;
+            std::vector<int2> sorted;
+            sorted.reserve(row_ij.size());
+            for (size_t k = 0; k < slot.size(); ++k)
+                if (slot[k] >= 0) sorted.push_back(row_ij[(size_t)slot[k]]);
+            row_ij.swap(sorted);
+        }
         std::fill(rowmap.begin(), rowmap.end(), -1);
         rowoff.assign(row_ij.size() + 1, 0);
         rowsec.assign(6 * row_ij.size() + 6, 0);
@@ -908,6 +917,15 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     }
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
     if (packed) {
+        if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, rowsec, &ctx->d_rowsec, false))) return rc;
+        ctx->db.bl = ctx->bl;
+        ctx->db.RLS = H.RLS;
+    }
+    // The tables only the CONSUMERS of the tensor need (work tables of the J/K kernel, reduction lists, rows by class) are built on the
+    // host while the generation kernels run: called behind the launches of the last slab (7 ms of host time at N = 400).
+    auto consumer_tables = [&]() -> int {
+        if (!packed) return TF_OK;
+        int rc2;
         {
             // rows listed class by class (the AO->MO transformation works on one class at a time: a row of class c is nonzero only in
             // the blocks (k of class a) x (l of class a ^ c))
@@ -919,13 +937,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                     if ((H.cls[row_ij[r].x] ^ H.cls[row_ij[r].y]) == c) { row_pos[r] = (int)class_rows.size(); class_rows.push_back((int)r); }
             }
             ctx->class_row_off[4] = (long long)class_rows.size();
-            if ((rc = upload(ctx, class_rows, &ctx->d_class_rows, false)) || (rc = upload(ctx, row_pos, &ctx->d_row_pos, false))) return rc;
+            if ((rc2 = upload(ctx, class_rows, &ctx->d_class_rows, false)) || (rc2 = upload(ctx, row_pos, &ctx->d_row_pos, false))) return rc2;
         }
-        if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, rowsec, &ctx->d_rowsec, false)) ||
-            (rc = build_jk_tables(JKShape<1>::RB, ctx->jkt[0])) || (rc = build_jk_tables(JKShape<2>::RB, ctx->jkt[1])))
-            return rc;
-        ctx->db.bl = ctx->bl;
-        ctx->db.RLS = H.RLS;
+        if ((rc2 = build_jk_tables(JKShape<1>::RB, ctx->jkt[0])) || (rc2 = build_jk_tables(JKShape<2>::RB, ctx->jkt[1]))) return rc2;
         // reduction table: the rows (z, x), z != x, listed by their second index x (internal)
         std::vector<int> jptr((size_t)N + 1, 0), jrows;
         for (size_t r = 0; r < row_ij.size(); ++r) {
@@ -941,8 +955,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 if (iI != jI) jrows[fill[jI]++] = (int)r;
             }
         }
-        if ((rc = upload(ctx, jptr, &ctx->d_jptr, false)) || (rc = upload(ctx, jrows, &ctx->d_jrows, false))) return rc;
-    }
+        if ((rc2 = upload(ctx, jptr, &ctx->d_jptr, false)) || (rc2 = upload(ctx, jrows, &ctx->d_jrows, false))) return rc2;
+        return TF_OK;
+    };
 
     DBG("rows=%lld N=%d ld=%d (tensor + row tables allocated)", ctx->n_rows, N, ld);
     // ---- slabs of bra pairs: Cartesian block -> ket transform -> bra transform -> tensor rows
@@ -1070,6 +1085,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->streams[k], hipStreamNonBlocking));
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->sev[k], hipEventDisableTiming));
         }
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->cstream, hipStreamNonBlocking));
+        for (auto &e : ctx->slab_done) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : ctx->slab_lists) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->have_streams = true;
     }
     hipStream_t *streams = ctx->streams;
@@ -1643,12 +1661,18 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     const size_t cap_out = (size_t)std::min<long long>(ctx->n_rows, max_rows_c * 2 + (long long)max_out) + 1;
     int *d_bra = nullptr; long long *d_braoff = nullptr; void *d_out = nullptr;
     signed char *d_rowcls = nullptr;                               // parity class of every slab row (small-problem mode, packed layout)
-    HIPCHK(ctx, hipMalloc((void **)&d_bra, cap_bra * sizeof(int)));
-    HIPCHK(ctx, hipMalloc((void **)&d_braoff, cap_bra * sizeof(long long)));
-    if (use_team_pc) HIPCHK(ctx, hipMalloc((void **)&d_brarec, cap_bra * sizeof(BraRec)));
+    // two sets of a slab's index lists: the lists of slab k + 1 are uploaded (on a stream of their own) while the kernels of slab k run;
+    // the kernels themselves stay ordered by the streams (one half-transformed slab)
+    const size_t out_bytes = cap_out * std::max(sizeof(OutRow), sizeof(OutRowP)), rowcls_bytes = (size_t)max_rows_c + 1;
+    HIPCHK(ctx, hipMalloc((void **)&d_bra, 2 * cap_bra * sizeof(int)));
+    HIPCHK(ctx, hipMalloc((void **)&d_braoff, 2 * cap_bra * sizeof(long long)));
+    if (use_team_pc) HIPCHK(ctx, hipMalloc((void **)&d_brarec, 2 * cap_bra * sizeof(BraRec)));
+    HIPCHK(ctx, hipMalloc((void **)&d_out, 2 * out_bytes));
+    if (packed && !per_class) HIPCHK(ctx, hipMalloc((void **)&d_rowcls, 2 * rowcls_bytes));
+    int *const d_bra_alloc = d_bra; long long *const d_braoff_alloc = d_braoff; void *const d_out_alloc = d_out;
+    BraRec *const d_brarec_alloc = d_brarec; signed char *const d_rowcls_alloc = d_rowcls;
     d_bra_base = d_bra;
-    HIPCHK(ctx, hipMalloc((void **)&d_out, cap_out * std::max(sizeof(OutRow), sizeof(OutRowP))));
-    if (packed && !per_class) HIPCHK(ctx, hipMalloc((void **)&d_rowcls, (size_t)max_rows_c + 1));
+    long long slab_no = 0;
     std::vector<hipEvent_t> tev;                                   // 4 timing events per slab, read at the end
     std::vector<hipEvent_t> tev2;                                  // 2 per slab around the task-list team kernels (they count as ERI kernels)
     // ---- small-problem mode with team kernels (eri_teamc_kernel): class records per (bra class, ket class), created on demand; tasks
@@ -1744,22 +1768,32 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             }
             ++cursor;
         }
-        // the previous slab's kernels (stream 0 and the class streams) read these buffers: drain before overwriting
-        HIPCHK(ctx, hipDeviceSynchronize());
-        HIPCHK(ctx, hipMemcpy(d_bra, bra.data(), bra.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(ctx, hipMemcpy(d_braoff, braoff.data(), braoff.size() * sizeof(long long), hipMemcpyHostToDevice));
+        // this set of index lists was last read by the kernels of the slab before the previous one: wait for that slab only
+        const int set = (int)(slab_no & 1);
+        if (slab_no >= 2) HIPCHK(ctx, hipEventSynchronize(ctx->slab_done[set]));
+        d_bra = d_bra_alloc + (size_t)set * cap_bra; d_braoff = d_braoff_alloc + (size_t)set * cap_bra;
+        d_out = (char *)d_out_alloc + (size_t)set * out_bytes;
+        if (d_brarec_alloc) d_brarec = d_brarec_alloc + (size_t)set * cap_bra;
+        if (d_rowcls_alloc) d_rowcls = d_rowcls_alloc + (size_t)set * rowcls_bytes;
+        d_bra_base = d_bra;
+        ++slab_no;
+        const hipStream_t cst = ctx->cstream;
+        HIPCHK(ctx, hipMemcpyAsync(d_bra, bra.data(), bra.size() * sizeof(int), hipMemcpyHostToDevice, cst));
+        HIPCHK(ctx, hipMemcpyAsync(d_braoff, braoff.data(), braoff.size() * sizeof(long long), hipMemcpyHostToDevice, cst));
+        std::vector<BraRec> brec;
         if (use_team_pc) {
-            std::vector<BraRec> brec(bra.size());
+            brec.resize(bra.size());
             for (size_t k = 0; k < bra.size(); ++k) {
                 const tf::Pair &pr = bs.pairs[bra[k]];
                 const double pp = bs.pp_p[pr.pp_off];
                 brec[k] = BraRec{pp, bs.pp_Pz[pr.pp_off], bs.pp_K[pr.pp_off] / pp, (unsigned)pr.e_off, pr.A, braoff[k], 0};
             }
-            HIPCHK(ctx, hipMemcpy(d_brarec, brec.data(), brec.size() * sizeof(BraRec), hipMemcpyHostToDevice));
+            HIPCHK(ctx, hipMemcpyAsync(d_brarec, brec.data(), brec.size() * sizeof(BraRec), hipMemcpyHostToDevice, cst));
         }
-        if (!outs.empty()) HIPCHK(ctx, hipMemcpy(d_out, outs.data(), outs.size() * sizeof(OutRow), hipMemcpyHostToDevice));
-        if (!outsP.empty()) HIPCHK(ctx, hipMemcpy(d_out, outsP.data(), outsP.size() * sizeof(OutRowP), hipMemcpyHostToDevice));
-        if (!rowcls.empty()) HIPCHK(ctx, hipMemcpy(d_rowcls, rowcls.data(), rowcls.size(), hipMemcpyHostToDevice));
+        if (!outs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_out, outs.data(), outs.size() * sizeof(OutRow), hipMemcpyHostToDevice, cst));
+        if (!outsP.empty()) HIPCHK(ctx, hipMemcpyAsync(d_out, outsP.data(), outsP.size() * sizeof(OutRowP), hipMemcpyHostToDevice, cst));
+        if (!rowcls.empty()) HIPCHK(ctx, hipMemcpyAsync(d_rowcls, rowcls.data(), rowcls.size(), hipMemcpyHostToDevice, cst));
+        HIPCHK(ctx, hipStreamSynchronize(cst));                // (pageable sources: the copies are complete; the host vectors may go)
         DBG("slab: %zu bra pairs, %lld cart rows, %zu out rows", bra.size(), rows_c, outs.size() + outsP.size());
         hipEvent_t e4[4];
         for (auto &e : e4) { HIPCHK(ctx, hipEventCreate(&e)); tev.push_back(e); }
@@ -1914,8 +1948,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             }
         }
         HIPCHK(ctx, hipEventRecord(e4[3], 0));
+        HIPCHK(ctx, hipEventRecord(ctx->slab_done[set], 0));
     }
     DBG("all slabs launched (%d class launches)", launch_count);
+    if ((rc = consumer_tables())) { (void)hipDeviceSynchronize(); return rc; }
+    DBG("consumer tables built");
     HIPCHK(ctx, hipDeviceSynchronize());
     DBG("device drained");
     HIPCHK(ctx, hipGetLastError());
@@ -1930,8 +1967,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     }
     for (hipEvent_t e : tev) (void)hipEventDestroy(e);
     for (hipEvent_t e : tev2) (void)hipEventDestroy(e);
-    (void)hipFree(d_bra); (void)hipFree(d_braoff); (void)hipFree(d_out);
-    if (d_rowcls) (void)hipFree(d_rowcls);
+    (void)hipFree(d_bra_alloc); (void)hipFree(d_braoff_alloc); (void)hipFree(d_out_alloc);
+    if (d_rowcls_alloc) (void)hipFree(d_rowcls_alloc);
+    d_brarec = d_brarec_alloc;
     (void)hipFree(d_kets); (void)hipFree(d_kets_all);
     for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c, (void *)d_ketrec, (void *)d_brarec, (void *)d_kcnt,
                      (void *)d_tcs, (void *)d_tasks, (void *)d_tflat})
