@@ -100,6 +100,31 @@ def test_lockstep_cycles_equal_cycles_run_one_by_one(engine):
     assert abs(Ee[0] - Eb[0]) < 1e-9
 
 
+def test_lockstep_batch_reports_cycles_that_do_not_converge(engine):
+    """tf_scf_rhf_batch: cycles that run out of iterations end with the reference's message (scf:1435) and their partial results, and
+    nobody is left waiting in a Fock build (the call returns); the same batch with enough iterations converges afterwards."""
+    from tuna_amd._lib import TunaError
+    from tuna_amd.scf import _opts
+    g = FIELDS["hf_631g"]
+    molecule, calc, integrals, V_NN, X, guess = _setup(engine, g)
+    P, _, _, E = guess
+    h = g["steps"][1]
+    fields = ([0, 0, h], [0, 0, -h], [h, 0, 0])
+    terms = [props.apply_electric_field(integrals.D, f) for f in fields]
+    o = _opts(calc)
+    o["max_iter"] = 3
+    with pytest.raises(TunaError, match="not converged in 3 iterations") as e:
+        engine.scf_rhf_batch(integrals.S, integrals.T, integrals.V_NE, [P] * 3, [E] * 3, molecule.n_doubly_occ, V_NN, X=X, Fexts=terms,
+                             n_atom_ao=molecule.partition_ranges, **o)
+    part = e.value.partial
+    assert [r["rc"] for r in part] == [-4, -4, -4] and all(r["n_iter"] == 3 and not r["converged"] for r in part)
+    o["max_iter"] = 100
+    res = engine.scf_rhf_batch(integrals.S, integrals.T, integrals.V_NE, [P] * 3, [E] * 3, molecule.n_doubly_occ, V_NN, X=X, Fexts=terms,
+                               n_atom_ao=molecule.partition_ranges, **o)
+    ref = props.FieldEnergies(molecule, calc, integrals, V_NN, X, guess, batched=False).energies(fields)
+    assert all(r["converged"] for r in res) and max(abs(r["energy"] - x) for r, x in zip(res, ref)) < 1e-9
+
+
 def test_polarisability_input_line(engine):
     """`SPE : F H 0.917 : HF 6-31G : POLAR COREGUESS` -- the reference's keyword (calc:139) and its EXTREME default for second derivatives."""
     from tuna_amd.energy import run
