@@ -48,6 +48,64 @@ def test_mixed_orbital_blocks_against_oracle(engine):
     assert np.abs(engine.ao_to_mo(C1, C2, C3, C4) - ref).max() < 1e-11
 
 
+@pytest.mark.parametrize("n3", [1, 7, 16, 18, 31, 32, 33])
+def test_first_quarter_kernel_against_the_einsum_and_the_block_path(engine, n3, monkeypatch):
+    """tfmp2::mo_q1_kernel (hand-written MFMA-f64 first quarter on the packed segments, taken when the first ket coefficient matrix has at most
+    32 columns): one and two column tiles, odd widths, the edge 32 | 33, against the NumPy einsum of the engine's own dense tensor (pinned
+    to the oracle elsewhere) and against the expanded-block path (TF_MO_Q1=0) on N2/cc-pVTZ (N = 60, all four parity classes, f shells)."""
+    atoms, shells, aos, nocc = make_system("c2_n2_ccpvtz")
+    engine.set_basis(aos).build_eri(True)
+    E = engine.copy_eri()
+    rng = np.random.default_rng(10 + n3)
+    N = engine.N
+    C1, C2, C3, C4 = rng.standard_normal((N, 5)), rng.standard_normal((N, 9)), rng.standard_normal((N, n3)), rng.standard_normal((N, 11))
+    ref = np.einsum("mnls,mp,nq,lr,st->pqrt", E, C1, C2, C3, C4, optimize=True)
+    scale = np.abs(ref).max()
+    monkeypatch.delenv("TF_MO_Q1", raising=False)
+    fast = engine.ao_to_mo(C1, C2, C3, C4)
+    assert np.abs(fast - ref).max() < 1e-12 * max(1.0, scale)
+    monkeypatch.setenv("TF_MO_Q1", "0")
+    blocks = engine.ao_to_mo(C1, C2, C3, C4)
+    assert np.abs(blocks - ref).max() < 1e-12 * max(1.0, scale)
+    assert np.abs(fast - blocks).max() < 1e-12 * max(1.0, scale)
+    # the same matrices on both sides (the (ia|jb) case: one transformation serves both halves of the tensor)
+    monkeypatch.delenv("TF_MO_Q1", raising=False)
+    if n3 <= 18:
+        same = engine.ao_to_mo(C3, C2, C3, C2)
+        ref2 = np.einsum("mnls,mp,nq,lr,st->pqrt", E, C3, C2, C3, C2, optimize=True)
+        assert np.abs(same - ref2).max() < 1e-12 * max(1.0, np.abs(ref2).max())
+
+
+def test_first_quarter_kernel_with_wide_classes(engine, monkeypatch):
+    """N = 200 (81 / 48 / 48 / 23 AOs per parity class): blocks of 16 output AOs per class in numbers, walks of several pipelined passes in
+    both images, rows of every length.  The dense copy of the GPU tensor (pinned block-wise to the oracle by the parity tests) through the
+    reference's einsum (tuna_ci.py:204-255, contracted in NumPy in a cheaper order) against tf_ao_to_mo on both paths."""
+    counts = mol.synthetic_counts(200)
+    atoms = mol.make_atoms(["AR", "AR"], 7.1)
+    aos = mol.expand_cartesian_aos(mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)}))
+    engine.set_basis(aos).build_eri(True, layout="packed")
+    N = engine.N
+    E = engine.copy_eri()
+    rng = np.random.default_rng(5)
+    C1, C2, C3, C4 = rng.standard_normal((N, 4)), rng.standard_normal((N, 6)), rng.standard_normal((N, 18)), rng.standard_normal((N, 7))
+    t = np.tensordot(E, C3, axes=([2], [0]))                    # [m n s r]
+    t = np.tensordot(t, C4, axes=([2], [0]))                    # [m n r t]
+    t = np.tensordot(C1, t, axes=([0], [0]))                    # [p n r t]
+    ref = np.tensordot(C2, t, axes=([0], [1])).transpose(1, 0, 2, 3)
+    monkeypatch.delenv("TF_MO_Q1", raising=False)
+    fast = engine.ao_to_mo(C1, C2, C3, C4)
+    assert np.abs(fast - ref).max() < 1e-11 * np.abs(ref).max()
+    monkeypatch.setenv("TF_MO_Q1", "0")
+    assert np.abs(engine.ao_to_mo(C1, C2, C3, C4) - ref).max() < 1e-11 * np.abs(ref).max()
+    monkeypatch.delenv("TF_MO_Q1", raising=False)
+    Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    eps = np.concatenate([-np.arange(18, 0, -1.0), np.arange(1.0, N - 18 + 1)])
+    r1 = engine.mp2_rhf(Q, eps, 18)
+    monkeypatch.setenv("TF_MO_Q1", "0")
+    r0 = engine.mp2_rhf(Q, eps, 18)
+    assert abs(r1["E_OS"] - r0["E_OS"]) < 1e-10 * abs(r0["E_OS"]) and abs(r1["E_SS"] - r0["E_SS"]) < 1e-10 * abs(r0["E_SS"])
+
+
 def test_scf_then_mp2_end_to_end(engine, mp2_golden):
     """Own orbitals (native RHF on the GPU) -> RMP2: total energy of BASELINE config 5, N2 MP2/cc-pVTZ."""
     from tuna_amd.energy import run

@@ -135,6 +135,8 @@ struct tf_ctx {
     size_t gtab_bytes = 0;
     double *scr[3] = {nullptr, nullptr, nullptr};
     size_t scr_bytes[3] = {0, 0, 0};
+    double *mo_pool = nullptr;               // work space of the short-index-first AO->MO transformation (tfmp2::transform_q1), kept across calls
+    size_t mo_pool_bytes = 0;
 };
 
 static int ensure_scratch(tf_ctx *ctx, int k, size_t bytes)
@@ -473,6 +475,7 @@ void tf_destroy(tf_ctx *ctx)
         for (int k = 0; k < tf_ctx::NSTREAM_MAX; ++k) { (void)hipStreamDestroy(ctx->streams[k]); (void)hipEventDestroy(ctx->sev[k]); }
     for (int k = 0; k < 3; ++k)
         if (ctx->scr[k]) (void)hipFree(ctx->scr[k]);
+    if (ctx->mo_pool) (void)hipFree(ctx->mo_pool);
     if (ctx->d_jkstage) (void)hipFree(ctx->d_jkstage);
     if (ctx->d_agree) (void)hipFree(ctx->d_agree);
     if (ctx->d_lrec) (void)hipFree(ctx->d_lrec);
@@ -2642,8 +2645,30 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
         if (hipMemcpy(dC[k], hC[k], (size_t)N * nk[k] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation: copy failed");
     }
     if (hipMalloc((void **)d_out, total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+    // the short index first: a ket coefficient matrix of at most 32 columns (the occupied orbitals of (ia|jb)) goes through the hand-written
+    // first quarter on the packed segments (tfmp2::mo_q1_kernel); TF_MO_Q1=0 keeps the expanded-block path (A/B, tests)
+    const char *q1env = getenv("TF_MO_Q1");
+    const bool q1_allowed = packed && !(q1env && q1env[0] == '0');
     auto run = [&](int a, int b, int c, int d, double *dst) {
         double s1 = 0.0;
+        if (q1_allowed && nk[c] <= 32) {
+            const size_t need = tfmp2::q1_pool_doubles(N, nk[a], nk[c], nk[d]) * sizeof(double);
+            size_t free_b = 0, total_b = 0;
+            const bool fits = need <= ctx->mo_pool_bytes || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) <= free_b + ctx->mo_pool_bytes);
+            if (fits) {
+                if (need > ctx->mo_pool_bytes) {
+                    if (ctx->mo_pool) { (void)hipFree(ctx->mo_pool); ctx->mo_pool = nullptr; ctx->mo_pool_bytes = 0; }
+                    if (hipMalloc((void **)&ctx->mo_pool, need) == hipSuccess) ctx->mo_pool_bytes = need;
+                    else { ctx->mo_pool = nullptr; (void)hipGetLastError(); }
+                }
+                if (ctx->mo_pool) {
+                    int r = tfmp2::transform_q1(ctx->scf.blas, ctx->d_eri, ctx->d_rowoff, ctx->d_rowsec, ctx->bl, ctx->d_row_ij, ctx->n_rows, N, dC[a], nk[a],
+                                                dC[b], nk[b], dC[c], nk[c], dC[d], nk[d], dst, ctx->mo_pool, ctx->world > 1, &s1, msg);
+                    secs += s1;
+                    return r;
+                }
+            }
+        }
         tfmp2::PackedRows pr{};
         if (packed) {
             for (int q = 0; q < 4; ++q) { pr.csize[q] = ctx->hl.csize[q]; pr.cstart[q] = ctx->hl.cstart[q]; pr.NP[q] = ctx->hl.NP[q]; }

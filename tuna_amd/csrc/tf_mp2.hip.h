@@ -87,6 +87,230 @@ __global__ void permute_rows_kernel(const double *__restrict__ C, const int *__r
     Ci[e] = C[(size_t)origI[x] * n + p];
 }
 
+// ---- hand-written first quarter on the packed rows (round 3) ---------------------------------------------------------------------
+// R[(mu nu)][sigma][p] = sum_lambda C3[lambda][p] Lsym[(mu nu)][lambda][sigma]   for the n3 <= 32 columns of C3 (the occupied orbitals of
+// an (ia|jb) transformation: tuna_ci.py:204-255 contracts a full index first, 2 N^5; contracting the SHORT index first leaves 2 o N^4
+// and a tensor 1/(N/o) the size).  Lsym = the stored part of the row as a symmetric matrix (unpack_own_rows_kernel above: pairs
+// (lambda sigma) <= (mu nu), the pair equal to (mu nu) halved).  The kernel reads the packed segments themselves -- 7 GB at N = 400
+// instead of 26 GB of expanded blocks -- on the FP64 matrix core (v_mfma_f64_16x16x4_f64), C3 as the B operand:
+//   * one workgroup (4 waves) per stored row; the output AOs sigma are cut into blocks of 16 of one parity class x, a block belongs to
+//     ONE wave, which accumulates both images of the stored triangle into the block's 16 x n3 tile:
+//       "column" image  R[l][p] += sum_k V[k][l] C3[k][p]   (k of class x ^ c walks the segments that reach the block's columns l),
+//       "row" image     R[k][p] += sum_l V[k][l] C3[l][p]   (the block's own 16 segments k, all their columns l; l == k skipped);
+//     so every value is loaded twice (the second time from L2: a row is ~90 KB) and nothing is ever merged between waves: no LDS,
+//     no atomics, one store per output element, bitwise reproducible;
+//   * operands go from global memory straight into the MFMA lane layout (A[row = lane & 15][k = lane >> 4]): the column image reads
+//     four segments x 128 contiguous bytes per instruction, the row image 16 segments x 64-byte runs (eight K steps per four loads);
+//   * the tile is written twice, to R[mu][nu] and R[nu][mu] (ORIGINAL bra indices, internal sigma), so that the bra half is three
+//     plain rocBLAS GEMMs on contiguous matrices (transform_q1 below).
+typedef double tfm_v4d __attribute__((ext_vector_type(4)));
+
+struct Q1Args {
+    const double *eri;
+    const long long *rowoff;
+    const int *rowsec;
+    const int2 *row_ij;            // original (i >= j) of every local row
+    const double *C3p;             // [N internal][16 NT]: C3 in internal AO order, columns padded with zeros
+    double *R;                     // [N][N][N][n3]
+    int n3;
+    int dbg;                       // timing experiments (TF_Q1_DBG bits: 1 no mirrored store, 2 no store, 4 no column image, 8 no row image)
+};
+
+// BLDS: C3 is staged in LDS ([N][n3r], n3r = n3 rounded up to even) once per workgroup, which then walks `rpw` consecutive rows -- the
+// B operands of every MFMA are then LDS reads; from global memory (L2) they were two thirds of the bytes through the texture
+// addresser, which ran at ~75 % for the four waves of a CU.  Without (N n3r doubles do not fit): B operands from C3p in global memory.
+template <int NT, bool BLDS>
+__global__ __launch_bounds__(256) void mo_q1_kernel(Q1Args Q, BLayout L, int n3r, int rpw, long long n_rows)
+{
+    extern __shared__ double sQ1[];
+    const int N = L.N;
+    int2 *sSeg = reinterpret_cast<int2 *>(sQ1);                     // [N]: per internal AO k: offset of its segment in this row's unit; columns it holds
+    double *sC3 = sQ1 + N;                                          // [N][n3r] (BLDS)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, kk = lane >> 4;
+    constexpr int NP = 16 * NT;
+    if (BLDS) {
+        for (int e = threadIdx.x; e < N * n3r; e += 256) { const int x = e / n3r, p = e - x * n3r; sC3[e] = Q.C3p[(size_t)x * NP + p]; }
+    }
+    bool colok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) colok[t] = 16 * t + m < n3r;
+  for (long long r = (long long)blockIdx.x * rpw; r < min(n_rows, ((long long)blockIdx.x + 1) * rpw); ++r) {
+    __syncthreads();                                                // (the previous row's table is dead; C3 is staged)
+    const int2 ij = Q.row_ij[r];
+    const int wi = L.ao[ij.x], wj = L.ao[ij.y];
+    const int c = ao_cls(wi) ^ ao_cls(wj), iI = ao_sigma(L, wi), lamj = ao_loc(wj);
+    const int *rs = Q.rowsec + 6 * (size_t)r;
+    const int unr = rs[5], pos = rs[4];
+    const double *__restrict__ T = Q.eri + Q.rowoff[r];
+    // segment table of the row: AOs beyond i (original order) hold nothing, the segment of k == i ends at l == j
+    {
+        const KInfo *__restrict__ kinf = L.kinfo + (size_t)c * N;
+        for (int kI = threadIdx.x; kI < N; kI += 256) {
+            const int a = L.clsI[kI];
+            const KInfo ki = kinf[kI];
+            const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);
+            const bool have = kI - bl_cstart(L, a) < L.cntA[(size_t)a * N + iI];
+            sSeg[kI] = make_int2(unr * (rs[a] + ki.offA) + pos * pc, have ? (kI == iI ? lamj + 1 : ki.cnt) : 0);
+        }
+    }
+    __syncthreads();
+    // blocks of 16 output AOs, class by class; wave w takes every fourth
+    int bfirst[5];
+    bfirst[0] = 0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) bfirst[x + 1] = bfirst[x] + (L.itab[BL_CSIZE + x] + 15) / 16;
+    for (int blk = w; blk < bfirst[4]; blk += 4) {
+        const int x = blk >= bfirst[3] ? 3 : (blk >= bfirst[2] ? 2 : (blk >= bfirst[1] ? 1 : 0));
+        const int s0 = 16 * (blk - (x == 3 ? bfirst[3] : (x == 2 ? bfirst[2] : (x == 1 ? bfirst[1] : 0))));
+        const int nx = L.itab[BL_CSIZE + x], x0 = bl_cstart(L, x);
+        const int a = x ^ c, a0 = bl_cstart(L, a), na = L.itab[BL_CSIZE + a];
+        tfm_v4d acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = tfm_v4d{0.0, 0.0, 0.0, 0.0};
+        // Both images run as software pipelines: the loads of the next pass are issued before the MFMAs of the current one, and the first
+        // pass of the row image before the column image starts (a wave has one or two partners on its SIMD, not enough to hide an HBM miss
+        // behind 16 MFMAs by occupancy alone).
+        // ---- row image: the block's own segments k = s0 .. s0 + 15 of class x, all their columns l of class x ^ c, l != k
+        const int klimR = L.cntA[(size_t)x * N + iI];
+        const bool have_row = s0 < klimR && !(Q.dbg & 8);
+        const int klR = s0 + m;
+        const bool vkR = have_row && klR < klimR;
+        const int kIR = x0 + (vkR ? klR : 0);
+        const int2 sgR = sSeg[kIR];
+        const int pcR = vkR ? ((sgR.y + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1)) : 0;   // (the slots between cnt and the pad hold zeros; so do those beyond l == j of k == i)
+        const double *__restrict__ segR = T + sgR.x;
+        int cmax = 0;                                                                // the longest segment of the block: its last one, or -- the
+        if (have_row) {                                                              // segment of k == i being cut at l == j -- the one before
+            const int last = min(s0 + 15, klimR - 1);
+            cmax = sSeg[x0 + last].y;
+            if (last > s0) cmax = max(cmax, sSeg[x0 + last - 1].y);
+        }
+        const bool diag_cls = c == 0;                                                // l and k are of one class: l == k <=> lam == kl
+        auto row_load = [&](int l0, double (&v)[8]) {
+            const int lb = l0 + 8 * kk;                                              // this lane's eight columns
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = lb + 2 * u < pcR;
+                const double2 t2 = in ? *reinterpret_cast<const double2 *>(segR + lb + 2 * u) : make_double2(0.0, 0.0);
+                v[2 * u] = t2.x; v[2 * u + 1] = t2.y;
+            }
+        };
+        auto row_mma = [&](int l0, double (&v)[8]) {
+            const int lb = l0 + 8 * kk;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int lam = lb + u;
+                if (lam >= sgR.y || (diag_cls && lam == klR)) v[u] = 0.0;
+                if (kIR == iI && lam == lamj) v[u] *= 0.5;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int lam = lb + u;
+                const bool vl = lam < na;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double b = BLDS ? ((vl && colok[t]) ? sC3[(a0 + (vl ? lam : 0)) * n3r + 16 * t + m] : 0.0)
+                                          : (vl ? Q.C3p[(size_t)(a0 + (vl ? lam : 0)) * NP + 16 * t + m] : 0.0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], b, acc[t], 0, 0, 0);
+                }
+            }
+        };
+        double rA[8], rB[8];
+        if (cmax > 0) row_load(0, rA);
+        // ---- column image: the segments k of class a = x ^ c that reach the columns s0 .. s0 + 15 of class x; a lane takes eight
+        //      consecutive k per pass (eight loads in flight, then eight K steps)
+        if (!(Q.dbg & 4)) {
+            const int klim = L.cntA[(size_t)a * N + iI];
+            // first member whose segment is longer than s0: cnt is non-decreasing, except that the segment of k == i (the last member when i is
+            // of this class) is cut at l == j -- it stays out of the search and is tested like every element (lam < cnt)
+            int lo = 0, hi = (klim > 0 && a0 + klim - 1 == iI) ? klim - 1 : klim;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (sSeg[a0 + mid].y > s0) hi = mid; else lo = mid + 1; }
+            const int lam = s0 + m;
+            auto col_load = [&](int kl0, double (&v)[8], int (&kIs)[8]) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kl = kl0 + 8 * kk + u;
+                    const bool vk = kl < klim;
+                    const int kI = a0 + (vk ? kl : 0);
+                    const int2 sg = sSeg[kI];
+                    const bool ok = vk && lam < sg.y;
+                    v[u] = ok ? __builtin_nontemporal_load(T + sg.x + lam) : 0.0;
+                    kIs[u] = vk ? kI : -1;
+                }
+            };
+            auto col_mma = [&](double (&v)[8], const int (&kIs)[8]) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (kIs[u] == iI && lam == lamj) v[u] *= 0.5;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const double b = BLDS ? ((kIs[u] >= 0 && colok[t]) ? sC3[kIs[u] * n3r + 16 * t + m] : 0.0)
+                                              : (kIs[u] >= 0 ? Q.C3p[(size_t)kIs[u] * NP + 16 * t + m] : 0.0);
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], b, acc[t], 0, 0, 0);
+                    }
+                }
+            };
+            int kl0 = lo & ~7;
+            if (kl0 < klim) {
+                double vA[8], vB[8];
+                int kA[8], kB[8];
+                col_load(kl0, vA, kA);
+                for (;;) {
+                    const int k1 = kl0 + 32;
+                    if (k1 < klim) col_load(k1, vB, kB);
+                    col_mma(vA, kA);
+                    if (k1 >= klim) break;
+                    const int k2 = k1 + 32;
+                    if (k2 < klim) col_load(k2, vA, kA);
+                    col_mma(vB, kB);
+                    if (k2 >= klim) break;
+                    kl0 = k2;
+                }
+            }
+        }
+        if (cmax > 0) {
+            int l0 = 0;
+            for (;;) {
+                const int l1 = l0 + 32;
+                if (l1 < cmax) row_load(l1, rB);
+                row_mma(l0, rA);
+                if (l1 >= cmax) break;
+                const int l2 = l1 + 32;
+                if (l2 < cmax) row_load(l2, rA);
+                row_mma(l1, rB);
+                if (l2 >= cmax) break;
+                l0 = l2;
+            }
+        }
+        // ---- the tile: rows sigma = x0 + s0 + 4 v + (lane >> 4), columns p = 16 t + (lane & 15); both bra orders
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) {
+            const int row = s0 + 4 * vv + kk;
+            if (row >= nx) continue;
+            const size_t sig = (size_t)(x0 + row);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int p = 16 * t + m;
+                if (p >= Q.n3) continue;
+                const double val = acc[t][vv];
+                if (!(Q.dbg & 2)) Q.R[(((size_t)ij.x * N + ij.y) * N + sig) * Q.n3 + p] = val;
+                if (ij.x != ij.y && !(Q.dbg & 3)) Q.R[(((size_t)ij.y * N + ij.x) * N + sig) * Q.n3 + p] = val;
+            }
+        }
+    }
+  }
+}
+
+// Cp[x][0 .. NP) = C[origI[x]][0 .. n) padded with zeros: coefficient rows in internal AO order, MFMA column tiles
+__global__ void permute_rows_padded_kernel(const double *__restrict__ C, const int *__restrict__ origI, int N, int n, int NP, double *__restrict__ Cp)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * NP) return;
+    const int x = e / NP, p = e - x * NP;
+    Cp[e] = p < n ? C[(size_t)origI[x] * n + p] : 0.0;
+}
+
 // host view of the packed layout for the transformation: class sizes / starts (internal order), pair spaces, rows listed by class
 struct PackedRows {
     int csize[4], cstart[4];
@@ -202,6 +426,72 @@ done:
     if (dQ) (void)hipFree(dQ);
     if (dQfull) (void)hipFree(dQfull);
     if (dW) (void)hipFree(dW);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// The packed-layout transformation with the short index first (n3 <= 32): first quarter by mo_q1_kernel, then three rocBLAS GEMMs
+//     T [p1][nu][sigma][p3]  = sum_mu C1[mu][p1] R[mu][nu][sigma][p3]                 (one GEMM, K = N)
+//     T2[p1][p2][sigma][p3]  = sum_nu C2[nu][p2] T[p1][nu][sigma][p3]                 (batched over p1)
+//     out[p1][p2][p3][p4]    = sum_sigma T2[p1][p2][sigma][p3] C4[sigma][p4]          (batched over (p1, p2))
+// on a caller-owned pool of q1_pool_doubles() doubles (kept by the context: no allocation per call).  Same contract as transform():
+// d_out is the transform of L (the stored part, its diagonal halved); rows the rank does not own contribute zeros (zero_R).
+inline size_t q1_pool_doubles(int N, int n1, int n3, int n4)
+{
+    const size_t NP = (size_t)16 * ((n3 + 15) / 16);
+    return (size_t)N * N * N * n3 + (size_t)n1 * N * N * n3 + (size_t)N * NP + (size_t)N * n4 + 64;
+}
+
+inline int transform_q1(rocblas_handle blas, const double *d_eri, const long long *d_rowoff, const int *d_rowsec, const BLayout &BL,
+                        const int2 *d_row_ij, long long n_rows, int N, const double *dC1, int n1, const double *dC2, int n2, const double *dC3,
+                        int n3, const double *dC4, int n4, double *d_out, double *pool, bool zero_R, double *seconds, std::string &msg)
+{
+    int rc = TF_OK;
+    const double one = 1.0, zero = 0.0;
+    const int NT = (n3 + 15) / 16, NP = 16 * NT;
+    const size_t X = (size_t)N * N * n3, Y = (size_t)N * n3;
+    double *dR = pool, *dT = dR + (size_t)N * X, *dC3p = dT + (size_t)n1 * X, *dC4i = dC3p + (size_t)N * NP, *dT2 = dR;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (X > 0x7fffffffULL || (size_t)n1 * n2 > 0x7fffffffULL) { msg = "AO->MO transformation: dimension overflow"; return TF_EINVAL; }
+    TFM_HIP(hipEventCreate(&e0));
+    TFM_HIP(hipEventCreate(&e1));
+    TFM_HIP(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(permute_rows_padded_kernel, dim3((unsigned)((N * NP + 255) / 256)), dim3(256), 0, 0, dC3, BL.origI, N, n3, NP, dC3p);
+    hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)((N * n4 + 255) / 256)), dim3(256), 0, 0, dC4, BL.origI, N, n4, dC4i);
+    if (zero_R) TFM_HIP(hipMemsetAsync(dR, 0, (size_t)N * X * sizeof(double), 0));
+    if (n_rows > 0) {
+        const char *dbg = getenv("TF_Q1_DBG");
+        Q1Args Q{d_eri, d_rowoff, d_rowsec, d_row_ij, dC3p, dR, n3, dbg ? atoi(dbg) : 0};
+        const int n3r = (n3 + 1) & ~1;
+        const size_t lds_tab = (size_t)N * sizeof(int2), lds_c3 = (size_t)N * n3r * sizeof(double);
+        const bool blds = lds_tab + lds_c3 <= (size_t)72 << 10;       // two workgroups per CU
+        const int rpw = blds ? 4 : 1;
+        const unsigned grid = (unsigned)((n_rows + rpw - 1) / rpw);
+        const size_t lds = lds_tab + (blds ? lds_c3 : 0);
+        if (lds > ((size_t)64 << 10)) {
+            TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (NT == 1 && blds) hipLaunchKernelGGL((mo_q1_kernel<1, true>), dim3(grid), dim3(256), lds, 0, Q, BL, n3r, rpw, n_rows);
+        else if (NT == 1) hipLaunchKernelGGL((mo_q1_kernel<1, false>), dim3(grid), dim3(256), lds, 0, Q, BL, n3r, rpw, n_rows);
+        else if (blds) hipLaunchKernelGGL((mo_q1_kernel<2, true>), dim3(grid), dim3(256), lds, 0, Q, BL, n3r, rpw, n_rows);
+        else hipLaunchKernelGGL((mo_q1_kernel<2, false>), dim3(grid), dim3(256), lds, 0, Q, BL, n3r, rpw, n_rows);
+        TFM_HIP(hipGetLastError());
+    }
+    // T (column-major X x n1) = R (X x N) * C1^T (N x n1)
+    TFM_BLAS(rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)X, n1, N, &one, dR, (rocblas_int)X, dC1, n1, &zero,
+                           dT, (rocblas_int)X));
+    // T2[p1] (Y x n2) = T[p1] (Y x N) * C2^T (N x n2)
+    TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)Y, n2, N, &one, dT, (rocblas_int)Y,
+                                           (rocblas_stride)N * Y, dC2, n2, 0, &zero, dT2, (rocblas_int)Y, (rocblas_stride)n2 * Y, n1));
+    // out[p1 p2] (n4 x n3) = C4i (n4 x N) * T2[p1 p2]^T (N x n3)
+    TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, n4, n3, N, &one, dC4i, n4, 0, dT2, n3,
+                                           (rocblas_stride)Y, &zero, d_out, n4, (rocblas_stride)n3 * n4, n1 * n2));
+    TFM_HIP(hipEventRecord(e1, 0));
+    TFM_HIP(hipEventSynchronize(e1));
+    if (seconds) { float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1); *seconds = ms * 1e-3; }
+done:
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     return rc;
