@@ -155,6 +155,68 @@ def test_native_scf_cycle_on_a_sharded_tensor(kind, tag, golden, uhf_golden):
         np.testing.assert_allclose(res[0][3][:n, 6], ref_table[:n, 6], atol=1e-6)    # damping factors
 
 
+def _nccl_single_rank(rank, port, ret):
+    """RCCL itself: a ONE-rank `nccl` process group (RCCL refuses two ranks on one device, so one rank is what a one-GPU box can run) around
+    rank 0's context of a TWO-way shard.  The registered hook then really issues ncclAllReduce on the library's buffer and stream --
+    the sum over a one-rank group is the rank's own partial [J;K], which is what is checked."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from conftest import atom_arrays, make_system
+        from oracle import scf_oracle as so
+        from tuna_amd import distributed as tdist, molecule as mol
+        from tuna_amd._lib import TunaError
+        from tuna_amd.engine import Engine
+        atoms, shells, aos, nocc = make_system("n2_ccpvdz")
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "n2_ccpvdz.npz"))
+        with Engine(0, 0, 2) as eng:                                   # rank 0 of 2: half of the rows
+            eng.set_basis(aos).build_eri(True)
+            N = eng.N
+            dev = torch.device("cuda", 0)
+            dP = torch.from_numpy(np.ascontiguousarray(g["P_rand"])).to(dev)
+            dJK = torch.zeros((2, N, N), dtype=torch.float64, device=dev)
+            eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+            partial = dJK.cpu().numpy().copy()
+            dist.all_reduce(dJK)                                        # what bench.py --gpus N issues per build
+            after = dJK.cpu().numpy()
+            # the native cycle: every Fock build of it calls the hook (ncclAllReduce on the staging buffer, status word, agreement vector)
+            tdist.attach_allreduce(eng)
+            xyz, chg, org = atom_arrays(atoms)
+            S, T, V, _, _ = eng.one_electron(xyz, chg, org, spherical=True)
+            X, _, _ = eng.orthogonaliser(S)
+            P0, E0 = so.core_guess(T, V, X, nocc)
+            ranges = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
+            try:
+                r = eng.scf_rhf(S, T, V, P0, E0, nocc, mol.nuclear_repulsion(atoms), X=X, conv="loose", damping="none", n_atom_ao=ranges, max_iter=4)
+                outcome = ("ran", r["n_iter"])
+            except TunaError as e:                                     # half a tensor does not have to converge in four iterations
+                outcome = ("error", str(e))
+            # the same first Fock build through the hook-less path: J, K of P0 from this rank's rows
+            dP0 = torch.from_numpy(np.ascontiguousarray(P0)).to(dev)
+            eng.fock_jk_device(dP0.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+            ret[0] = (float(np.abs(partial - after).max()), float(np.abs(partial).max()), outcome, dist.get_backend(), bool(np.isfinite(dJK.cpu().numpy()).all()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_branch_of_the_exchange_step_runs_on_a_single_rank_group():
+    """The `nccl` (= RCCL) branches -- bench.py's all-reduce of [J;K] and the hook of the native cycles -- executed on hardware."""
+    import torch.multiprocessing as mp
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_nccl_single_rank, args=(_free_port(), ret), nprocs=1, join=True)
+        res = dict(ret)
+    diff, scale, outcome, backend, finite = res[0]
+    assert backend == "nccl" and finite
+    assert diff == 0.0 and scale > 0.0                               # the sum over a one-rank communicator is the rank's own partial sums
+    # the native cycle went through the hook (ncclAllReduce of [J;K] + status word, then of the agreement vector); its agreement test then
+    # notices, correctly, that the one-rank group sums ONE rank's decision values where the context expects the sum over two
+    assert outcome[0] == "error" and "disagree on a control decision" in outcome[1], outcome
+
+
 def _rank_mp2(rank, world, port, tag, layout, ret):
     """One rank of an RMP2 / AO->MO transformation on a sharded tensor: every rank transforms the rows it owns, one all-reduce of the
     transformed tensor (the hook of attach_allreduce)."""

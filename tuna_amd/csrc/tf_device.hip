@@ -71,7 +71,8 @@ struct tf_ctx {
     int layout = 0;
     long long n_elems = 0;              // stored doubles
     long long *d_rowoff = nullptr;
-    int *d_jptr = nullptr, *d_jrows = nullptr;   // rows by second index x (internal): d_jrows[d_jptr[x] .. d_jptr[x + 1])
+    int *d_jptr = nullptr;                       // rows by second index x (internal): d_jrows[d_jptr[x] .. d_jptr[x + 1])
+    int2 *d_jrows = nullptr;                     // (local row, ORIGINAL first index of the row)
     int *d_rowsec = nullptr;            // [n_rows][6]: start of section a inside local row r; position in its storage unit, rows of the unit
     // parity-blocked layout tables (tf_layout.hip.h), host mirror and device view
     struct HostLayout {
@@ -944,18 +945,19 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
         if ((rc2 = build_jk_tables(JKShape<1>::RB, ctx->jkt[0])) || (rc2 = build_jk_tables(JKShape<2>::RB, ctx->jkt[1]))) return rc2;
         // reduction table: the rows (z, x), z != x, listed by their second index x (internal)
-        std::vector<int> jptr((size_t)N + 1, 0), jrows;
+        std::vector<int> jptr((size_t)N + 1, 0);
+        std::vector<int2> jrows;
         for (size_t r = 0; r < row_ij.size(); ++r) {
             const int iI = H.sigma[row_ij[r].x], jI = H.sigma[row_ij[r].y];
             if (iI != jI) ++jptr[jI + 1];
         }
         for (int x = 0; x < N; ++x) jptr[x + 1] += jptr[x];
-        jrows.assign((size_t)std::max(1, jptr[N]), 0);
+        jrows.assign((size_t)std::max(1, jptr[N]), make_int2(0, 0));
         {
             std::vector<int> fill(jptr.begin(), jptr.end() - 1);
             for (size_t r = 0; r < row_ij.size(); ++r) {            // (ascending local row: a fixed summation order)
                 const int iI = H.sigma[row_ij[r].x], jI = H.sigma[row_ij[r].y];
-                if (iI != jI) jrows[fill[jI]++] = (int)r;
+                if (iI != jI) jrows[fill[jI]++] = make_int2((int)r, row_ij[r].x);
             }
         }
         if ((rc2 = upload(ctx, jptr, &ctx->d_jptr, false)) || (rc2 = upload(ctx, jrows, &ctx->d_jrows, false))) return rc2;
@@ -2185,6 +2187,7 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
     R.DIc = DIc; R.sDIc = S.DIc; R.DIr = DIr; R.sDIr = S.DIr; R.DJc = DJc; R.sDJc = S.DJc; R.DJr = DJr; R.sDJr = S.DJr;
     R.gfirst = T.d_gfirst; R.jptr = ctx->d_jptr; R.jrows = ctx->d_jrows; R.row_ij = ctx->d_row_ij;
     for (int d = 0; d < ND; ++d) R.D[d] = dDout[d];
+    { static const int jkr_dbg = getenv("TF_JKR_DBG") ? atoi(getenv("TF_JKR_DBG")) : 0; R.dbg = jkr_dbg; }
     const unsigned nblk = (unsigned)ND * ((unsigned)N * ((N + 127) / 128) + (unsigned)T.jp.bfirst[4] * T.nseg);
     hipLaunchKernelGGL(jk_reduce_kernel, dim3(nblk), dim3(TF_JKR_THREADS), 0, st, R, L);
     return TF_OK;

@@ -799,6 +799,32 @@ __device__ __forceinline__ void jt_reduce_block(int bx, int by, int nseg, const 
 // validity tests: the set of entries a pass writes does not depend on the density, the buffers are zeroed once at allocation, and
 // entries no task writes stay zero.  Block (x, bx) of an (N, ceil(N/128)) grid, 256 threads = 4 slices x 64 lanes x 2 columns;
 // four partial vectors at a time so that their loads are in flight together; fixed summation order: bitwise reproducible.
+// (every load of a partial vector -- the column part and up to TF_JKR_MCMAX row-part slots -- is issued before the first add: with a
+// run-time slot loop the four rounds of a vector were four memory latencies one after the other, and that chain, not bandwidth, was the
+// 0.30 ms of this kernel at N = 400)
+#ifndef TF_JKR_MCMAX
+#define TF_JKR_MCMAX 4
+#endif
+struct KdLoads { double2 c, s[TF_JKR_MCMAX]; };
+__device__ __forceinline__ void kd_issue(KdLoads &q, const double *__restrict__ colp, const double *__restrict__ rowp, int N, int MC, int y, bool two, bool on)
+{
+    const double2 z = make_double2(0.0, 0.0);
+    q.c = !on ? z : (two ? *reinterpret_cast<const double2 *>(colp + y) : make_double2(colp[y], 0.0));
+#pragma unroll
+    for (int sl = 0; sl < TF_JKR_MCMAX; ++sl)
+        q.s[sl] = !(on && sl < MC) ? z : (two ? *reinterpret_cast<const double2 *>(rowp + (size_t)sl * N + y) : make_double2(rowp[(size_t)sl * N + y], 0.0));
+}
+__device__ __forceinline__ double2 kd_sum(const KdLoads &q, const double *__restrict__ rowp, int N, int MC, int y, bool two, bool on)
+{
+    double2 t = q.c;
+#pragma unroll
+    for (int sl = 0; sl < TF_JKR_MCMAX; ++sl) { t.x += q.s[sl].x; t.y += q.s[sl].y; }
+    for (int sl = TF_JKR_MCMAX; sl < MC && on; ++sl) {                   // (more chunks per class than the unrolled part holds: N > 512)
+        const double2 v = two ? *reinterpret_cast<const double2 *>(rowp + (size_t)sl * N + y) : make_double2(rowp[(size_t)sl * N + y], 0.0);
+        t.x += v.x; t.y += v.y;
+    }
+    return t;
+}
 __device__ __forceinline__ double2 kd_vec(const double *__restrict__ colp, const double *__restrict__ rowp, int N, int MC, int y, bool two)
 {
     double2 t = two ? *reinterpret_cast<const double2 *>(colp + y) : make_double2(colp[y], 0.0);
@@ -812,8 +838,8 @@ __device__ __forceinline__ double2 kd_vec(const double *__restrict__ colp, const
 __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, const double *__restrict__ DIc, const double *__restrict__ DIr,
                                                 const double *__restrict__ DJc, const double *__restrict__ DJr, int N, int MC, int MP,
                                                 size_t planeI, size_t planeJ,
-                                                const int *__restrict__ gfirst, const int *__restrict__ jptr, const int *__restrict__ jrows,
-                                                const int *__restrict__ origI, const int2 *__restrict__ row_ij, double *__restrict__ D)
+                                                const int *__restrict__ gfirst, const int *__restrict__ jptr, const int2 *__restrict__ jrows,
+                                                const int *__restrict__ origI, double *__restrict__ D)
 {
     const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int y = bx * 128 + 2 * lane;
@@ -830,30 +856,41 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, c
             double2 acc = make_double2(0.0, 0.0);
             constexpr int NSL = TF_JKR_THREADS / 64;                   // slices
             for (int g0 = gfirst[x] + sl, ge = groups_reach ? gfirst[N + x] : 0; g0 < ge; g0 += 4 * NSL) {
-                double2 t[4];
+                KdLoads q[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int g = g0 + NSL * u;
-                    t[u] = (g < ge) ? kd_vec(DIc + (size_t)g * N, DIr + (size_t)g * RS, N, MC, yy, two) : make_double2(0.0, 0.0);
-                    for (int pl = 1; pl < MP; ++pl)                 // column parts of the further parts of a cut walk
-                        if (g < ge) { const double2 v = kd_vec(DIc + pl * planeI + (size_t)g * N, DIr, N, 0, yy, two); t[u].x += v.x; t[u].y += v.y; }
+                    kd_issue(q[u], DIc + (size_t)g * N, DIr + (size_t)g * RS, N, MC, yy, two, g < ge);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { acc.x += t[u].x; acc.y += t[u].y; }
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + NSL * u;
+                    double2 t = kd_sum(q[u], DIr + (size_t)g * RS, N, MC, yy, two, g < ge);
+                    for (int pl = 1; pl < MP; ++pl)                 // column parts of the further parts of a cut walk
+                        if (g < ge) { const double2 v = kd_vec(DIc + pl * planeI + (size_t)g * N, DIr, N, 0, yy, two); t.x += v.x; t.y += v.y; }
+                    acc.x += t.x; acc.y += t.y;
+                }
             }
             for (int p0 = jptr[x] + sl, pe = jptr[x + 1]; p0 < pe; p0 += 4 * NSL) {
-                double2 t[4];
+                KdLoads q[4];
+                int rr[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int p = p0 + NSL * u;
-                    int r = (p < pe) ? jrows[p] : -1;
-                    if (r >= 0 && row_ij[r].x < yo) r = -1;              // (the row's first index lies below both columns)
-                    t[u] = (r >= 0) ? kd_vec(DJc + (size_t)r * N, DJr + (size_t)r * RS, N, MC, yy, two) : make_double2(0.0, 0.0);
-                    for (int pl = 1; pl < MP; ++pl)
-                        if (r >= 0) { const double2 v = kd_vec(DJc + pl * planeJ + (size_t)r * N, DJr, N, 0, yy, two); t[u].x += v.x; t[u].y += v.y; }
+                    const int2 e = (p < pe) ? jrows[p] : make_int2(-1, 0);
+                    rr[u] = (e.x >= 0 && e.y >= yo) ? e.x : -1;            // (a row whose first index lies below both columns holds nothing for them)
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { acc.x += t[u].x; acc.y += t[u].y; }
+                for (int u = 0; u < 4; ++u)
+                    kd_issue(q[u], DJc + (size_t)max(rr[u], 0) * N, DJr + (size_t)max(rr[u], 0) * RS, N, MC, yy, two, rr[u] >= 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = rr[u];
+                    double2 t = kd_sum(q[u], DJr + (size_t)max(r, 0) * RS, N, MC, yy, two, r >= 0);
+                    for (int pl = 1; pl < MP; ++pl)
+                        if (r >= 0) { const double2 v = kd_vec(DJc + pl * planeJ + (size_t)r * N, DJr, N, 0, yy, two); t.x += v.x; t.y += v.y; }
+                    acc.x += t.x; acc.y += t.y;
+                }
             }
             if (pass == 0) s = acc; else s.y = acc.x;
         }
@@ -875,13 +912,15 @@ struct JKReduce {
     const double *ypart, *DIc, *DIr, *DJc, *DJr;
     double *Jt, *D[2];
     const JKSuper *supers;
-    const int *gfirst, *jptr, *jrows;
+    const int *gfirst, *jptr;
+    const int2 *jrows;                                   // (local row, original first index) of the rows listed by second index
     const int2 *row_ij;                                  // original (i, j) of the local rows
     int MC, MP;                                          // slots of a row part vector: most chunks of one class; parts of a walk
     size_t planeI, planeJ;                               // between the column-part planes of the parts
     JKJtPlan jp;
     size_t sy, sJt, sDIc, sDIr, sDJc, sDJr;              // strides between densities
     int nseg;
+    int dbg;                                             // timing experiments (TF_JKR_DBG: 1 = exchange blocks only, 2 = Jt blocks only)
 };
 __global__ __launch_bounds__(TF_JKR_THREADS) void jk_reduce_kernel(JKReduce R, BLayout L)
 {
@@ -891,9 +930,10 @@ __global__ __launch_bounds__(TF_JKR_THREADS) void jk_reduce_kernel(JKReduce R, B
     int b = blockIdx.x;
     const int d = b / (nK + nJ);
     b -= d * (nK + nJ);
+    if (R.dbg && (b < nK) == (R.dbg == 2)) return;
     if (b < nK)
         kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, L.N, R.MC, R.MP,
-                        R.planeI, R.planeJ, R.gfirst, R.jptr, R.jrows, L.origI, R.row_ij, R.D[d]);
+                        R.planeI, R.planeJ, R.gfirst, R.jptr, R.jrows, L.origI, R.D[d]);
     else {
         b -= nK;
         jt_reduce_block(b % gxJ, b / gxJ, R.nseg, R.ypart + d * R.sy, R.supers, R.jp, L, R.Jt + d * R.sJt);
