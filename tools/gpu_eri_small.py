@@ -26,7 +26,8 @@ print(json.dumps(out))
 """
 for name in (sys.argv[1:] or ["base"]):
     env = dict(os.environ)
-    if "=" in name:
-        k, v = name.split("=", 1); env[k] = v
+    for kv in name.split(","):
+        if "=" in kv:
+            k, v = kv.split("=", 1); env[k] = v
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, capture_output=True, text=True)
     print(name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-800:], flush=True)

@@ -1077,6 +1077,64 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         if ((rc = upload(ctx, all, &d_kets_all, false))) return rc;
         kets_all_host = all;
     }
+    // Families of ket pairs (general contractions, eri_cfact_kernel<.., MM>): shells with identical primitives -- same centre, L, exponents,
+    // components -- get the same primitive-set id; the contracted pairs of a group with the same (id, id) differ only in their primitive-pair
+    // weights and in the AOs they write.  Per contracted group: heads (first member, the group's cost order kept), members of each head.
+    constexpr int FAM_MM = 9;
+    static const bool fam_off = getenv("TF_ERI_FAMILIES") && getenv("TF_ERI_FAMILIES")[0] == '0';
+    std::vector<int> fam_heads, fam_ptr{0}, fam_mem;
+    int fam_goff[NGRP + 1] = {};
+    int *d_fam_heads = nullptr, *d_fam_ptr = nullptr, *d_fam_mem = nullptr;
+    bool fam_any = false;
+    {
+        std::vector<int> psid(bs.shells.size(), -1);
+        int nid = 0;
+        for (size_t a = 0; a < bs.shells.size(); ++a) {
+            if (psid[a] >= 0) continue;
+            psid[a] = nid;
+            const tf::Shell &sa = bs.shells[a];
+            for (size_t b = a + 1; b < bs.shells.size(); ++b) {
+                const tf::Shell &sb = bs.shells[b];
+                if (psid[b] >= 0 || sb.z != sa.z || sb.L != sa.L || sb.nprim != sa.nprim || sb.ncomp != sa.ncomp || sb.full != sa.full) continue;
+                bool same = true;
+                for (int q = 0; q < sa.nprim && same; ++q) same = bs.s_exp[sa.prim_off + q] == bs.s_exp[sb.prim_off + q];
+                for (int q = 0; q < sa.ncomp && same; ++q)
+                    same = bs.c_lx[sa.comp_off + q] == bs.c_lx[sb.comp_off + q] && bs.c_ly[sa.comp_off + q] == bs.c_ly[sb.comp_off + q] &&
+                           bs.c_lz[sa.comp_off + q] == bs.c_lz[sb.comp_off + q] && bs.c_scale[sa.comp_off + q] == bs.c_scale[sb.comp_off + q];
+                if (same) psid[b] = nid;
+            }
+            ++nid;
+        }
+        for (int g = 0; g < NGRP; ++g) {
+            fam_goff[g] = (int)fam_heads.size();
+            if (!(g & 1) || fam_off) continue;                     // contracted groups only
+            std::map<std::pair<int, int>, std::vector<int>> open_fam;   // key -> index of the family still taking members (in fam_ptr order)
+            std::vector<std::vector<int>> fams;
+            for (int k = kets_goff[g]; k < kets_goff[g + 1]; ++k) {
+                const int p = kets_all_host[k];
+                const auto key = std::make_pair(psid[bs.pairs[p].A], psid[bs.pairs[p].B]);
+                auto it = open_fam.find(key);
+                if (it == open_fam.end() || (int)fams[it->second.back()].size() >= FAM_MM) {
+                    fams.emplace_back();
+                    open_fam[key].push_back((int)fams.size() - 1);
+                    it = open_fam.find(key);
+                }
+                fams[it->second.back()].push_back(p);
+            }
+            for (const auto &f : fams) {
+                fam_heads.push_back(f[0]);
+                fam_mem.insert(fam_mem.end(), f.begin(), f.end());
+                fam_ptr.push_back((int)fam_mem.size());
+                if (f.size() > 1) fam_any = true;
+            }
+        }
+        fam_goff[NGRP] = (int)fam_heads.size();
+        if (fam_any) {
+            if ((rc = upload(ctx, fam_heads, &d_fam_heads, false)) || (rc = upload(ctx, fam_ptr, &d_fam_ptr, false)) ||
+                (rc = upload(ctx, fam_mem, &d_fam_mem, false)))
+                return rc;
+        }
+    }
     // my bra pairs ordered by class: a slab is a run of that list, launches go per (bra class run, ket class)
     std::vector<int> mine_sorted;
     for (int c = 0; c < ncls; ++c)
@@ -1394,6 +1452,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 c.offEab = o; c.capEab = std::min(sb.maxE, k_e); o += c.capEab;
                 c.offEcd = o; c.capEcd = std::min(sk.maxE, k_e); o += c.capEcd;
                 c.offRed = o; o += TF_ERI_THREADS;
+                c.offKm = o; c.capKm = ((gk & 1) && fam_any) ? FAM_MM * sk.maxnpp : 0; o += c.capKm;
                 c.lds_doubles = o;
                 c.tri = packed ? 1 : 0;
                 c.dbg_npq_lo = 0; c.dbg_npq_hi = 0x7fffffff;
@@ -1415,6 +1474,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                     d.offEab = q; q += d.capEab;
                     d.offEcd = q; q += d.capEcd;
                     d.offRed = q; q += TF_ERI_THREADS;
+                    d.offKm = q; q += d.capKm;
                     d.lds_doubles = q;
                     d.capG = gsz; d.capXZ = xz;
                     d.offG = 0; d.offX = gsz; d.offZ = gsz + xz;
@@ -1537,7 +1597,16 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             } else if (((gb | gk) & 1) == 0)                     // both groups uncontracted: one primitive quartet per shell quartet
                 hipLaunchKernelGGL(eri_cfact_kernel<true>, dim3((unsigned)nk, (unsigned)(b1 - b0)), dim3(TF_ERI_THREADS), bytes, st, ctx->db, c,
                                    d_bra + b0, d_braoff + b0, d_kets_all + kets_goff[gk], Nc, d_C);
-            else
+            else if ((gk & 1) && fam_any) {                       // contracted kets: one workgroup per (bra pair, family of ket pairs)
+                static bool fam_attr_set = false;                 // (per process and device: the attribute belongs to the function)
+                if (bytes > 64 * 1024 && !fam_attr_set) {
+                    HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<false, false, FAM_MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    fam_attr_set = true;
+                }
+                hipLaunchKernelGGL((eri_cfact_kernel<false, false, FAM_MM>), dim3((unsigned)(fam_goff[gk + 1] - fam_goff[gk]), (unsigned)(b1 - b0)),
+                                   dim3(TF_ERI_THREADS), bytes, st, ctx->db, c, d_bra + b0, d_braoff + b0, d_fam_heads + fam_goff[gk], Nc, d_C,
+                                   (double *)nullptr, d_fam_ptr + fam_goff[gk], d_fam_mem);
+            } else
                 hipLaunchKernelGGL(eri_cfact_kernel<false>, dim3((unsigned)nk, (unsigned)(b1 - b0)), dim3(TF_ERI_THREADS), bytes, st, ctx->db, c,
                                    d_bra + b0, d_braoff + b0, d_kets_all + kets_goff[gk], Nc, d_C);
             ++launch_count;
@@ -1976,6 +2045,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     if (d_rowcls_alloc) (void)hipFree(d_rowcls_alloc);
     d_brarec = d_brarec_alloc;
     (void)hipFree(d_kets); (void)hipFree(d_kets_all);
+    for (void *pt : {(void *)d_fam_heads, (void *)d_fam_ptr, (void *)d_fam_mem})
+        if (pt) (void)hipFree(pt);
     for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c, (void *)d_ketrec, (void *)d_brarec, (void *)d_kcnt,
                      (void *)d_tcs, (void *)d_tasks, (void *)d_tflat})
         if (pt) (void)hipFree(pt);

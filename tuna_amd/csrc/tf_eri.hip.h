@@ -188,7 +188,7 @@ __device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, 
 // pairs (ab[e], cd[e]).  Lanes e*(L+1)+n, n = 0..L; one barrier per table row.  All threads of the block must call.
 template <bool DENSE, class PairOf>
 __device__ __forceinline__ void coop_tables_en(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
-                                               PairOf pair_of, int e, int n, int tid);
+                                               PairOf pair_of, int e, int n, int tid, bool with_ket_weight = true);
 template <class PairOf>
 __device__ __forceinline__ void coop_tables(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
                                             PairOf pair_of, int tid)
@@ -201,7 +201,7 @@ __device__ __forceinline__ void coop_tables(const DBasis &B, int L, int n_entrie
 // row layout -- one wave instead of L + 1 runs the expensive part of the build.
 template <bool DENSE, class PairOf>
 __device__ __forceinline__ void coop_tables_en(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
-                                               PairOf pair_of, int e, int n, int tid)
+                                               PairOf pair_of, int e, int n, int tid, bool with_ket_weight)
 {
     const bool mine = e < n_entries;
     if (DENSE ? tid < n_entries : (mine && n == 0)) {
@@ -214,7 +214,7 @@ __device__ __forceinline__ void coop_tables_en(const DBasis &B, int L, int n_ent
         build_R_row0(sR, stride, le, L, alpha, PQ, B.boys);
         sPQ[le] = PQ;
         // 2 pi^(5/2) / (p q sqrt(p+q)) * coefficient product, pyx:1219-1221
-        sPref[le] = B.pp_K[ppab] * B.pp_K[ppcd] * (34.986836655249725 / (p * q * sqrt(s)));
+        sPref[le] = B.pp_K[ppab] * (with_ket_weight ? B.pp_K[ppcd] : 1.0) * (34.986836655249725 / (p * q * sqrt(s)));
     }
     for (int v = 1; v <= L; ++v) {
         __syncthreads();
@@ -706,22 +706,39 @@ struct CFCaps {
     int offRed, lds_doubles, tri;
     int gtab_doubles;                // GTAB launches: offG / offX / offZ are relative to the workgroup's block of this many doubles in global memory
     int dbg_npq_lo, dbg_npq_hi;      // profiling aid (TF_ERI_DBG_NPQ=lo:hi): only quartets with lo <= primitive quartets <= hi are computed
+    int offKm, capKm;                // FAMILY launches: weights of the members' primitive pairs, [member][primitive pair] (capKm doubles)
     int team_lmax, team_pqmax;       // quartets with both pair sums <= team_lmax and <= team_pqmax primitive quartets belong to eri_teamc_kernel (-1: none)
 };
 
 // GTAB: the G / X / Z tables of the workgroup live in global memory (gtab, one block of cap.gtab_doubles per workgroup, L2-resident)
 // instead of LDS -- the very top of the angular momenta ((hh|hh): 2 x 14 256 + 4 356 doubles) does not fit the 160 KB.
-template <bool UNC, bool GTAB = false>
-__global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, CFCaps cap, const int *__restrict__ bra_pairs,
+// FAMILIES (MM > 1; general contractions, round 3): TUNA keeps every contracted function of a generally contracted set as a shell of its
+// own that repeats the whole primitive list (mol:553-574: Ar cc-pVQZ = three s shells on the same 13 primitives, two p shells on the same
+// 8), so the ket pairs (C_i, D_j) over shells with identical primitives differ in NOTHING but the weights of their primitive pairs and
+// the AOs they write.  A workgroup takes one bra pair and a FAMILY of up to MM such ket pairs (ket_pairs[] lists the family heads;
+// members fam_mem[fam_ptr[x] .. fam_ptr[x + 1])): the tables of a primitive quartet and the triple-table sum of a component are
+// evaluated once and feed one accumulator per member -- (xx|s13 s13) nine for the price of one.  Same terms as before, the member's
+// weight multiplied in last.
+template <bool UNC, bool GTAB = false, int MM = 1>
+__global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kernel(DBasis B, CFCaps cap, const int *__restrict__ bra_pairs,
                                                                    const long long *__restrict__ bra_rowoff,
                                                                    const int *__restrict__ ket_pairs, int Nc, double *__restrict__ Cslab,
-                                                                   double *__restrict__ gtab = nullptr)
+                                                                   double *__restrict__ gtab = nullptr, const int *__restrict__ fam_ptr = nullptr,
+                                                                   const int *__restrict__ fam_mem = nullptr)
 {
     extern __shared__ double smem[];
     const int tid = threadIdx.x;
     const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
     const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
-    if (cap.tri && cd.A > ab.A) return;
+    int nmem = 1;
+    const int *__restrict__ mem = nullptr;
+    if (MM > 1) {
+        mem = fam_mem + fam_ptr[blockIdx.x];
+        nmem = fam_ptr[blockIdx.x + 1] - fam_ptr[blockIdx.x];
+        bool any = false;
+        for (int mm = 0; mm < nmem; ++mm) any = any || !(cap.tri && B.pairs[mem[mm]].A > ab.A);
+        if (!any) return;
+    } else if (cap.tri && cd.A > ab.A) return;
     if (ab.npp * cd.npp < cap.dbg_npq_lo || ab.npp * cd.npp > cap.dbg_npq_hi) return;
     if (cap.team_lmax >= 0 && ab.La + ab.Lb <= cap.team_lmax && cd.La + cd.Lb <= cap.team_lmax && ab.npp * cd.npp <= cap.team_pqmax) return;
     const LRec lr = B.lrec[((ab.La * 6 + ab.Lb) * 6 + cd.La) * 6 + cd.Lb];
@@ -780,13 +797,20 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
         yo = (((pa >> 8) & 255) * LcLd + ((pc >> 8) & 255)) * nM;
         zo = (((pa >> 16) & 255) * LcLd + ((pc >> 16) & 255)) * nM;
     };
-    auto store = [&](int iab, int icd, double val) {
+    auto store_to = [&](const DPair &kp, int iab, int icd, double val) {
         const int pos = posCD[icd];
         const size_t row = (size_t)(row0 + iab);
-        const int k = cd.cartoff_a + (pos >> 8), l = cd.cartoff_b + (pos & 255);
+        const int k = kp.cartoff_a + (pos >> 8), l = kp.cartoff_b + (pos & 255);
         Cslab[row * NcNc + (size_t)k * Nc + l] = val;
-        if (cd.A != cd.B && !cap.tri) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
+        if (kp.A != kp.B && !cap.tri) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
     };
+    auto store = [&](int iab, int icd, double val) { store_to(cd, iab, icd, val); };
+    // FAMILY: the members' primitive-pair weights [member][primitive pair of the ket], staged once
+    double *sKm = smem + cap.offKm;
+    if (MM > 1) {
+        for (int e = tid; e < nmem * npp_cd; e += TF_ERI_THREADS) { const int mm = e / npp_cd; sKm[e] = B.pp_K[B.pairs[mem[mm]].pp_off + (e - mm * npp_cd)]; }
+        // (made visible by the barriers of the first build_tables)
+    }
 
     // tables of the primitive quartets b0 .. b0 + nb - 1
     const int lgG = lr.lgG, lgX = lr.lgX, rstepG = 1 << lgG, rstepX = 1 << lgX;
@@ -798,7 +822,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
                            const int pab = pq / npp_cd, pcd = pq - pab * npp_cd;
                            sPP[e] = pab; sPP[TF_ERI_THREADS + e] = pcd;
                            ppab = ab.pp_off + pab; ppcd = cd.pp_off + pcd;
-                       }, ce, cn, tid);
+                       }, ce, cn, tid, MM == 1);
         __syncthreads();
         // ket half of the z tables: G_q[c,d][v][n] = sum_phi (-1)^phi Ez34[phi] R_q[v + phi][n]
         for (int p0 = 0; p0 < nb; p0 += TF_ERI_THREADS >> lgG) {
@@ -869,11 +893,13 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
     const bool lane_on = g < NG;
     for (int cbase = 0; cbase < nnz; cbase += TF_ERI_THREADS * TF_CF_KMAX) {
         int xo[TF_CF_KMAX], yo[TF_CF_KMAX], zo[TF_CF_KMAX], iab[TF_CF_KMAX], icd[TF_CF_KMAX];
-        double acc[TF_CF_KMAX];
+        double acc[TF_CF_KMAX][MM];
         const int nk = min(TF_CF_KMAX, (nnz - cbase + TF_ERI_THREADS - 1) / TF_ERI_THREADS);
 #pragma unroll
         for (int k = 0; k < TF_CF_KMAX; ++k) {
-            acc[k] = 0.0; xo[k] = -1; yo[k] = zo[k] = iab[k] = icd[k] = 0;
+#pragma unroll
+            for (int mm = 0; mm < MM; ++mm) acc[k][mm] = 0.0;
+            xo[k] = -1; yo[k] = zo[k] = iab[k] = icd[k] = 0;
             const int j = cbase + k * TF_ERI_THREADS + c0;
             if (k < nk && j < nnz && lane_on) comp_rows(j, xo[k], yo[k], zo[k], iab[k], icd[k]);
         }
@@ -883,25 +909,50 @@ __global__ __launch_bounds__(TF_ERI_THREADS, 4) void eri_cfact_kernel(DBasis B, 
 #pragma unroll
             for (int k = 0; k < TF_CF_KMAX; ++k) {
                 if (k >= nk || xo[k] < 0) continue;
-                double a = 0.0;
-                for (int q = g; q < nb; q += NG) a += sPref[q] * fact_sum_small(nM, sX + q * xz + xo[k], sX + q * xz + yo[k], sZ + q * xz + zo[k]);
-                acc[k] += a;
+                if (MM == 1) {
+                    double a = 0.0;
+                    for (int q = g; q < nb; q += NG) a += sPref[q] * fact_sum_small(nM, sX + q * xz + xo[k], sX + q * xz + yo[k], sZ + q * xz + zo[k]);
+                    acc[k][0] += a;
+                } else {
+                    for (int q = g; q < nb; q += NG) {
+                        const double f = sPref[q] * fact_sum_small(nM, sX + q * xz + xo[k], sX + q * xz + yo[k], sZ + q * xz + zo[k]);
+                        const double *Kq = sKm + sPP[TF_ERI_THREADS + q];             // weight of this primitive pair in member mm: Kq[mm * npp_cd]
+#pragma unroll
+                        for (int mm = 0; mm < MM; ++mm)
+                            if (mm < nmem) acc[k][mm] += f * Kq[mm * npp_cd];
+                    }
+                }
             }
             __syncthreads();                                          // the tables are rebuilt by the next batch
         }
         if (NG > 1) {                                                 // combine the lane groups in fixed order (reproducible)
-            sRed[tid] = acc[0];
-            __syncthreads();
-            if (g == 0) {
-                double t = 0.0;
-                for (int gg = 0; gg < NG; ++gg) t += sRed[gg * ncp + c0];
-                acc[0] = t;
+#pragma unroll
+            for (int mm = 0; mm < MM; ++mm) {
+                if (mm >= nmem) break;
+                sRed[tid] = acc[0][mm];
+                __syncthreads();
+                if (g == 0) {
+                    double t = 0.0;
+                    for (int gg = 0; gg < NG; ++gg) t += sRed[gg * ncp + c0];
+                    acc[0][mm] = t;
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
 #pragma unroll
-        for (int k = 0; k < TF_CF_KMAX; ++k)
-            if (k < nk && xo[k] >= 0 && g == 0) store(iab[k], icd[k], acc[k] * (scAB[iab[k]] * scCD[icd[k]]));
+        for (int k = 0; k < TF_CF_KMAX; ++k) {
+            if (!(k < nk && xo[k] >= 0 && g == 0)) continue;
+            if (MM == 1) store(iab[k], icd[k], acc[k][0] * (scAB[iab[k]] * scCD[icd[k]]));
+            else {
+#pragma unroll
+                for (int mm = 0; mm < MM; ++mm) {
+                    if (mm >= nmem) break;
+                    const DPair kp = B.pairs[mem[mm]];
+                    if (cap.tri && kp.A > ab.A) continue;             // (every (kl) of this member lies above every (ij) of the bra)
+                    store_to(kp, iab[k], icd[k], acc[k][mm] * (scAB[iab[k]] * scCD[icd[k]]));
+                }
+            }
+        }
     }
 }
 
