@@ -389,6 +389,24 @@ def test_full_tensor_both_eri_modes(engine, monkeypatch, tag, mode):
     assert np.abs(J - so.coulomb(P, Eos)).max() < 1e-10 and np.abs(K - so.exchange(P, Eos)).max() < 1e-10
 
 
+@pytest.mark.parametrize("env", [{"TF_ERI_FAMILIES": "1"}, {"TF_ERI_FAMILIES": "1", "TF_ERI_CC_FAMILIES": "0"},
+                                 {"TF_ERI_FAMILIES": "1", "TF_ERI_BRA_FAMILIES": "1"}, {"TF_ERI_FAMILIES": "0"}])
+@pytest.mark.parametrize("tag", ["c2_n2_ccpvtz", "c4_co_def2tzvp"])
+def test_families_of_generally_contracted_shell_pairs(engine, monkeypatch, tag, env):
+    """eri_cfact_kernel with families of shell pairs over shells that repeat one primitive list (general contractions: N cc-pVTZ keeps two s
+    shells on the same 8 primitives; def2-TZVP has none and must be left alone): ket families (1 x 9), families on both sides of the
+    contracted-against-contracted launches (3 x 9), bra families (9 x 1, off by default), and everything off -- every element of the
+    spherical tensor against the oracle.  (By default families start at 8e6 primitive shell quartets: BASELINE config 3, Ar2/cc-pVQZ, runs
+    them in test_golden_samples / the sharded tests; here they are forced on small systems whose whole tensor the oracle can afford.)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    atoms, shells, aos, _ = make_system(tag)
+    engine.set_basis(aos)
+    Eos = so.eri_to_spherical(engine.sph_matrix(), orc.eri(aos))
+    engine.build_eri(spherical=True)
+    assert np.abs(engine.copy_eri() - Eos).max() < TOL_INT
+
+
 def test_alternating_one_and_two_density_passes(engine, golden):
     """The partial-sum buffers are zeroed once per build and the reductions add every slot without a validity test: one- and
     two-density passes (different row groups, separate buffer regions) must not disturb each other, in any order, on one build."""

@@ -1080,14 +1080,20 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // Families of ket pairs (general contractions, eri_cfact_kernel<.., MM>): shells with identical primitives -- same centre, L, exponents,
     // components -- get the same primitive-set id; the contracted pairs of a group with the same (id, id) differ only in their primitive-pair
     // weights and in the AOs they write.  Per contracted group: heads (first member, the group's cost order kept), members of each head.
-    constexpr int FAM_MM = 9;
-    static const bool fam_off = getenv("TF_ERI_FAMILIES") && getenv("TF_ERI_FAMILIES")[0] == '0';
+    constexpr int FAM_MM = 9, FAM_MA_CC = 3;
+    // (on when the build has the work to fill the chip with fewer, longer workgroups: Ar2/cc-pVQZ -- 5.0e7 primitive shell quartets -- gains
+    // 20 %, N2/cc-pVTZ -- 1.2e6 -- loses 20 %; TF_ERI_FAMILIES=0 / 1 forces)
+    const double prim_quartets_est = 0.5 * (double)cum_pp[nsh] * (double)cum_pp[nsh];
+    const bool fam_off = getenv("TF_ERI_FAMILIES") ? getenv("TF_ERI_FAMILIES")[0] == '0' : prim_quartets_est < 8.0e6;
+    const bool cc_fam_off = getenv("TF_ERI_CC_FAMILIES") && getenv("TF_ERI_CC_FAMILIES")[0] == '0';
+    const bool bra_fam_on = !fam_off && getenv("TF_ERI_BRA_FAMILIES") && getenv("TF_ERI_BRA_FAMILIES")[0] == '1';
     std::vector<int> fam_heads, fam_ptr{0}, fam_mem;
     int fam_goff[NGRP + 1] = {};
     int *d_fam_heads = nullptr, *d_fam_ptr = nullptr, *d_fam_mem = nullptr;
     bool fam_any = false;
+    std::vector<int> psid(bs.shells.size(), -1);
+    std::vector<void *> fam_allocs;                              // per-slab lists of the bra families (freed with the other lists of the build)
     {
-        std::vector<int> psid(bs.shells.size(), -1);
         int nid = 0;
         for (size_t a = 0; a < bs.shells.size(); ++a) {
             if (psid[a] >= 0) continue;
@@ -1452,7 +1458,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 c.offEab = o; c.capEab = std::min(sb.maxE, k_e); o += c.capEab;
                 c.offEcd = o; c.capEcd = std::min(sk.maxE, k_e); o += c.capEcd;
                 c.offRed = o; o += TF_ERI_THREADS;
-                c.offKm = o; c.capKm = ((gk & 1) && fam_any) ? FAM_MM * sk.maxnpp : 0; o += c.capKm;
+                c.offKm = o; c.capKm = fam_off ? 0 : FAM_MM * (((gk & 1) ? sk.maxnpp : 0) + ((gb & 1) ? sb.maxnpp : 0)); o += c.capKm;
                 c.lds_doubles = o;
                 c.tri = packed ? 1 : 0;
                 c.dbg_npq_lo = 0; c.dbg_npq_hi = 0x7fffffff;
@@ -1563,6 +1569,33 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         std::stable_sort(launches.begin(), launches.end(), [](const Launch &x, const Launch &y) { return x.cost > y.cost; });
         const int NQ = std::min(NSTREAM, getenv("TF_ERI_NQ") ? std::max(1, atoi(getenv("TF_ERI_NQ"))) : 4);
         std::vector<double> load(NQ, 0.0);
+        struct BraFam { int *d_ptr = nullptr, *d_mem = nullptr; unsigned n = 0; };
+        std::map<std::pair<size_t, int>, BraFam> bra_fams;       // by (first position of the run of bra pairs, largest family)
+        // families of the bra pairs [b0, b1) of the slab's list, at most `most` members each: built and uploaded once per (slab, bra group)
+        auto bra_families = [&](size_t b0, size_t b1, int most) -> const BraFam * {
+            auto bf = bra_fams.find(std::make_pair(b0, most));
+            if (bf != bra_fams.end()) return &bf->second;
+            BraFam nf;
+            std::vector<int> bptr{0}, bmem;
+            std::map<std::pair<int, int>, int> open_fam;
+            std::vector<std::vector<int>> fams;
+            for (size_t y = b0; y < b1; ++y) {
+                const tf::Pair &pr = bs.pairs[bra_host[y]];
+                const auto key = std::make_pair(psid[pr.A], psid[pr.B]);
+                auto it = open_fam.find(key);
+                if (it == open_fam.end() || (int)fams[it->second].size() >= most) {
+                    fams.emplace_back();
+                    open_fam[key] = (int)fams.size() - 1;
+                    it = open_fam.find(key);
+                }
+                fams[it->second].push_back((int)y);
+            }
+            for (const auto &f : fams) { bmem.insert(bmem.end(), f.begin(), f.end()); bptr.push_back((int)bmem.size()); }
+            if (upload(ctx, bptr, &nf.d_ptr, false) || upload(ctx, bmem, &nf.d_mem, false)) return nullptr;
+            fam_allocs.push_back(nf.d_ptr); fam_allocs.push_back(nf.d_mem);
+            nf.n = (unsigned)(bptr.size() - 1);
+            return &bra_fams.emplace(std::make_pair(b0, most), nf).first->second;
+        };
         for (const Launch &l : launches) {
             const int qi = (int)(std::min_element(load.begin(), load.end()) - load.begin());
             load[qi] += l.cost;
@@ -1597,13 +1630,42 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             } else if (((gb | gk) & 1) == 0)                     // both groups uncontracted: one primitive quartet per shell quartet
                 hipLaunchKernelGGL(eri_cfact_kernel<true>, dim3((unsigned)nk, (unsigned)(b1 - b0)), dim3(TF_ERI_THREADS), bytes, st, ctx->db, c,
                                    d_bra + b0, d_braoff + b0, d_kets_all + kets_goff[gk], Nc, d_C);
+            else if ((gb & 1) && !(gk & 1) && bra_fam_on) {       // contracted bras against uncontracted kets: (family of bra pairs, ket pair).
+                // Off by default (TF_ERI_BRA_FAMILIES=1): the packed layout evaluates the kets whose first shell does not exceed the bra's,
+                // and the contracted shells come first on each atom -- the contracted pairs sit on the ket side; measured on Ar2/cc-pVQZ these
+                // bra families cost 5 % (fewer, longer workgroups) where the ket families gain 24 %.
+                const BraFam *bf = bra_families(b0, b1, FAM_MM);
+                if (!bf) return TF_ENOMEM;
+                static bool bfam_attr_set = false;
+                if (bytes > 64 * 1024 && !bfam_attr_set) {
+                    HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<false, false, FAM_MM, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    bfam_attr_set = true;
+                }
+                hipLaunchKernelGGL((eri_cfact_kernel<false, false, FAM_MM, 1>), dim3((unsigned)nk, bf->n), dim3(TF_ERI_THREADS), bytes, st,
+                                   ctx->db, c, d_bra, d_braoff, d_kets_all + kets_goff[gk], Nc, d_C, (double *)nullptr, (const int *)nullptr,
+                                   (const int *)nullptr, bf->d_ptr, bf->d_mem);
+            }
+            else if ((gb & 1) && (gk & 1) && fam_any && !cc_fam_off) {
+                // contracted against contracted: families on both sides -- up to 3 bra pairs x up to 9 ket pairs per workgroup (27 accumulators
+                // per component: the deepest quartets, (s13 s13|s13 s13) and friends, spend their time in the tables of 28 561 primitive quartets)
+                const BraFam *bf = bra_families(b0, b1, FAM_MA_CC);
+                if (!bf) return TF_ENOMEM;
+                static bool ccfam_attr_set = false;
+                if (bytes > 64 * 1024 && !ccfam_attr_set) {
+                    HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<false, false, FAM_MA_CC, FAM_MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    ccfam_attr_set = true;
+                }
+                hipLaunchKernelGGL((eri_cfact_kernel<false, false, FAM_MA_CC, FAM_MM>), dim3((unsigned)(fam_goff[gk + 1] - fam_goff[gk]), bf->n),
+                                   dim3(TF_ERI_THREADS), bytes, st, ctx->db, c, d_bra, d_braoff, d_fam_heads + fam_goff[gk], Nc, d_C, (double *)nullptr,
+                                   d_fam_ptr + fam_goff[gk], d_fam_mem, bf->d_ptr, bf->d_mem);
+            }
             else if ((gk & 1) && fam_any) {                       // contracted kets: one workgroup per (bra pair, family of ket pairs)
                 static bool fam_attr_set = false;                 // (per process and device: the attribute belongs to the function)
                 if (bytes > 64 * 1024 && !fam_attr_set) {
-                    HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<false, false, FAM_MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    HIPCHK(ctx, hipFuncSetAttribute((const void *)eri_cfact_kernel<false, false, 1, FAM_MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
                     fam_attr_set = true;
                 }
-                hipLaunchKernelGGL((eri_cfact_kernel<false, false, FAM_MM>), dim3((unsigned)(fam_goff[gk + 1] - fam_goff[gk]), (unsigned)(b1 - b0)),
+                hipLaunchKernelGGL((eri_cfact_kernel<false, false, 1, FAM_MM>), dim3((unsigned)(fam_goff[gk + 1] - fam_goff[gk]), (unsigned)(b1 - b0)),
                                    dim3(TF_ERI_THREADS), bytes, st, ctx->db, c, d_bra + b0, d_braoff + b0, d_fam_heads + fam_goff[gk], Nc, d_C,
                                    (double *)nullptr, d_fam_ptr + fam_goff[gk], d_fam_mem);
             } else
@@ -2047,6 +2109,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     (void)hipFree(d_kets); (void)hipFree(d_kets_all);
     for (void *pt : {(void *)d_fam_heads, (void *)d_fam_ptr, (void *)d_fam_mem})
         if (pt) (void)hipFree(pt);
+    for (void *pt : fam_allocs) (void)hipFree(pt);
     for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c, (void *)d_ketrec, (void *)d_brarec, (void *)d_kcnt,
                      (void *)d_tcs, (void *)d_tasks, (void *)d_tflat})
         if (pt) (void)hipFree(pt);

@@ -188,7 +188,7 @@ __device__ __forceinline__ void ket_epilogue(const DBasis &B, const QClass &qc, 
 // pairs (ab[e], cd[e]).  Lanes e*(L+1)+n, n = 0..L; one barrier per table row.  All threads of the block must call.
 template <bool DENSE, class PairOf>
 __device__ __forceinline__ void coop_tables_en(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
-                                               PairOf pair_of, int e, int n, int tid, bool with_ket_weight = true);
+                                               PairOf pair_of, int e, int n, int tid, bool with_ket_weight = true, bool with_bra_weight = true);
 template <class PairOf>
 __device__ __forceinline__ void coop_tables(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
                                             PairOf pair_of, int tid)
@@ -201,7 +201,7 @@ __device__ __forceinline__ void coop_tables(const DBasis &B, int L, int n_entrie
 // row layout -- one wave instead of L + 1 runs the expensive part of the build.
 template <bool DENSE, class PairOf>
 __device__ __forceinline__ void coop_tables_en(const DBasis &B, int L, int n_entries, int stride, double *sR, double *sPref, double *sPQ,
-                                               PairOf pair_of, int e, int n, int tid, bool with_ket_weight)
+                                               PairOf pair_of, int e, int n, int tid, bool with_ket_weight, bool with_bra_weight)
 {
     const bool mine = e < n_entries;
     if (DENSE ? tid < n_entries : (mine && n == 0)) {
@@ -214,7 +214,7 @@ __device__ __forceinline__ void coop_tables_en(const DBasis &B, int L, int n_ent
         build_R_row0(sR, stride, le, L, alpha, PQ, B.boys);
         sPQ[le] = PQ;
         // 2 pi^(5/2) / (p q sqrt(p+q)) * coefficient product, pyx:1219-1221
-        sPref[le] = B.pp_K[ppab] * (with_ket_weight ? B.pp_K[ppcd] : 1.0) * (34.986836655249725 / (p * q * sqrt(s)));
+        sPref[le] = (with_bra_weight ? B.pp_K[ppab] : 1.0) * (with_ket_weight ? B.pp_K[ppcd] : 1.0) * (34.986836655249725 / (p * q * sqrt(s)));
     }
     for (int v = 1; v <= L; ++v) {
         __syncthreads();
@@ -719,24 +719,34 @@ struct CFCaps {
 // members fam_mem[fam_ptr[x] .. fam_ptr[x + 1])): the tables of a primitive quartet and the triple-table sum of a component are
 // evaluated once and feed one accumulator per member -- (xx|s13 s13) nine for the price of one.  Same terms as before, the member's
 // weight multiplied in last.
-template <bool UNC, bool GTAB = false, int MM = 1>
-__global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kernel(DBasis B, CFCaps cap, const int *__restrict__ bra_pairs,
+template <bool UNC, bool GTAB = false, int MA = 1, int MC = 1>
+__global__ __launch_bounds__(TF_ERI_THREADS, MA * MC > 9 ? 2 : (MA * MC > 1 ? 3 : 4)) void eri_cfact_kernel(DBasis B, CFCaps cap, const int *__restrict__ bra_pairs,
                                                                    const long long *__restrict__ bra_rowoff,
                                                                    const int *__restrict__ ket_pairs, int Nc, double *__restrict__ Cslab,
                                                                    double *__restrict__ gtab = nullptr, const int *__restrict__ fam_ptr = nullptr,
-                                                                   const int *__restrict__ fam_mem = nullptr)
+                                                                   const int *__restrict__ fam_mem = nullptr, const int *__restrict__ bfam_ptr = nullptr,
+                                                                   const int *__restrict__ bfam_mem = nullptr)
 {
+    // MC > 1: blockIdx.x runs over the heads of ket families (ket_pairs[] = heads, members fam_mem[fam_ptr[x] ..]: pair indices);
+    // MA > 1: blockIdx.y over the heads of bra families (bra_pairs[] / bra_rowoff[] = the slab's lists as before; bfam_mem[bfam_ptr[y] ..]:
+    // positions in those lists, the first one the head)
+    constexpr int MM = MA * MC;
+    constexpr int KM = MM > 9 ? 1 : TF_CF_KMAX;                        // components per lane and pass (registers: KM x MM accumulators)
     extern __shared__ double smem[];
     const int tid = threadIdx.x;
-    const DPair ab = B.pairs[bra_pairs[blockIdx.y]];
+    int nma = 1, nmc = 1;
+    const int *__restrict__ memA = nullptr, *__restrict__ mem = nullptr;
+    if (MA > 1) { memA = bfam_mem + bfam_ptr[blockIdx.y]; nma = bfam_ptr[blockIdx.y + 1] - bfam_ptr[blockIdx.y]; }
+    const int ybra = MA > 1 ? memA[0] : (int)blockIdx.y;
+    const DPair ab = B.pairs[bra_pairs[ybra]];
     const DPair cd = B.pairs[ket_pairs[blockIdx.x]];
-    int nmem = 1;
-    const int *__restrict__ mem = nullptr;
+    if (MC > 1) { mem = fam_mem + fam_ptr[blockIdx.x]; nmc = fam_ptr[blockIdx.x + 1] - fam_ptr[blockIdx.x]; }
     if (MM > 1) {
-        mem = fam_mem + fam_ptr[blockIdx.x];
-        nmem = fam_ptr[blockIdx.x + 1] - fam_ptr[blockIdx.x];
         bool any = false;
-        for (int mm = 0; mm < nmem; ++mm) any = any || !(cap.tri && B.pairs[mem[mm]].A > ab.A);
+        for (int ma = 0; ma < nma; ++ma) {
+            const int Aab = MA > 1 ? B.pairs[bra_pairs[memA[ma]]].A : ab.A;
+            for (int mc = 0; mc < nmc; ++mc) any = any || !(cap.tri && (MC > 1 ? B.pairs[mem[mc]].A : cd.A) > Aab);
+        }
         if (!any) return;
     } else if (cap.tri && cd.A > ab.A) return;
     if (ab.npp * cd.npp < cap.dbg_npq_lo || ab.npp * cd.npp > cap.dbg_npq_hi) return;
@@ -753,7 +763,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kern
     double *sG = tab + cap.offG, *sX = tab + cap.offX, *sZ = tab + cap.offZ;
     int *sPP = reinterpret_cast<int *>(smem + cap.offPP);            // [2][256]: primitive pair indices (within the pairs) of the batch
     unsigned short *sTupG = reinterpret_cast<unsigned short *>(smem + cap.offTupG), *sTupXZ = reinterpret_cast<unsigned short *>(smem + cap.offTupXZ);
-    const long long row0 = bra_rowoff[blockIdx.y];
+    const long long row0 = bra_rowoff[ybra];
     const size_t NcNc = (size_t)Nc * Nc;
     // primitive quartets per batch: what the cooperative R build and the table capacities of this launch allow (LRec::nb_cap)
     const int NB = min(npq, lr.nb_cap);
@@ -797,20 +807,22 @@ __global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kern
         yo = (((pa >> 8) & 255) * LcLd + ((pc >> 8) & 255)) * nM;
         zo = (((pa >> 16) & 255) * LcLd + ((pc >> 16) & 255)) * nM;
     };
-    auto store_to = [&](const DPair &kp, int iab, int icd, double val) {
+    auto store_to = [&](const DPair &kp, long long rowbase, int iab, int icd, double val) {
         const int pos = posCD[icd];
-        const size_t row = (size_t)(row0 + iab);
+        const size_t row = (size_t)(rowbase + iab);
         const int k = kp.cartoff_a + (pos >> 8), l = kp.cartoff_b + (pos & 255);
         Cslab[row * NcNc + (size_t)k * Nc + l] = val;
         if (kp.A != kp.B && !cap.tri) Cslab[row * NcNc + (size_t)l * Nc + k] = val;
     };
-    auto store = [&](int iab, int icd, double val) { store_to(cd, iab, icd, val); };
-    // FAMILY: the members' primitive-pair weights [member][primitive pair of the ket], staged once
-    double *sKm = smem + cap.offKm;
-    if (MM > 1) {
-        for (int e = tid; e < nmem * npp_cd; e += TF_ERI_THREADS) { const int mm = e / npp_cd; sKm[e] = B.pp_K[B.pairs[mem[mm]].pp_off + (e - mm * npp_cd)]; }
-        // (made visible by the barriers of the first build_tables)
-    }
+    auto store = [&](int iab, int icd, double val) { store_to(cd, row0, iab, icd, val); };
+    // FAMILIES: the members' primitive-pair weights, staged once: [ket member][primitive pair of the ket], then [bra member][.. of the bra]
+    double *sKc = smem + cap.offKm, *sKa = sKc + (MC > 1 ? nmc * npp_cd : 0);
+    const int npp_ab = ab.npp;
+    if (MC > 1)
+        for (int e = tid; e < nmc * npp_cd; e += TF_ERI_THREADS) { const int mm = e / npp_cd; sKc[e] = B.pp_K[B.pairs[mem[mm]].pp_off + (e - mm * npp_cd)]; }
+    if (MA > 1)
+        for (int e = tid; e < nma * npp_ab; e += TF_ERI_THREADS) { const int mm = e / npp_ab; sKa[e] = B.pp_K[B.pairs[bra_pairs[memA[mm]]].pp_off + (e - mm * npp_ab)]; }
+    // (made visible by the barriers of the first build_tables)
 
     // tables of the primitive quartets b0 .. b0 + nb - 1
     const int lgG = lr.lgG, lgX = lr.lgX, rstepG = 1 << lgG, rstepX = 1 << lgX;
@@ -822,7 +834,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kern
                            const int pab = pq / npp_cd, pcd = pq - pab * npp_cd;
                            sPP[e] = pab; sPP[TF_ERI_THREADS + e] = pcd;
                            ppab = ab.pp_off + pab; ppcd = cd.pp_off + pcd;
-                       }, ce, cn, tid, MM == 1);
+                       }, ce, cn, tid, MC == 1, MA == 1);
         __syncthreads();
         // ket half of the z tables: G_q[c,d][v][n] = sum_phi (-1)^phi Ez34[phi] R_q[v + phi][n]
         for (int p0 = 0; p0 < nb; p0 += TF_ERI_THREADS >> lgG) {
@@ -891,12 +903,12 @@ __global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kern
     const int NG = nnz < TF_ERI_THREADS ? TF_ERI_THREADS / nnz : 1, ncp = NG > 1 ? nnz : TF_ERI_THREADS;
     const int g = tid / ncp, c0 = tid - g * ncp;
     const bool lane_on = g < NG;
-    for (int cbase = 0; cbase < nnz; cbase += TF_ERI_THREADS * TF_CF_KMAX) {
-        int xo[TF_CF_KMAX], yo[TF_CF_KMAX], zo[TF_CF_KMAX], iab[TF_CF_KMAX], icd[TF_CF_KMAX];
-        double acc[TF_CF_KMAX][MM];
-        const int nk = min(TF_CF_KMAX, (nnz - cbase + TF_ERI_THREADS - 1) / TF_ERI_THREADS);
+    for (int cbase = 0; cbase < nnz; cbase += TF_ERI_THREADS * KM) {
+        int xo[KM], yo[KM], zo[KM], iab[KM], icd[KM];
+        double acc[KM][MM];
+        const int nk = min(KM, (nnz - cbase + TF_ERI_THREADS - 1) / TF_ERI_THREADS);
 #pragma unroll
-        for (int k = 0; k < TF_CF_KMAX; ++k) {
+        for (int k = 0; k < KM; ++k) {
 #pragma unroll
             for (int mm = 0; mm < MM; ++mm) acc[k][mm] = 0.0;
             xo[k] = -1; yo[k] = zo[k] = iab[k] = icd[k] = 0;
@@ -907,7 +919,7 @@ __global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kern
             const int nb = min(NB, npq - b0);
             build_tables(b0, nb);
 #pragma unroll
-            for (int k = 0; k < TF_CF_KMAX; ++k) {
+            for (int k = 0; k < KM; ++k) {
                 if (k >= nk || xo[k] < 0) continue;
                 if (MM == 1) {
                     double a = 0.0;
@@ -916,10 +928,16 @@ __global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kern
                 } else {
                     for (int q = g; q < nb; q += NG) {
                         const double f = sPref[q] * fact_sum_small(nM, sX + q * xz + xo[k], sX + q * xz + yo[k], sZ + q * xz + zo[k]);
-                        const double *Kq = sKm + sPP[TF_ERI_THREADS + q];             // weight of this primitive pair in member mm: Kq[mm * npp_cd]
+                        // weights of this primitive quartet's pairs in the members: Kc[mc * npp_cd], Ka[ma * npp_ab]
+                        const double *Kc = sKc + sPP[TF_ERI_THREADS + q], *Ka = sKa + sPP[q];
 #pragma unroll
-                        for (int mm = 0; mm < MM; ++mm)
-                            if (mm < nmem) acc[k][mm] += f * Kq[mm * npp_cd];
+                        for (int ma = 0; ma < MA; ++ma) {
+                            if (ma >= nma) break;
+                            const double fa = MA > 1 ? f * Ka[ma * npp_ab] : f;
+#pragma unroll
+                            for (int mc = 0; mc < MC; ++mc)
+                                if (mc < nmc) acc[k][ma * MC + mc] += MC > 1 ? fa * Kc[mc * npp_cd] : fa;
+                        }
                     }
                 }
             }
@@ -928,7 +946,8 @@ __global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kern
         if (NG > 1) {                                                 // combine the lane groups in fixed order (reproducible)
 #pragma unroll
             for (int mm = 0; mm < MM; ++mm) {
-                if (mm >= nmem) break;
+                if (mm / MC >= nma) break;
+                if (mm % MC >= nmc) continue;                         // (uniform over the workgroup: the barriers below match)
                 sRed[tid] = acc[0][mm];
                 __syncthreads();
                 if (g == 0) {
@@ -940,16 +959,23 @@ __global__ __launch_bounds__(TF_ERI_THREADS, MM > 1 ? 3 : 4) void eri_cfact_kern
             }
         }
 #pragma unroll
-        for (int k = 0; k < TF_CF_KMAX; ++k) {
+        for (int k = 0; k < KM; ++k) {
             if (!(k < nk && xo[k] >= 0 && g == 0)) continue;
             if (MM == 1) store(iab[k], icd[k], acc[k][0] * (scAB[iab[k]] * scCD[icd[k]]));
             else {
 #pragma unroll
-                for (int mm = 0; mm < MM; ++mm) {
-                    if (mm >= nmem) break;
-                    const DPair kp = B.pairs[mem[mm]];
-                    if (cap.tri && kp.A > ab.A) continue;             // (every (kl) of this member lies above every (ij) of the bra)
-                    store_to(kp, iab[k], icd[k], acc[k][mm] * (scAB[iab[k]] * scCD[icd[k]]));
+                for (int ma = 0; ma < MA; ++ma) {
+                    if (ma >= nma) break;
+                    const int yb = MA > 1 ? memA[ma] : ybra;
+                    const int Aab = MA > 1 ? B.pairs[bra_pairs[yb]].A : ab.A;
+                    const long long rowb = MA > 1 ? bra_rowoff[yb] : row0;
+#pragma unroll
+                    for (int mc = 0; mc < MC; ++mc) {
+                        if (mc >= nmc) break;
+                        const DPair kp = MC > 1 ? B.pairs[mem[mc]] : cd;
+                        if (cap.tri && kp.A > Aab) continue;         // (every (kl) of this member lies above every (ij) of that bra)
+                        store_to(kp, rowb, iab[k], icd[k], acc[k][ma * MC + mc] * (scAB[iab[k]] * scCD[icd[k]]));
+                    }
                 }
             }
         }
