@@ -73,8 +73,9 @@ __global__ __launch_bounds__(TFJ_THREADS) void jacobi_eigh_kernel(int n, double 
         }
         __syncthreads();
     }
+    const int lane = tid & 63, wv = tid >> 6;
     for (; sweeps < max_sweeps; ++sweeps) {
-        // convergence: off-diagonal weight relative to the whole matrix
+        // convergence: off-diagonal weight relative to the whole matrix (wave shuffles, then the 16 wave sums: two barriers)
         double off = 0.0, tot = 0.0;
         for (int e = tid; e < n * n; e += TFJ_THREADS) {
             const int i = e / n, j = e - i * n;
@@ -82,20 +83,21 @@ __global__ __launch_bounds__(TFJ_THREADS) void jacobi_eigh_kernel(int n, double 
             tot += a * a;
             if (i != j) off += a * a;
         }
-        sRed[tid] = off; sRed[TFJ_THREADS + tid] = tot;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { off += __shfl_xor(off, d, 64); tot += __shfl_xor(tot, d, 64); }
+        if (lane == 0) { sRed[wv] = off; sRed[TFJ_THREADS + wv] = tot; }
         __syncthreads();
-        for (int s = TFJ_THREADS / 2; s > 0; s >>= 1) {
-            if (tid < s) { sRed[tid] += sRed[tid + s]; sRed[TFJ_THREADS + tid] += sRed[TFJ_THREADS + tid + s]; }
-            __syncthreads();
+        if (tid == 0) {
+            double o2 = 0.0, t2 = 0.0;
+            for (int u = 0; u < TFJ_THREADS / 64; ++u) { o2 += sRed[u]; t2 += sRed[TFJ_THREADS + u]; }
+            sDone = (o2 <= 1e-31 * t2) ? 1 : 0;
         }
-        if (tid == 0) sDone = (sRed[0] <= 1e-31 * sRed[TFJ_THREADS]) ? 1 : 0;
         __syncthreads();
         if (sDone) break;
         for (int r = 0; r < m - 1; ++r) {
             if (tid < half) {
                 int p, q;
                 tournament_pair(m, r, tid, p, q);
-                int code = -1;
                 double c = 1.0, s = 0.0;
                 if (q < n) {
                     const double apq = sA[p * lda + q];
@@ -104,37 +106,41 @@ __global__ __launch_bounds__(TFJ_THREADS) void jacobi_eigh_kernel(int n, double 
                         const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                         c = 1.0 / sqrt(1.0 + t * t);
                         s = t * c;
-                        code = p | (q << 16);
                     }
                 }
-                sPQ[tid] = code; sC[tid] = c; sS[tid] = s;
+                sPQ[tid] = p | (q << 16); sC[tid] = c; sS[tid] = s;          // (q == n: the bye of an odd n -- identity, its row / column does not exist)
             }
             __syncthreads();
-            // A <- A J   (columns p, q of every row)
-            for (int e = tid; e < half * n; e += TFJ_THREADS) {
-                const int k = e / n, i = e - k * n;
-                const int code = sPQ[k];
-                if (code < 0) continue;
-                const int p = code & 0xffff, q = code >> 16;
-                const double c = sC[k], s = sS[k];
-                const double aip = sA[i * lda + p], aiq = sA[i * lda + q];
-                sA[i * lda + p] = c * aip - s * aiq;
-                sA[i * lda + q] = s * aip + c * aiq;
-            }
-            __syncthreads();
-            // A <- J^T A  (rows p, q), V^T rows likewise
-            for (int e = tid; e < half * n; e += TFJ_THREADS) {
-                const int k = e / n, j = e - k * n;
-                const int code = sPQ[k];
-                if (code < 0) continue;
-                const int p = code & 0xffff, q = code >> 16;
-                const double c = sC[k], s = sS[k];
-                const double apj = sA[p * lda + j], aqj = sA[q * lda + j];
-                sA[p * lda + j] = (j == q) ? 0.0 : c * apj - s * aqj;
-                sA[q * lda + j] = (j == p) ? 0.0 : s * apj + c * aqj;
-                const double vp = sV[p * ldv + j], vq = sV[q * ldv + j];
-                sV[p * ldv + j] = c * vp - s * vq;
-                sV[q * ldv + j] = s * vp + c * vq;
+            // A <- J^T A J in ONE phase: the pairs of the round are disjoint, so the 2 x 2 block (rows p, q of pair k) x (columns p', q' of
+            // pair k') belongs to one thread, which applies the column rotation of k' and the row rotation of k (three barriers and two
+            // passes over A per round before: the round is bound by barriers and LDS latency, not arithmetic); rows of V in the same phase
+            for (int e = tid; e < half * half + half * n; e += TFJ_THREADS) {
+                if (e < half * half) {
+                    const int k = e / half, k2 = e - k * half;
+                    const int cr = sPQ[k], cc = sPQ[k2];
+                    const int p = cr & 0xffff, q = cr >> 16, p2 = cc & 0xffff, q2 = cc >> 16;
+                    const bool vq = q < n, vq2 = q2 < n;
+                    const double c = sC[k], sn = sS[k], c2 = sC[k2], s2 = sS[k2];
+                    const double b00 = sA[p * lda + p2], b01 = vq2 ? sA[p * lda + q2] : 0.0;
+                    const double b10 = vq ? sA[q * lda + p2] : 0.0, b11 = (vq && vq2) ? sA[q * lda + q2] : 0.0;
+                    const double t00 = c2 * b00 - s2 * b01, t01 = s2 * b00 + c2 * b01;
+                    const double t10 = c2 * b10 - s2 * b11, t11 = s2 * b10 + c2 * b11;
+                    const bool dg = k == k2 && sn != 0.0;                      // the rotated pair itself: its off-diagonal element is annihilated
+                    sA[p * lda + p2] = c * t00 - sn * t10;
+                    if (vq2) sA[p * lda + q2] = dg ? 0.0 : c * t01 - sn * t11;
+                    if (vq) sA[q * lda + p2] = dg ? 0.0 : sn * t00 + c * t10;
+                    if (vq && vq2) sA[q * lda + q2] = sn * t01 + c * t11;
+                } else {
+                    const int f = e - half * half, k = f / n, j = f - k * n;
+                    const int cr = sPQ[k];
+                    const int p = cr & 0xffff, q = cr >> 16;
+                    const double c = sC[k], sn = sS[k];
+                    if (q < n && sn != 0.0) {
+                        const double vp = sV[p * ldv + j], vq = sV[q * ldv + j];
+                        sV[p * ldv + j] = c * vp - sn * vq;
+                        sV[q * ldv + j] = sn * vp + c * vq;
+                    }
+                }
             }
             __syncthreads();
         }
