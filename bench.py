@@ -20,6 +20,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before torch initialises HIP (tuna_amd/__init__.py: concurrent launches of the tensor build)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 FP64_MATRIX_PEAK_FLOPS = 78.6e12 # MI355X FP64 matrix (MFMA) peak: the FP64 matrix cores run at the FP64 vector rate on CDNA4

@@ -8,6 +8,7 @@ ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLD = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")       # as tuna_amd/__init__.py sets it: before anything initialises HIP
 
 
 def pytest_configure(config):

@@ -11,6 +11,13 @@ __version__ = "0.1.0"
 
 import os as _os
 
+# Hardware queues of the process: the HIP runtime maps all streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and the launches
+# of one queue run one after the other, each as long as its slowest workgroup.  A tensor build of a contracted basis set issues ~70
+# launches of very different lengths on 8 streams: with 16 queues Ar2/cc-pVQZ's ERI kernels take 8.7 ms instead of 14.7.
+# The runtime reads the variable when it initialises, so it has to be in the environment before the first HIP call of the process --
+# importing this package before torch touches the GPU is enough; an explicit setting of the caller is left alone.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 
 def cpu_quota() -> int:
     """CPUs this process may actually use: the cgroup quota if there is one, else the affinity mask."""

@@ -441,6 +441,9 @@ int tf_shard_plan(int n_blocks, const int64_t *weight, int world, int32_t *owner
 
 tf_ctx *tf_create(int device, int rank, int world)
 {
+    // more hardware queues for the concurrent launches of the tensor build (effective if this is the first HIP call of the process;
+    // the Python package and INTEGRATION.md say the same); a setting of the host application is left alone
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -1567,7 +1570,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             b0 = b1;
         }
         std::stable_sort(launches.begin(), launches.end(), [](const Launch &x, const Launch &y) { return x.cost > y.cost; });
-        const int NQ = std::min(NSTREAM, getenv("TF_ERI_NQ") ? std::max(1, atoi(getenv("TF_ERI_NQ"))) : 4);
+        // (as many streams as the process has hardware queues: 4 unless GPU_MAX_HW_QUEUES says otherwise -- tuna_amd sets 16)
+        const int hwq = getenv("GPU_MAX_HW_QUEUES") ? std::max(1, atoi(getenv("GPU_MAX_HW_QUEUES"))) : 4;
+        const int NQ = std::min(NSTREAM, getenv("TF_ERI_NQ") ? std::max(1, atoi(getenv("TF_ERI_NQ"))) : std::max(4, std::min(8, hwq)));
         std::vector<double> load(NQ, 0.0);
         struct BraFam { int *d_ptr = nullptr, *d_mem = nullptr; unsigned n = 0; };
         std::map<std::pair<size_t, int>, BraFam> bra_fams;       // by (first position of the run of bra pairs, largest family)
