@@ -2297,11 +2297,19 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
         static const bool serial = getenv("TF_JK_SERIAL") != nullptr;
         int n_launch = 0;
         for (int b = 0; b < 3; ++b) n_launch += (T.bucket[b + 1] > T.bucket[b] && (TF_JKP_W >> b) >= 1) ? 1 : 0;
-        const bool fork = !serial && ctx->have_streams && n_launch > 1;
+        // Few tasks (small tensors: N2/cc-pVTZ has 1 400): ONE launch of full-size workgroups over all of them -- the idle waves of the
+        // narrower tasks cost nothing on a chip the build cannot fill, two launches and the fork / join events of the side streams do
+        // (a Fock build at N = 60 is ~90 us of launches, not of work)
+        static const int one_launch_below = getenv("TF_JK_ONE_LAUNCH") ? atoi(getenv("TF_JK_ONE_LAUNCH")) : 12000;   // (measured: N = 60 99 -> 69 us per build, 118: 155 -> 108, 160: 202 -> 183, 200: equal, 300: 874 against 907)
+        const bool one_launch = n_launch > 1 && T.n_tasks < one_launch_below;
+        const bool fork = !serial && !one_launch && ctx->have_streams && n_launch > 1;
         if (fork) (void)hipEventRecord(ctx->sev[0], st);
         int side = 0;
         bool first = true;
-        for (int b = 0; b < 3; ++b) {
+        if (one_launch)
+            hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)T.n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, T.d_groups,
+                               T.d_supers, T.d_tasks, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+        for (int b = 0; b < 3 && !one_launch; ++b) {
             const int t0 = T.bucket[b], t1 = T.bucket[b + 1];
             if (!(t1 > t0 && (TF_JKP_W >> b) >= 1)) continue;
             hipStream_t ls = st;

@@ -323,7 +323,8 @@ inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, st
 {
     static const bool force_rocsolver = getenv("TF_EIGH") && std::string(getenv("TF_EIGH")) == "rocsolver";
     static const bool force_jacobi = getenv("TF_EIGH") && std::string(getenv("TF_EIGH")) == "jacobi";
-    if (!force_rocsolver && n >= 2 && n <= (force_jacobi ? TFJ_NMAX : 64)) {
+    static const int jac_nmax = getenv("TF_JACOBI_NMAX") ? std::min(TFJ_NMAX, std::max(2, atoi(getenv("TF_JACOBI_NMAX")))) : 64;
+    if (!force_rocsolver && n >= 2 && n <= (force_jacobi ? TFJ_NMAX : jac_nmax)) {
         if (w.jac_cap < (size_t)n * n) {
             if (w.jac_scratch) (void)hipFree(w.jac_scratch);
             w.jac_scratch = nullptr; w.jac_cap = 0;
