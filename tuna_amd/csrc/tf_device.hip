@@ -2364,7 +2364,9 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
         // narrower tasks cost nothing on a chip the build cannot fill, two launches and the fork / join events of the side streams do
         // (a Fock build at N = 60 is ~90 us of launches, not of work)
         static const int one_launch_below = getenv("TF_JK_ONE_LAUNCH") ? atoi(getenv("TF_JK_ONE_LAUNCH")) : 12000;   // (measured: N = 60 99 -> 69 us per build, 118: 155 -> 108, 160: 202 -> 183, 200: equal, 300: 874 against 907)
-        const bool one_launch = n_launch > 1 && T.n_tasks < one_launch_below;
+        // (one rank only: the rows of a rank of several are short runs of j -- mostly one group per super-group, three of four waves idle
+        // in the barriers of a LONG walk; measured at N = 400 on 8 ranks: 0.72 ms per local build in one launch against 0.46 ms in three)
+        const bool one_launch = n_launch > 1 && T.n_tasks < one_launch_below && ctx->world == 1;
         const bool fork = !serial && !one_launch && ctx->have_streams && n_launch > 1;
         if (fork) (void)hipEventRecord(ctx->sev[0], st);
         int side = 0;
