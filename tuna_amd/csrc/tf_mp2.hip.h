@@ -119,52 +119,92 @@ struct Q1Args {
 // BLDS: C3 is staged in LDS ([N][n3r], n3r = n3 rounded up to even) once per workgroup, which then walks `rpw` consecutive rows -- the
 // B operands of every MFMA are then LDS reads; from global memory (L2) they were two thirds of the bytes through the texture
 // addresser, which ran at ~75 % for the four waves of a CU.  Without (N n3r doubles do not fit): B operands from C3p in global memory.
+// The rows of a workgroup (`rpw` consecutive ones) are prepared together -- per row a header, the segment table and, per block, the first
+// segment that reaches it -- and the (row, block) items then go through a work queue (an LDS counter): a wave takes the next item when
+// it is free, whatever row it belongs to (every fourth block of a row per wave left the slowest wave 20 % behind the mean; and no
+// barrier separates the rows any more).  Which wave computes an item does not change its result: one owner, fixed order inside.
+#define TFQ1_RPW 4
+#ifndef TFQ1_THREADS
+#define TFQ1_THREADS 512            // eight waves share one staging of C3 (two workgroups per CU by LDS: four waves per SIMD)
+#endif
+struct Q1Row { long long rowoff; int i, j, c, iI, lamj, pad; };
 template <int NT, bool BLDS>
-__global__ __launch_bounds__(256) void mo_q1_kernel(Q1Args Q, BLayout L, int n3r, int rpw, long long n_rows)
+__global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayout L, int n3r, int rpw, long long n_rows, int nblk)
 {
     extern __shared__ double sQ1[];
     const int N = L.N;
-    int2 *sSeg = reinterpret_cast<int2 *>(sQ1);                     // [N]: per internal AO k: offset of its segment in this row's unit; columns it holds
-    double *sC3 = sQ1 + N;                                          // [N][n3r] (BLDS)
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // LDS: [rpw][N] segment tables | [rpw] row headers | [rpw][nblk] block starts | counter | C3 [N][n3r] (BLDS)
+    int2 *sSegAll = reinterpret_cast<int2 *>(sQ1);                  // per row and internal AO k: offset of its segment in the row's unit; columns it holds
+    Q1Row *sRow = reinterpret_cast<Q1Row *>(sSegAll + (size_t)TFQ1_RPW * N);
+    int *sLo = reinterpret_cast<int *>(sRow + TFQ1_RPW);            // [rpw][nblk]: first member of the column walk of block b
+    int *sCounter = sLo + TFQ1_RPW * nblk;
+    double *sC3 = reinterpret_cast<double *>(sCounter + 2 + ((TFQ1_RPW * nblk) & 1));   // 8-byte aligned: sLo holds rpw * nblk ints, + 2 for the counter
+    const int lane = threadIdx.x & 63;
     const int m = lane & 15, kk = lane >> 4;
     constexpr int NP = 16 * NT;
     if (BLDS) {
-        for (int e = threadIdx.x; e < N * n3r; e += 256) { const int x = e / n3r, p = e - x * n3r; sC3[e] = Q.C3p[(size_t)x * NP + p]; }
+        for (int e = threadIdx.x; e < N * n3r; e += TFQ1_THREADS) { const int x = e / n3r, p = e - x * n3r; sC3[e] = Q.C3p[(size_t)x * NP + p]; }
     }
     bool colok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) colok[t] = 16 * t + m < n3r;
-  for (long long r = (long long)blockIdx.x * rpw; r < min(n_rows, ((long long)blockIdx.x + 1) * rpw); ++r) {
-    __syncthreads();                                                // (the previous row's table is dead; C3 is staged)
-    const int2 ij = Q.row_ij[r];
-    const int wi = L.ao[ij.x], wj = L.ao[ij.y];
-    const int c = ao_cls(wi) ^ ao_cls(wj), iI = ao_sigma(L, wi), lamj = ao_loc(wj);
-    const int *rs = Q.rowsec + 6 * (size_t)r;
-    const int unr = rs[5], pos = rs[4];
-    const double *__restrict__ T = Q.eri + Q.rowoff[r];
-    // segment table of the row: AOs beyond i (original order) hold nothing, the segment of k == i ends at l == j
-    {
-        const KInfo *__restrict__ kinf = L.kinfo + (size_t)c * N;
-        for (int kI = threadIdx.x; kI < N; kI += 256) {
-            const int a = L.clsI[kI];
-            const KInfo ki = kinf[kI];
-            const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);
-            const bool have = kI - bl_cstart(L, a) < L.cntA[(size_t)a * N + iI];
-            sSeg[kI] = make_int2(unr * (rs[a] + ki.offA) + pos * pc, have ? (kI == iI ? lamj + 1 : ki.cnt) : 0);
-        }
-    }
-    __syncthreads();
-    // blocks of 16 output AOs, class by class; wave w takes every fourth
+    const long long r_first = (long long)blockIdx.x * rpw;
+    const int nrow = (int)min((long long)rpw, n_rows - r_first);
     int bfirst[5];
     bfirst[0] = 0;
 #pragma unroll
     for (int x = 0; x < 4; ++x) bfirst[x + 1] = bfirst[x] + (L.itab[BL_CSIZE + x] + 15) / 16;
-    for (int blk = w; blk < bfirst[4]; blk += 4) {
+    if (threadIdx.x < nrow) {
+        const long long r = r_first + threadIdx.x;
+        const int2 ij = Q.row_ij[r];
+        const int wi = L.ao[ij.x], wj = L.ao[ij.y];
+        sRow[threadIdx.x] = Q1Row{Q.rowoff[r], ij.x, ij.y, ao_cls(wi) ^ ao_cls(wj), ao_sigma(L, wi), ao_loc(wj), 0};
+    }
+    if (threadIdx.x == 0) *sCounter = 0;
+    __syncthreads();
+    // segment tables: AOs beyond i (original order) hold nothing, the segment of k == i ends at l == j
+    for (int e = threadIdx.x; e < nrow * N; e += TFQ1_THREADS) {
+        const int rr = e / N, kI = e - rr * N;
+        const Q1Row R = sRow[rr];
+        const int *rs = Q.rowsec + 6 * (size_t)(r_first + rr);
+        const int a = L.clsI[kI];
+        const KInfo ki = L.kinfo[(size_t)R.c * N + kI];
+        const int pc = (ki.cnt + TF_SEG_PAD - 1) & ~(TF_SEG_PAD - 1);
+        const bool have = kI - bl_cstart(L, a) < L.cntA[(size_t)a * N + R.iI];
+        sSegAll[e] = make_int2(rs[5] * (rs[a] + ki.offA) + rs[4] * pc, have ? (kI == R.iI ? R.lamj + 1 : ki.cnt) : 0);
+    }
+    __syncthreads();
+    // per block: the first member of class a = x ^ c whose segment is longer than s0 (cnt is non-decreasing, except that the segment of
+    // k == i -- the last member when i is of that class -- is cut at l == j: it stays out of the search and is tested like every element)
+    for (int e = threadIdx.x; e < nrow * nblk; e += TFQ1_THREADS) {
+        const int rr = e / nblk, blk = e - rr * nblk;
+        const Q1Row R = sRow[rr];
+        const int x = blk >= bfirst[3] ? 3 : (blk >= bfirst[2] ? 2 : (blk >= bfirst[1] ? 1 : 0));
+        const int s0 = 16 * (blk - (x == 3 ? bfirst[3] : (x == 2 ? bfirst[2] : (x == 1 ? bfirst[1] : 0))));
+        const int a = x ^ R.c, a0 = bl_cstart(L, a);
+        const int klim = L.cntA[(size_t)a * N + R.iI];
+        const int2 *sg = sSegAll + (size_t)rr * N;
+        int lo = 0, hi = (klim > 0 && a0 + klim - 1 == R.iI) ? klim - 1 : klim;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sg[a0 + mid].y > s0) hi = mid; else lo = mid + 1; }
+        sLo[e] = lo;
+    }
+    __syncthreads();
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(sCounter, 1);
+        item = __shfl(item, 0, 64);
+        if (item >= nrow * nblk) break;
+        const int rr = __builtin_amdgcn_readfirstlane(item / nblk), blk = __builtin_amdgcn_readfirstlane(item - (item / nblk) * nblk);
+        const Q1Row R = sRow[rr];
+        const int2 ij = make_int2(R.i, R.j);
+        const int c = R.c, iI = R.iI, lamj = R.lamj;
+        const double *__restrict__ T = Q.eri + R.rowoff;
+        const int2 *sSeg = sSegAll + (size_t)rr * N;
         const int x = blk >= bfirst[3] ? 3 : (blk >= bfirst[2] ? 2 : (blk >= bfirst[1] ? 1 : 0));
         const int s0 = 16 * (blk - (x == 3 ? bfirst[3] : (x == 2 ? bfirst[2] : (x == 1 ? bfirst[1] : 0))));
         const int nx = L.itab[BL_CSIZE + x], x0 = bl_cstart(L, x);
         const int a = x ^ c, a0 = bl_cstart(L, a), na = L.itab[BL_CSIZE + a];
+        const int lo_col = sLo[item];
         tfm_v4d acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = tfm_v4d{0.0, 0.0, 0.0, 0.0};
@@ -222,10 +262,7 @@ __global__ __launch_bounds__(256) void mo_q1_kernel(Q1Args Q, BLayout L, int n3r
         //      consecutive k per pass (eight loads in flight, then eight K steps)
         if (!(Q.dbg & 4)) {
             const int klim = L.cntA[(size_t)a * N + iI];
-            // first member whose segment is longer than s0: cnt is non-decreasing, except that the segment of k == i (the last member when i is
-            // of this class) is cut at l == j -- it stays out of the search and is tested like every element (lam < cnt)
-            int lo = 0, hi = (klim > 0 && a0 + klim - 1 == iI) ? klim - 1 : klim;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (sSeg[a0 + mid].y > s0) hi = mid; else lo = mid + 1; }
+            const int lo = lo_col;
             const int lam = s0 + m;
             auto col_load = [&](int kl0, double (&v)[8], int (&kIs)[8]) {
 #pragma unroll
@@ -299,7 +336,6 @@ __global__ __launch_bounds__(256) void mo_q1_kernel(Q1Args Q, BLayout L, int n3r
             }
         }
     }
-  }
 }
 
 // Cp[x][0 .. NP) = C[origI[x]][0 .. n) padded with zeros: coefficient rows in internal AO order, MFMA column tiles
@@ -431,6 +467,71 @@ done:
     return rc;
 }
 
+// T[p][x] = sum_mu C1[mu][p] R[mu][x]  (p < n1 <= 32, x < X = N N n3, mu < N): the bra index mu -> occupied orbital over the 9.2 GB of R.
+// rocBLAS takes a 128 x 128 macro tile for this 18-wide output and runs compute-bound on the padding (4.6 ms at N = 400); here the
+// orbitals are the M dimension of v_mfma_f64_16x16x4_f64 (one or two tiles), 64 consecutive x per wave the N dimension (four tiles: 512
+// contiguous bytes of every plane mu), C1 in LDS as the A operand, the next K step's loads in flight: the kernel streams R once.
+#define TFB1_THREADS 384          // six waves share one staging of C1: two workgroups per CU by LDS = three waves per SIMD (157 VGPRs)
+template <int MT>
+__global__ __launch_bounds__(TFB1_THREADS, 3) void mo_bra1_kernel(const double *__restrict__ R, const double *__restrict__ C1, int N, int n1, size_t X,
+                                                      double *__restrict__ T)
+{
+    extern __shared__ double sC1[];                                 // [N][n1r]
+    const int n1r = (n1 + 1) & ~1;
+    for (int e = threadIdx.x; e < N * n1r; e += TFB1_THREADS) { const int mu = e / n1r, p = e - mu * n1r; sC1[e] = p < n1 ? C1[(size_t)mu * n1 + p] : 0.0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = lane & 15, kk = lane >> 4;
+    const size_t x0 = ((size_t)blockIdx.x * (TFB1_THREADS / 64) + w) * 64;
+    if (x0 >= X) return;
+    bool rowok[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) rowok[t] = 16 * t + m < n1r;
+    tfm_v4d acc[MT][4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = tfm_v4d{0.0, 0.0, 0.0, 0.0};
+    bool xok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xok[j] = x0 + 16 * j + m < X;
+    const double *__restrict__ Rx = R + x0 + m;
+    auto load = [&](int mu0, double (&b)[4]) {
+        const int mu = mu0 + kk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = (mu < N && xok[j]) ? __builtin_nontemporal_load(Rx + (size_t)mu * X + 16 * j) : 0.0;
+    };
+    auto mma = [&](int mu0, const double (&b)[4]) {
+        const int mu = mu0 + kk;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const double a = (mu < N && rowok[t]) ? sC1[mu * n1r + 16 * t + m] : 0.0;       // A[row p = lane & 15][k = mu]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[t][j], 0, 0, 0);
+        }
+    };
+    double bA[4], bB[4];
+    load(0, bA);
+    for (int mu0 = 0; mu0 < N; mu0 += 8) {                            // two buffers: the loads of the next K step are in flight
+        if (mu0 + 4 < N) load(mu0 + 4, bB);
+        mma(mu0, bA);
+        if (mu0 + 4 >= N) break;
+        if (mu0 + 8 < N) load(mu0 + 8, bA);
+        mma(mu0 + 4, bB);
+    }
+    // D[row p = 4 v + (lane >> 4)][col x = lane & 15]
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int p = 16 * t + 4 * v + kk;
+            if (p >= n1) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (xok[j]) T[(size_t)p * X + x0 + 16 * j + m] = acc[t][j][v];
+        }
+}
+
 // The packed-layout transformation with the short index first (n3 <= 32): first quarter by mo_q1_kernel, then three rocBLAS GEMMs
 //     T [p1][nu][sigma][p3]  = sum_mu C1[mu][p1] R[mu][nu][sigma][p3]                 (one GEMM, K = N)
 //     T2[p1][p2][sigma][p3]  = sum_nu C2[nu][p2] T[p1][nu][sigma][p3]                 (batched over p1)
@@ -464,24 +565,44 @@ inline int transform_q1(rocblas_handle blas, const double *d_eri, const long lon
         const char *dbg = getenv("TF_Q1_DBG");
         Q1Args Q{d_eri, d_rowoff, d_rowsec, d_row_ij, dC3p, dR, n3, dbg ? atoi(dbg) : 0};
         const int n3r = (n3 + 1) & ~1;
-        const size_t lds_tab = (size_t)N * sizeof(int2), lds_c3 = (size_t)N * n3r * sizeof(double);
-        const bool blds = lds_tab + lds_c3 <= (size_t)72 << 10;       // two workgroups per CU
-        const int rpw = blds ? 4 : 1;
+        int nblk = 0;
+        {
+            int csz[4];
+            TFM_HIP(hipMemcpy(csz, BL.itab + BL_CSIZE, sizeof(csz), hipMemcpyDeviceToHost));
+            for (int x = 0; x < 4; ++x) nblk += (csz[x] + 15) / 16;
+        }
+        const size_t lds_tab = (size_t)TFQ1_RPW * N * sizeof(int2) + TFQ1_RPW * sizeof(Q1Row) + ((size_t)TFQ1_RPW * nblk + 4) * sizeof(int);
+        const size_t lds_c3 = (size_t)N * n3r * sizeof(double);
+        const bool blds = lds_tab + lds_c3 <= (size_t)80 << 10;       // two workgroups per CU
+        const int rpw = TFQ1_RPW;
         const unsigned grid = (unsigned)((n_rows + rpw - 1) / rpw);
         const size_t lds = lds_tab + (blds ? lds_c3 : 0);
+        if (lds > ((size_t)160 << 10) - 256) { msg = "AO->MO first quarter: the row tables do not fit LDS"; rc = TF_EINVAL; goto done; }
         if (lds > ((size_t)64 << 10)) {
             TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        if (NT == 1 && blds) hipLaunchKernelGGL((mo_q1_kernel<1, true>), dim3(grid), dim3(256), lds, 0, Q, BL, n3r, rpw, n_rows);
-        else if (NT == 1) hipLaunchKernelGGL((mo_q1_kernel<1, false>), dim3(grid), dim3(256), lds, 0, Q, BL, n3r, rpw, n_rows);
-        else if (blds) hipLaunchKernelGGL((mo_q1_kernel<2, true>), dim3(grid), dim3(256), lds, 0, Q, BL, n3r, rpw, n_rows);
-        else hipLaunchKernelGGL((mo_q1_kernel<2, false>), dim3(grid), dim3(256), lds, 0, Q, BL, n3r, rpw, n_rows);
+        if (NT == 1 && blds) hipLaunchKernelGGL((mo_q1_kernel<1, true>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
+        else if (NT == 1) hipLaunchKernelGGL((mo_q1_kernel<1, false>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
+        else if (blds) hipLaunchKernelGGL((mo_q1_kernel<2, true>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
+        else hipLaunchKernelGGL((mo_q1_kernel<2, false>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
         TFM_HIP(hipGetLastError());
     }
-    // T (column-major X x n1) = R (X x N) * C1^T (N x n1)
-    TFM_BLAS(rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)X, n1, N, &one, dR, (rocblas_int)X, dC1, n1, &zero,
-                           dT, (rocblas_int)X));
+    // T (column-major X x n1) = R (X x N) * C1^T (N x n1): hand-written for n1 <= 32 (TF_MO_BRA1=0: rocBLAS)
+    {
+        const char *b1 = getenv("TF_MO_BRA1");
+        const size_t lds1 = (size_t)N * ((n1 + 1) & ~1) * sizeof(double);
+        if (n1 <= 32 && lds1 <= ((size_t)64 << 10) && !(b1 && b1[0] == '0')) {
+            const unsigned grid1 = (unsigned)((X + TFB1_THREADS - 1) / TFB1_THREADS);
+            if (n1 <= 16) hipLaunchKernelGGL(mo_bra1_kernel<1>, dim3(grid1), dim3(TFB1_THREADS), lds1, 0, dR, dC1, N, n1, X, dT);
+            else hipLaunchKernelGGL(mo_bra1_kernel<2>, dim3(grid1), dim3(TFB1_THREADS), lds1, 0, dR, dC1, N, n1, X, dT);
+            TFM_HIP(hipGetLastError());
+        } else
+            TFM_BLAS(rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)X, n1, N, &one, dR, (rocblas_int)X, dC1, n1, &zero,
+                                   dT, (rocblas_int)X));
+    }
     // T2[p1] (Y x n2) = T[p1] (Y x N) * C2^T (N x n2)
     TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)Y, n2, N, &one, dT, (rocblas_int)Y,
                                            (rocblas_stride)N * Y, dC2, n2, 0, &zero, dT2, (rocblas_int)Y, (rocblas_stride)n2 * Y, n1));
