@@ -134,6 +134,7 @@ struct tf_ctx {
     long long *d_rowoff = nullptr;
     int *d_jptr = nullptr;                       // rows by second index x (internal): d_jrows[d_jptr[x] .. d_jptr[x + 1])
     int2 *d_jrows = nullptr;                     // (local row, ORIGINAL first index of the row)
+    int *d_xorder = nullptr;                     // output rows of the exchange reduction, most partial vectors first
     int *d_rowsec = nullptr;            // [n_rows][6]: start of section a inside local row r; position in its storage unit, rows of the unit
     // parity-blocked layout tables (tf_layout.hip.h), host mirror and device view
     struct HostLayout {
@@ -249,9 +250,9 @@ static void free_eri(tf_ctx *ctx)
             if (p) (void)hipFree(p);
         t = tf_ctx::JKTables();
     }
-    for (void *p : {(void *)ctx->d_jptr, (void *)ctx->d_jrows})
+    for (void *p : {(void *)ctx->d_jptr, (void *)ctx->d_jrows, (void *)ctx->d_xorder})
         if (p) (void)hipFree(p);
-    ctx->d_jptr = nullptr; ctx->d_jrows = nullptr;
+    ctx->d_jptr = nullptr; ctx->d_jrows = nullptr; ctx->d_xorder = nullptr;
     for (void *p : ctx->layout_allocs) (void)hipFree(p);
     ctx->layout_allocs.clear();
     if (ctx->d_rowsec) { (void)hipFree(ctx->d_rowsec); ctx->d_rowsec = nullptr; }
@@ -1027,6 +1028,16 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             }
         }
         if ((rc2 = upload(ctx, jptr, &ctx->d_jptr, false)) || (rc2 = upload(ctx, jrows, &ctx->d_jrows, false))) return rc2;
+        {
+            // dispatch order of the exchange reduction: the output rows with the most partial vectors (rows listed under x + groups of x) first
+            std::vector<long long> work((size_t)N, 0);
+            for (int x = 0; x < N; ++x) work[x] = jptr[x + 1] - jptr[x];
+            for (const int2 &ij : row_ij) work[H.sigma[ij.x]] += 1;          // (8 rows of a group: weight 1/8 each would do; the order is what counts)
+            std::vector<int> xorder((size_t)N);
+            std::iota(xorder.begin(), xorder.end(), 0);
+            std::stable_sort(xorder.begin(), xorder.end(), [&](int a, int b) { return work[a] > work[b]; });
+            if ((rc2 = upload(ctx, xorder, &ctx->d_xorder, false))) return rc2;
+        }
         return TF_OK;
     };
 
@@ -2397,7 +2408,7 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
     R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.MC = ctx->hl.MC; R.MP = MP; R.planeI = S.planeI; R.planeJ = S.planeJ; R.nseg = T.nseg; R.jp = T.jp;
     R.Jt = ctx->d_Jt; R.sJt = (size_t)T.nseg * npr;
     R.DIc = DIc; R.sDIc = S.DIc; R.DIr = DIr; R.sDIr = S.DIr; R.DJc = DJc; R.sDJc = S.DJc; R.DJr = DJr; R.sDJr = S.DJr;
-    R.gfirst = T.d_gfirst; R.jptr = ctx->d_jptr; R.jrows = ctx->d_jrows; R.row_ij = ctx->d_row_ij;
+    R.gfirst = T.d_gfirst; R.jptr = ctx->d_jptr; R.jrows = ctx->d_jrows; R.row_ij = ctx->d_row_ij; R.xorder = ctx->d_xorder;
     for (int d = 0; d < ND; ++d) R.D[d] = dDout[d];
     { static const int jkr_dbg = getenv("TF_JKR_DBG") ? atoi(getenv("TF_JKR_DBG")) : 0; R.dbg = jkr_dbg; }
     const unsigned nblk = (unsigned)ND * ((unsigned)N * ((N + 127) / 128) + (unsigned)T.jp.bfirst[4] * T.nseg);

@@ -802,6 +802,9 @@ __device__ __forceinline__ void jt_reduce_block(int bx, int by, int nseg, const 
 // (every load of a partial vector -- the column part and up to TF_JKR_MCMAX row-part slots -- is issued before the first add: with a
 // run-time slot loop the four rounds of a vector were four memory latencies one after the other, and that chain, not bandwidth, was the
 // 0.30 ms of this kernel at N = 400)
+#ifndef TF_JKR_U
+#define TF_JKR_U 2                 // partial vectors of a slice in flight together (measured at N = 400: 1: 0.247 ms, 2: 0.251, 3: 0.270, 4: 0.271, 8: 0.322)
+#endif
 #ifndef TF_JKR_MCMAX
 #define TF_JKR_MCMAX 4
 #endif
@@ -855,15 +858,15 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, c
             const int yy = y + pass;
             double2 acc = make_double2(0.0, 0.0);
             constexpr int NSL = TF_JKR_THREADS / 64;                   // slices
-            for (int g0 = gfirst[x] + sl, ge = groups_reach ? gfirst[N + x] : 0; g0 < ge; g0 += 4 * NSL) {
-                KdLoads q[4];
+            for (int g0 = gfirst[x] + sl, ge = groups_reach ? gfirst[N + x] : 0; g0 < ge; g0 += TF_JKR_U * NSL) {
+                KdLoads q[TF_JKR_U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < TF_JKR_U; ++u) {
                     const int g = g0 + NSL * u;
                     kd_issue(q[u], DIc + (size_t)g * N, DIr + (size_t)g * RS, N, MC, yy, two, g < ge);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < TF_JKR_U; ++u) {
                     const int g = g0 + NSL * u;
                     double2 t = kd_sum(q[u], DIr + (size_t)g * RS, N, MC, yy, two, g < ge);
                     for (int pl = 1; pl < MP; ++pl)                 // column parts of the further parts of a cut walk
@@ -871,20 +874,20 @@ __device__ __forceinline__ void kd_reduce_block(int x, int bx, double2 *sPart, c
                     acc.x += t.x; acc.y += t.y;
                 }
             }
-            for (int p0 = jptr[x] + sl, pe = jptr[x + 1]; p0 < pe; p0 += 4 * NSL) {
-                KdLoads q[4];
-                int rr[4];
+            for (int p0 = jptr[x] + sl, pe = jptr[x + 1]; p0 < pe; p0 += TF_JKR_U * NSL) {
+                KdLoads q[TF_JKR_U];
+                int rr[TF_JKR_U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < TF_JKR_U; ++u) {
                     const int p = p0 + NSL * u;
                     const int2 e = (p < pe) ? jrows[p] : make_int2(-1, 0);
                     rr[u] = (e.x >= 0 && e.y >= yo) ? e.x : -1;            // (a row whose first index lies below both columns holds nothing for them)
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < TF_JKR_U; ++u)
                     kd_issue(q[u], DJc + (size_t)max(rr[u], 0) * N, DJr + (size_t)max(rr[u], 0) * RS, N, MC, yy, two, rr[u] >= 0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < TF_JKR_U; ++u) {
                     const int r = rr[u];
                     double2 t = kd_sum(q[u], DJr + (size_t)max(r, 0) * RS, N, MC, yy, two, r >= 0);
                     for (int pl = 1; pl < MP; ++pl)
@@ -914,6 +917,7 @@ struct JKReduce {
     const JKSuper *supers;
     const int *gfirst, *jptr;
     const int2 *jrows;                                   // (local row, original first index) of the rows listed by second index
+    const int *xorder;                                   // output rows x of the exchange blocks, most partial vectors first (dispatch order)
     const int2 *row_ij;                                  // original (i, j) of the local rows
     int MC, MP;                                          // slots of a row part vector: most chunks of one class; parts of a walk
     size_t planeI, planeJ;                               // between the column-part planes of the parts
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(TF_JKR_THREADS) void jk_reduce_kernel(JKReduce R, B
     b -= d * (nK + nJ);
     if (R.dbg && (b < nK) == (R.dbg == 2)) return;
     if (b < nK)
-        kd_reduce_block(b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, L.N, R.MC, R.MP,
+        kd_reduce_block(R.xorder ? R.xorder[b / gxK] : b / gxK, b % gxK, sPart, R.DIc + d * R.sDIc, R.DIr + d * R.sDIr, R.DJc + d * R.sDJc, R.DJr + d * R.sDJr, L.N, R.MC, R.MP,
                         R.planeI, R.planeJ, R.gfirst, R.jptr, R.jrows, L.origI, R.D[d]);
     else {
         b -= nK;
