@@ -48,10 +48,10 @@ def test_mixed_orbital_blocks_against_oracle(engine):
     assert np.abs(engine.ao_to_mo(C1, C2, C3, C4) - ref).max() < 1e-11
 
 
-@pytest.mark.parametrize("n3", [1, 7, 16, 18, 31, 32, 33])
+@pytest.mark.parametrize("n3", [1, 7, 16, 17, 18, 19, 20, 21, 31, 32, 33])
 def test_first_quarter_kernel_against_the_einsum_and_the_block_path(engine, n3, monkeypatch):
     """tfmp2::mo_q1_kernel (hand-written MFMA-f64 first quarter on the packed segments, taken when the first ket coefficient matrix has at most
-    32 columns): one and two column tiles, odd widths, the edge 32 | 33, against the NumPy einsum of the engine's own dense tensor (pinned
+    32 columns): one and two column tiles, 17 - 20 columns (one tile + the vector-ALU columns), odd widths, the edge 32 | 33, against the NumPy einsum of the engine's own dense tensor (pinned
     to the oracle elsewhere) and against the expanded-block path (TF_MO_Q1=0) on N2/cc-pVTZ (N = 60, all four parity classes, f shells)."""
     atoms, shells, aos, nocc = make_system("c2_n2_ccpvtz")
     engine.set_basis(aos).build_eri(True)

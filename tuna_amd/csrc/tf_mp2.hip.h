@@ -113,6 +113,7 @@ struct Q1Args {
     const double *C3p;             // [N internal][16 NT]: C3 in internal AO order, columns padded with zeros
     double *R;                     // [N][N][N][n3]
     int n3;
+    int c3ld;                      // leading dimension of C3p (16 x column tiles of the whole n3)
     int dbg;                       // timing experiments (TF_Q1_DBG bits: 1 no mirrored store, 2 no store, 4 no column image, 8 no row image)
 };
 
@@ -128,7 +129,10 @@ struct Q1Args {
 #define TFQ1_THREADS 512            // eight waves share one staging of C3 (two workgroups per CU by LDS: four waves per SIMD)
 #endif
 struct Q1Row { long long rowoff; int i, j, c, iI, lamj, pad; };
-template <int NT, bool BLDS>
+// NX > 0 (with NT = 1, BLDS): the columns 16 .. 16 + NX - 1 of C3 (an occupied space of 17 - 20 orbitals: Ar2 has 18) do not get a second MFMA
+// column tile, of which they would fill an eighth -- NX multiply-adds per loaded value on the vector ALU instead (the C3 element is a
+// broadcast LDS read; the partial sums of a lane's share of the K index are added up over the four lane groups at the end of the block).
+template <int NT, bool BLDS, int NX = 0>
 __global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayout L, int n3r, int rpw, long long n_rows, int nblk)
 {
     extern __shared__ double sQ1[];
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayou
     const int m = lane & 15, kk = lane >> 4;
     constexpr int NP = 16 * NT;
     if (BLDS) {
-        for (int e = threadIdx.x; e < N * n3r; e += TFQ1_THREADS) { const int x = e / n3r, p = e - x * n3r; sC3[e] = Q.C3p[(size_t)x * NP + p]; }
+        for (int e = threadIdx.x; e < N * n3r; e += TFQ1_THREADS) { const int x = e / n3r, p = e - x * n3r; sC3[e] = Q.C3p[(size_t)x * Q.c3ld + p]; }
     }
     bool colok[NT];
 #pragma unroll
@@ -208,6 +212,9 @@ __global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayou
         tfm_v4d acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = tfm_v4d{0.0, 0.0, 0.0, 0.0};
+        double accx[NX > 0 ? NX : 1];
+#pragma unroll
+        for (int q = 0; q < (NX > 0 ? NX : 1); ++q) accx[q] = 0.0;
         // Both images run as software pipelines: the loads of the next pass are issued before the MFMAs of the current one, and the first
         // pass of the row image before the column image starts (a wave has one or two partners on its SIMD, not enough to hide an HBM miss
         // behind 16 MFMAs by occupancy alone).
@@ -251,8 +258,12 @@ __global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayou
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const double b = BLDS ? ((vl && colok[t]) ? sC3[(a0 + (vl ? lam : 0)) * n3r + 16 * t + m] : 0.0)
-                                          : (vl ? Q.C3p[(size_t)(a0 + (vl ? lam : 0)) * NP + 16 * t + m] : 0.0);
+                                          : (vl ? Q.C3p[(size_t)(a0 + (vl ? lam : 0)) * Q.c3ld + 16 * t + m] : 0.0);
                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], b, acc[t], 0, 0, 0);
+                }
+                if (NX > 0 && vl) {
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) accx[q] += v[u] * sC3[(a0 + lam) * n3r + 16 + q];
                 }
             }
         };
@@ -283,8 +294,12 @@ __global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayou
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const double b = BLDS ? ((kIs[u] >= 0 && colok[t]) ? sC3[kIs[u] * n3r + 16 * t + m] : 0.0)
-                                              : (kIs[u] >= 0 ? Q.C3p[(size_t)kIs[u] * NP + 16 * t + m] : 0.0);
+                                              : (kIs[u] >= 0 ? Q.C3p[(size_t)kIs[u] * Q.c3ld + 16 * t + m] : 0.0);
                         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u], b, acc[t], 0, 0, 0);
+                    }
+                    if (NX > 0 && kIs[u] >= 0) {
+#pragma unroll
+                        for (int q = 0; q < NX; ++q) accx[q] += v[u] * sC3[kIs[u] * n3r + 16 + q];
                     }
                 }
             };
@@ -318,6 +333,22 @@ __global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayou
                 row_mma(l1, rB);
                 if (l2 >= cmax) break;
                 l0 = l2;
+            }
+        }
+        if (NX > 0) {
+            // the extra columns: lane (m, kk) holds the part of row sigma = x0 + s0 + m that its share of the K index gave; the four lane groups
+            // are added in fixed order (xor 16, xor 32) and the group kk == 0 writes
+#pragma unroll
+            for (int q = 0; q < NX; ++q) {
+                double t = accx[q];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                const int row = s0 + m;
+                if (kk == 0 && row < nx) {
+                    const size_t sig = (size_t)(x0 + row);
+                    if (!(Q.dbg & 2)) Q.R[(((size_t)ij.x * N + ij.y) * N + sig) * Q.n3 + 16 + q] = t;
+                    if (ij.x != ij.y && !(Q.dbg & 3)) Q.R[(((size_t)ij.y * N + ij.x) * N + sig) * Q.n3 + 16 + q] = t;
+                }
             }
         }
         // ---- the tile: rows sigma = x0 + s0 + 4 v + (lane >> 4), columns p = 16 t + (lane & 15); both bra orders
@@ -563,7 +594,7 @@ inline int transform_q1(rocblas_handle blas, const double *d_eri, const long lon
     if (zero_R) TFM_HIP(hipMemsetAsync(dR, 0, (size_t)N * X * sizeof(double), 0));
     if (n_rows > 0) {
         const char *dbg = getenv("TF_Q1_DBG");
-        Q1Args Q{d_eri, d_rowoff, d_rowsec, d_row_ij, dC3p, dR, n3, dbg ? atoi(dbg) : 0};
+        Q1Args Q{d_eri, d_rowoff, d_rowsec, d_row_ij, dC3p, dR, n3, NP, dbg ? atoi(dbg) : 0};
         const int n3r = (n3 + 1) & ~1;
         int nblk = 0;
         {
@@ -584,7 +615,20 @@ inline int transform_q1(rocblas_handle blas, const double *d_eri, const long lon
             TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        if (NT == 1 && blds) hipLaunchKernelGGL((mo_q1_kernel<1, true>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
+        const int nx_cols = (blds && n3 > 16 && n3 <= 20 && !(getenv("TF_Q1_NX") && getenv("TF_Q1_NX")[0] == '0')) ? n3 - 16 : 0;
+        if (nx_cols > 0) {
+            if (lds > ((size_t)64 << 10)) {
+                TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<1, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<1, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<1, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                TFM_HIP(hipFuncSetAttribute((const void *)mo_q1_kernel<1, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            if (nx_cols == 1) hipLaunchKernelGGL((mo_q1_kernel<1, true, 1>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
+            else if (nx_cols == 2) hipLaunchKernelGGL((mo_q1_kernel<1, true, 2>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
+            else if (nx_cols == 3) hipLaunchKernelGGL((mo_q1_kernel<1, true, 3>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
+            else hipLaunchKernelGGL((mo_q1_kernel<1, true, 4>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
+        }
+        else if (NT == 1 && blds) hipLaunchKernelGGL((mo_q1_kernel<1, true>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
         else if (NT == 1) hipLaunchKernelGGL((mo_q1_kernel<1, false>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
         else if (blds) hipLaunchKernelGGL((mo_q1_kernel<2, true>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
         else hipLaunchKernelGGL((mo_q1_kernel<2, false>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
