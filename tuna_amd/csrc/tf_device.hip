@@ -2878,8 +2878,8 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     const bool q1_allowed = packed && !(q1env && q1env[0] == '0');
     auto run = [&](int a, int b, int c, int d, double *dst) {
         double s1 = 0.0;
-        if (q1_allowed && nk[c] <= 32) {
-            const size_t need = tfmp2::q1_pool_doubles(N, nk[a], nk[c], nk[d]) * sizeof(double);
+        if (q1_allowed && nk[c] <= 32 && nk[a] <= 32 && (size_t)N * ((nk[a] + 1) & ~1) * sizeof(double) + (size_t)N * sizeof(int) <= ((size_t)64 << 10)) {
+            const size_t need = tfmp2::q1_pool_doubles(N, ctx->n_rows, nk[a], nk[b], nk[c], nk[d]) * sizeof(double);
             size_t free_b = 0, total_b = 0;
             const bool fits = need <= ctx->mo_pool_bytes || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) <= free_b + ctx->mo_pool_bytes);
             if (fits) {
@@ -2889,8 +2889,8 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
                     else { ctx->mo_pool = nullptr; (void)hipGetLastError(); }
                 }
                 if (ctx->mo_pool) {
-                    int r = tfmp2::transform_q1(ctx->scf.blas, ctx->d_eri, ctx->d_rowoff, ctx->d_rowsec, ctx->bl, ctx->d_row_ij, ctx->n_rows, N, dC[a], nk[a],
-                                                dC[b], nk[b], dC[c], nk[c], dC[d], nk[d], dst, ctx->mo_pool, ctx->world > 1, &s1, msg);
+                    int r = tfmp2::transform_q1(ctx->scf.blas, ctx->d_eri, ctx->d_rowoff, ctx->d_rowsec, ctx->bl, ctx->d_row_ij, ctx->d_rowmap, ctx->n_rows, N,
+                                                dC[a], nk[a], dC[b], nk[b], dC[c], nk[c], dC[d], nk[d], dst, ctx->mo_pool, &s1, msg);
                     secs += s1;
                     return r;
                 }

@@ -111,7 +111,7 @@ struct Q1Args {
     const int *rowsec;
     const int2 *row_ij;            // original (i >= j) of every local row
     const double *C3p;             // [N internal][16 NT]: C3 in internal AO order, columns padded with zeros
-    double *R;                     // [N][N][N][n3]
+    double *R;                     // [local row][N internal sigma][n3]
     int n3;
     int c3ld;                      // leading dimension of C3p (16 x column tiles of the whole n3)
     int dbg;                       // timing experiments (TF_Q1_DBG bits: 1 no mirrored store, 2 no store, 4 no column image, 8 no row image)
@@ -128,7 +128,7 @@ struct Q1Args {
 #ifndef TFQ1_THREADS
 #define TFQ1_THREADS 512            // eight waves share one staging of C3 (two workgroups per CU by LDS: four waves per SIMD)
 #endif
-struct Q1Row { long long rowoff; int i, j, c, iI, lamj, pad; };
+struct Q1Row { long long rowoff; int i, j, c, iI, lamj, pad; };   // (R row = the local row number: r_first + position in the workgroup)
 // NX > 0 (with NT = 1, BLDS): the columns 16 .. 16 + NX - 1 of C3 (an occupied space of 17 - 20 orbitals: Ar2 has 18) do not get a second MFMA
 // column tile, of which they would fill an eighth -- NX multiply-adds per loaded value on the vector ALU instead (the C3 element is a
 // broadcast LDS read; the partial sums of a lane's share of the K index are added up over the four lane groups at the end of the block).
@@ -200,7 +200,6 @@ __global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayou
         if (item >= nrow * nblk) break;
         const int rr = __builtin_amdgcn_readfirstlane(item / nblk), blk = __builtin_amdgcn_readfirstlane(item - (item / nblk) * nblk);
         const Q1Row R = sRow[rr];
-        const int2 ij = make_int2(R.i, R.j);
         const int c = R.c, iI = R.iI, lamj = R.lamj;
         const double *__restrict__ T = Q.eri + R.rowoff;
         const int2 *sSeg = sSegAll + (size_t)rr * N;
@@ -346,8 +345,7 @@ __global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayou
                 const int row = s0 + m;
                 if (kk == 0 && row < nx) {
                     const size_t sig = (size_t)(x0 + row);
-                    if (!(Q.dbg & 2)) Q.R[(((size_t)ij.x * N + ij.y) * N + sig) * Q.n3 + 16 + q] = t;
-                    if (ij.x != ij.y && !(Q.dbg & 3)) Q.R[(((size_t)ij.y * N + ij.x) * N + sig) * Q.n3 + 16 + q] = t;
+                    if (!(Q.dbg & 2)) Q.R[((size_t)(r_first + rr) * N + sig) * Q.n3 + 16 + q] = t;
                 }
             }
         }
@@ -362,8 +360,7 @@ __global__ __launch_bounds__(TFQ1_THREADS, 4) void mo_q1_kernel(Q1Args Q, BLayou
                 const int p = 16 * t + m;
                 if (p >= Q.n3) continue;
                 const double val = acc[t][vv];
-                if (!(Q.dbg & 2)) Q.R[(((size_t)ij.x * N + ij.y) * N + sig) * Q.n3 + p] = val;
-                if (ij.x != ij.y && !(Q.dbg & 3)) Q.R[(((size_t)ij.y * N + ij.x) * N + sig) * Q.n3 + p] = val;
+                if (!(Q.dbg & 2)) Q.R[((size_t)(r_first + rr) * N + sig) * Q.n3 + p] = val;
             }
         }
     }
@@ -498,23 +495,38 @@ done:
     return rc;
 }
 
-// T[p][x] = sum_mu C1[mu][p] R[mu][x]  (p < n1 <= 32, x < X = N N n3, mu < N): the bra index mu -> occupied orbital over the 9.2 GB of R.
-// rocBLAS takes a 128 x 128 macro tile for this 18-wide output and runs compute-bound on the padding (4.6 ms at N = 400); here the
-// orbitals are the M dimension of v_mfma_f64_16x16x4_f64 (one or two tiles), 64 consecutive x per wave the N dimension (four tiles: 512
-// contiguous bytes of every plane mu), C1 in LDS as the A operand, the next K step's loads in flight: the kernel streams R once.
+// T[p][nu][y] = sum_mu C1[mu][p] R[row(mu, nu)][y]  (p < n1 <= 32, y < Y = N n3): the bra index mu -> occupied orbital.  R holds one block
+// of Y doubles per STORED row (mu >= nu, this rank's); the kernel follows the row map -- row(mu, nu) = row(nu, mu), absent rows (another
+// rank's) contribute nothing -- so the first quarter writes every block once (4.6 GB at N = 400 instead of 9.2 for both bra orders).
+// rocBLAS took a 128 x 128 macro tile for the 18-wide output and ran compute-bound on the padding (4.6 ms); here the orbitals are the M
+// dimension of v_mfma_f64_16x16x4_f64 (one or two tiles), 64 consecutive y per wave the N dimension (four tiles: 512 contiguous bytes of
+// every block), C1 (original AO order) and the row numbers of the workgroup's nu in LDS, the next K step's loads in flight.
+// Grid: (ceil(Y / (64 waves)), N); a workgroup works on ONE nu.
 #define TFB1_THREADS 384          // six waves share one staging of C1: two workgroups per CU by LDS = three waves per SIMD (157 VGPRs)
 template <int MT>
-__global__ __launch_bounds__(TFB1_THREADS, 3) void mo_bra1_kernel(const double *__restrict__ R, const double *__restrict__ C1, int N, int n1, size_t X,
-                                                      double *__restrict__ T)
+__global__ __launch_bounds__(TFB1_THREADS, 3) void mo_bra1_kernel(const double *__restrict__ R, const double *__restrict__ C1, const int *__restrict__ rowmap,
+                                                                 BLayout L, int n1, int Y, double *__restrict__ T)
 {
-    extern __shared__ double sC1[];                                 // [N][n1r]
+    extern __shared__ double sB1[];
+    const int N = L.N;
     const int n1r = (n1 + 1) & ~1;
+    double *sC1 = sB1;                                              // [N][n1r], rows = ORIGINAL AO index mu
+    int *sRowOf = reinterpret_cast<int *>(sB1 + (size_t)N * n1r);    // [N]: local row of (mu, nu), -1 = not on this rank
+    const int nu = blockIdx.y;
     for (int e = threadIdx.x; e < N * n1r; e += TFB1_THREADS) { const int mu = e / n1r, p = e - mu * n1r; sC1[e] = p < n1 ? C1[(size_t)mu * n1 + p] : 0.0; }
+    {
+        const int snu = ao_sigma(L, L.ao[nu]);
+        for (int mu = threadIdx.x; mu < N; mu += TFB1_THREADS) {
+            const int smu = ao_sigma(L, L.ao[mu]);
+            const int hi = max(smu, snu), lo = min(smu, snu);
+            sRowOf[mu] = rowmap[(size_t)hi * (hi + 1) / 2 + lo];
+        }
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, kk = lane >> 4;
-    const size_t x0 = ((size_t)blockIdx.x * (TFB1_THREADS / 64) + w) * 64;
-    if (x0 >= X) return;
+    const int y0 = (blockIdx.x * (TFB1_THREADS / 64) + w) * 64;
+    if (y0 >= Y) return;
     bool rowok[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) rowok[t] = 16 * t + m < n1r;
@@ -523,14 +535,15 @@ __global__ __launch_bounds__(TFB1_THREADS, 3) void mo_bra1_kernel(const double *
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][j] = tfm_v4d{0.0, 0.0, 0.0, 0.0};
-    bool xok[4];
+    bool yok[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xok[j] = x0 + 16 * j + m < X;
-    const double *__restrict__ Rx = R + x0 + m;
+    for (int j = 0; j < 4; ++j) yok[j] = y0 + 16 * j + m < Y;
+    const double *__restrict__ Ry = R + y0 + m;
     auto load = [&](int mu0, double (&b)[4]) {
         const int mu = mu0 + kk;
+        const int r = mu < N ? sRowOf[mu] : -1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = (mu < N && xok[j]) ? __builtin_nontemporal_load(Rx + (size_t)mu * X + 16 * j) : 0.0;
+        for (int j = 0; j < 4; ++j) b[j] = (r >= 0 && yok[j]) ? __builtin_nontemporal_load(Ry + (size_t)r * Y + 16 * j) : 0.0;
     };
     auto mma = [&](int mu0, const double (&b)[4]) {
         const int mu = mu0 + kk;
@@ -550,7 +563,8 @@ __global__ __launch_bounds__(TFB1_THREADS, 3) void mo_bra1_kernel(const double *
         if (mu0 + 8 < N) load(mu0 + 8, bA);
         mma(mu0 + 4, bB);
     }
-    // D[row p = 4 v + (lane >> 4)][col x = lane & 15]
+    // D[row p = 4 v + (lane >> 4)][col y = lane & 15]
+    const size_t X = (size_t)N * Y;
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(TFB1_THREADS, 3) void mo_bra1_kernel(const double *
             if (p >= n1) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (xok[j]) T[(size_t)p * X + x0 + 16 * j + m] = acc[t][j][v];
+                if (yok[j]) T[(size_t)p * X + (size_t)nu * Y + y0 + 16 * j + m] = acc[t][j][v];
         }
 }
 
@@ -568,22 +582,26 @@ __global__ __launch_bounds__(TFB1_THREADS, 3) void mo_bra1_kernel(const double *
 //     T2[p1][p2][sigma][p3]  = sum_nu C2[nu][p2] T[p1][nu][sigma][p3]                 (batched over p1)
 //     out[p1][p2][p3][p4]    = sum_sigma T2[p1][p2][sigma][p3] C4[sigma][p4]          (batched over (p1, p2))
 // on a caller-owned pool of q1_pool_doubles() doubles (kept by the context: no allocation per call).  Same contract as transform():
-// d_out is the transform of L (the stored part, its diagonal halved); rows the rank does not own contribute zeros (zero_R).
-inline size_t q1_pool_doubles(int N, int n1, int n3, int n4)
+// d_out is the transform of L (the stored part, its diagonal halved); rows the rank does not own are absent from the row map and
+// contribute nothing.  Condition (checked by the caller): n1 <= 32 and n3 <= 32.
+inline size_t q1_pool_doubles(int N, long long n_rows, int n1, int n2, int n3, int n4)
 {
     const size_t NP = (size_t)16 * ((n3 + 15) / 16);
-    return (size_t)N * N * N * n3 + (size_t)n1 * N * N * n3 + (size_t)N * NP + (size_t)N * n4 + 64;
+    const size_t Y = (size_t)N * n3;
+    // R [rows][Y] (later T2 [n1][n2][Y] in the same place) | T [n1][N][Y] | C3 padded | C4 in internal order
+    return std::max((size_t)std::max<long long>(1, n_rows) * Y, (size_t)n1 * n2 * Y) + (size_t)n1 * N * Y + (size_t)N * NP + (size_t)N * n4 + 64;
 }
 
 inline int transform_q1(rocblas_handle blas, const double *d_eri, const long long *d_rowoff, const int *d_rowsec, const BLayout &BL,
-                        const int2 *d_row_ij, long long n_rows, int N, const double *dC1, int n1, const double *dC2, int n2, const double *dC3,
-                        int n3, const double *dC4, int n4, double *d_out, double *pool, bool zero_R, double *seconds, std::string &msg)
+                        const int2 *d_row_ij, const int *d_rowmap, long long n_rows, int N, const double *dC1, int n1, const double *dC2, int n2,
+                        const double *dC3, int n3, const double *dC4, int n4, double *d_out, double *pool, double *seconds, std::string &msg)
 {
     int rc = TF_OK;
     const double one = 1.0, zero = 0.0;
     const int NT = (n3 + 15) / 16, NP = 16 * NT;
     const size_t X = (size_t)N * N * n3, Y = (size_t)N * n3;
-    double *dR = pool, *dT = dR + (size_t)N * X, *dC3p = dT + (size_t)n1 * X, *dC4i = dC3p + (size_t)N * NP, *dT2 = dR;
+    const size_t r_doubles = std::max((size_t)std::max<long long>(1, n_rows) * Y, (size_t)n1 * n2 * Y);
+    double *dR = pool, *dT = dR + r_doubles, *dC3p = dT + (size_t)n1 * X, *dC4i = dC3p + (size_t)N * NP, *dT2 = dR;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (X > 0x7fffffffULL || (size_t)n1 * n2 > 0x7fffffffULL) { msg = "AO->MO transformation: dimension overflow"; return TF_EINVAL; }
     TFM_HIP(hipEventCreate(&e0));
@@ -591,7 +609,6 @@ inline int transform_q1(rocblas_handle blas, const double *d_eri, const long lon
     TFM_HIP(hipEventRecord(e0, 0));
     hipLaunchKernelGGL(permute_rows_padded_kernel, dim3((unsigned)((N * NP + 255) / 256)), dim3(256), 0, 0, dC3, BL.origI, N, n3, NP, dC3p);
     hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)((N * n4 + 255) / 256)), dim3(256), 0, 0, dC4, BL.origI, N, n4, dC4i);
-    if (zero_R) TFM_HIP(hipMemsetAsync(dR, 0, (size_t)N * X * sizeof(double), 0));
     if (n_rows > 0) {
         const char *dbg = getenv("TF_Q1_DBG");
         Q1Args Q{d_eri, d_rowoff, d_rowsec, d_row_ij, dC3p, dR, n3, NP, dbg ? atoi(dbg) : 0};
@@ -634,18 +651,14 @@ inline int transform_q1(rocblas_handle blas, const double *d_eri, const long lon
         else hipLaunchKernelGGL((mo_q1_kernel<2, false>), dim3(grid), dim3(TFQ1_THREADS), lds, 0, Q, BL, n3r, rpw, n_rows, nblk);
         TFM_HIP(hipGetLastError());
     }
-    // T (column-major X x n1) = R (X x N) * C1^T (N x n1): hand-written for n1 <= 32 (TF_MO_BRA1=0: rocBLAS)
+    // T[p1][nu][y] = sum_mu C1[mu][p1] R[row(mu, nu)][y]: the hand-written bra kernel follows the row map (n1 <= 32)
     {
-        const char *b1 = getenv("TF_MO_BRA1");
-        const size_t lds1 = (size_t)N * ((n1 + 1) & ~1) * sizeof(double);
-        if (n1 <= 32 && lds1 <= ((size_t)64 << 10) && !(b1 && b1[0] == '0')) {
-            const unsigned grid1 = (unsigned)((X + TFB1_THREADS - 1) / TFB1_THREADS);
-            if (n1 <= 16) hipLaunchKernelGGL(mo_bra1_kernel<1>, dim3(grid1), dim3(TFB1_THREADS), lds1, 0, dR, dC1, N, n1, X, dT);
-            else hipLaunchKernelGGL(mo_bra1_kernel<2>, dim3(grid1), dim3(TFB1_THREADS), lds1, 0, dR, dC1, N, n1, X, dT);
-            TFM_HIP(hipGetLastError());
-        } else
-            TFM_BLAS(rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)X, n1, N, &one, dR, (rocblas_int)X, dC1, n1, &zero,
-                                   dT, (rocblas_int)X));
+        const size_t lds1 = (size_t)N * ((n1 + 1) & ~1) * sizeof(double) + (size_t)N * sizeof(int);
+        if (n1 > 32 || lds1 > ((size_t)64 << 10)) { msg = "AO->MO transformation: the bra kernel holds at most 32 orbitals of at most ~450 AOs"; rc = TF_EINVAL; goto done; }
+        const dim3 grid1((unsigned)((Y + TFB1_THREADS - 1) / TFB1_THREADS), (unsigned)N);
+        if (n1 <= 16) hipLaunchKernelGGL(mo_bra1_kernel<1>, grid1, dim3(TFB1_THREADS), lds1, 0, dR, dC1, d_rowmap, BL, n1, (int)Y, dT);
+        else hipLaunchKernelGGL(mo_bra1_kernel<2>, grid1, dim3(TFB1_THREADS), lds1, 0, dR, dC1, d_rowmap, BL, n1, (int)Y, dT);
+        TFM_HIP(hipGetLastError());
     }
     // T2[p1] (Y x n2) = T[p1] (Y x N) * C2^T (N x n2)
     TFM_BLAS(rocblas_dgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)Y, n2, N, &one, dT, (rocblas_int)Y,
