@@ -2809,7 +2809,7 @@ int tf_dft_setup(tf_ctx *ctx, int64_t n_points, const double *xyz, const double 
     HIPCHK(ctx, (hipMalloc)((void **)&g.D, GN * sizeof(double)));
     for (double **p : {&g.rho, &g.vrho, &g.vsig, &g.ex, &g.ec}) HIPCHK(ctx, (hipMalloc)((void **)p, (size_t)G * sizeof(double)));
     HIPCHK(ctx, (hipMalloc)((void **)&g.grad, (size_t)3 * G * sizeof(double)));
-    HIPCHK(ctx, (hipMalloc)((void **)&g.V, (size_t)(tfdft::VSPLIT + 1) * N * N * sizeof(double)));
+    HIPCHK(ctx, (hipMalloc)((void **)&g.V, (size_t)(tfdft::VSPLIT + 2) * N * N * sizeof(double)));
     HIPCHK(ctx, (hipMalloc)((void **)&g.part, (size_t)3 * tfdft::NPART * sizeof(double)));
     tfdft::DAOs D{A.z, A.lmn, A.prim_off, A.exps, A.w};
     hipLaunchKernelGGL(tfdft::ao_on_grid_kernel, dim3((unsigned)((GN + 127) / 128)), dim3(128), 0, 0, D, d_xyz, G, N, ctx->d_csr_ptr,

@@ -166,22 +166,42 @@ __device__ inline XcOut lyp_c(double n, double sigma)                           
     return o;
 }
 
-// rho (floored), grad, sigma (floored) from B = Phi P; then functional derivatives and energy densities
-__global__ void xc_point_kernel(long long G, int N, const double *__restrict__ phi, const double *__restrict__ dphi,
-                                const double *__restrict__ B, int gga, int xid, int cid, double dfx, double dfc, double x_alpha,
-                                double *__restrict__ rho, double *__restrict__ grad, double *__restrict__ vrho, double *__restrict__ vsig,
+// rho (raw) and 2 grad rho from B = Phi P: rho(g) = sum_i B[g][i] Phi[g][i], grad_a = 2 sum_i B[g][i] dPhi_a[g][i].  Sixteen lanes per grid
+// point, each a sixteenth of the AOs (coalesced 128-byte reads of the point's rows; one thread per point walked its own row of every
+// array with a stride of N doubles between neighbouring threads: 0.30 ms per call for CO / def2-TZVP, 3.6 ms of a 27 ms single point).
+__global__ __launch_bounds__(256) void xc_density_kernel(long long G, int N, const double *__restrict__ phi, const double *__restrict__ dphi,
+                                                         const double *__restrict__ B, int gga, double *__restrict__ rho, double *__restrict__ grad)
+{
+    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const long long g = (long long)blockIdx.x * 16 + grp;
+    double n = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+    if (g < G) {
+        const double *b = B + g * N, *f = phi + g * N;
+        for (int i = l; i < N; i += 16) n += b[i] * f[i];
+        if (gga) {
+            const double *fx = dphi + g * N, *fy = dphi + G * N + g * N, *fz = dphi + 2 * G * N + g * N;
+            for (int i = l; i < N; i += 16) { const double bi = b[i]; gx += bi * fx[i]; gy += bi * fy[i]; gz += bi * fz[i]; }
+        }
+    }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) {
+        n += __shfl_xor(n, d, 16); gx += __shfl_xor(gx, d, 16); gy += __shfl_xor(gy, d, 16); gz += __shfl_xor(gz, d, 16);
+    }
+    if (l == 0 && g < G) {
+        rho[g] = n;
+        if (gga) { grad[g] = 2.0 * gx; grad[G + g] = 2.0 * gy; grad[2 * G + g] = 2.0 * gz; }
+    }
+}
+
+// rho (floored), sigma (floored) of a point from xc_density_kernel's sums; then functional derivatives and energy densities
+__global__ void xc_point_kernel(long long G, int gga, int xid, int cid, double dfx, double dfc, double x_alpha,
+                                double *__restrict__ rho, const double *__restrict__ grad, double *__restrict__ vrho, double *__restrict__ vsig,
                                 double *__restrict__ ex, double *__restrict__ ec)
 {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
-    const double *b = B + g * N, *f = phi + g * N;
-    double n = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-    for (int i = 0; i < N; ++i) n += b[i] * f[i];
-    if (gga) {
-        const double *fx = dphi + g * N, *fy = dphi + G * N + g * N, *fz = dphi + 2 * G * N + g * N;
-        for (int i = 0; i < N; ++i) { gx += b[i] * fx[i]; gy += b[i] * fy[i]; gz += b[i] * fz[i]; }
-        gx *= 2.0; gy *= 2.0; gz *= 2.0;
-    }
+    double n = rho[g], gx = 0.0, gy = 0.0, gz = 0.0;
+    if (gga) { gx = grad[g]; gy = grad[G + g]; gz = grad[2 * G + g]; }
     n = fmax(n, 1e-23);                                                     // xc.clean, density_floor
     const double sigma = fmax(gx * gx + gy * gy + gz * gz, 1e-46);          // sigma_floor
     XcOut X{0, 0, 0}, C{0, 0, 0};
@@ -200,7 +220,6 @@ __global__ void xc_point_kernel(long long G, int N, const double *__restrict__ p
         C.dfdn = 0.81 * y.dfdn + 0.19 * l.dfdn; C.dfds = 0.81 * y.dfds; C.e = 0.81 * y.e + 0.19 * l.e;
     }
     rho[g] = n;
-    if (gga) { grad[g] = gx; grad[G + g] = gy; grad[2 * G + g] = gz; }
     vrho[g] = dfx * X.dfdn + dfc * C.dfdn;
     vsig[g] = dfx * X.dfds + dfc * C.dfds;
     ex[g] = X.e * n;
@@ -238,21 +257,26 @@ __global__ void xc_reduce_kernel(long long G, const double *__restrict__ w, cons
     if (threadIdx.x == 0) { part[3 * blockIdx.x] = s0[0]; part[3 * blockIdx.x + 1] = s1[0]; part[3 * blockIdx.x + 2] = s2[0]; }
 }
 
-// out = sym(sum_s in[s]) over the nparts split-K partials (fixed order)
-__global__ void sum_sym_kernel(const double *__restrict__ in, int nparts, double *__restrict__ out, int n)
+// tmp = sum_s in[s] over the nparts split-K partials (fixed order; coalesced), then out = sym(tmp)
+__global__ void sum_parts_kernel(const double *__restrict__ in, int nparts, double *__restrict__ tmp, int nn)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nn) return;
+    double a = 0.0;
+    for (int s = 0; s < nparts; ++s) a += in[(size_t)s * nn + e];
+    tmp[e] = a;
+}
+__global__ void sym_kernel(const double *__restrict__ tmp, double *__restrict__ out, int n)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * n) return;
     const int i = e / n, j = e - i * n;
-    const size_t nn = (size_t)n * n;
-    double a = 0.0, b = 0.0;
-    for (int s = 0; s < nparts; ++s) { a += in[s * nn + e]; b += in[s * nn + (size_t)j * n + i]; }
-    out[e] = (1.0 / 2.0) * (a + b);
+    out[e] = (1.0 / 2.0) * (tmp[e] + tmp[(size_t)j * n + i]);
 }
 
 // V = Phi^T D contracts over ~10^5 grid points into an N x N matrix: as ONE GEMM rocBLAS runs it in a single workgroup (4.7 ms for CO /
 // def2-TZVP); split over the grid points into VSPLIT batch entries it fills the GPU, and the partials are added in fixed order.
-const int VSPLIT = 512;
+const int VSPLIT = 128;            // (512 partials of 200 grid points each cost more to add up -- 0.18 ms -- than the GEMM they split)
 
 #define TFD_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { msg = std::string(#call) + " failed: " + hipGetErrorString(_e); return (_e == hipErrorOutOfMemory ? TF_ENOMEM : TF_ENODEVICE); } } while (0)
 #define TFD_BLAS(call) do { rocblas_status _s = (call); if (_s != rocblas_status_success) { msg = std::string(#call) + " failed (rocBLAS status " + std::to_string((int)_s) + ")"; return TF_ELINALG; } } while (0)
@@ -267,7 +291,8 @@ inline int vxc(rocblas_handle blas, Grid &g, const double *dP, double *dVxc, dou
     const double one = 1.0, zero = 0.0;
     // B (G x N, row-major) = Phi (G x N) * P (N x N)
     TFD_BLAS(rocblas_dgemm(blas, rocblas_operation_none, rocblas_operation_none, N, (rocblas_int)G, N, &one, dP, N, g.phi, N, &zero, g.B, N));
-    hipLaunchKernelGGL(xc_point_kernel, dim3((unsigned)((G + 127) / 128)), dim3(128), 0, 0, G, N, g.phi, g.dphi, g.B, g.gga ? 1 : 0, g.xid, g.cid,
+    hipLaunchKernelGGL(xc_density_kernel, dim3((unsigned)((G + 15) / 16)), dim3(256), 0, 0, G, N, g.phi, g.dphi, g.B, g.gga ? 1 : 0, g.rho, g.grad);
+    hipLaunchKernelGGL(xc_point_kernel, dim3((unsigned)((G + 127) / 128)), dim3(128), 0, 0, G, g.gga ? 1 : 0, g.xid, g.cid,
                        g.dfx, g.dfc, g.x_alpha, g.rho, g.grad, g.vrho, g.vsig, g.ex, g.ec);
     hipLaunchKernelGGL(xc_dmat_kernel, dim3((unsigned)((G * N + 255) / 256)), dim3(256), 0, 0, G, N, g.w, g.phi, g.dphi, g.grad, g.vrho, g.vsig,
                        g.gga ? 1 : 0, g.D);
@@ -287,7 +312,9 @@ inline int vxc(rocblas_handle blas, Grid &g, const double *dP, double *dVxc, dou
                                    g.phi + Kc * VSPLIT * N, N, &zero, g.V + (size_t)nparts * nn, N));
             ++nparts;
         }
-        hipLaunchKernelGGL(sum_sym_kernel, dim3((N * N + 255) / 256), dim3(256), 0, 0, g.V, nparts, dVxc, N);
+        double *tmp = g.V + (size_t)(VSPLIT + 1) * nn;                  // (the slot behind the partials)
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((N * N + 255) / 256), dim3(256), 0, 0, g.V, nparts, tmp, N * N);
+        hipLaunchKernelGGL(sym_kernel, dim3((N * N + 255) / 256), dim3(256), 0, 0, tmp, dVxc, N);
     }
     hipLaunchKernelGGL(xc_reduce_kernel, dim3(NPART), dim3(256), 0, 0, G, g.w, g.rho, g.ex, g.ec, g.part);
     std::vector<double> h(3 * NPART);
