@@ -88,8 +88,10 @@ static hipError_t cfree(void *p)
     return ::hipFree(p);
 }
 }  // namespace tfcache
-#define hipMalloc(p, b) tfcache::cmalloc((void **)(p), (b))
-#define hipFree(p) tfcache::cfree((void *)(p))
+// every device allocation of this file goes through the cache (blocks released elsewhere with the runtime's hipFree use ::hipMalloc)
+static inline hipError_t tf_malloc(void **p, size_t bytes) { return tfcache::cmalloc(p, bytes); }
+template <class T> static inline hipError_t tf_malloc(T **p, size_t bytes) { return tfcache::cmalloc((void **)p, bytes); }
+static inline hipError_t tf_free(void *p) { return tfcache::cfree(p); }
 
 using namespace tfk;
 
@@ -205,8 +207,8 @@ struct tf_ctx {
 static int ensure_scratch(tf_ctx *ctx, int k, size_t bytes)
 {
     if (bytes <= ctx->scr_bytes[k]) return TF_OK;
-    if (ctx->scr[k]) { (void)hipFree(ctx->scr[k]); ctx->scr[k] = nullptr; ctx->scr_bytes[k] = 0; }
-    hipError_t e = hipMalloc((void **)&ctx->scr[k], bytes);
+    if (ctx->scr[k]) { (void)tf_free(ctx->scr[k]); ctx->scr[k] = nullptr; ctx->scr_bytes[k] = 0; }
+    hipError_t e = tf_malloc((void **)&ctx->scr[k], bytes);
     if (e != hipSuccess) { ctx->err = std::string("hipMalloc of ERI scratch failed: ") + hipGetErrorString(e); return TF_ENOMEM; }
     ctx->scr_bytes[k] = bytes;
     return TF_OK;
@@ -232,7 +234,7 @@ template <class T>
 static int upload(tf_ctx *ctx, const std::vector<T> &h, T **d, bool track = true)
 {
     size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
-    HIPCHK(ctx, hipMalloc((void **)d, bytes));
+    HIPCHK(ctx, tf_malloc((void **)d, bytes));
     if (track) ctx->basis_allocs.push_back(*d);
     if (!h.empty()) HIPCHK(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return TF_OK;
@@ -244,18 +246,18 @@ static void free_eri(tf_ctx *ctx)
     for (void *p : {(void *)ctx->d_class_rows, (void *)ctx->d_row_pos, (void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
                     (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_Psym,
                     (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ, (void *)ctx->d_Jt, (void *)ctx->d_D})
-        if (p) (void)hipFree(p);
+        if (p) (void)tf_free(p);
     for (auto &t : ctx->jkt) {
         for (void *p : {(void *)t.d_groups, (void *)t.d_tasks, (void *)t.d_supers, (void *)t.d_gfirst})
-            if (p) (void)hipFree(p);
+            if (p) (void)tf_free(p);
         t = tf_ctx::JKTables();
     }
     for (void *p : {(void *)ctx->d_jptr, (void *)ctx->d_jrows, (void *)ctx->d_xorder})
-        if (p) (void)hipFree(p);
+        if (p) (void)tf_free(p);
     ctx->d_jptr = nullptr; ctx->d_jrows = nullptr; ctx->d_xorder = nullptr;
-    for (void *p : ctx->layout_allocs) (void)hipFree(p);
+    for (void *p : ctx->layout_allocs) (void)tf_free(p);
     ctx->layout_allocs.clear();
-    if (ctx->d_rowsec) { (void)hipFree(ctx->d_rowsec); ctx->d_rowsec = nullptr; }
+    if (ctx->d_rowsec) { (void)tf_free(ctx->d_rowsec); ctx->d_rowsec = nullptr; }
     ctx->bl = BLayout{};
     ctx->d_class_rows = nullptr; ctx->d_row_pos = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
     ctx->d_Ppad = nullptr; ctx->d_J = nullptr; ctx->d_K = nullptr; ctx->d_P = nullptr;
@@ -268,10 +270,10 @@ static void free_eri(tf_ctx *ctx)
 static void free_basis(tf_ctx *ctx)
 {
     (void)hipDeviceSynchronize();
-    for (void *p : ctx->basis_allocs) (void)hipFree(p);
+    for (void *p : ctx->basis_allocs) (void)tf_free(p);
     ctx->basis_allocs.clear();
     for (void *p : {(void *)ctx->d_csr_ptr, (void *)ctx->d_csr_idx, (void *)ctx->d_csr_val})
-        if (p) (void)hipFree(p);
+        if (p) (void)tf_free(p);
     ctx->d_csr_ptr = ctx->d_csr_idx = nullptr; ctx->d_csr_val = nullptr;
     ctx->have_basis = false;
 }
@@ -532,7 +534,7 @@ void tf_destroy(tf_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     free_eri(ctx);
-    if (ctx->d_eri) { (void)hipFree(ctx->d_eri); ctx->d_eri = nullptr; ctx->eri_cap = 0; }
+    if (ctx->d_eri) { (void)tf_free(ctx->d_eri); ctx->d_eri = nullptr; ctx->eri_cap = 0; }
     free_basis(ctx);
     tfscf::release(ctx->scf);
     for (auto &wsp : ctx->scf_batch) if (wsp) tfscf::release(*wsp);
@@ -542,13 +544,13 @@ void tf_destroy(tf_ctx *ctx)
     if (ctx->have_streams)
         for (int k = 0; k < tf_ctx::NSTREAM_MAX; ++k) { (void)hipStreamDestroy(ctx->streams[k]); (void)hipEventDestroy(ctx->sev[k]); }
     for (int k = 0; k < 3; ++k)
-        if (ctx->scr[k]) (void)hipFree(ctx->scr[k]);
-    if (ctx->mo_pool) (void)hipFree(ctx->mo_pool);
-    if (ctx->d_jkstage) (void)hipFree(ctx->d_jkstage);
-    if (ctx->d_agree) (void)hipFree(ctx->d_agree);
-    if (ctx->d_lrec) (void)hipFree(ctx->d_lrec);
-    if (ctx->d_tup) (void)hipFree(ctx->d_tup);
-    if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
+        if (ctx->scr[k]) (void)tf_free(ctx->scr[k]);
+    if (ctx->mo_pool) (void)tf_free(ctx->mo_pool);
+    if (ctx->d_jkstage) (void)tf_free(ctx->d_jkstage);
+    if (ctx->d_agree) (void)tf_free(ctx->d_agree);
+    if (ctx->d_lrec) (void)tf_free(ctx->d_lrec);
+    if (ctx->d_tup) (void)tf_free(ctx->d_tup);
+    if (ctx->d_gtab) (void)tf_free(ctx->d_gtab);
     ctx->arena1e.release();
     delete ctx;
 }
@@ -718,7 +720,7 @@ static int upload_csr(tf_ctx *ctx, int spherical)
         for (int i = 0; i < bs.n_cart; ++i) { idx.push_back(i); val.push_back(1.0); ptr.push_back(i + 1); }
     }
     for (void *p : {(void *)ctx->d_csr_ptr, (void *)ctx->d_csr_idx, (void *)ctx->d_csr_val})
-        if (p) (void)hipFree(p);
+        if (p) (void)tf_free(p);
     int rc;
     if ((rc = upload(ctx, ptr, &ctx->d_csr_ptr, false)) || (rc = upload(ctx, idx, &ctx->d_csr_idx, false)) ||
         (rc = upload(ctx, val, &ctx->d_csr_val, false)))
@@ -978,11 +980,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         const size_t need = std::max<size_t>(1, (size_t)ctx->n_elems * sizeof(double));
 #endif
         if (ctx->d_eri && (ctx->eri_cap < need || ctx->eri_cap > 2 * need + (64u << 20))) {
-            (void)hipFree(ctx->d_eri);
+            (void)tf_free(ctx->d_eri);
             ctx->d_eri = nullptr; ctx->eri_cap = 0;
         }
         if (!ctx->d_eri) {
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_eri, need));
+            HIPCHK(ctx, tf_malloc((void **)&ctx->d_eri, need));
             ctx->eri_cap = need;
         }
     }
@@ -1615,8 +1617,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 }
                 recs[ab * 36 + cd] = r;
             }
-        if (ctx->d_lrec) { (void)hipFree(ctx->d_lrec); ctx->d_lrec = nullptr; }
-        if (ctx->d_tup) { (void)hipFree(ctx->d_tup); ctx->d_tup = nullptr; }
+        if (ctx->d_lrec) { (void)tf_free(ctx->d_lrec); ctx->d_lrec = nullptr; }
+        if (ctx->d_tup) { (void)tf_free(ctx->d_tup); ctx->d_tup = nullptr; }
         int rc2;
         if ((rc2 = upload(ctx, recs, &ctx->d_lrec, false)) || (rc2 = upload(ctx, tup, &ctx->d_tup, false))) return rc2;
         ctx->db.lrec = ctx->d_lrec; ctx->db.tup = ctx->d_tup;
@@ -1697,9 +1699,9 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 const size_t need = (size_t)nk * (b1 - b0) * (size_t)c.gtab_doubles * sizeof(double);
                 if (need > ctx->gtab_bytes) {
                     HIPCHK(ctx, hipDeviceSynchronize());           // (earlier launches of this build may still use the old block)
-                    if (ctx->d_gtab) (void)hipFree(ctx->d_gtab);
+                    if (ctx->d_gtab) (void)tf_free(ctx->d_gtab);
                     ctx->d_gtab = nullptr; ctx->gtab_bytes = 0;
-                    HIPCHK(ctx, hipMalloc((void **)&ctx->d_gtab, need));
+                    HIPCHK(ctx, tf_malloc((void **)&ctx->d_gtab, need));
                     ctx->gtab_bytes = need;
                 }
                 // launches that share the block must not overlap: they all go to one stream
@@ -1879,11 +1881,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // two sets of a slab's index lists: the lists of slab k + 1 are uploaded (on a stream of their own) while the kernels of slab k run;
     // the kernels themselves stay ordered by the streams (one half-transformed slab)
     const size_t out_bytes = cap_out * std::max(sizeof(OutRow), sizeof(OutRowP)), rowcls_bytes = (size_t)max_rows_c + 1;
-    HIPCHK(ctx, hipMalloc((void **)&d_bra, 2 * cap_bra * sizeof(int)));
-    HIPCHK(ctx, hipMalloc((void **)&d_braoff, 2 * cap_bra * sizeof(long long)));
-    if (use_team_pc) HIPCHK(ctx, hipMalloc((void **)&d_brarec, 2 * cap_bra * sizeof(BraRec)));
-    HIPCHK(ctx, hipMalloc((void **)&d_out, 2 * out_bytes));
-    if (packed && !per_class) HIPCHK(ctx, hipMalloc((void **)&d_rowcls, 2 * rowcls_bytes));
+    HIPCHK(ctx, tf_malloc((void **)&d_bra, 2 * cap_bra * sizeof(int)));
+    HIPCHK(ctx, tf_malloc((void **)&d_braoff, 2 * cap_bra * sizeof(long long)));
+    if (use_team_pc) HIPCHK(ctx, tf_malloc((void **)&d_brarec, 2 * cap_bra * sizeof(BraRec)));
+    HIPCHK(ctx, tf_malloc((void **)&d_out, 2 * out_bytes));
+    if (packed && !per_class) HIPCHK(ctx, tf_malloc((void **)&d_rowcls, 2 * rowcls_bytes));
     int *const d_bra_alloc = d_bra; long long *const d_braoff_alloc = d_braoff; void *const d_out_alloc = d_out;
     BraRec *const d_brarec_alloc = d_brarec; signed char *const d_rowcls_alloc = d_rowcls;
     d_bra_base = d_bra;
@@ -2063,14 +2065,14 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 all.insert(all.end(), TL.tasks.begin(), TL.tasks.end());
             }
             if (tcs_host.size() > d_tcs_cap) {
-                if (d_tcs) (void)hipFree(d_tcs);
+                if (d_tcs) (void)tf_free(d_tcs);
                 d_tcs_cap = tcs_host.size() + 64;
-                HIPCHK(ctx, hipMalloc((void **)&d_tcs, d_tcs_cap * sizeof(TClass)));
+                HIPCHK(ctx, tf_malloc((void **)&d_tcs, d_tcs_cap * sizeof(TClass)));
             }
             if (all.size() > d_tasks_cap) {
-                if (d_tasks) (void)hipFree(d_tasks);
+                if (d_tasks) (void)tf_free(d_tasks);
                 d_tasks_cap = all.size() + 1024;
-                HIPCHK(ctx, hipMalloc((void **)&d_tasks, d_tasks_cap * sizeof(TeamTask)));
+                HIPCHK(ctx, tf_malloc((void **)&d_tasks, d_tasks_cap * sizeof(TeamTask)));
             }
             if (!tcs_host.empty()) HIPCHK(ctx, hipMemcpy(d_tcs, tcs_host.data(), tcs_host.size() * sizeof(TClass), hipMemcpyHostToDevice));
             if (!all.empty()) HIPCHK(ctx, hipMemcpy(d_tasks, all.data(), all.size() * sizeof(TeamTask), hipMemcpyHostToDevice));
@@ -2182,16 +2184,16 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     }
     for (hipEvent_t e : tev) (void)hipEventDestroy(e);
     for (hipEvent_t e : tev2) (void)hipEventDestroy(e);
-    (void)hipFree(d_bra_alloc); (void)hipFree(d_braoff_alloc); (void)hipFree(d_out_alloc);
-    if (d_rowcls_alloc) (void)hipFree(d_rowcls_alloc);
+    (void)tf_free(d_bra_alloc); (void)tf_free(d_braoff_alloc); (void)tf_free(d_out_alloc);
+    if (d_rowcls_alloc) (void)tf_free(d_rowcls_alloc);
     d_brarec = d_brarec_alloc;
-    (void)hipFree(d_kets); (void)hipFree(d_kets_all);
+    (void)tf_free(d_kets); (void)tf_free(d_kets_all);
     for (void *pt : {(void *)d_fam_heads, (void *)d_fam_ptr, (void *)d_fam_mem})
-        if (pt) (void)hipFree(pt);
-    for (void *pt : fam_allocs) (void)hipFree(pt);
+        if (pt) (void)tf_free(pt);
+    for (void *pt : fam_allocs) (void)tf_free(pt);
     for (void *pt : {(void *)d_kq_ptr, (void *)d_kq_off, (void *)d_kt_ptr, (void *)d_kt_k, (void *)d_kt_c, (void *)d_ketrec, (void *)d_brarec, (void *)d_kcnt,
                      (void *)d_tcs, (void *)d_tasks, (void *)d_tflat})
-        if (pt) (void)hipFree(pt);
+        if (pt) (void)tf_free(pt);
     ctx->db.kq_ptr = ctx->db.kq_off = ctx->db.kt_ptr = ctx->db.kt_k = nullptr; ctx->db.kt_c = nullptr;
     if (team_error != hipSuccess) TF_FAIL(ctx, TF_ENODEVICE, "launch of a team ERI kernel failed: %s", hipGetErrorString(team_error));
     t_stage[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wall0).count();
@@ -2204,7 +2206,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     const size_t nn = (size_t)N * N;
     // (sized for two densities per pass)
     const int NWjk = packed ? std::max(1, H.NW) * H.MP : 1;         // column chunks of jk_packed_kernel x parts of a walk
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jrow, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&ctx->d_Jrow, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     HIPCHK(ctx, hipMemset(ctx->d_Jrow, 0, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     if (packed) {
         // everything sized for a two-density pass (second density behind the first)
@@ -2212,10 +2214,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         const size_t ny = (size_t)std::max(ctx->jkt[0].ypart_len, 2 * ctx->jkt[1].ypart_len);
         const size_t ng = (size_t)std::max(ctx->jkt[0].n_groups, 2 * ctx->jkt[1].n_groups);
         const int nsegmax = std::max(ctx->jkt[0].nseg, ctx->jkt[1].nseg);
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Psym, 2 * nn * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Pp, 2 * npr * sizeof(double)));
+        HIPCHK(ctx, tf_malloc((void **)&ctx->d_Psym, 2 * nn * sizeof(double)));
+        HIPCHK(ctx, tf_malloc((void **)&ctx->d_Pp, 2 * npr * sizeof(double)));
         HIPCHK(ctx, hipMemset(ctx->d_Pp, 0, 2 * npr * sizeof(double)));   // pad slots stay zero
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_ypart, std::max<size_t>(1, ny) * sizeof(double)));
+        HIPCHK(ctx, tf_malloc((void **)&ctx->d_ypart, std::max<size_t>(1, ny) * sizeof(double)));
         // column parts [.][N] followed by the row parts [.][RS]
         // partial sums: [one-density pass | two-density pass], each [column parts | row parts] per density.  The passes have separate
         // regions (their groups differ), every region is zeroed once: the set of entries a pass writes does not depend on the density,
@@ -2223,19 +2225,19 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         const size_t per_g = (size_t)N * H.MP + H.RS, nr1 = std::max<size_t>(1, (size_t)ctx->n_rows);
         const size_t di_doubles = ((size_t)std::max(1, ctx->jkt[0].n_groups) + 2 * (size_t)std::max(1, ctx->jkt[1].n_groups)) * per_g;
         const size_t dj_doubles = 3 * nr1 * per_g;
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DI, di_doubles * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_DJ, dj_doubles * sizeof(double)));
+        HIPCHK(ctx, tf_malloc((void **)&ctx->d_DI, di_doubles * sizeof(double)));
+        HIPCHK(ctx, tf_malloc((void **)&ctx->d_DJ, dj_doubles * sizeof(double)));
         HIPCHK(ctx, hipMemset(ctx->d_DI, 0, di_doubles * sizeof(double)));
         HIPCHK(ctx, hipMemset(ctx->d_DJ, 0, dj_doubles * sizeof(double)));
         HIPCHK(ctx, hipMemset(ctx->d_ypart, 0, std::max<size_t>(1, ny) * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Jt, 2 * (size_t)nsegmax * npr * sizeof(double)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_D, 2 * nn * sizeof(double)));
+        HIPCHK(ctx, tf_malloc((void **)&ctx->d_Jt, 2 * (size_t)nsegmax * npr * sizeof(double)));
+        HIPCHK(ctx, tf_malloc((void **)&ctx->d_D, 2 * nn * sizeof(double)));
     } else
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_Kp, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * 2 * ld * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_Ppad, 2 * (size_t)N * ld * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_J, 2 * nn * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_K, 2 * nn * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_P, 2 * nn * sizeof(double)));
+        HIPCHK(ctx, tf_malloc((void **)&ctx->d_Kp, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * 2 * ld * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&ctx->d_Ppad, 2 * (size_t)N * ld * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&ctx->d_J, 2 * nn * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&ctx->d_K, 2 * nn * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&ctx->d_P, 2 * nn * sizeof(double)));
     DBG("build_eri done");
     ctx->have_eri = true;
     return TF_OK;
@@ -2291,14 +2293,14 @@ int tf_copy_eri(tf_ctx *ctx, double *host_out)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t total = (size_t)ctx->N * ctx->N * ctx->N * ctx->N;
     double *d_dense = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_dense, total * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&d_dense, total * sizeof(double)));
     const unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 1 << 20);
     if (ctx->layout == 1)
         hipLaunchKernelGGL(expand_dense_packed_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->d_rowoff, ctx->d_rowsec, ctx->bl, d_dense);
     else
         hipLaunchKernelGGL(expand_dense_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N, ctx->ld, d_dense);
     hipError_t e = hipMemcpy(host_out, d_dense, total * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(d_dense);
+    (void)tf_free(d_dense);
     HIPCHK(ctx, e);
     return TF_OK;
 }
@@ -2312,8 +2314,8 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
     if (n_idx == 0) return TF_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int *d_idx = nullptr; double *d_val = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_idx, (size_t)n_idx * 4 * sizeof(int)));
-    HIPCHK(ctx, hipMalloc((void **)&d_val, (size_t)n_idx * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&d_idx, (size_t)n_idx * 4 * sizeof(int)));
+    HIPCHK(ctx, tf_malloc((void **)&d_val, (size_t)n_idx * sizeof(double)));
     HIPCHK(ctx, hipMemcpy(d_idx, idx, (size_t)n_idx * 4 * sizeof(int), hipMemcpyHostToDevice));
     if (ctx->layout == 1)
         hipLaunchKernelGGL(sample_packed_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap,
@@ -2322,7 +2324,7 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
         hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N,
                            ctx->ld, (long long)n_idx, d_idx, d_val);
     hipError_t e = hipMemcpy(values, d_val, (size_t)n_idx * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(d_idx); (void)hipFree(d_val);
+    (void)tf_free(d_idx); (void)tf_free(d_val);
     HIPCHK(ctx, e);
     return TF_OK;
 }
@@ -2533,9 +2535,9 @@ static int allreduce_jk(tf_ctx *ctx, int nd, double *const *dJ, double *const *d
     // one slot beyond the payload carries a status word through the same collective: a rank whose exchange step failed locally (the
     // hook sets it) makes the sum non-zero on EVERY rank, so that all of them return an error instead of some waiting in a collective
     if (ctx->jkstage_doubles < need + 1) {
-        if (ctx->d_jkstage) (void)hipFree(ctx->d_jkstage);
+        if (ctx->d_jkstage) (void)tf_free(ctx->d_jkstage);
         ctx->d_jkstage = nullptr; ctx->jkstage_doubles = 0;
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_jkstage, (need + 1) * sizeof(double)));
+        HIPCHK(ctx, tf_malloc((void **)&ctx->d_jkstage, (need + 1) * sizeof(double)));
         ctx->jkstage_doubles = need + 1;
     }
     for (int d = 0; d < nd; ++d) {
@@ -2566,7 +2568,7 @@ static int agree_over_ranks(tf_ctx *ctx, const double *vals, int n, std::string 
     double h[16] = {0};
     h[0] = 1.0;
     for (int k = 0; k < n; ++k) { h[1 + k] = vals[k]; h[8 + k] = vals[k] * vals[k]; }
-    if (!ctx->d_agree && hipMalloc((void **)&ctx->d_agree, 16 * sizeof(double)) != hipSuccess) { msg = "hipMalloc failed (agree buffer)"; return TF_ENOMEM; }
+    if (!ctx->d_agree && tf_malloc((void **)&ctx->d_agree, 16 * sizeof(double)) != hipSuccess) { msg = "hipMalloc failed (agree buffer)"; return TF_ENOMEM; }
     if (hipMemcpy(ctx->d_agree, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { msg = "hipMemcpy failed (agree buffer)"; return TF_ENODEVICE; }
     const int rc = ctx->allreduce(ctx->allreduce_user, ctx->d_agree, 16, nullptr);
     if (rc) { msg = "the registered all-reduce failed (code " + std::to_string(rc) + ")"; return TF_ENODEVICE; }
@@ -2801,16 +2803,16 @@ int tf_dft_setup(tf_ctx *ctx, int64_t n_points, const double *xyz, const double 
     HIPCHK(ctx, hipMemcpy(d_xyz, xyz, (size_t)3 * G * sizeof(double), hipMemcpyHostToDevice));
     const size_t GN = (size_t)G * N;
     // (the grid's buffers are released by tfdft::release in tf_dft.hip.h with the runtime's own hipFree: they bypass this file's block cache)
-    HIPCHK(ctx, (hipMalloc)((void **)&g.w, (size_t)G * sizeof(double)));
+    HIPCHK(ctx, ::hipMalloc((void **)&g.w, (size_t)G * sizeof(double)));
     HIPCHK(ctx, hipMemcpy(g.w, weights, (size_t)G * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(ctx, (hipMalloc)((void **)&g.phi, GN * sizeof(double)));
-    HIPCHK(ctx, (hipMalloc)((void **)&g.dphi, (g.gga ? 3 : 1) * GN * sizeof(double)));
-    HIPCHK(ctx, (hipMalloc)((void **)&g.B, GN * sizeof(double)));
-    HIPCHK(ctx, (hipMalloc)((void **)&g.D, GN * sizeof(double)));
-    for (double **p : {&g.rho, &g.vrho, &g.vsig, &g.ex, &g.ec}) HIPCHK(ctx, (hipMalloc)((void **)p, (size_t)G * sizeof(double)));
-    HIPCHK(ctx, (hipMalloc)((void **)&g.grad, (size_t)3 * G * sizeof(double)));
-    HIPCHK(ctx, (hipMalloc)((void **)&g.V, (size_t)(tfdft::VSPLIT + 2) * N * N * sizeof(double)));
-    HIPCHK(ctx, (hipMalloc)((void **)&g.part, (size_t)3 * tfdft::NPART * sizeof(double)));
+    HIPCHK(ctx, ::hipMalloc((void **)&g.phi, GN * sizeof(double)));
+    HIPCHK(ctx, ::hipMalloc((void **)&g.dphi, (g.gga ? 3 : 1) * GN * sizeof(double)));
+    HIPCHK(ctx, ::hipMalloc((void **)&g.B, GN * sizeof(double)));
+    HIPCHK(ctx, ::hipMalloc((void **)&g.D, GN * sizeof(double)));
+    for (double **p : {&g.rho, &g.vrho, &g.vsig, &g.ex, &g.ec}) HIPCHK(ctx, ::hipMalloc((void **)p, (size_t)G * sizeof(double)));
+    HIPCHK(ctx, ::hipMalloc((void **)&g.grad, (size_t)3 * G * sizeof(double)));
+    HIPCHK(ctx, ::hipMalloc((void **)&g.V, (size_t)(tfdft::VSPLIT + 2) * N * N * sizeof(double)));
+    HIPCHK(ctx, ::hipMalloc((void **)&g.part, (size_t)3 * tfdft::NPART * sizeof(double)));
     tfdft::DAOs D{A.z, A.lmn, A.prim_off, A.exps, A.w};
     hipLaunchKernelGGL(tfdft::ao_on_grid_kernel, dim3((unsigned)((GN + 127) / 128)), dim3(128), 0, 0, D, d_xyz, G, N, ctx->d_csr_ptr,
                        ctx->d_csr_idx, ctx->d_csr_val, g.phi, g.dphi, g.gga ? 1 : 0);
@@ -2864,14 +2866,14 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     const bool same_pairs = n1 == n3 && n2 == n4 && std::memcmp(C1, C3, (size_t)N * n1 * sizeof(double)) == 0 &&
                             std::memcmp(C2, C4, (size_t)N * n2 * sizeof(double)) == 0;
     double secs = 0.0;
-    auto cleanup = [&]() { for (int k = 0; k < 4; ++k) if (dC[k]) (void)hipFree(dC[k]); for (int k = 0; k < 2; ++k) if (dG[k]) (void)hipFree(dG[k]); };
-    auto fail = [&](int code, const std::string &m) { ctx->err = m; cleanup(); if (*d_out) { (void)hipFree(*d_out); *d_out = nullptr; } return code; };
+    auto cleanup = [&]() { for (int k = 0; k < 4; ++k) if (dC[k]) (void)tf_free(dC[k]); for (int k = 0; k < 2; ++k) if (dG[k]) (void)tf_free(dG[k]); };
+    auto fail = [&](int code, const std::string &m) { ctx->err = m; cleanup(); if (*d_out) { (void)tf_free(*d_out); *d_out = nullptr; } return code; };
     *d_out = nullptr;
     for (int k = 0; k < 4; ++k) {
-        if (hipMalloc((void **)&dC[k], (size_t)N * nk[k] * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+        if (tf_malloc((void **)&dC[k], (size_t)N * nk[k] * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
         if (hipMemcpy(dC[k], hC[k], (size_t)N * nk[k] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation: copy failed");
     }
-    if (hipMalloc((void **)d_out, total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+    if (tf_malloc((void **)d_out, total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
     // the short index first: a ket coefficient matrix of at most 32 columns (the occupied orbitals of (ia|jb)) goes through the hand-written
     // first quarter on the packed segments (tfmp2::mo_q1_kernel); TF_MO_Q1=0 keeps the expanded-block path (A/B, tests)
     const char *q1env = getenv("TF_MO_Q1");
@@ -2884,8 +2886,8 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
             const bool fits = need <= ctx->mo_pool_bytes || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) <= free_b + ctx->mo_pool_bytes);
             if (fits) {
                 if (need > ctx->mo_pool_bytes) {
-                    if (ctx->mo_pool) { (void)hipFree(ctx->mo_pool); ctx->mo_pool = nullptr; ctx->mo_pool_bytes = 0; }
-                    if (hipMalloc((void **)&ctx->mo_pool, need) == hipSuccess) ctx->mo_pool_bytes = need;
+                    if (ctx->mo_pool) { (void)tf_free(ctx->mo_pool); ctx->mo_pool = nullptr; ctx->mo_pool_bytes = 0; }
+                    if (tf_malloc((void **)&ctx->mo_pool, need) == hipSuccess) ctx->mo_pool_bytes = need;
                     else { ctx->mo_pool = nullptr; (void)hipGetLastError(); }
                 }
                 if (ctx->mo_pool) {
@@ -2910,10 +2912,10 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     if (!packed) {
         if ((rc = run(0, 1, 2, 3, *d_out))) return fail(rc, msg);
     } else {
-        if (hipMalloc((void **)&dG[0], total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+        if (tf_malloc((void **)&dG[0], total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
         if ((rc = run(0, 1, 2, 3, dG[0]))) return fail(rc, msg);
         if (!same_pairs) {
-            if (hipMalloc((void **)&dG[1], total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+            if (tf_malloc((void **)&dG[1], total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
             if ((rc = run(2, 3, 0, 1, dG[1]))) return fail(rc, msg);
         }
         const long long A = (long long)n1 * n2, B = (long long)n3 * n4;
@@ -2943,7 +2945,7 @@ int tf_ao_to_mo(tf_ctx *ctx, int n1, const double *C1, int n2, const double *C2,
     int rc = mo_transform_device(ctx, C1, n1, C2, n2, C3, n3, C4, n4, &d_out, nullptr);
     if (rc) return rc;
     hipError_t e = hipMemcpy(out, d_out, (size_t)n1 * n2 * n3 * n4 * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(d_out);
+    (void)tf_free(d_out);
     HIPCHK(ctx, e);
     return TF_OK;
 }
@@ -2967,13 +2969,13 @@ int tf_mp2_rhf(tf_ctx *ctx, int n_occ, int n_frozen, const double *C, const doub
     if (rc) return rc;
     double *d_eps = nullptr, *d_part = nullptr;
     const int nblk = 1024;
-    HIPCHK(ctx, hipMalloc((void **)&d_eps, (size_t)N * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&d_part, (size_t)2 * nblk * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&d_eps, (size_t)N * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&d_part, (size_t)2 * nblk * sizeof(double)));
     HIPCHK(ctx, hipMemcpy(d_eps, eps, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(tfmp2::mp2_energy_kernel, dim3(nblk), dim3(256), 0, 0, d_g, d_eps, n_frozen, o, v, n_occ, d_part);
     std::vector<double> part(2 * nblk);
     hipError_t e = hipMemcpy(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(d_g); (void)hipFree(d_eps); (void)hipFree(d_part);
+    (void)tf_free(d_g); (void)tf_free(d_eps); (void)tf_free(d_part);
     HIPCHK(ctx, e);
     double os = 0.0, ss = 0.0;
     for (int b = 0; b < nblk; ++b) { os += part[2 * b]; ss += part[2 * b + 1]; }
