@@ -2880,7 +2880,7 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     const bool q1_allowed = packed && !(q1env && q1env[0] == '0');
     auto run = [&](int a, int b, int c, int d, double *dst) {
         double s1 = 0.0;
-        if (q1_allowed && nk[c] <= 32 && nk[a] <= 32 && (size_t)N * ((nk[a] + 1) & ~1) * sizeof(double) + (size_t)N * sizeof(int) <= ((size_t)64 << 10)) {
+        if (q1_allowed && nk[c] <= 32 && nk[a] <= 32 && (size_t)N * ((nk[a] + 1) & ~1) * sizeof(double) + (size_t)N * sizeof(int) <= ((size_t)150 << 10)) {
             const size_t need = tfmp2::q1_pool_doubles(N, ctx->n_rows, nk[a], nk[b], nk[c], nk[d]) * sizeof(double);
             size_t free_b = 0, total_b = 0;
             const bool fits = need <= ctx->mo_pool_bytes || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) <= free_b + ctx->mo_pool_bytes);

@@ -654,7 +654,11 @@ inline int transform_q1(rocblas_handle blas, const double *d_eri, const long lon
     // T[p1][nu][y] = sum_mu C1[mu][p1] R[row(mu, nu)][y]: the hand-written bra kernel follows the row map (n1 <= 32)
     {
         const size_t lds1 = (size_t)N * ((n1 + 1) & ~1) * sizeof(double) + (size_t)N * sizeof(int);
-        if (n1 > 32 || lds1 > ((size_t)64 << 10)) { msg = "AO->MO transformation: the bra kernel holds at most 32 orbitals of at most ~450 AOs"; rc = TF_EINVAL; goto done; }
+        if (n1 > 32 || lds1 > ((size_t)150 << 10)) { msg = "AO->MO transformation: the bra kernel holds at most 32 orbitals in 150 KB of LDS"; rc = TF_EINVAL; goto done; }
+        if (lds1 > ((size_t)64 << 10)) {                              // (N > ~450 at 18 orbitals: one workgroup per CU)
+            TFM_HIP(hipFuncSetAttribute((const void *)mo_bra1_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+            TFM_HIP(hipFuncSetAttribute((const void *)mo_bra1_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        }
         const dim3 grid1((unsigned)((Y + TFB1_THREADS - 1) / TFB1_THREADS), (unsigned)N);
         if (n1 <= 16) hipLaunchKernelGGL(mo_bra1_kernel<1>, grid1, dim3(TFB1_THREADS), lds1, 0, dR, dC1, d_rowmap, BL, n1, (int)Y, dT);
         else hipLaunchKernelGGL(mo_bra1_kernel<2>, grid1, dim3(TFB1_THREADS), lds1, 0, dR, dC1, d_rowmap, BL, n1, (int)Y, dT);
