@@ -124,6 +124,31 @@ def test_shard_plan_deterministic_and_consistent_with_rows(layout):
                 assert len(idx) == 0 or idx[-1] - idx[0] + 1 == len(idx)
 
 
+def test_whole_shell_plan_on_the_bench_workload(monkeypatch):
+    """The plan on the 400-AO bench workload (116 shells): whole bra shells per rank -- every (A, B <= A) of a shell A on one rank -- with
+    the stored values within 3 % of the mean on 2, 4 and 8 ranks; TF_SHARD_PLAN=segments gives the segment plan (several owners per A)."""
+    from tuna_amd import molecule as mol
+    counts = mol.synthetic_counts(400)
+    atoms = mol.make_atoms(["AR", "AR"], 7.1)
+    shells = mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)})
+    w = tdist.shell_pair_rows(shells, layout="packed")
+    ns = len(shells)
+    monkeypatch.delenv("TF_SHARD_PLAN", raising=False)
+    for world in (2, 4, 8):
+        o = tdist.shard_owner(shells, world, layout="packed")
+        loads = np.array([w[o == r].sum() for r in range(world)])
+        assert loads.max() <= 1.03 * loads.mean()
+        for A in range(ns):
+            row = o[A * (A + 1) // 2: A * (A + 1) // 2 + A + 1]
+            assert (row == row[0]).all()
+    monkeypatch.setenv("TF_SHARD_PLAN", "segments")
+    o = tdist.shard_owner(shells, 8, layout="packed")
+    A = ns - 1
+    assert len(set(o[A * (A + 1) // 2: A * (A + 1) // 2 + A + 1].tolist())) == 8
+    loads = np.array([w[o == r].sum() for r in range(8)])
+    assert loads.max() <= 1.05 * loads.mean()
+
+
 def test_generic_lpt_plan():
     w = np.array([9, 7, 6, 5, 5, 4, 3, 1], dtype=np.int64)
     owner = np.zeros(len(w), dtype=np.int32)

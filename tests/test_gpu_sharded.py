@@ -70,6 +70,46 @@ def test_config3_ar2_ccpvqz_sharded_and_four_ranks(world, tag, mode, layout):
     assert max(v[3] for v in res.values()) - min(v[3] for v in res.values()) <= 0.08 * n_total
 
 
+def test_whole_shell_plan_numerics(monkeypatch):
+    """The whole-shell plan (TF_SHARD_PLAN=shells: what a large problem gets by default) forced on BASELINE config 3 with two ranks: a rank
+    holds complete runs of j for its rows -- J, K and tensor samples against the reference's golden values on both ranks (the balance of
+    34 shells over two ranks is not asserted: the default would fall back to the segment plan if it were off by more than 3 %)."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("TF_SHARD_PLAN", "shells")
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rank_main_plain, args=(2, _free_port(), "c3_ar2_ccpvqz", ret), nprocs=2, join=True)
+        res = dict(ret)
+    assert set(res) == {0, 1}
+    for eJ, eK, eV in res.values():
+        assert eJ < 1e-9 and eK < 1e-9 and eV < 1e-12
+
+
+def _rank_main_plain(rank, world, port, tag, ret):
+    """A rank of a sharded build under whatever plan the environment selects: Fock build + tensor samples against the golden values."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import make_system
+        from tuna_amd.engine import Engine
+        from tuna_amd import distributed as tdist
+        atoms, shells, aos, nocc = make_system(tag)
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", tag + ".npz"))
+        with Engine(0, rank, world) as eng:
+            eng.set_basis(aos).build_eri(True)
+            owner = tdist.row_owner_matrix(shells, world)
+            assert eng.eri_storage()["rows"] == int((owner == rank).sum())
+            Jf, Kf = tdist.ShardedFock(eng)(g["P_rand"])
+            v = torch.from_numpy(eng.sample_eri(g["eri_sph_idx"][:2000]))
+            dist.all_reduce(v)
+            ret[rank] = (float(np.abs(Jf - g["J_rand"]).max()), float(np.abs(Kf - g["K_rand"]).max()),
+                         float(np.abs(v.numpy() - g["eri_sph_val"][:2000]).max()))
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("layout", ["packed", "rows"])
 @pytest.mark.parametrize("tag,mode", [("n2_ccpvdz", ""), ("c2_n2_ccpvtz", "class"), ("c4_co_def2tzvp", "generic")])
 def test_two_ranks_on_one_card(tag, mode, layout):

@@ -449,6 +449,41 @@ static void shard_plan_pairs(const std::vector<int> &dim, bool packed, int world
     owner.assign((size_t)ns * (ns + 1) / 2, 0);
     std::vector<long long> load(world, 0);
     std::vector<long long> w;
+    // WHOLE bra shells per rank when that balances (round 3): a rank then holds complete runs of j for its rows i -- super-groups as full
+    // as on one GPU, and an eighth of the super-groups, so that the Jt partials and their reduction shrink with the shard.  (With every A
+    // cut into `world` segments each rank keeps a short run of j under EVERY i: at N = 400 on 8 ranks the per-rank reduction stayed at
+    // 0.08 ms -- as many super-groups per rank as on one GPU -- and the J/K kernel ran on one-group workgroups.)  Longest-processing-time
+    // over the shells' weights; taken if the heaviest rank is within 3 % of the mean, else the segment plan below.  TF_SHARD_PLAN=segments
+    // / shells forces one of the two (identically on every rank, of course).
+    {
+        const char *pe = getenv("TF_SHARD_PLAN");
+        const bool force_seg = pe && pe[0] == 's' && pe[1] == 'e', force_sh = pe && pe[0] == 's' && pe[1] == 'h';
+        if (world > 1 && !force_seg) {
+            std::vector<long long> wA(ns, 0);
+            long long total = 0;
+            for (int A = 0; A < ns; ++A) {
+                for (long long i = off[A]; i < off[A + 1]; ++i)
+                    for (long long j = 0; j <= i; ++j) wA[A] += packed ? packed_row_len(i, j) : 1;
+                total += wA[A];
+            }
+            std::vector<int> ord(ns);
+            std::iota(ord.begin(), ord.end(), 0);
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return wA[x] > wA[y]; });
+            std::vector<long long> ld(world, 0);
+            std::vector<int> rankA(ns, 0);
+            for (int A : ord) {
+                const int r = (int)(std::min_element(ld.begin(), ld.end()) - ld.begin());
+                ld[r] += wA[A];
+                rankA[A] = r;
+            }
+            const long long heaviest = *std::max_element(ld.begin(), ld.end());
+            if (force_sh || (double)heaviest * world <= 1.03 * (double)total) {
+                for (int A = 0; A < ns; ++A)
+                    for (int B = 0; B <= A; ++B) owner[(size_t)A * (A + 1) / 2 + B] = rankA[A];
+                return;
+            }
+        }
+    }
     for (int A = ns - 1; A >= 0; --A) {                           // heaviest rows first
         w.assign(A + 1, 0);
         long long total = 0;
