@@ -2414,7 +2414,10 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
         static const int one_launch_below = getenv("TF_JK_ONE_LAUNCH") ? atoi(getenv("TF_JK_ONE_LAUNCH")) : 12000;   // (measured: N = 60 99 -> 69 us per build, 118: 155 -> 108, 160: 202 -> 183, 200: equal, 300: 874 against 907)
         // (one rank only: the rows of a rank of several are short runs of j -- mostly one group per super-group, three of four waves idle
         // in the barriers of a LONG walk; measured at N = 400 on 8 ranks: 0.72 ms per local build in one launch against 0.46 ms in three)
-        const bool one_launch = n_launch > 1 && T.n_tasks < one_launch_below && ctx->world == 1;
+        // (a rank of several only when its super-groups are full -- the whole-shell plan: >= 24 rows per super-group on average; 0.382 -> 0.363 ms
+        // per local build on 8 ranks.  Under the segment plan a rank's super-groups hold a few rows each: see above.)
+        const bool full_supers = T.n_supers > 0 && ctx->n_rows >= 24LL * T.n_supers;
+        const bool one_launch = n_launch > 1 && T.n_tasks < one_launch_below && (ctx->world == 1 || full_supers);
         const bool fork = !serial && !one_launch && ctx->have_streams && n_launch > 1;
         if (fork) (void)hipEventRecord(ctx->sev[0], st);
         int side = 0;
