@@ -166,12 +166,15 @@ def _rank_scf(rank, world, port, kind, tag, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,tag", [("rhf", "n2_ccpvdz"), ("rhf", "c4_co_def2tzvp"), ("uhf", "oh_doublet_ccpvdz")])
-def test_native_scf_cycle_on_a_sharded_tensor(kind, tag, golden, uhf_golden):
+@pytest.mark.parametrize("kind,tag,plan", [("rhf", "n2_ccpvdz", ""), ("rhf", "c4_co_def2tzvp", ""), ("uhf", "oh_doublet_ccpvdz", ""),
+                                           ("rhf", "c4_co_def2tzvp", "shells")])
+def test_native_scf_cycle_on_a_sharded_tensor(kind, tag, plan, golden, uhf_golden, monkeypatch):
     """The native cycles with the tensor split over two ranks: per iteration ONE all-reduce of the stacked [J;K], everything else on
     the device of each rank -- same trajectory as the reference run (golden) on every rank."""
     import torch.multiprocessing as mp
     world = 2
+    if plan:
+        monkeypatch.setenv("TF_SHARD_PLAN", plan)                      # (the whole-shell plan of large problems, forced on a small one)
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_rank_scf, args=(world, _free_port(), kind, tag, ret), nprocs=world, join=True)
