@@ -103,6 +103,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical);
 #define TF_LAYOUT_AUTO (-1)
 #define TF_LAYOUT_ROWS 0
 #define TF_LAYOUT_PACKED 1
+#define TF_LAYOUT_TILES 2
 /* Layout for the next tf_build_eri (TF_LAYOUT_AUTO = packed when the J/K kernel covers N, i.e. N <= 1024). */
 int tf_set_eri_layout(tf_ctx *ctx, int layout);
 /* Layout of the stored tensor (TF_LAYOUT_ROWS / TF_LAYOUT_PACKED), or TF_EINVAL before tf_build_eri. */
@@ -192,7 +193,13 @@ typedef struct {
     double *P_spin[2];          /* [N,N]                                           */
     double *C_spin[2];          /* [N,N]                                           */
     double *eps_spin[2];        /* [N]                                             */
-    double *F_spin[2];          /* Several restricted cycles on the SAME tensor advanced in lockstep: what the reference's finite-field drivers run one after the other
+    double *F_spin[2];          /* [N,N]                                           */
+} tf_scf_uhf_result;
+int tf_scf_uhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const double *T, const double *V,
+               const double *Fext, const double *X, const double *P0_alpha, const double *P0_beta, double E0,
+               int n_alpha, int n_beta, double V_NN, tf_scf_uhf_result *out);
+
+/* Several restricted cycles on the SAME tensor advanced in lockstep: what the reference's finite-field drivers run one after the other
  * (tuna_energy.py:315-540: 2, 8 or 12 energy evaluations that differ only in the field term F_fld, kernel:660-677).  Arguments as
  * tf_scf_rhf, with one Fext (may be NULL, or entries NULL), P0, E0 and result per cycle; every cycle follows the iteration order of
  * a run on its own (scf:1072-1154) and stops by its own criteria, but the Fock builds of an iteration go through the tensor together
@@ -202,11 +209,6 @@ int tf_scf_rhf_batch(tf_ctx *ctx, int n_cycles, const tf_scf_opts *opts, const d
                      const double *const *Fext, const double *X, const double *const *P0, const double *E0, int n_occ, double V_NN,
                      tf_scf_result *out, int32_t *rc_out, int64_t *passes_out);
 
-/* [N,N]                                           */
-} tf_scf_uhf_result;
-int tf_scf_uhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const double *T, const double *V,
-               const double *Fext, const double *X, const double *P0_alpha, const double *P0_beta, double E0,
-               int n_alpha, int n_beta, double V_NN, tf_scf_uhf_result *out);
 
 /* X = S^-1/2, S^-1 and the smallest overlap eigenvalue (kernel:756-816), host buffers [N,N]. */
 int tf_orthogonaliser(tf_ctx *ctx, int n, const double *S, double *X, double *S_inv, double *smallest_eig);

@@ -79,3 +79,43 @@ def test_stored_bytes_are_close_to_the_unique_elements():
     T = tm.Tables(cls, rows, 64, 48)
     ratio = T.n_elems / tm.stored_count(T)
     assert ratio < 1.06, ratio
+
+
+@pytest.mark.parametrize("shell_L,part_steps", [([0, 1, 1, 2, 0, 1, 2, 2, 3, 0, 1], 3), ([0] * 70 + [1] * 5, 7)])
+def test_address_function_reaches_every_stored_element_once(shell_L, part_steps):
+    """tt_elem_addr (what the writer and tf_copy_eri / tf_sample_eri use) against the regions: every canonical element of the owned rows
+    has its own slot, and the slot holds that element in the packed buffer of the model"""
+    cls = classes_of(shell_L)
+    N = len(cls)
+    rng = np.random.default_rng(3)
+    cls = list(rng.permutation(cls))
+    rows = [(i, j) for i in range(N) for j in range(i + 1) if (i + 2 * j) % 5 != 0 or i == j]
+    rows = [(i, j) for (i, j) in rows]
+    try:
+        T = tm.Tables(cls, rows, 64, part_steps)
+    except ValueError:
+        rows = [(i, j) for i in range(N) for j in range(i + 1)]
+        T = tm.Tables(cls, rows, 64, part_steps)
+    E = tm.random_parity_tensor(cls, 4)
+    buf, written = tm.pack_tensor(T, E)
+    s, o = T.sigma, T.origI
+    owned = set(rows)
+    seen = set()
+    n = 0
+    for i in range(N):
+        for j in range(i + 1):
+            for k in range(i + 1):
+                for l in range(k + 1):
+                    if k == i and l > j:
+                        continue
+                    if (cls[i] ^ cls[j]) != (cls[k] ^ cls[l]):
+                        continue
+                    ad = T.elem_addr(s[i], s[j], s[k], s[l])
+                    if (i, j) not in owned:
+                        assert ad == -1
+                        continue
+                    assert 0 <= ad < T.n_elems and ad not in seen, (i, j, k, l, ad)
+                    seen.add(ad)
+                    assert buf[ad] == E[i, j, k, l]
+                    n += 1
+    assert n == tm.stored_count(T)

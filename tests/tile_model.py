@@ -23,7 +23,8 @@ class TTask(C.Structure):
     _fields_ = [("base", C.c_longlong), ("jt_base", C.c_longlong), ("dj_base", C.c_longlong), ("i", C.c_int), ("j0", C.c_int), ("nj", C.c_int),
                 ("a", C.c_int), ("b", C.c_int), ("k0", C.c_int), ("nks", C.c_int), ("roff0", C.c_int), ("lb0", C.c_int), ("nw", C.c_int),
                 ("nk", C.c_int), ("nl", C.c_int), ("slice", C.c_int), ("woff", C.c_int * 4), ("jt_pitch", C.c_int), ("dj_len", C.c_int),
-                ("dj_koff", C.c_int), ("dj_loff", C.c_int * 4), ("di_base", C.c_int), ("jd_base", C.c_int), ("self_last", C.c_int), ("pid", C.c_int)]
+                ("dj_koff", C.c_int), ("dj_loff", C.c_int * 4), ("di_base", C.c_int), ("jd_base", C.c_int), ("self_last", C.c_int), ("pid", C.c_int),
+                ("kbase", C.c_int), ("lbase", C.c_int), ("ncol", C.c_int), ("pm_off", C.c_int), ("pm_pitch", C.c_int), ("pad_", C.c_int)]
 
 
 class TPairI(C.Structure):
@@ -53,6 +54,8 @@ def lib():
         L.ttm_count.restype = C.c_longlong
         L.ttm_count.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ttm_copy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.ttm_elem_addr.restype = C.c_longlong
+        L.ttm_elem_addr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _LIB = L
     return _LIB
 
@@ -68,6 +71,7 @@ class Tables:
         self.cls = cls
         self.ksub = ksub
         h = L.ttm_build(N, cls.ctypes.data, len(rows), rows.ctypes.data, ksub, part_steps)
+        self._h = h
         try:
             err = L.ttm_error(h).decode()
             if err:
@@ -105,8 +109,19 @@ class Tables:
             self.bucket = ints(5, 14)
             self.cntA = ints(4 * N, 15).reshape(4, N)
             self.csize = np.bincount(cls, minlength=4)
-        finally:
+        except Exception:
             L.ttm_free(h)
+            self._h = None
+            raise
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ttm_free(self._h)
+            self._h = None
+
+    def elem_addr(self, iI, jI, kI, lI):
+        """tt_elem_addr of tf_tiles.h (the address function of the writer and of the element accessors)"""
+        return int(lib().ttm_elem_addr(self._h, int(iI), int(jI), int(kI), int(lI)))
 
     # shape functions of tf_tiles.h
     def row_len(self, tri, ks, lb, r, nl): return lib().ttm_row_len(int(tri), ks, lb, r, nl)

@@ -98,3 +98,17 @@ int ttm_dj_first_sub(int tri, int lb, int ksub) { return tt_dj_first_sub(tri != 
 int ttm_nlb(int tri, int ks, int nk, int nl) { return tt_nlb(tri != 0, ks, nk, nl); }
 void ttm_chunks(int nlb, int *nch, int *w) { tt_chunks(nlb, nch, w); }
 }
+
+// address of the canonical element (internal indices) through the library's own address function (tf_tiles.h: tt_elem_addr)
+extern "C" long long ttm_elem_addr(void *p, int iI, int jI, int kI, int lI)
+{
+    Handle *h = (Handle *)p;
+    std::vector<int> tab(TVT_LEN, 0);
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) tab[TVT_PID + 4 * a + b] = std::max(0, h->T.pid[a][b]);
+    for (int q = 0; q < h->T.npair; ++q) { tab[TVT_PA + q] = h->T.pa[q]; tab[TVT_PB + q] = h->T.pb[q]; tab[TVT_PMOFF + q] = h->T.pm_off[q]; tab[TVT_PMPITCH + q] = h->T.pm_pitch[q]; }
+    for (int q = 0; q < 4; ++q) { tab[TVT_CSTART + q] = h->C.cstart[q]; tab[TVT_CSIZE + q] = h->C.csize[q]; }
+    TView V{};
+    V.regions = h->T.primary.tasks_by_region.data(); V.prim_pairs = h->T.primary.pairs.data(); V.prim_runs = h->T.primary.runs.data();
+    V.edge_base = h->T.edge_base; V.N = h->C.N; V.pm_len = h->T.pm_len; V.tab = tab.data();
+    return tt_elem_addr(V, h->C.clsI.data(), iI, jI, kI, lI);
+}

@@ -21,6 +21,8 @@
 #include "tf_internal.h"
 #include "tf_kernels.hip.h"
 #include "tf_jkpacked.hip.h"
+#include "tf_tiles_host.h"
+#include "tf_jktile.hip.h"
 #include "tf_eri.hip.h"
 #include "tf_eri_team.hip.h"
 #include "tf_eri_teamc.hip.h"
@@ -170,6 +172,24 @@ struct tf_ctx {
         JKJtPlan jp{};
     } jkt[2];
     double *d_Psym = nullptr, *d_Pp = nullptr, *d_ypart = nullptr, *d_DI = nullptr, *d_DJ = nullptr, *d_Jt = nullptr, *d_D = nullptr;
+    // tiles layout (tf_tiles.h, tf_jktile.hip.h): host tables, their device copies and the partial-sum buffers of the Fock kernel
+    tft::Tables tiles;
+    tft::TaskList tsub1;                 // the one-density task list when its strips are shorter than the stored ones (TF_TILE_KSUB)
+    int ksub1 = TT_KS;
+    TView tv{};
+    struct TileList {                    // device copy of a tft::TaskList
+        TTask *d_tasks = nullptr;
+        TPairI *d_pairs = nullptr;
+        TRunI *d_runs = nullptr;
+        int *d_itask_ptr = nullptr, *d_itasks = nullptr;
+        int n_tasks = 0, bucket[TT_W + 1] = {0, 0, 0, 0, 0}, ksub = TT_KS, n_di = 0;
+        long long dj_len = 0, jd_len = 0, jt_len = 0;
+    } tl1;
+    int *d_jlist_ptr = nullptr, *d_jlist = nullptr, *d_tvtab = nullptr;
+    double *t_X = nullptr, *t_Pm = nullptr, *t_DJ = nullptr, *t_Jt = nullptr, *t_Jd = nullptr, *t_DIk = nullptr, *t_DIl = nullptr;
+    double *t_out = nullptr;             // [2 passes][Dj, Di, ED, EDT, JD, EJ][N][N]
+    double *t_JtTot = nullptr;
+    std::vector<void *> tile_allocs;
     // instrumentation
     bool prof_jk = false;
     std::vector<hipEvent_t> prof_ev;     // pairs (before, after) around the row kernel, on the launch stream
@@ -257,6 +277,12 @@ static void free_eri(tf_ctx *ctx)
     ctx->d_jptr = nullptr; ctx->d_jrows = nullptr; ctx->d_xorder = nullptr;
     for (void *p : ctx->layout_allocs) (void)tf_free(p);
     ctx->layout_allocs.clear();
+    for (void *p : ctx->tile_allocs) (void)tf_free(p);
+    ctx->tile_allocs.clear();
+    ctx->tl1 = tf_ctx::TileList();
+    ctx->tv = TView{};
+    ctx->d_jlist_ptr = ctx->d_jlist = ctx->d_tvtab = nullptr;
+    ctx->t_X = ctx->t_Pm = ctx->t_DJ = ctx->t_Jt = ctx->t_Jd = ctx->t_DIk = ctx->t_DIl = ctx->t_out = ctx->t_JtTot = nullptr;
     if (ctx->d_rowsec) { (void)tf_free(ctx->d_rowsec); ctx->d_rowsec = nullptr; }
     ctx->bl = BLayout{};
     ctx->d_class_rows = nullptr; ctx->d_row_pos = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
@@ -525,7 +551,7 @@ int tf_shard_plan_pairs(int n_shells, const int32_t *dim, int layout, int world,
 {
     if (n_shells < 0 || world < 1 || !dim || !owner || layout < 0 || layout > 1) return TF_EINVAL;
     std::vector<int> d(dim, dim + n_shells), o;
-    shard_plan_pairs(d, layout == 1, world, o);
+    shard_plan_pairs(d, layout >= 1, world, o);
     std::copy(o.begin(), o.end(), owner);
     return TF_OK;
 }
@@ -799,10 +825,12 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     HIPCHK(ctx, hipMemcpy(ctx->d_pairs, ctx->host_pairs.data(), (size_t)npairs * sizeof(DPair), hipMemcpyHostToDevice));
     // layout: packed (8-fold unique, tf_jkpacked.hip.h) unless asked otherwise
     int layout = ctx->layout_req;
-    if (const char *e = getenv("TF_ERI_LAYOUT")) layout = (e[0] == 'p') ? 1 : (e[0] == 'r' ? 0 : layout);
-    if (layout < 0) layout = 1;
+    if (const char *e = getenv("TF_ERI_LAYOUT")) layout = (e[0] == 't') ? 2 : ((e[0] == 'p') ? 1 : (e[0] == 'r' ? 0 : layout));
+    if (layout < 0) layout = 2;
     ctx->layout = layout;
-    const bool packed = layout == 1;
+    // packed: the symmetry-unique, parity-allowed values (layouts 1 and 2: the generation and its slab are the same); tiles: stored
+    // j-innermost in (i, class pair, strip, chunk) regions (tf_tiles.h) instead of row by row (tf_jkpacked.hip.h)
+    const bool packed = layout >= 1, tiles = layout == 2;
     std::vector<long long> pair_rows(npairs), pair_weight(npairs);
     for (int p = 0; p < npairs; ++p) {
         const tf::Shell &a = bs.shells[bs.pairs[p].A], &b = bs.shells[bs.pairs[p].B];
@@ -888,8 +916,48 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         for (size_t r = 0; r < row_ij.size(); ++r) {
             const int i = row_ij[r].x, j = row_ij[r].y;
             rowmap[ikey(H.sigma[i], H.sigma[j])] = (int)r;
-            rowlen[r] = H.row_shape(H.cls[i] ^ H.cls[j], H.sigma[i], &rowsec[6 * r]);
+            if (!tiles) rowlen[r] = H.row_shape(H.cls[i] ^ H.cls[j], H.sigma[i], &rowsec[6 * r]);
         }
+    }
+    if (tiles) {
+        // regions of the stored tensor and the task list of the Fock kernel (tf_tiles_host.h)
+        tft::ClassInfo C;
+        C.N = N;
+        for (int q = 0; q < 4; ++q) { C.cstart[q] = H.cstart[q]; C.csize[q] = H.csize[q]; }
+        C.clsI = H.clsI; C.origI = H.origI; C.cntA = H.cntA;
+        std::vector<std::pair<int, int>> rows_ij(row_ij.size());
+        for (size_t r = 0; r < row_ij.size(); ++r) rows_ij[r] = {H.sigma[row_ij[r].x], H.sigma[row_ij[r].y]};
+        static const int part_steps = getenv("TF_TILE_PART_STEPS") ? std::max(1, atoi(getenv("TF_TILE_PART_STEPS"))) : 48;
+        std::string e = tft::build(C, rows_ij, part_steps, ctx->tiles);
+        if (!e.empty()) TF_FAIL(ctx, TF_EINVAL, "%s", e.c_str());
+        static const int ksub_env = getenv("TF_TILE_KSUB") ? atoi(getenv("TF_TILE_KSUB")) : TT_KS;
+        ctx->ksub1 = (ksub_env == 32 || ksub_env == 16) ? ksub_env : TT_KS;
+        if (ctx->ksub1 != TT_KS) {
+            e = tft::build_list(C, ctx->tiles, rows_ij, ctx->ksub1, part_steps, ctx->tsub1);
+            if (!e.empty()) TF_FAIL(ctx, TF_EINVAL, "%s", e.c_str());
+        }
+        if (ctx->tiles.max_slice * (long long)part_steps * 8 > 0x7fffffffLL) TF_FAIL(ctx, TF_EINVAL, "tiles layout: a task's region exceeds the 32-bit offsets of the Fock kernel");
+        ctx->n_elems = ctx->tiles.n_elems;
+        const tft::Tables &TT = ctx->tiles;
+        std::vector<int> tab(TVT_LEN, 0);
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) tab[TVT_PID + 4 * a + b] = std::max(0, TT.pid[a][b]);
+        for (int p2 = 0; p2 < TT.npair; ++p2) { tab[TVT_PA + p2] = TT.pa[p2]; tab[TVT_PB + p2] = TT.pb[p2]; tab[TVT_PMOFF + p2] = TT.pm_off[p2]; tab[TVT_PMPITCH + p2] = TT.pm_pitch[p2]; }
+        for (int q = 0; q < 4; ++q) { tab[TVT_CSTART + q] = H.cstart[q]; tab[TVT_CSIZE + q] = H.csize[q]; }
+        auto up_t = [&](const auto &h, auto **d) -> int {
+            int rc2 = upload(ctx, h, d, false);
+            if (!rc2) ctx->tile_allocs.push_back(*d);
+            return rc2;
+        };
+        TTask *d_regions = nullptr; TPairI *d_pp = nullptr; TRunI *d_rr = nullptr;
+        if ((rc = up_t(TT.primary.tasks_by_region, &d_regions)) || (rc = up_t(TT.primary.pairs, &d_pp)) || (rc = up_t(TT.primary.runs, &d_rr)) ||
+            (rc = up_t(tab, &ctx->d_tvtab)))
+            return rc;
+        TView V{};
+        V.regions = d_regions; V.prim_pairs = d_pp; V.prim_runs = d_rr; V.edge_base = TT.edge_base; V.N = N; V.pm_len = TT.pm_len; V.tab = ctx->d_tvtab;
+        ctx->tv = V;
+        ctx->tl1.d_pairs = d_pp; ctx->tl1.d_runs = d_rr;
+    }
+    if (packed && !tiles) {
         // storage units: runs of up to 8 consecutive j of one class with the same i, cut from the top (the row groups of the kernel; its
         // groups of 4 for two densities are halves of them); the rows of a unit are interleaved segment by segment
         long long off = 0;
@@ -1025,10 +1093,11 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     }
     if ((rc = upload(ctx, row_ij, &ctx->d_row_ij, false)) || (rc = upload(ctx, rowmap, &ctx->d_rowmap, false))) return rc;
     if (packed) {
-        if ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, rowsec, &ctx->d_rowsec, false))) return rc;
+        if (!tiles && ((rc = upload(ctx, rowoff, &ctx->d_rowoff, false)) || (rc = upload(ctx, rowsec, &ctx->d_rowsec, false)))) return rc;
         ctx->db.bl = ctx->bl;
         ctx->db.RLS = H.RLS;
     }
+    if (tiles) HIPCHK(ctx, hipMemsetAsync(ctx->d_eri, 0, (size_t)ctx->n_elems * sizeof(double), 0));   // the pad slots of the rows and pieces stay zero
     // The tables only the CONSUMERS of the tensor need (work tables of the J/K kernel, reduction lists, rows by class) are built on the
     // host while the generation kernels run: called behind the launches of the last slab (7 ms of host time at N = 400).
     auto consumer_tables = [&]() -> int {
@@ -1046,6 +1115,23 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             }
             ctx->class_row_off[4] = (long long)class_rows.size();
             if ((rc2 = upload(ctx, class_rows, &ctx->d_class_rows, false)) || (rc2 = upload(ctx, row_pos, &ctx->d_row_pos, false))) return rc2;
+        }
+        if (tiles) {
+            const tft::Tables &TT = ctx->tiles;
+            const tft::TaskList &TL = ctx->ksub1 == TT_KS ? TT.primary : ctx->tsub1;
+            auto up_t = [&](const auto &h, auto **d) -> int {
+                int rc3 = upload(ctx, h, d, false);
+                if (!rc3) ctx->tile_allocs.push_back(*d);
+                return rc3;
+            };
+            tf_ctx::TileList &D = ctx->tl1;
+            if (ctx->ksub1 != TT_KS && ((rc2 = up_t(TL.pairs, &D.d_pairs)) || (rc2 = up_t(TL.runs, &D.d_runs)))) return rc2;   // (the shapes of the DJ vectors differ)
+            if ((rc2 = up_t(TL.tasks, &D.d_tasks)) || (rc2 = up_t(TL.itask_ptr, &D.d_itask_ptr)) || (rc2 = up_t(TL.itasks, &D.d_itasks)) ||
+                (rc2 = up_t(TT.jlist_ptr, &ctx->d_jlist_ptr)) || (rc2 = up_t(TT.jlist, &ctx->d_jlist)))
+                return rc2;
+            D.n_tasks = (int)TL.tasks.size(); D.ksub = TL.ksub; D.n_di = TL.n_di; D.dj_len = TL.dj_len; D.jd_len = TL.jd_len; D.jt_len = TL.jt_len;
+            for (int b = 0; b <= TT_W; ++b) D.bucket[b] = TL.bucket[b];
+            return TF_OK;
         }
         if ((rc2 = build_jk_tables(JKShape<1>::RB, ctx->jkt[0])) || (rc2 = build_jk_tables(JKShape<2>::RB, ctx->jkt[1]))) return rc2;
         // reduction table: the rows (z, x), z != x, listed by their second index x (internal)
@@ -1915,7 +2001,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     signed char *d_rowcls = nullptr;                               // parity class of every slab row (small-problem mode, packed layout)
     // two sets of a slab's index lists: the lists of slab k + 1 are uploaded (on a stream of their own) while the kernels of slab k run;
     // the kernels themselves stay ordered by the streams (one half-transformed slab)
-    const size_t out_bytes = cap_out * std::max(sizeof(OutRow), sizeof(OutRowP)), rowcls_bytes = (size_t)max_rows_c + 1;
+    const size_t out_bytes = cap_out * std::max(std::max(sizeof(OutRow), sizeof(OutRowP)), sizeof(OutRowT)), rowcls_bytes = (size_t)max_rows_c + 1;
     HIPCHK(ctx, tf_malloc((void **)&d_bra, 2 * cap_bra * sizeof(int)));
     HIPCHK(ctx, tf_malloc((void **)&d_braoff, 2 * cap_bra * sizeof(long long)));
     if (use_team_pc) HIPCHK(ctx, tf_malloc((void **)&d_brarec, 2 * cap_bra * sizeof(BraRec)));
@@ -1974,13 +2060,14 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     while (cursor < mine_sorted.size()) {
         std::vector<int> bra; std::vector<long long> braoff; std::vector<OutRow> outs;
         std::vector<OutRowP> outsP;
+        std::vector<OutRowT> outsT;
         std::vector<signed char> rowcls;
         long long rows_c = 0;
         while (cursor < mine_sorted.size()) {
             const int p = mine_sorted[cursor];
             const tf::Shell &a = bs.shells[bs.pairs[p].A], &b = bs.shells[bs.pairs[p].B];
             const long long nr = (long long)a.ncomp * b.ncomp;
-            if (!bra.empty() && (rows_c + nr > max_rows_c || bra.size() >= 65535 || outs.size() + outsP.size() + (size_t)pair_rows[p] >= cap_out)) break;
+            if (!bra.empty() && (rows_c + nr > max_rows_c || bra.size() >= 65535 || outs.size() + outsP.size() + outsT.size() + (size_t)pair_rows[p] >= cap_out)) break;
             bra.push_back(p); braoff.push_back(rows_c);
             long long r = pair_first_row[p];
             for (int x = 0; x < out_dim(a); ++x)
@@ -1988,6 +2075,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                     const int i = out_off(a) + x, j = out_off(b) + y;
                     if (i < j) continue;
                     if (!packed) { outs.push_back(OutRow{i, j, a.cart_off, b.cart_off, b.ncomp, 0, rows_c, r++}); continue; }
+                    if (tiles) { outsT.push_back(OutRowT{i, j, H.sigma[i], H.sigma[j], H.cls[i] ^ H.cls[j], b.ncomp, a.cart_off, b.cart_off, rows_c}); continue; }
                     const int lr = rowmap[ikey(H.sigma[i], H.sigma[j])];
                     OutRowP o{};
                     o.i = i; o.j = j; o.iI = H.sigma[i]; o.lamj = H.loc[j]; o.c = H.cls[i] ^ H.cls[j]; o.ncb = b.ncomp;
@@ -2044,9 +2132,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
         if (!outs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_out, outs.data(), outs.size() * sizeof(OutRow), hipMemcpyHostToDevice, cst));
         if (!outsP.empty()) HIPCHK(ctx, hipMemcpyAsync(d_out, outsP.data(), outsP.size() * sizeof(OutRowP), hipMemcpyHostToDevice, cst));
+        if (!outsT.empty()) HIPCHK(ctx, hipMemcpyAsync(d_out, outsT.data(), outsT.size() * sizeof(OutRowT), hipMemcpyHostToDevice, cst));
         if (!rowcls.empty()) HIPCHK(ctx, hipMemcpyAsync(d_rowcls, rowcls.data(), rowcls.size(), hipMemcpyHostToDevice, cst));
         HIPCHK(ctx, hipStreamSynchronize(cst));                // (pageable sources: the copies are complete; the host vectors may go)
-        DBG("slab: %zu bra pairs, %lld cart rows, %zu out rows", bra.size(), rows_c, outs.size() + outsP.size());
+        DBG("slab: %zu bra pairs, %lld cart rows, %zu out rows", bra.size(), rows_c, outs.size() + outsP.size() + outsT.size());
         hipEvent_t e4[4];
         for (auto &e : e4) { HIPCHK(ctx, hipEventCreate(&e)); tev.push_back(e); }
         if (per_class && !packed && ld != N) HIPCHK(ctx, hipMemsetAsync(d_T2, 0, (size_t)rows_c * N * ld * sizeof(double), 0));   // pad columns
@@ -2199,6 +2288,14 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                                    ctx->d_csr_val);
             }
         }
+        if (!outsT.empty()) {
+            for (size_t o0 = 0; o0 < outsT.size(); o0 += 65535) {
+                const unsigned ny = (unsigned)std::min<size_t>(65535, outsT.size() - o0);
+                hipLaunchKernelGGL(xform_bra_store_tiles, dim3((unsigned)((H.RLS + 255) / 256), ny), dim3(256), 0, 0, d_T2, ctx->d_eri,
+                                   reinterpret_cast<const OutRowT *>(d_out) + o0, (long long)H.RLS, ctx->bl, ctx->tv, ctx->d_csr_ptr, ctx->d_csr_idx,
+                                   ctx->d_csr_val);
+            }
+        }
         HIPCHK(ctx, hipEventRecord(e4[3], 0));
         HIPCHK(ctx, hipEventRecord(ctx->slab_done[set], 0));
     }
@@ -2243,7 +2340,22 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     const int NWjk = packed ? std::max(1, H.NW) * H.MP : 1;         // column chunks of jk_packed_kernel x parts of a walk
     HIPCHK(ctx, tf_malloc((void **)&ctx->d_Jrow, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     HIPCHK(ctx, hipMemset(ctx->d_Jrow, 0, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
-    if (packed) {
+    if (tiles) {
+        // partial sums of jk_tile_kernel (one density per pass for now) and the per-pass outputs of its reductions
+        const tf_ctx::TileList &D = ctx->tl1;
+        const size_t pml = (size_t)std::max(1, ctx->tiles.pm_len);
+        auto alloc_t = [&](double **p, size_t doubles, bool zero) -> int {
+            HIPCHK(ctx, tf_malloc((void **)p, std::max<size_t>(1, doubles) * sizeof(double)));
+            ctx->tile_allocs.push_back(*p);
+            if (zero) HIPCHK(ctx, hipMemset(*p, 0, std::max<size_t>(1, doubles) * sizeof(double)));
+            return TF_OK;
+        };
+        if ((rc = alloc_t(&ctx->t_X, nn, false)) || (rc = alloc_t(&ctx->t_Pm, pml, true)) || (rc = alloc_t(&ctx->t_DJ, (size_t)D.dj_len, false)) ||
+            (rc = alloc_t(&ctx->t_Jt, (size_t)D.jt_len, false)) || (rc = alloc_t(&ctx->t_Jd, (size_t)D.jd_len, false)) ||
+            (rc = alloc_t(&ctx->t_DIk, (size_t)D.n_di * 64, false)) || (rc = alloc_t(&ctx->t_DIl, (size_t)D.n_di * 16, false)) ||
+            (rc = alloc_t(&ctx->t_out, 2 * 6 * nn, true)) || (rc = alloc_t(&ctx->t_JtTot, pml, true)))
+            return rc;
+    } else if (packed) {
         // everything sized for a two-density pass (second density behind the first)
         const size_t npr = (size_t)std::max<long long>(1, H.NPtot);    // padded pair index space
         const size_t ny = (size_t)std::max(ctx->jkt[0].ypart_len, 2 * ctx->jkt[1].ypart_len);
@@ -2290,7 +2402,7 @@ int tf_eri_storage(const tf_ctx *ctx, int64_t *bytes, int64_t *n_rows, int32_t *
 
 int tf_set_eri_layout(tf_ctx *ctx, int layout)
 {
-    if (!ctx || layout < -1 || layout > 1) return TF_EINVAL;
+    if (!ctx || layout < -1 || layout > 2) return TF_EINVAL;
     ctx->layout_req = layout;
     return TF_OK;
 }
@@ -2330,7 +2442,9 @@ int tf_copy_eri(tf_ctx *ctx, double *host_out)
     double *d_dense = nullptr;
     HIPCHK(ctx, tf_malloc((void **)&d_dense, total * sizeof(double)));
     const unsigned g = (unsigned)std::min<size_t>((total + 255) / 256, 1 << 20);
-    if (ctx->layout == 1)
+    if (ctx->layout == 2)
+        hipLaunchKernelGGL(expand_dense_tiles_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->tv, ctx->bl, d_dense);
+    else if (ctx->layout == 1)
         hipLaunchKernelGGL(expand_dense_packed_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->d_rowoff, ctx->d_rowsec, ctx->bl, d_dense);
     else
         hipLaunchKernelGGL(expand_dense_kernel, dim3(g), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap, ctx->N, ctx->ld, d_dense);
@@ -2352,7 +2466,9 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
     HIPCHK(ctx, tf_malloc((void **)&d_idx, (size_t)n_idx * 4 * sizeof(int)));
     HIPCHK(ctx, tf_malloc((void **)&d_val, (size_t)n_idx * sizeof(double)));
     HIPCHK(ctx, hipMemcpy(d_idx, idx, (size_t)n_idx * 4 * sizeof(int), hipMemcpyHostToDevice));
-    if (ctx->layout == 1)
+    if (ctx->layout == 2)
+        hipLaunchKernelGGL(sample_tiles_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->tv, ctx->bl, (long long)n_idx, d_idx, d_val);
+    else if (ctx->layout == 1)
         hipLaunchKernelGGL(sample_packed_kernel, dim3((unsigned)((n_idx + 255) / 256)), dim3(256), 0, 0, ctx->d_eri, ctx->d_rowmap,
                            ctx->d_rowoff, ctx->d_rowsec, ctx->bl, (long long)n_idx, d_idx, d_val);
     else
@@ -2494,9 +2610,99 @@ static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double
     return TF_OK;
 }
 
+// Fock build from the tiles layout (tf_jktile.hip.h): per density pack -> jk_tile_kernel (one launch per workgroup size) beside
+// jk_edge_kernel -> jk_tile_reduce_kernel -> jk_tile_final_kernel.  A non-symmetric density takes two passes (K = D(P^T) + D(P)^T).
+static int launch_jk_tiles(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st, const int *nonsym)
+{
+    const int N = ctx->N;
+    const size_t nn = (size_t)N * N;
+    const tf_ctx::TileList &D = ctx->tl1;
+    const tft::Tables &TT = ctx->tiles;
+    const dim3 gN((unsigned)((nn + 255) / 256)), b256(256);
+    int xtiles = 0, jt_rows = 0;
+    for (int c = 0; c < 4; ++c) xtiles += (ctx->hl.csize[c] + 63) / 64;
+    for (int p = 0; p < TT.npair; ++p) jt_rows += ctx->hl.csize[TT.pa[p]];
+    for (int d = 0; d < nd; ++d) {
+        const bool general = nonsym && nonsym[d];
+        for (int pass = 0; pass < (general ? 2 : 1); ++pass) {
+            double *out = ctx->t_out + (size_t)pass * 6 * nn;              // Dj, Di, ED, EDT, JD, EJ of this pass
+            hipLaunchKernelGGL(pack_density_tiles_kernel, gN, b256, 0, st, dP[d], ctx->bl, ctx->tv, (general && pass == 0) ? 1 : 0, ctx->t_X, ctx->t_Pm);
+            TJArgs A{};
+            A.DJ = ctx->t_DJ; A.Jt = ctx->t_Jt; A.Jd = ctx->t_Jd; A.DIk = ctx->t_DIk; A.DIl = ctx->t_DIl; A.N = N; A.pm_len = TT.pm_len;
+            TEArgs E{};
+            E.runs = ctx->tl1.d_runs; E.edge_base = TT.edge_base; E.N = N; E.tab = ctx->d_tvtab; E.EJ = out + 5 * nn; E.ED = out + 2 * nn; E.EDT = out + 3 * nn; E.sE = 0;
+            if (D.n_tasks > 0) {
+                hipEvent_t ev_after = nullptr;
+                if (ctx->prof_jk) {
+                    if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+                        hipEvent_t a, b;
+                        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { ctx->prof_ev.push_back(a); ctx->prof_ev.push_back(b); }
+                    }
+                    if (ctx->prof_used + 2 <= ctx->prof_ev.size()) {
+                        (void)hipEventRecord(ctx->prof_ev[ctx->prof_used], st);
+                        ev_after = ctx->prof_ev[ctx->prof_used + 1];
+                        ctx->prof_used += 2;
+                    }
+                }
+                static const bool serial = getenv("TF_JK_SERIAL") != nullptr;
+                static const int one_launch_below = getenv("TF_JK_ONE_LAUNCH") ? atoi(getenv("TF_JK_ONE_LAUNCH")) : 3000;
+                int n_launch = 0;
+                for (int b = 0; b < TT_W; ++b) n_launch += D.bucket[b + 1] > D.bucket[b] ? 1 : 0;
+                const bool one_launch = n_launch > 1 && D.n_tasks < one_launch_below;
+                const bool fork = !serial && ctx->have_streams;
+                if (fork) (void)hipEventRecord(ctx->sev[0], st);
+                int side = 0;
+                bool first = true;
+                auto launch_tiles = [&](int t0, int nt, int nwv, hipStream_t ls) {
+                    if (D.ksub == 16) hipLaunchKernelGGL((jk_tile_kernel<1, 1>), dim3((unsigned)nt), dim3(64 * nwv), 0, ls, ctx->d_eri, D.d_tasks + t0, ctx->t_X, ctx->t_Pm, A);
+                    else if (D.ksub == 32) hipLaunchKernelGGL((jk_tile_kernel<1, 2>), dim3((unsigned)nt), dim3(64 * nwv), 0, ls, ctx->d_eri, D.d_tasks + t0, ctx->t_X, ctx->t_Pm, A);
+                    else hipLaunchKernelGGL((jk_tile_kernel<1, 4>), dim3((unsigned)nt), dim3(64 * nwv), 0, ls, ctx->d_eri, D.d_tasks + t0, ctx->t_X, ctx->t_Pm, A);
+                };
+                if (one_launch) launch_tiles(0, D.n_tasks, TT_W, st);
+                for (int b = 0; b < TT_W && !one_launch; ++b) {
+                    const int t0 = D.bucket[b], t1 = D.bucket[b + 1];
+                    if (t1 <= t0) continue;
+                    hipStream_t ls = st;
+                    if (fork && !first) { ++side; ls = ctx->streams[side]; (void)hipStreamWaitEvent(ls, ctx->sev[0], 0); }
+                    first = false;
+                    launch_tiles(t0, t1 - t0, TT_W - b, ls);
+                    if (ls != st) { (void)hipEventRecord(ctx->sev[side], ls); (void)hipStreamWaitEvent(st, ctx->sev[side], 0); }
+                }
+                if (ev_after) (void)hipEventRecord(ev_after, st);
+                // the edge elements beside the tile launches
+                {
+                    hipStream_t ls = st;
+                    if (fork) { ++side; ls = ctx->streams[side]; (void)hipStreamWaitEvent(ls, ctx->sev[0], 0); }
+                    hipLaunchKernelGGL((jk_edge_kernel<1>), dim3((unsigned)N), dim3(256), 0, ls, ctx->d_eri, ctx->t_X, ctx->bl.clsI, E);
+                    if (ls != st) { (void)hipEventRecord(ctx->sev[side], ls); (void)hipStreamWaitEvent(st, ctx->sev[side], 0); }
+                }
+            } else
+                hipLaunchKernelGGL((jk_edge_kernel<1>), dim3((unsigned)N), dim3(256), 0, st, ctx->d_eri, ctx->t_X, ctx->bl.clsI, E);
+            TRArgs R{};
+            R.tasks = D.d_tasks; R.pairs = D.d_pairs; R.runs = D.d_runs; R.itask_ptr = D.d_itask_ptr; R.itasks = D.d_itasks;
+            R.jlist_ptr = ctx->d_jlist_ptr; R.jlist = ctx->d_jlist; R.clsI = ctx->bl.clsI; R.origI = ctx->bl.origI; R.cntA = ctx->bl.cntA;
+            R.DJ = ctx->t_DJ; R.Jt = ctx->t_Jt; R.Jd = ctx->t_Jd; R.DIk = ctx->t_DIk; R.DIl = ctx->t_DIl; R.T = ctx->d_eri; R.X = ctx->t_X;
+            R.Dj = out; R.Di = out + nn; R.JD = out + 4 * nn; R.JtTot = ctx->t_JtTot;
+            R.edge_base = TT.edge_base; R.N = N; R.ksub = D.ksub; R.npair = TT.npair; R.nd = 1; R.pm_len = TT.pm_len; R.tab = ctx->d_tvtab;
+            R.jt_rows = jt_rows; R.xtiles = xtiles;
+            const unsigned nblk = (unsigned)(N * xtiles + jt_rows * xtiles + N);
+            hipLaunchKernelGGL(jk_tile_reduce_kernel, dim3(nblk), dim3(TT_RED_THREADS), 0, st, R);
+            if (general && pass == 0) continue;
+            const double *o0 = ctx->t_out, *o1 = out;                        // D of the first pass, D2 of the last
+            TFArgs F{};
+            F.Dj = o0; F.Di = o0 + nn; F.ED = o0 + 2 * nn; F.EDT = o0 + 3 * nn;
+            F.Dj2 = o1; F.Di2 = o1 + nn; F.ED2 = o1 + 2 * nn; F.EDT2 = o1 + 3 * nn;
+            F.JD = o1 + 4 * nn; F.EJ = o1 + 5 * nn; F.JtTot = ctx->t_JtTot; F.tab = ctx->d_tvtab;
+            hipLaunchKernelGGL(jk_tile_final_kernel, gN, b256, 0, st, F, ctx->bl, dJ[d], dK[d]);
+        }
+    }
+    return TF_OK;
+}
+
 static int launch_jk(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st,
                      const int *nonsym = nullptr)
 {
+    if (ctx->layout == 2) return launch_jk_tiles(ctx, nd, dP, dJ, dK, st, nonsym);
     if (ctx->layout == 1) return launch_jk_packed(ctx, nd, dP, dJ, dK, st, nonsym);
     const int N = ctx->N, ld = ctx->ld;
     const double *Ppad[2] = {dP[0], nd > 1 ? dP[1] : dP[0]};
@@ -2894,7 +3100,7 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     if (rc) { ctx->err = msg; return rc; }
     if (ctx->world > 1 && !ctx->allreduce)
         TF_FAIL(ctx, TF_EINVAL, "AO->MO transformation of a sharded tensor (world > 1) needs the all-reduce hook (tf_set_allreduce)");
-    const bool packed = ctx->layout == 1;
+    const bool packed = ctx->layout >= 1, tiles = ctx->layout == 2;
     double *dC[4] = {nullptr, nullptr, nullptr, nullptr}, *dG[2] = {nullptr, nullptr};
     const double *hC[4] = {C1, C2, C3, C4};
     const int nk[4] = {n1, n2, n3, n4};
@@ -2915,7 +3121,7 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     // the short index first: a ket coefficient matrix of at most 32 columns (the occupied orbitals of (ia|jb)) goes through the hand-written
     // first quarter on the packed segments (tfmp2::mo_q1_kernel); TF_MO_Q1=0 keeps the expanded-block path (A/B, tests)
     const char *q1env = getenv("TF_MO_Q1");
-    const bool q1_allowed = packed && !(q1env && q1env[0] == '0');
+    const bool q1_allowed = packed && !tiles && !(q1env && q1env[0] == '0');
     auto run = [&](int a, int b, int c, int d, double *dst) {
         double s1 = 0.0;
         if (q1_allowed && nk[c] <= 32 && nk[a] <= 32 && (size_t)N * ((nk[a] + 1) & ~1) * sizeof(double) + (size_t)N * sizeof(int) <= ((size_t)150 << 10)) {
@@ -2942,8 +3148,9 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
             for (int q = 0; q < 5; ++q) pr.class_row_off[q] = ctx->class_row_off[q];
             pr.d_class_rows = ctx->d_class_rows; pr.d_row_pos = ctx->d_row_pos;
         }
-        int r = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, packed ? ctx->d_rowoff : nullptr, ctx->d_rowsec, ctx->bl, pr,
-                                 ctx->d_row_ij, ctx->n_rows, N, ctx->ld, dC[a], nk[a], dC[b], nk[b], dC[c], nk[c], dC[d], nk[d], dst, &s1, msg);
+        int r = tfmp2::transform(ctx->scf.blas, ctx->d_eri, ctx->d_rowmap, (packed && !tiles) ? ctx->d_rowoff : nullptr, ctx->d_rowsec, ctx->bl, pr,
+                                 ctx->d_row_ij, ctx->n_rows, N, ctx->ld, dC[a], nk[a], dC[b], nk[b], dC[c], nk[c], dC[d], nk[d], dst, &s1, msg,
+                                 tiles ? &ctx->tv : nullptr);
         secs += s1;
         return r;
     };

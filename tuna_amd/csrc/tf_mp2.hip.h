@@ -390,13 +390,13 @@ struct PackedRows {
 // result is linear in the rows a rank owns: the sum over ranks is the transformed tensor.
 inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowmap, const long long *d_rowoff, const int *d_rowsec,
                      const BLayout &BL, const PackedRows &PR, const int2 *d_row_ij, long long n_rows, int N, int ld, const double *dC1, int n1, const double *dC2, int n2, const double *dC3, int n3,
-                     const double *dC4, int n4, double *d_out, double *gemm_seconds, std::string &msg)
+                     const double *dC4, int n4, double *d_out, double *gemm_seconds, std::string &msg, const TView *tiles = nullptr)
 {
     int rc = TF_OK;
     const long long n34 = (long long)n3 * n4;
     const long long row_len = (long long)N * ld;
     double *dR = nullptr, *dQ = nullptr, *dQfull = nullptr, *dW = nullptr, *dM = nullptr, *dC3i = nullptr, *dC4i = nullptr;
-    const bool packed = d_rowoff != nullptr;
+    const bool packed = d_rowoff != nullptr || tiles != nullptr;      // rows that hold the pairs (kl) <= (ij) only
     const double one = 1.0, zero = 0.0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     RowBlocks RBc[4];
@@ -446,8 +446,12 @@ inline int transform(rocblas_handle blas, const double *d_eri, const int *d_rowm
                 const long long q0 = PR.class_row_off[c] + t0;
                 TFM_HIP(hipMemsetAsync(dM, 0, (size_t)nb * RB.rstride * sizeof(double), 0));
                 TFM_HIP(hipMemsetAsync(dR, 0, (size_t)nb * n3 * N * sizeof(double), 0));      // (a class without members leaves its columns untouched)
-                hipLaunchKernelGGL(unpack_own_rows_blocked_kernel, dim3((unsigned)((PR.NP[c] + 255) / 256), (unsigned)nb), dim3(256), 0, 0, d_eri,
-                                   d_rowoff, d_rowsec, BL, d_row_ij, PR.d_class_rows + q0, c, RB, dM);
+                if (tiles)
+                    hipLaunchKernelGGL(unpack_own_rows_blocked_tiles_kernel, dim3((unsigned)((PR.NP[c] + 255) / 256), (unsigned)nb), dim3(256), 0, 0, d_eri,
+                                       *tiles, BL, d_row_ij, PR.d_class_rows + q0, c, RB, dM);
+                else
+                    hipLaunchKernelGGL(unpack_own_rows_blocked_kernel, dim3((unsigned)((PR.NP[c] + 255) / 256), (unsigned)nb), dim3(256), 0, 0, d_eri,
+                                       d_rowoff, d_rowsec, BL, d_row_ij, PR.d_class_rows + q0, c, RB, dM);
                 for (int b = 0; b < 4; ++b) {
                     const int a = b ^ c;
                     if (PR.csize[b] == 0 || PR.csize[a] == 0) continue;

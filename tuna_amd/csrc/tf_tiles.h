@@ -125,6 +125,10 @@ struct TTask {                   // one workgroup of jk_tile_kernel
     int di_base, jd_base;        // per-task outputs: DIk[(di_base + w) 64 ..], DIl[(di_base + w) 16 ..]; Jd[jd_base + w nj + s]
     int self_last;               // 1: the last step is j == i (its D[j][.] terms are dropped)
     int pid;                     // class pair id
+    int kbase, lbase;            // internal index of the first AO of class a / class b
+    int ncol;                    // AOs of class b (columns beyond read as zero)
+    int pm_off, pm_pitch;        // the pair's block of the pair matrices (packed density, Jt totals): [k loc][pitch]
+    int pad_;
 };
 
 struct TPairI {                  // (i, class pair): where the stored elements and the partial sums live
@@ -144,3 +148,43 @@ struct TRunI {                   // (i, class of j): the owned rows (i, j0 .. j0
     long long dj_base;           // DJ vectors of the run
     long long e_base;            // edge elements E[i][j][l], l <= j: e_base + T(loc j) - T(loc j0) + loc l, T(n) = n (n + 1) / 2
 };
+
+// view of the tables of tf_tiles_host.h (device pointers in the kernels; host pointers in the CPU test library)
+struct TView {
+    const TTask *regions;         // tasks_by_region of the primary list
+    const TPairI *prim_pairs;     // [N][10] of the primary list (regions of a pair)
+    const TRunI *prim_runs;       // [N][4]
+    long long edge_base;
+    int N, pm_len;
+    const int *tab;               // the small tables below (device memory: kernels index them with run-time class numbers, and a
+                                  // dynamically indexed kernel argument would be copied to scratch memory)
+};
+// tab: pair id of two classes [4][4]; row / column class of a pair; internal range of a class; the pairs' blocks of the pair matrices
+// (packed densities, Jt totals): block of pair p = [k loc][pitch]
+enum { TVT_PID = 0, TVT_PA = 16, TVT_PB = 26, TVT_CSTART = 36, TVT_CSIZE = 40, TVT_PMOFF = 44, TVT_PMPITCH = 54, TVT_LEN = 64 };
+
+// Address of the canonical element (ij|kl) -- internal indices; i >= j, k >= l, (kl) <= (ij) in ORIGINAL order -- or -1 (row not owned).
+TT_HD long long tt_elem_addr(const TView &V, const int *clsI, int iI, int jI, int kI, int lI)
+{
+    const int cj = clsI[jI], ck = clsI[kI], cl = clsI[lI];
+    const TRunI R = V.prim_runs[(size_t)iI * 4 + cj];
+    if (jI < R.j0 || jI >= R.j0 + R.nj) return -1;
+    if (kI == iI) {                                                       // edge: l <= j, of j's class
+        const long long lj = jI - V.tab[TVT_CSTART + cj], l0 = R.j0 - V.tab[TVT_CSTART + cj];
+        return V.edge_base + R.e_base + lj * (lj + 1) / 2 - l0 * (l0 + 1) / 2 + (lI - V.tab[TVT_CSTART + cl]);
+    }
+    const int p = V.tab[TVT_PID + ck * 4 + cl], a = V.tab[TVT_PA + p], b = V.tab[TVT_PB + p];
+    const bool tri = a == b;
+    int kr = kI - V.tab[TVT_CSTART + ck], lc = lI - V.tab[TVT_CSTART + cl];
+    if (!tri && ck != a) { const int t = kr; kr = lc; lc = t; }
+    const TPairI P = V.prim_pairs[(size_t)iI * 10 + p];
+    if (P.first_task < 0) return -1;
+    const int sj = jI - R.j0, part = sj / P.pj, s = sj - part * P.pj;
+    const int ks = kr / TT_KS, lb = lc / TT_LB;
+    int nch, w;
+    tt_chunks(tt_nlb(tri, ks, P.nk, P.nl), &nch, &w);
+    const int ch = lb / w, wv = lb - ch * w;
+    const int before = tri ? ks * (ks + 1) / 2 : ks * nch;                 // chunks of the (full) strips in front
+    const TTask *Rg = V.regions + (size_t)P.first_task + (size_t)part * P.tasks_per_part + before + ch;
+    return Rg->base + (long long)s * Rg->slice + Rg->woff[wv] + tt_row_off(tri, ks, lb, kr - TT_KS * ks, P.nl) + (lc - TT_LB * lb);
+}

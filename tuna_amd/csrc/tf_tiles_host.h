@@ -39,6 +39,7 @@ struct Tables {
     long long n_elems = 0;            // doubles of the stored tensor (interior regions, then the edge elements)
     long long edge_base = 0;
     long long max_slice = 0;
+    int pm_off[10], pm_pitch[10], pm_len = 0;   // pair matrices: block of pair p = [csize[a]][pad2(csize[b])]
     TaskList primary;                 // ksub = 64: its tasks are also the REGIONS of the stored tensor (TPairI::first_task)
     std::vector<int> jlist_ptr, jlist;    // per second index j (internal): the first indices i != j of the owned rows (i, j), ascending
 };
@@ -54,6 +55,12 @@ inline void class_pairs(const ClassInfo &C, Tables &T)
             T.pa[T.npair] = a; T.pb[T.npair] = b;
             T.pid[a][b] = T.pid[b][a] = T.npair++;
         }
+    T.pm_len = 0;
+    for (int p = 0; p < 10; ++p) { T.pm_off[p] = 0; T.pm_pitch[p] = 0; }
+    for (int p = 0; p < T.npair; ++p) {
+        T.pm_off[p] = T.pm_len; T.pm_pitch[p] = tt_pad2(C.csize[T.pb[p]]);
+        T.pm_len += C.csize[T.pa[p]] * T.pm_pitch[p];
+    }
 }
 
 // Task list of strip height ksub over the regions of `T.primary` (ksub == 64: builds the regions themselves).
@@ -174,6 +181,7 @@ inline std::string build_list(const ClassInfo &C, Tables &T, const std::vector<s
                             for (int u = 0; u < TT_W; ++u) t.woff[u] = woff[u];
                             t.i = iI; t.j0 = R.j0 + s0; t.nj = ns; t.a = a; t.b = b; t.k0 = k0; t.nks = nks; t.roff0 = r0;
                             t.lb0 = lb0; t.nw = nw; t.nk = nk; t.nl = nl; t.pid = p;
+                            t.kbase = C.cstart[a]; t.lbase = C.cstart[b]; t.ncol = C.csize[b]; t.pm_off = T.pm_off[p]; t.pm_pitch = T.pm_pitch[p];
                             t.jt_base = P.jt_base + (long long)part * P.jt_part_stride; t.jt_pitch = P.jt_pitch;
                             t.dj_len = R.dj_len; t.dj_base = R.dj_base + (long long)s0 * R.dj_len;
                             t.dj_koff = P.dj_k + tt_dj_koff(tri, ks, nl) + ch * nks_st + r0;

@@ -93,7 +93,7 @@ class Engine:
         return S
 
     # ---- two-electron ------------------------------------------------------------------------
-    LAYOUTS = {"auto": -1, "rows": 0, "packed": 1}
+    LAYOUTS = {"auto": -1, "rows": 0, "packed": 1, "tiles": 2}
 
     def build_eri(self, spherical: bool = True, layout: str | None = None):
         """layout: "packed" (8-fold unique values, the default where the J/K kernel covers N), "rows" ((i >= j) x full [k][l])
@@ -110,7 +110,7 @@ class Engine:
         n, ld = C.c_int32(), C.c_int32()
         self._check(self._L.tf_eri_storage(self._ctx, b, r, n, ld))
         return {"bytes": b.value, "rows": r.value, "N": n.value, "ld": ld.value,
-                "layout": "packed" if self._L.tf_eri_layout(self._ctx) == 1 else "rows"}
+                "layout": {2: "tiles", 1: "packed"}.get(self._L.tf_eri_layout(self._ctx), "rows")}
 
     def eri_timings(self) -> dict:
         t = np.zeros(4)
