@@ -126,6 +126,7 @@ class Tables:
     # shape functions of tf_tiles.h
     def row_len(self, tri, ks, lb, r, nl): return lib().ttm_row_len(int(tri), ks, lb, r, nl)
     def row_off(self, tri, ks, lb, r, nl): return lib().ttm_row_off(int(tri), ks, lb, r, nl)
+    def elem_off(self, tri, ks, lb, r, c, nks, nl): return lib().ttm_elem_off(int(tri), ks, lb, r, c, nks, nl)
     def dj_koff(self, tri, ks, nl): return lib().ttm_dj_koff(int(tri), ks, nl)
     def dj_loff(self, tri, lb, nk): return lib().ttm_dj_loff(int(tri), lb, nk, self.ksub)
     def dj_first_sub(self, tri, lb): return lib().ttm_dj_first_sub(int(tri), lb, self.ksub)
@@ -158,13 +159,14 @@ def pack_tensor(T: Tables, E):
                 for r in range(t.nks):
                     ko = o[T.cstart[t.a] + t.k0 + r]
                     n = T.row_len(tri, ks, lb, r, t.nl)
-                    off = t.base + s * t.slice + t.woff[w] + T.row_off(tri, ks, lb, r, t.nl)
                     for u in range(n):
                         ll = 16 * lb + u
-                        assert not written[off + u]
-                        written[off + u] = True
+                        off = t.base + s * t.slice + t.woff[w] + T.elem_off(tri, ks, lb, r, u, t.nks, t.nl)
+                        assert t.woff[w] <= off - t.base - s * t.slice < (t.woff[w + 1] if w + 1 < t.nw else t.slice)
+                        assert not written[off]
+                        written[off] = True
                         if ll < (t.k0 + r + 1 if tri else t.nl):
-                            buf[off + u] = E[io, jo, ko, o[T.cstart[t.b] + ll]]
+                            buf[off] = E[io, jo, ko, o[T.cstart[t.b] + ll]]
     for iI in range(T.N):
         for cj in range(4):
             R = T.runs[iI * 4 + cj]
@@ -227,10 +229,11 @@ def fock(T: Tables, buf, P):
                 lval = (16 * lb + np.arange(16)) < T.csize[t.b]
                 lIc = np.where(lval, lI, 0)
                 m = np.zeros((t.nks, 16))
+                nst = min(64, t.nk - 64 * ks)
                 for r in range(t.nks):
                     n = T.row_len(tri, ks, lb, t.roff0 + r, t.nl)
-                    off = t.base + s * t.slice + t.woff[w] + T.row_off(tri, ks, lb, t.roff0 + r, t.nl)
-                    m[r, :n] = buf[off:off + n]
+                    for u in range(n):
+                        m[r, u] = buf[t.base + s * t.slice + t.woff[w] + T.elem_off(tri, ks, lb, t.roff0 + r, u, nst, t.nl)]
                 assert not m[:, ~lval].any()
                 mo = np.where(kI[:, None] == lI[None, :], 0.0, m)         # without the diagonal k == l
                 Jdp[t.jd_base + w * t.nj + s] = (m * Ppair[np.ix_(kI, lIc)]).sum()

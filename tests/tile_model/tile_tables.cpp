@@ -92,6 +92,7 @@ void ttm_copy(void *p, int which, int what, void *out)
 // the shape functions of tf_tiles.h, for the model
 int ttm_row_len(int tri, int ks, int lb, int r, int nl) { return tt_row_len(tri != 0, ks, lb, r, nl); }
 int ttm_row_off(int tri, int ks, int lb, int r, int nl) { return tt_row_off(tri != 0, ks, lb, r, nl); }
+int ttm_elem_off(int tri, int ks, int lb, int r, int c, int nks, int nl) { return tt_elem_off(tri != 0, ks, lb, r, c, nks, nl); }
 int ttm_dj_koff(int tri, int ks, int nl) { return tt_dj_koff(tri != 0, ks, nl); }
 int ttm_dj_loff(int tri, int lb, int nk, int ksub) { return tt_dj_loff(tri != 0, lb, nk, ksub); }
 int ttm_dj_first_sub(int tri, int lb, int ksub) { return tt_dj_first_sub(tri != 0, lb, ksub); }

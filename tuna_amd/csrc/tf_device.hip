@@ -190,6 +190,7 @@ struct tf_ctx {
     double *t_out = nullptr;             // [2 passes][Dj, Di, ED, EDT, JD, EJ][N][N]
     double *t_JtTot = nullptr;
     std::vector<void *> tile_allocs;
+    size_t tile_lds_set = 48 * 1024;     // dynamic LDS limit requested for the tiles layout's edge / reduce kernels
     // instrumentation
     bool prof_jk = false;
     std::vector<hipEvent_t> prof_ev;     // pairs (before, after) around the row kernel, on the launch stream
@@ -927,7 +928,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         C.clsI = H.clsI; C.origI = H.origI; C.cntA = H.cntA;
         std::vector<std::pair<int, int>> rows_ij(row_ij.size());
         for (size_t r = 0; r < row_ij.size(); ++r) rows_ij[r] = {H.sigma[row_ij[r].x], H.sigma[row_ij[r].y]};
-        static const int part_steps = getenv("TF_TILE_PART_STEPS") ? std::max(1, atoi(getenv("TF_TILE_PART_STEPS"))) : 48;
+        static const int part_steps = std::min(TT_STEPS_MAX, getenv("TF_TILE_PART_STEPS") ? std::max(1, atoi(getenv("TF_TILE_PART_STEPS"))) : TT_STEPS_MAX);
         std::string e = tft::build(C, rows_ij, part_steps, ctx->tiles);
         if (!e.empty()) TF_FAIL(ctx, TF_EINVAL, "%s", e.c_str());
         static const int ksub_env = getenv("TF_TILE_KSUB") ? atoi(getenv("TF_TILE_KSUB")) : TT_KS;
@@ -2619,18 +2620,24 @@ static int launch_jk_tiles(tf_ctx *ctx, int nd, const double *const *dP, double 
     const tf_ctx::TileList &D = ctx->tl1;
     const tft::Tables &TT = ctx->tiles;
     const dim3 gN((unsigned)((nn + 255) / 256)), b256(256);
-    int xtiles = 0, jt_rows = 0;
-    for (int c = 0; c < 4; ++c) xtiles += (ctx->hl.csize[c] + 63) / 64;
+    int jt_rows = 0;
     for (int p = 0; p < TT.npair; ++p) jt_rows += ctx->hl.csize[TT.pa[p]];
     for (int d = 0; d < nd; ++d) {
         const bool general = nonsym && nonsym[d];
         for (int pass = 0; pass < (general ? 2 : 1); ++pass) {
             double *out = ctx->t_out + (size_t)pass * 6 * nn;              // Dj, Di, ED, EDT, JD, EJ of this pass
             hipLaunchKernelGGL(pack_density_tiles_kernel, gN, b256, 0, st, dP[d], ctx->bl, ctx->tv, (general && pass == 0) ? 1 : 0, ctx->t_X, ctx->t_Pm);
+            const size_t edge_lds = (size_t)(2 + 3 * TT_EDGE_WAVES) * N * sizeof(double), red_lds = std::max((size_t)2 * TT_RED_WAVES * N, (size_t)TT_RED_WAVES * 64 * TT_RED_CT) * sizeof(double);
+            if (std::max(edge_lds, red_lds) > ctx->tile_lds_set) {                                // (beyond the default 64 KB per workgroup: N > 580)
+                if (std::max(edge_lds, red_lds) > (size_t)160 * 1024 - 1024) TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the LDS rows of the tiles layout's reductions", N);
+                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_edge_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(edge_lds, red_lds)));
+                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_tile_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(edge_lds, red_lds)));
+                ctx->tile_lds_set = std::max(edge_lds, red_lds);
+            }
             TJArgs A{};
             A.DJ = ctx->t_DJ; A.Jt = ctx->t_Jt; A.Jd = ctx->t_Jd; A.DIk = ctx->t_DIk; A.DIl = ctx->t_DIl; A.N = N; A.pm_len = TT.pm_len;
             TEArgs E{};
-            E.runs = ctx->tl1.d_runs; E.edge_base = TT.edge_base; E.N = N; E.tab = ctx->d_tvtab; E.EJ = out + 5 * nn; E.ED = out + 2 * nn; E.EDT = out + 3 * nn; E.sE = 0;
+            E.edge_base = TT.edge_base; E.N = N; E.tab = ctx->d_tvtab; E.EJ = out + 5 * nn; E.ED = out + 2 * nn; E.EDT = out + 3 * nn; E.sE = 0;
             if (D.n_tasks > 0) {
                 hipEvent_t ev_after = nullptr;
                 if (ctx->prof_jk) {
@@ -2645,7 +2652,7 @@ static int launch_jk_tiles(tf_ctx *ctx, int nd, const double *const *dP, double 
                     }
                 }
                 static const bool serial = getenv("TF_JK_SERIAL") != nullptr;
-                static const int one_launch_below = getenv("TF_JK_ONE_LAUNCH") ? atoi(getenv("TF_JK_ONE_LAUNCH")) : 3000;
+                static const int one_launch_below = getenv("TF_JK_ONE_LAUNCH") ? atoi(getenv("TF_JK_ONE_LAUNCH")) : 1 << 30;   // (measured at N = 400: one launch of full-size workgroups 1.57 ms, four launches side by side 1.82 -- loads only)
                 int n_launch = 0;
                 for (int b = 0; b < TT_W; ++b) n_launch += D.bucket[b + 1] > D.bucket[b] ? 1 : 0;
                 const bool one_launch = n_launch > 1 && D.n_tasks < one_launch_below;
@@ -2653,10 +2660,13 @@ static int launch_jk_tiles(tf_ctx *ctx, int nd, const double *const *dP, double 
                 if (fork) (void)hipEventRecord(ctx->sev[0], st);
                 int side = 0;
                 bool first = true;
+                static const int pf_env = getenv("TF_TILE_PF") ? atoi(getenv("TF_TILE_PF")) : 2;
                 auto launch_tiles = [&](int t0, int nt, int nwv, hipStream_t ls) {
-                    if (D.ksub == 16) hipLaunchKernelGGL((jk_tile_kernel<1, 1>), dim3((unsigned)nt), dim3(64 * nwv), 0, ls, ctx->d_eri, D.d_tasks + t0, ctx->t_X, ctx->t_Pm, A);
-                    else if (D.ksub == 32) hipLaunchKernelGGL((jk_tile_kernel<1, 2>), dim3((unsigned)nt), dim3(64 * nwv), 0, ls, ctx->d_eri, D.d_tasks + t0, ctx->t_X, ctx->t_Pm, A);
-                    else hipLaunchKernelGGL((jk_tile_kernel<1, 4>), dim3((unsigned)nt), dim3(64 * nwv), 0, ls, ctx->d_eri, D.d_tasks + t0, ctx->t_X, ctx->t_Pm, A);
+#define TF_TJ_LAUNCH(MBV, PFV) hipLaunchKernelGGL((jk_tile_kernel<1, MBV, PFV>), dim3((unsigned)nt), dim3(64 * nwv), 0, ls, ctx->d_eri, D.d_tasks + t0, ctx->t_X, ctx->t_Pm, A)
+                    if (D.ksub == 16) { if (pf_env == 1) TF_TJ_LAUNCH(1, 1); else if (pf_env == 4) TF_TJ_LAUNCH(1, 4); else TF_TJ_LAUNCH(1, 2); }
+                    else if (D.ksub == 32) { if (pf_env == 1) TF_TJ_LAUNCH(2, 1); else TF_TJ_LAUNCH(2, 2); }
+                    else { if (pf_env == 1) TF_TJ_LAUNCH(4, 1); else TF_TJ_LAUNCH(4, 2); }
+#undef TF_TJ_LAUNCH
                 };
                 if (one_launch) launch_tiles(0, D.n_tasks, TT_W, st);
                 for (int b = 0; b < TT_W && !one_launch; ++b) {
@@ -2673,20 +2683,19 @@ static int launch_jk_tiles(tf_ctx *ctx, int nd, const double *const *dP, double 
                 {
                     hipStream_t ls = st;
                     if (fork) { ++side; ls = ctx->streams[side]; (void)hipStreamWaitEvent(ls, ctx->sev[0], 0); }
-                    hipLaunchKernelGGL((jk_edge_kernel<1>), dim3((unsigned)N), dim3(256), 0, ls, ctx->d_eri, ctx->t_X, ctx->bl.clsI, E);
+                    hipLaunchKernelGGL((jk_edge_kernel<1>), dim3((unsigned)N), dim3(64 * TT_EDGE_WAVES), edge_lds, ls, ctx->d_eri, ctx->t_X, ctx->tl1.d_runs, E);
                     if (ls != st) { (void)hipEventRecord(ctx->sev[side], ls); (void)hipStreamWaitEvent(st, ctx->sev[side], 0); }
                 }
             } else
-                hipLaunchKernelGGL((jk_edge_kernel<1>), dim3((unsigned)N), dim3(256), 0, st, ctx->d_eri, ctx->t_X, ctx->bl.clsI, E);
+                hipLaunchKernelGGL((jk_edge_kernel<1>), dim3((unsigned)N), dim3(64 * TT_EDGE_WAVES), edge_lds, st, ctx->d_eri, ctx->t_X, ctx->tl1.d_runs, E);
             TRArgs R{};
-            R.tasks = D.d_tasks; R.pairs = D.d_pairs; R.runs = D.d_runs; R.itask_ptr = D.d_itask_ptr; R.itasks = D.d_itasks;
-            R.jlist_ptr = ctx->d_jlist_ptr; R.jlist = ctx->d_jlist; R.clsI = ctx->bl.clsI; R.origI = ctx->bl.origI; R.cntA = ctx->bl.cntA;
+            R.itask_ptr = D.d_itask_ptr; R.itasks = D.d_itasks; R.jlist_ptr = ctx->d_jlist_ptr; R.clsI = ctx->bl.clsI;
             R.DJ = ctx->t_DJ; R.Jt = ctx->t_Jt; R.Jd = ctx->t_Jd; R.DIk = ctx->t_DIk; R.DIl = ctx->t_DIl; R.T = ctx->d_eri; R.X = ctx->t_X;
             R.Dj = out; R.Di = out + nn; R.JD = out + 4 * nn; R.JtTot = ctx->t_JtTot;
             R.edge_base = TT.edge_base; R.N = N; R.ksub = D.ksub; R.npair = TT.npair; R.nd = 1; R.pm_len = TT.pm_len; R.tab = ctx->d_tvtab;
-            R.jt_rows = jt_rows; R.xtiles = xtiles;
-            const unsigned nblk = (unsigned)(N * xtiles + jt_rows * xtiles + N);
-            hipLaunchKernelGGL(jk_tile_reduce_kernel, dim3(nblk), dim3(TT_RED_THREADS), 0, st, R);
+            R.jt_rows = jt_rows;
+            const unsigned nblk = (unsigned)(5 * N + jt_rows);
+            hipLaunchKernelGGL(jk_tile_reduce_kernel, dim3(nblk), dim3(TT_RED_THREADS), red_lds, st, D.d_tasks, D.d_pairs, D.d_runs, ctx->d_jlist, R);
             if (general && pass == 0) continue;
             const double *o0 = ctx->t_out, *o1 = out;                        // D of the first pass, D2 of the last
             TFArgs F{};

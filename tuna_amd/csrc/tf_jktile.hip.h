@@ -199,23 +199,39 @@ __device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, dou
 // LDS of a workgroup: the row-sum slots of TT_KB steps, the Jd weights of every wave's tile, and the density rows of the next TT_KB steps
 // (P_d[j][k] of the strip, P_d[j][l] of the chunk, P_d[i][j], P_d[j][i]: staged by all waves together -- vector memory operations
 // complete in order, so nothing a step needs may be loaded at the step itself: it would wait for the prefetched slice).
-#define TT_PST (TT_KS + TT_LB + 4)                // doubles of one staged row of a wave: 64 k + 16 l + {P[i][j], P[j][i]} (+ pad)
+#ifndef TT_STEPS_MAX
+#define TT_STEPS_MAX 48
+#endif
+#define TT_STEPS_MAX_DOC                          // steps of a task at most (tf_tiles_host.h: part_steps): its density rows are staged in LDS once
 template <int ND, int MB>
 struct TJLds {
     double slots[TT_KB * TT_W * ND * 64];
     double2 pp[TT_W][ND][MB * 2][64];
-    double pst[TT_W][ND][TT_KB][TT_PST];         // every wave stages its own rows: no barrier between the staging and its use
+    double jdl[TT_W][ND][TT_KB][64];             // Jd: the lanes' partial sums of a block's steps (summed over the wave four steps at a time)
+    // the density rows of ALL steps of the task, staged by the whole workgroup in the prologue (nothing is loaded for them inside the loop:
+    // a wait for such a load would drain the prefetched slices): P_d[j][k] of the task's rows, P_d[j][l] of its column blocks, Pp_d[ij]
+    double pk[ND][TT_STEPS_MAX][16 * MB];
+    double pl[ND][TT_STEPS_MAX][TT_W * TT_LB];
+    double pij[ND][TT_STEPS_MAX];
 };
 
-template <int ND, int MB, bool DIAG>
+#define TJ_U(x) __builtin_amdgcn_readfirstlane(x)      // wave-uniform: keep it in a scalar register for the whole task
+template <int ND, int MB, int PF, bool DIAG>
 __device__ __forceinline__ void tj_run(const double *__restrict__ T, const double *__restrict__ X, const double *__restrict__ Pm, const TJArgs &A,
-                                       const TTask &t, int w, int lane, bool active, TJLds<ND, MB> &S)
+                                       const TTask *__restrict__ tp, int w, int lane, bool active, TJLds<ND, MB> &S)
 {
     const int N = A.N;
     const int m = lane & 15, kk = lane >> 4;
-    const bool tri = t.a == t.b;
-    const int lb = t.lb0 + w, ks = t.k0 / TT_KS;
-    const int iI = t.i, nj = t.nj, nwg = (int)(blockDim.x >> 6);
+    // the task record, once, into scalar registers (a field read inside the loop is a scalar load and a wait per step)
+    const int ta = TJ_U(tp->a), tb = TJ_U(tp->b), k0 = TJ_U(tp->k0), nks = TJ_U(tp->nks), roff0 = TJ_U(tp->roff0), lb0 = TJ_U(tp->lb0), tnw = TJ_U(tp->nw);
+    const int tnl = TJ_U(tp->nl), slice = TJ_U(tp->slice), woffw = TJ_U(tp->woff[w]), jt_pitch = TJ_U(tp->jt_pitch), dj_len = TJ_U(tp->dj_len);
+    const int dj_koff = TJ_U(tp->dj_koff), dj_loffw = TJ_U(tp->dj_loff[w]), di_base = TJ_U(tp->di_base), jd_base = TJ_U(tp->jd_base);
+    const int self_last = TJ_U(tp->self_last), kbase = TJ_U(tp->kbase), lbase = TJ_U(tp->lbase), ncol = TJ_U(tp->ncol), pm_off = TJ_U(tp->pm_off);
+    const int pm_pitch = TJ_U(tp->pm_pitch), iI = TJ_U(tp->i), j0 = TJ_U(tp->j0), nj = TJ_U(tp->nj);
+    const long long tbase = tp->base, jt_base = tp->jt_base, dj_base = tp->dj_base;
+    const bool tri = ta == tb;
+    const int lb = lb0 + w, ks = k0 / TT_KS;
+    const int nwg = (int)(blockDim.x >> 6);
     const size_t nn = (size_t)N * N;
     // ---- per-lane constants
     unsigned offA[MB], offB[MB];
@@ -225,43 +241,47 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const int r = 16 * mb + m;
-        rv[mb] = active && r < t.nks;
-        const int rs = t.roff0 + r;
-        const int rl = rv[mb] ? tt_row_len(tri, ks, lb, rs, t.nl) : 0;
-        const unsigned o = 8u * (unsigned)(t.woff[w] + tt_row_off(tri, ks, lb, rs, t.nl) + 4 * kk);
-        offA[mb] = (4 * kk < rl) ? o : TF_BUF_OOB;
-        offB[mb] = (4 * kk + 2 < rl) ? o + 16u : TF_BUF_OOB;
-        const int kI = t.kbase + t.k0 + r;
-        rdiag[mb] = (t.k0 + r) - (TT_LB * lb + 4 * kk);                  // the register of this lane that holds k == l (triangles)
+        rv[mb] = active && r < nks;
+        const int rs = roff0 + r;
+        const int rl = rv[mb] ? tt_row_len(tri, ks, lb, rs, tnl) : 0;
+        const int nst = tt_min(TT_KS, TJ_U(tp->nk) - TT_KS * ks);          // rows of the STORED strip (the chunk order inside a block of 16 rows depends on it)
+        offA[mb] = (4 * kk < rl) ? 8u * (unsigned)(woffw + tt_elem_off(tri, ks, lb, rs, 4 * kk, nst, tnl)) : TF_BUF_OOB;
+        offB[mb] = (4 * kk + 2 < rl) ? 8u * (unsigned)(woffw + tt_elem_off(tri, ks, lb, rs, 4 * kk + 2, nst, tnl)) : TF_BUF_OOB;
+        const int kI = kbase + k0 + r;
+        rdiag[mb] = (k0 + r) - (TT_LB * lb + 4 * kk);                    // the register of this lane that holds k == l (triangles)
 #pragma unroll
         for (int d = 0; d < ND; ++d) pik[d][mb] = rv[mb] ? X[d * nn + (size_t)iI * N + kI] : 0.0;
     }
     const int lcol0 = TT_LB * lb + 4 * kk;                                 // loc of the lane's first column
-    const int ncol = t.ncol;
-    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(T + t.base), 0, (int)min((long long)nj * t.slice * 8, 0x7fffffffLL), 0x00020000);
+    // buffer descriptors: the task's region of the tensor; its DJ vectors (row of step s at s * dj_len); this wave's Jd values
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(T + tbase), 0, (int)min((long long)nj * slice * 8, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdj = __builtin_amdgcn_make_buffer_rsrc(A.DJ + dj_base, 0, (int)min((long long)nj * dj_len * 8, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rjd = __builtin_amdgcn_make_buffer_rsrc(A.Jd + jd_base + (size_t)w * nj, 0, nj * 8, 0x00020000);
+    const unsigned st_l = ((m & 3) == 0) ? 8u * (unsigned)(dj_loffw + 4 * kk + (m >> 2)) : TF_BUF_OOB;        // column sums: lanes m = 0, 4, 8, 12 of every row
+    const int krel = 16 * (lane >> 4) + ((lane >> 2) & 3) + 4 * (lane & 3);
+    const unsigned st_k = (krel < nks && (lane >> 4) < MB) ? 8u * (unsigned)(dj_koff + krel) : TF_BUF_OOB;       // merged row sums: one lane per row
+    const unsigned st_jd = ((lane & 15) == 0) ? 8u * (unsigned)(lane >> 4) : TF_BUF_OOB;
     // B operand of the row sums: column d = P_d[i][l] (lanes m == d), zero elsewhere
     double b1[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b1[r] = (active && m < ND && lcol0 + r < ncol) ? X[(size_t)(m < ND ? m : 0) * nn + (size_t)iI * N + t.lbase + lcol0 + r] : 0.0;
+    for (int r = 0; r < 4; ++r) b1[r] = (active && m < ND && lcol0 + r < ncol) ? X[(size_t)(m < ND ? m : 0) * nn + (size_t)iI * N + lbase + lcol0 + r] : 0.0;
     // weights of Jd: Pp_d(k, l) of the lane's elements, kept in LDS (pad columns of the pair matrices are zero)
     if (active) {
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const double *src = Pm + (size_t)d * A.pm_len + t.pm_off + (size_t)(t.k0 + 16 * mb + m) * t.pm_pitch + lcol0;
-                S.pp[w][d][2 * mb][lane] = (rv[mb] && lcol0 < t.pm_pitch) ? *reinterpret_cast<const double2 *>(src) : make_double2(0.0, 0.0);
-                S.pp[w][d][2 * mb + 1][lane] = (rv[mb] && lcol0 + 2 < t.pm_pitch) ? *reinterpret_cast<const double2 *>(src + 2) : make_double2(0.0, 0.0);
+                const double *src = Pm + (size_t)d * A.pm_len + pm_off + (size_t)(k0 + 16 * mb + m) * pm_pitch + lcol0;
+                S.pp[w][d][2 * mb][lane] = (rv[mb] && lcol0 < pm_pitch) ? *reinterpret_cast<const double2 *>(src) : make_double2(0.0, 0.0);
+                S.pp[w][d][2 * mb + 1][lane] = (rv[mb] && lcol0 + 2 < pm_pitch) ? *reinterpret_cast<const double2 *>(src + 2) : make_double2(0.0, 0.0);
             }
     }
     // accumulators
-    double jt[ND][MB][4], x5[ND][4], x2[ND][MB], jdb[ND][TT_KB];
+    double jt[ND][MB][4], x5[ND][4], x2[ND][MB];
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) x5[d][r] = 0.0;
-#pragma unroll
-        for (int q = 0; q < TT_KB; ++q) jdb[d][q] = 0.0;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             x2[d][mb] = 0.0;
@@ -269,73 +289,85 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
             for (int r = 0; r < 4; ++r) jt[d][mb][r] = 0.0;
         }
     }
-    // staging of the density rows of the steps sb .. sb + TT_KB - 1 (this wave's copy): lane = row k of the strip for each of the steps;
-    // lane = (step, column) for the wave's 16 columns; lanes 0-7 = (step, P[i][j] / P[j][i])
-    double stk[ND][TT_KB], stl[ND], stx[ND];
-    auto stage_load = [&](int sb) {
+    // the density rows of the task's steps -> LDS (all threads of the workgroup; the barrier in front of the loop follows).  All loads of a
+    // thread are issued before its first LDS store (a loop of load - wait - store was 10 us of a 40 us task).
+    {
+        const int nthr = (int)blockDim.x, tid = (int)threadIdx.x;
+        constexpr int G = 8;                                                // loads in flight per thread
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const double *Xd = X + d * nn;
+            for (int e0 = tid; e0 < nj * 16 * MB; e0 += G * nthr) {
+                double v[G];
 #pragma unroll
-            for (int kq = 0; kq < TT_KB; ++kq) {
-                const int s = sb + kq;
-                stk[d][kq] = (active && s < nj && lane < t.nks) ? Xd[(size_t)(t.j0 + s) * N + t.kbase + t.k0 + lane] : 0.0;
+                for (int u = 0; u < G; ++u) {
+                    const int e = e0 + u * nthr, sq = e / (16 * MB), x = e - sq * (16 * MB);
+                    v[u] = (sq < nj && x < nks) ? Xd[(size_t)(j0 + sq) * N + kbase + k0 + x] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int e = e0 + u * nthr;
+                    if (e < nj * 16 * MB) (&S.pk[d][0][0])[e] = v[u];
+                }
             }
-            const int sq = sb + (lane >> 4), lc = TT_LB * lb + (lane & 15);
-            stl[d] = (active && sq < nj && lc < ncol) ? Xd[(size_t)(t.j0 + sq) * N + t.lbase + lc] : 0.0;
-            const int sx = sb + (lane >> 1);
-            const bool okx = active && lane < 2 * TT_KB && sx < nj;
-            stx[d] = !okx ? 0.0 : ((lane & 1) ? Xd[(size_t)(t.j0 + sx) * N + iI] : Xd[(size_t)iI * N + t.j0 + sx]);
-        }
-    };
-    auto stage_store = [&]() {
-        if (!active) return;
+            for (int e0 = tid; e0 < nj * TT_W * TT_LB; e0 += G * nthr) {
+                double v[G];
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
+                for (int u = 0; u < G; ++u) {
+                    const int e = e0 + u * nthr, sq = e / (TT_W * TT_LB), x = e - sq * (TT_W * TT_LB), lc = TT_LB * lb0 + x;
+                    v[u] = (sq < nj && lc < ncol) ? Xd[(size_t)(j0 + sq) * N + lbase + lc] : 0.0;
+                }
 #pragma unroll
-            for (int kq = 0; kq < TT_KB; ++kq) S.pst[w][d][kq][lane] = stk[d][kq];
-            S.pst[w][d][lane >> 4][TT_KS + (lane & 15)] = stl[d];
-            if (lane < 2 * TT_KB) S.pst[w][d][lane >> 1][TT_KS + TT_LB + (lane & 1)] = stx[d];
+                for (int u = 0; u < G; ++u) {
+                    const int e = e0 + u * nthr;
+                    if (e < nj * TT_W * TT_LB) (&S.pl[d][0][0])[e] = v[u];
+                }
+            }
+            if (tid < nj) {
+                const int jI = j0 + tid;
+                const double xij = Xd[(size_t)iI * N + jI];
+                S.pij[d][tid] = (jI == iI) ? xij : xij + Xd[(size_t)jI * N + iI];
+            }
         }
-    };
-    // the wave's piece of a slice lives in ONE set of registers: the loads of row block mb of the next step are issued as soon as
-    // row block mb of this step has been consumed (a full step of distance, nothing in flight twice)
+    }
+    // The wave's pieces of the next PF slices live in a ring of PF register sets: the loads of row block mb of step s + PF are issued as
+    // soon as row block mb of step s has been consumed (the last steps re-load the last slice: no branch, no copies between the sets).
     auto load_mb = [&](double2 (&B)[MB][2], int mb, int s) {
-        const unsigned so = (unsigned)s * (unsigned)t.slice * 8u;
+        const unsigned so = (unsigned)s * (unsigned)slice * 8u;
         B[mb][0] = buf_load2<2>(rt, offA[mb], so);
         B[mb][1] = buf_load2<2>(rt, offB[mb], so);
     };
     auto step = [&](double2 (&B)[MB][2], int s, int kq) {
-        const bool self = t.self_last && s == nj - 1;
+        const bool self = self_last && s == nj - 1;
+        const int sc = min(s, nj - 1);                                      // (every step of a block runs -- those beyond the last on the last step's
+        const double live = s < nj ? 1.0 : 0.0;                             // data with zero weights, their stores out of range: a branch around a
+        const int snext = min(s + PF, nj - 1);                              // step would make the ring a set of copies)
         double ppij[ND], pjl[ND][4], pjk[ND][MB];
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            const double *ps = S.pst[w][d][kq];
-            const double xij = ps[TT_KS + TT_LB], xji = ps[TT_KS + TT_LB + 1];
-            ppij[d] = self ? xij : xij + xji;
-            const double2 q0 = *reinterpret_cast<const double2 *>(ps + TT_KS + 4 * kk), q1 = *reinterpret_cast<const double2 *>(ps + TT_KS + 4 * kk + 2);
-            pjl[d][0] = q0.x; pjl[d][1] = q0.y; pjl[d][2] = q1.x; pjl[d][3] = q1.y;
+            ppij[d] = live * S.pij[d][sc];
+            const double2 q0 = *reinterpret_cast<const double2 *>(&S.pl[d][sc][TT_LB * w + 4 * kk]), q1 = *reinterpret_cast<const double2 *>(&S.pl[d][sc][TT_LB * w + 4 * kk + 2]);
+            pjl[d][0] = live * q0.x; pjl[d][1] = live * q0.y; pjl[d][2] = live * q1.x; pjl[d][3] = live * q1.y;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) pjk[d][mb] = ps[16 * mb + m];
+            for (int mb = 0; mb < MB; ++mb) pjk[d][mb] = live * S.pk[d][sc][16 * mb + m];
         }
-        double t4[ND][4];
+        double t4[ND][4], jd[ND];
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
+        for (int d = 0; d < ND; ++d) {
+            jd[d] = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) t4[d][r] = 0.0;
+        }
+        tt_v4d accs[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const double tv[4] = {B[mb][0].x, B[mb][0].y, B[mb][1].x, B[mb][1].y};
-            load_mb(B, mb, min(s + 1, nj - 1));
             tt_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#ifndef TJ_ABL_NOMFMA                    // (TJ_ABL_*: timing experiments only, wrong results -- tools/build_variant.sh)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[r], b1[r], acc, 0, 0, 0);
-            // row sums D_d[j][k]: column d of the result tile = lanes m == d, rows kk + 4 q
-            if (m < ND) {
-                double *sl = S.slots + ((size_t)(kq * TT_W + w) * ND + m) * 64 + mb * 16 + kk * 4;
-                *reinterpret_cast<double2 *>(sl) = make_double2(acc[0], acc[1]);
-                *reinterpret_cast<double2 *>(sl + 2) = make_double2(acc[2], acc[3]);
-            }
+#endif
+            accs[mb] = acc;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const double2 w0 = S.pp[w][d][2 * mb][lane], w1 = S.pp[w][d][2 * mb + 1][lane];
@@ -344,62 +376,90 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
                 for (int r = 0; r < 4; ++r) {
                     const double tm = tv[r];
                     const double to = (DIAG && r == rdiag[mb]) ? 0.0 : tm;          // without the diagonal k == l
+#ifdef TJ_ABL_NOVALU
+                    jd[d] += tm;
+#else
                     jt[d][mb][r] += tm * ppij[d];
-                    jdb[d][kq] += tm * ppv[r];
+                    jd[d] += tm * ppv[r];
                     x2[d][mb] += tm * pjl[d][r];
                     x5[d][r] += to * pjk[d][mb];
                     t4[d][r] += to * pik[d][mb];
+#endif
                 }
             }
+            // the slice of step s + PF into the registers this row block has just been read from (issued behind their last use: the
+            // ring positions stay the same physical registers around the loop -- no copies, no wait for the loads in flight)
+            __builtin_amdgcn_sched_barrier(0);
+            load_mb(B, mb, snext);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int d = 0; d < ND; ++d) S.jdl[w][d][kq][lane] = jd[d];
         // column sums D_d[j][l]: over the 16 rows of the lane's DPP row; lane m then holds column 4 kk + (m >> 2)
+        const unsigned srow = (self || s >= nj) ? TF_BUF_OOB : (unsigned)s * (unsigned)dj_len * 8u;     // (the row (i, i) takes no D[j][.] terms)
+#ifndef TJ_ABL_NOR4
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const double cs = row_sum4(t4[d][0], t4[d][1], t4[d][2], t4[d][3]);
-            if ((m & 3) == 0 && !self) A.DJ[d * A.sDJ + t.dj_base + (long long)s * t.dj_len + t.dj_loff[w] + 4 * kk + (m >> 2)] = cs;
+            buf_store1<0>(d == 0 ? rdj : __builtin_amdgcn_make_buffer_rsrc(A.DJ + d * A.sDJ + dj_base, 0, (int)min((long long)nj * dj_len * 8, 0x7fffffffLL), 0x00020000),
+                          st_l, srow, cs);
+        }
+#endif
+        // row sums D_d[j][k]: column d of the result tiles = lanes m == d, rows kk + 4 q (written behind the vector work: the matrix
+        // core has long delivered)
+        if (m < ND) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                double *sl = S.slots + ((size_t)(kq * TT_W + w) * ND + m) * 64 + mb * 16 + kk * 4;
+                *reinterpret_cast<double2 *>(sl) = make_double2(accs[mb][0], accs[mb][1]);
+                *reinterpret_cast<double2 *>(sl + 2) = make_double2(accs[mb][2], accs[mb][3]);
+            }
         }
     };
-    double2 R0[MB][2];
-    stage_load(0);
+    double2 R[PF][MB][2];
     if (active) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) load_mb(R0, mb, 0);
-    }
-    stage_store();
-    __syncthreads();                                                       // (also: the Jd weights are in place)
-    for (int sb = 0; sb < nj; sb += TT_KB) {
-        stage_load(sb + TT_KB);                                            // the density rows of the next block (written behind the first barrier)
-        if (active) {
+        for (int q = 0; q < PF; ++q)
 #pragma unroll
-            for (int kq = 0; kq < TT_KB; ++kq) {
-                const int s = sb + kq;
-                if (s < nj) step(R0, s, kq);
+            for (int mb = 0; mb < MB; ++mb) load_mb(R[q], mb, min(q, nj - 1));
+    }
+    __syncthreads();                                                       // the density rows and the Jd weights are in place
+    for (int sb = 0; sb < nj; sb += TT_KB) {
+        if (active) {
+            // (the steps of a block are a LOOP: unrolled, the compiler overlaps them and needs twice the registers; PF steps per
+            // iteration keep the ring positions compile-time constants)
+#pragma unroll 1
+            for (int kq0 = 0; kq0 < TT_KB; kq0 += PF) {
+#pragma unroll
+                for (int q = 0; q < PF; ++q) step(R[q], sb + kq0 + q, kq0 + q);
             }
-            // Jd of the steps sb .. sb + 3: the wave totals of four values together
+            // Jd of the steps sb .. sb + 3: the wave totals of four values together (steps beyond the last: out of the buffer's range)
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
-                const double v = wave_sum4(jdb[d][0], jdb[d][1], jdb[d][2], jdb[d][3]);
-                if ((lane & 15) == 0 && sb + (lane >> 4) < nj) A.Jd[d * A.sJd + t.jd_base + (size_t)w * nj + sb + (lane >> 4)] = v;
-#pragma unroll
-                for (int q = 0; q < TT_KB; ++q) jdb[d][q] = 0.0;
+                const double v = wave_sum4(S.jdl[w][d][0][lane], S.jdl[w][d][1][lane], S.jdl[w][d][2][lane], S.jdl[w][d][3][lane]);
+                buf_store1<0>(d == 0 ? rjd : __builtin_amdgcn_make_buffer_rsrc(A.Jd + d * A.sJd + jd_base + (size_t)w * nj, 0, nj * 8, 0x00020000), st_jd,
+                              (unsigned)sb * 8u, v);
             }
         }
+#ifndef TJ_ABL_NOMERGE
         jkp_lds_barrier();
+#endif
         // merge of the row sums: wave w adds the waves' partials of step sb + w (+ nwg ..) and writes the K slot of that row
         for (int kq = w; kq < TT_KB; kq += nwg) {
             const int s = sb + kq;
             if (s >= nj) break;
-            const bool self = t.self_last && s == nj - 1;
-            const int krel = 16 * (lane >> 4) + ((lane >> 2) & 3) + 4 * (lane & 3);
+            const bool self = self_last && s == nj - 1;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 double v = S.slots[((size_t)(kq * TT_W) * ND + d) * 64 + lane];
-                for (int u = 1; u < t.nw; ++u) v += S.slots[((size_t)(kq * TT_W + u) * ND + d) * 64 + lane];
-                if (krel < t.nks && (lane >> 4) < MB && !self) A.DJ[d * A.sDJ + t.dj_base + (long long)s * t.dj_len + t.dj_koff + krel] = v;
+                for (int u = 1; u < tnw; ++u) v += S.slots[((size_t)(kq * TT_W + u) * ND + d) * 64 + lane];
+                buf_store1<0>(d == 0 ? rdj : __builtin_amdgcn_make_buffer_rsrc(A.DJ + d * A.sDJ + dj_base, 0, (int)min((long long)nj * dj_len * 8, 0x7fffffffLL), 0x00020000),
+                              st_k, self ? TF_BUF_OOB : (unsigned)s * (unsigned)dj_len * 8u, v);
             }
         }
-        stage_store();
+#ifndef TJ_ABL_NOMERGE
         jkp_lds_barrier();
+#endif
     }
     if (!active) return;
     // ---- what was summed over the steps
@@ -407,256 +467,290 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
     for (int d = 0; d < ND; ++d) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {                                   // the Jt tile
-            double *dst = A.Jt + d * A.sJt + t.jt_base + (long long)(t.k0 + 16 * mb + m) * t.jt_pitch + lcol0;
-            if (rv[mb] && lcol0 < t.jt_pitch) *reinterpret_cast<double2 *>(dst) = make_double2(jt[d][mb][0], jt[d][mb][1]);
-            if (rv[mb] && lcol0 + 2 < t.jt_pitch) *reinterpret_cast<double2 *>(dst + 2) = make_double2(jt[d][mb][2], jt[d][mb][3]);
+            double *dst = A.Jt + d * A.sJt + jt_base + (long long)(k0 + 16 * mb + m) * jt_pitch + lcol0;
+            if (rv[mb] && lcol0 < jt_pitch) *reinterpret_cast<double2 *>(dst) = make_double2(jt[d][mb][0], jt[d][mb][1]);
+            if (rv[mb] && lcol0 + 2 < jt_pitch) *reinterpret_cast<double2 *>(dst + 2) = make_double2(jt[d][mb][2], jt[d][mb][3]);
         }
         const double cs = row_sum4(x5[d][0], x5[d][1], x5[d][2], x5[d][3]);   // D[i][l]: over the rows
-        if ((m & 3) == 0) A.DIl[d * A.sDIl + (size_t)(t.di_base + w) * 16 + 4 * kk + (m >> 2)] = cs;
+        if ((m & 3) == 0) A.DIl[d * A.sDIl + (size_t)(di_base + w) * 16 + 4 * kk + (m >> 2)] = cs;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {                                   // D[i][k]: over the four lane groups
             double v = x2[d][mb];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (kk == 0) A.DIk[d * A.sDIk + (size_t)(t.di_base + w) * 64 + 16 * mb + m] = v;
+            if (kk == 0) A.DIk[d * A.sDIk + (size_t)(di_base + w) * 64 + 16 * mb + m] = v;
         }
     }
 }
 
 // One workgroup per task; blockDim = 64 x (waves of the launch's bucket: >= the task's column blocks).  MB = row blocks of 16 of a
 // task's strip (4: strips of 64 rows, one density; fewer for the passes over several densities: tf_tiles.h, `ksub`).
-template <int ND, int MB>
-__global__ __launch_bounds__(64 * TT_W, (MB >= 4 ? 1 : 2)) void jk_tile_kernel(const double *__restrict__ T, const TTask *__restrict__ tasks,
-                                                               const double *__restrict__ X, const double *__restrict__ Pm, TJArgs A)
+template <int ND, int MB, int PF>
+__global__ __launch_bounds__(64 * TT_W, (MB >= 4 ? 1 : (MB == 1 && PF <= 2 ? 3 : 2))) void jk_tile_kernel(const double *__restrict__ T, const TTask *__restrict__ tasks,
+                                                                            const double *__restrict__ X, const double *__restrict__ Pm, TJArgs A)
 {
+    static_assert(TT_KB == 4 && TT_KB % PF == 0, "the ring position of a step must be a compile-time constant");
     __shared__ TJLds<ND, MB> S;
-    const TTask &t = tasks[blockIdx.x];
+    const TTask *__restrict__ tp = tasks + blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const bool active = w < t.nw;
+    const bool active = w < tp->nw;
     // a triangle's tile holds diagonal elements k == l only where its rows and columns overlap
-    const int lb = t.lb0 + w;
-    const bool diag = t.a == t.b && active && TT_LB * lb <= t.k0 + t.nks - 1 && TT_LB * lb + TT_LB - 1 >= t.k0;
-    if (diag) tj_run<ND, MB, true>(T, X, Pm, A, t, w, lane, active, S);
-    else tj_run<ND, MB, false>(T, X, Pm, A, t, w, lane, active, S);
+    const int lb = tp->lb0 + w;
+    const bool diag = tp->a == tp->b && active && TT_LB * lb <= tp->k0 + tp->nks - 1 && TT_LB * lb + TT_LB - 1 >= tp->k0;
+    if (diag) tj_run<ND, MB, PF, true>(T, X, Pm, A, tp, w, lane, active, S);
+    else tj_run<ND, MB, PF, false>(T, X, Pm, A, tp, w, lane, active, S);
 }
 
 // ---- the edge elements m = (ij|il), l <= j (k == i): one workgroup per first index i ---------------------------------------------------
 // Per-i outputs, internal indices: EJ[i][x] (J of the pair (i, x)), ED[i][x] (D[i][x]), EDT[i][x] (D[x][i]).  The term D[j][l] += w m P[i][i]
-// runs over i and is added by the D[j][.] blocks of jk_tile_reduce_kernel.  Fixed summation order per output.
+// runs over i and is added by the D[j][.] waves of jk_tile_reduce_kernel.  A wave takes every fourth row j of a class, its lanes the
+// columns l <= j (coalesced reads of E[j][.]); sums over l: over the wave; sums over j: in the wave's own copy of the output row in LDS;
+// the four copies are added in fixed order: bitwise reproducible.
 struct TEArgs {
-    const TRunI *runs;            // [N][4]
     long long edge_base;
     int N;
     const int *tab;               // TView::tab
     double *EJ, *ED, *EDT;
     size_t sE;                    // stride between densities
 };
+#define TT_EDGE_WAVES 4
 template <int ND>
-__global__ __launch_bounds__(256) void jk_edge_kernel(const double *__restrict__ T, const double *__restrict__ X, const int *__restrict__ clsI, TEArgs A)
+__global__ __launch_bounds__(64 * TT_EDGE_WAVES) void jk_edge_kernel(const double *__restrict__ T, const double *__restrict__ X, const TRunI *__restrict__ runs, TEArgs A)
 {
-    __shared__ double sred[256];
+    extern __shared__ double sE[];                                         // [Xi N | Xti N | per wave: J N, D N, DT N]
     const int N = A.N, iI = blockIdx.x;
     const size_t nn = (size_t)N * N;
-    const int ci = clsI[iI];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    double *Xi = sE, *Xti = sE + N, *accJ = sE + 2 * N + (size_t)w * 3 * N, *accD = accJ + N, *accT = accD + N;
     for (int d = 0; d < ND; ++d) {
         const double *Xd = X + d * nn;
-        double dii = 0.0;                                                  // this thread's share of D[i][i]
-        for (int x = threadIdx.x; x < N; x += 256) {
-            const int cx = clsI[x];
-            const int c0 = A.tab[TVT_CSTART + cx];
-            const TRunI R = A.runs[(size_t)iI * 4 + cx];
-            const int lx = x - c0, l0 = R.j0 - c0;
-            double ej = 0.0, ed = 0.0, edt = 0.0;
-            if (R.nj > 0) {
-                const double *E = T + A.edge_base + R.e_base - (long long)l0 * (l0 + 1) / 2;     // E[T(loc j) + loc l]
-                const double ppix = (x == iI) ? Xd[(size_t)iI * N + iI] : Xd[(size_t)iI * N + x] + Xd[(size_t)x * N + iI];
-                // x as j: the row (i, x), all l <= x
-                if (lx >= l0 && lx < l0 + R.nj) {
-                    const double *Ej = E + (long long)lx * (lx + 1) / 2;
-                    for (int ll = 0; ll <= lx; ++ll) {
-                        const int lI = c0 + ll;
-                        const double mv = Ej[ll], wgt = (ll == lx) ? 0.5 : 1.0;
-                        const double ppil = (lI == iI) ? Xd[(size_t)iI * N + iI] : Xd[(size_t)iI * N + lI] + Xd[(size_t)lI * N + iI];
-                        ej += mv * ppil;                                   // Jd[ij] += m Pp[il]
-                        dii += wgt * mv * Xd[(size_t)x * N + lI];          // D[i][i] += w m P[j][l]
-                        if (x != iI) edt += wgt * mv * Xd[(size_t)iI * N + lI];   // D[j][i] += w m P[i][l]   (i != j)
-                    }
-                }
-                // x as l: the rows (i, j), j >= x of x's class
-                for (int lj = max(lx, l0); lj < l0 + R.nj; ++lj) {
-                    const int jI = c0 + lj;
-                    const double mv = E[(long long)lj * (lj + 1) / 2 + lx], wgt = (lj == lx) ? 0.5 : 1.0;
-                    if (lj != lx) {
-                        const double ppij = (jI == iI) ? Xd[(size_t)iI * N + iI] : Xd[(size_t)iI * N + jI] + Xd[(size_t)jI * N + iI];
-                        ej += mv * ppij;                                   // Jt[il] += m Pp[ij]   (l != j)
-                    }
-                    if (x != iI) ed += wgt * mv * Xd[(size_t)jI * N + iI]; // D[i][l] += w m P[j][i]   (l != i)
-                }
-                (void)ppix;
-            }
-            A.EJ[d * A.sE + (size_t)iI * N + x] = ej;
-            A.ED[d * A.sE + (size_t)iI * N + x] = ed;
-            A.EDT[d * A.sE + (size_t)iI * N + x] = edt;
-        }
-        sred[threadIdx.x] = dii;
+        for (int x = threadIdx.x; x < N; x += blockDim.x) { Xi[x] = Xd[(size_t)iI * N + x]; Xti[x] = Xd[(size_t)x * N + iI]; }
+        for (int x = lane; x < 3 * N; x += 64) accJ[x] = 0.0;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double s = 0.0;
-            for (int q = 0; q < 256; ++q) s += sred[q];
-            A.ED[d * A.sE + (size_t)iI * N + iI] += s;
+        const double xii = Xi[iI];
+        double dii = 0.0;                                                  // this lane's share of D[i][i]
+        for (int cj = 0; cj < 4; ++cj) {
+            const TRunI R = runs[(size_t)iI * 4 + cj];
+            if (R.nj <= 0) continue;
+            const int c0 = A.tab[TVT_CSTART + cj], l0 = R.j0 - c0;
+            const double *E = T + A.edge_base + R.e_base - (long long)l0 * (l0 + 1) / 2;     // E[T(loc j) + loc l]
+            for (int lj = l0 + w; lj < l0 + R.nj; lj += TT_EDGE_WAVES) {   // row (i, j)
+                const int jI = c0 + lj;
+                const double *Ej = E + (long long)lj * (lj + 1) / 2;
+                const double ppij = (jI == iI) ? xii : Xi[jI] + Xti[jI], xji = Xti[jI];
+                double ej = 0.0, edt = 0.0;
+                for (int ll = lane; ll <= lj; ll += 64) {
+                    const int lI = c0 + ll;
+                    const double mv = Ej[ll], wgt = (ll == lj) ? 0.5 : 1.0;
+                    const double ppil = (lI == iI) ? xii : Xi[lI] + Xti[lI];
+                    ej += mv * ppil;                                       // Jd[ij] += m Pp[il]
+                    dii += wgt * mv * Xd[(size_t)jI * N + lI];             // D[i][i] += w m P[j][l]
+                    edt += wgt * mv * Xi[lI];                              // D[j][i] += w m P[i][l]   (i != j)
+                    if (ll != lj) accJ[lI] += mv * ppij;                   // Jt[il] += m Pp[ij]       (l != j)
+                    if (lI != iI) accD[lI] += wgt * mv * xji;              // D[i][l] += w m P[j][i]   (l != i)
+                }
+                const double s4 = wave_sum4(ej, edt, 0.0, 0.0);            // lane L: total of value L >> 4
+                if (lane == 0) accJ[jI] += s4;                             // (behind this wave's own column updates: one wave, program order)
+                if (lane == 16 && jI != iI) accT[jI] += s4;
+            }
+        }
+        dii = wave_sum1(dii);
+        if (lane == 0) accD[iI] += dii;
+        __syncthreads();
+        for (int x = threadIdx.x; x < N; x += blockDim.x) {
+            double j = 0.0, dd = 0.0, dt = 0.0;
+            for (int u = 0; u < TT_EDGE_WAVES; ++u) { const double *q = sE + 2 * N + (size_t)u * 3 * N; j += q[x]; dd += q[N + x]; dt += q[2 * N + x]; }
+            A.EJ[d * A.sE + (size_t)iI * N + x] = j;
+            A.ED[d * A.sE + (size_t)iI * N + x] = dd;
+            A.EDT[d * A.sE + (size_t)iI * N + x] = dt;
         }
         __syncthreads();
     }
-    (void)ci;
 }
 
-// ---- reductions: one launch, three kinds of blocks, fixed summation order inside every block ------------------------------------
+// ---- reductions: one launch, three kinds of workgroups (4 waves), fixed summation order everywhere ------------------------------
 struct TRArgs {
-    const TTask *tasks;           // launch order (the task list of the pass)
-    const TPairI *pairs;          // [N][10] of the list
-    const TRunI *runs;            // [N][4]
-    const int *itask_ptr, *itasks, *jlist_ptr, *jlist;
-    const int *clsI, *origI;
-    const int *cntA;              // [4][N]
+    const int *itask_ptr, *itasks, *jlist_ptr;
+    const int *clsI;
     const double *DJ, *Jt, *Jd, *DIk, *DIl, *T, *X;
     size_t sDJ, sJt, sJd, sDIk, sDIl, sO;
     double *Dj, *Di, *JtTot, *JD; // Dj[j][x], Di[i][x], JD[i][j]: [N][N] internal; JtTot: pair matrices
     long long edge_base;
     int N, ksub, npair, nd, pm_len;
     const int *tab;               // TView::tab
-    int jt_rows;                  // rows of all pair matrices together (blocks of kind 1)
-    int xtiles;                   // 64-column tiles of a row of N
+    int jt_rows;                  // rows of all pair matrices together
 };
-#define TT_RED_THREADS 256
+#define TT_RED_THREADS 512
+#define TT_RED_WAVES 8
+#define TT_RED_CT 4               // column tiles of 64 a wave keeps in registers (classes of up to 256 AOs per pass)
 
-// kind 0: D[j][x] for one j and 64 columns x of one class: the DJ vectors of the rows (i, j), i != j (jlist) + the edge term
-__device__ __forceinline__ void tr_dj_block(const TRArgs &R, int d, int jI, int X0, double *sPart)
+// the waves' partial rows -> the row: wave 0 adds them in fixed order (sPart: [TT_RED_WAVES][64 TT_RED_CT])
+__device__ __forceinline__ void tr_combine(double *sPart, const double (&acc)[TT_RED_CT], int w, int lane, double (&tot)[TT_RED_CT])
 {
-    const int N = R.N, lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int x = X0 + lane;
-    const int cX = R.clsI[X0], cj = R.clsI[jI];
+#pragma unroll
+    for (int u = 0; u < TT_RED_CT; ++u) sPart[((size_t)w * TT_RED_CT + u) * 64 + lane] = acc[u];
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int u = 0; u < TT_RED_CT; ++u) {
+            double t = 0.0;
+            for (int q = 0; q < TT_RED_WAVES; ++q) t += sPart[((size_t)q * TT_RED_CT + u) * 64 + lane];
+            tot[u] = t;
+        }
+    }
+    __syncthreads();
+}
+
+// kind 0, one workgroup per (j, class X): D[j][x] for the AOs x of class X: the DJ vectors of the rows (i, j), i != j (jlist) + the edge
+// term; the waves share the rows.
+__device__ __forceinline__ void tr_dj_block(const TRArgs &R, const TPairI *__restrict__ pairs, const TRunI *__restrict__ runs, const int *__restrict__ jlist,
+                                            int d, int jI, int cX, int w, int lane, double *sPart)
+{
+    const int N = R.N;
+    const int cj = R.clsI[jI];
     const int xs = R.tab[TVT_CSTART + cX], nX = R.tab[TVT_CSIZE + cX];
-    const bool in = x < xs + nX;
-    const int lx = x - xs, lj = jI - R.tab[TVT_CSTART + cj];
+    const int lj = jI - R.tab[TVT_CSTART + cj];
     const double *DJ = R.DJ + d * R.sDJ;
     const double *Xd = R.X + (size_t)d * N * N;
-    double acc = 0.0;
-    for (int q = R.jlist_ptr[jI] + sl; q < R.jlist_ptr[jI + 1]; q += TT_RED_THREADS / 64) {
-        const int iI = R.jlist[q];
-        const int c = R.clsI[iI] ^ cj;
-        const int p = R.tab[TVT_PID + cX * 4 + (cX ^ c)];
-        const TPairI P = R.pairs[(size_t)iI * 10 + p];
-        const TRunI Rn = R.runs[(size_t)iI * 4 + cj];
-        double v = 0.0;
-        if (P.first_task >= 0 && in) {
+    for (int t0 = 0; t0 < nX; t0 += 64 * TT_RED_CT) {
+        double acc[TT_RED_CT], tot[TT_RED_CT];
+#pragma unroll
+        for (int u = 0; u < TT_RED_CT; ++u) acc[u] = 0.0;
+        for (int q = R.jlist_ptr[jI] + w; q < R.jlist_ptr[jI + 1]; q += TT_RED_WAVES) {
+            const int iI = jlist[q];
+            const int c = R.clsI[iI] ^ cj;
+            const int p = R.tab[TVT_PID + cX * 4 + (cX ^ c)];
+            const TPairI P = pairs[(size_t)iI * 10 + p];
+            const TRunI Rn = runs[(size_t)iI * 4 + cj];
             const double *vec = DJ + Rn.dj_base + (long long)(jI - Rn.j0) * Rn.dj_len;
             const int a = R.tab[TVT_PA + p], b = R.tab[TVT_PB + p];
-            const bool tri = a == b;
-            if (cX == a && lx < P.nk) {                                   // x as a row index k: the chunks of its stored strip
-                const int ks = lx / TT_KS, nst = min(TT_KS, P.nk - TT_KS * ks);
-                int nch, w;
-                tt_chunks(tt_nlb(tri, ks, P.nk, P.nl), &nch, &w);
-                const double *src = vec + P.dj_k + tt_dj_koff(tri, ks, P.nl) + (lx - TT_KS * ks);
-                for (int ch = 0; ch < nch; ++ch) v += src[ch * nst];
-            }
-            if (cX == b && lx < P.nl) {                                   // x as a column index l: the sub-strips that reach its block
-                const int lb = lx / TT_LB, ns = (P.nk + R.ksub - 1) / R.ksub, f = tt_dj_first_sub(tri, lb, R.ksub);
-                const double *src = vec + P.dj_l + tt_dj_loff(tri, lb, P.nk, R.ksub) + (lx - TT_LB * lb);
-                for (int s2 = f; s2 < ns; ++s2) v += src[(s2 - f) * TT_LB];
-            }
-        }
-        if (in && cX == cj && lx <= lj) {                                   // edge: D[j][l] += w (ij|il) P[i][i]
+            const bool tri = a == b, have = P.first_task >= 0;
             const long long l0 = Rn.j0 - R.tab[TVT_CSTART + cj];
-            const double mv = R.T[R.edge_base + Rn.e_base + (long long)lj * (lj + 1) / 2 - l0 * (l0 + 1) / 2 + lx];
-            v += (lx == lj ? 0.5 : 1.0) * mv * Xd[(size_t)iI * N + iI];
+            const double *Ee = R.T + R.edge_base + Rn.e_base + (long long)lj * (lj + 1) / 2 - l0 * (l0 + 1) / 2;
+            const double xii = Xd[(size_t)iI * N + iI];
+#pragma unroll
+            for (int u = 0; u < TT_RED_CT; ++u) {
+                const int lx = t0 + 64 * u + lane;
+                double v = 0.0;
+                if (have && cX == a && lx < P.nk) {                       // x as a row index k: the chunks of its stored strip
+                    const int ks = lx / TT_KS, nst = min(TT_KS, P.nk - TT_KS * ks);
+                    int nch, wv;
+                    tt_chunks(tt_nlb(tri, ks, P.nk, P.nl), &nch, &wv);
+                    const double *src = vec + P.dj_k + tt_dj_koff(tri, ks, P.nl) + (lx - TT_KS * ks);
+                    for (int ch = 0; ch < nch; ++ch) v += src[ch * nst];
+                }
+                if (have && cX == b && lx < P.nl) {                       // x as a column index l: the sub-strips that reach its block
+                    const int lb = lx / TT_LB, ns = (P.nk + R.ksub - 1) / R.ksub, f = tt_dj_first_sub(tri, lb, R.ksub);
+                    const double *src = vec + P.dj_l + tt_dj_loff(tri, lb, P.nk, R.ksub) + (lx - TT_LB * lb);
+                    for (int s2 = f; s2 < ns; ++s2) v += src[(s2 - f) * TT_LB];
+                }
+                if (cX == cj && lx <= lj) v += (lx == lj ? 0.5 : 1.0) * Ee[lx] * xii;   // edge: D[j][l] += w (ij|il) P[i][i]
+                acc[u] += v;
+            }
         }
-        acc += v;
-    }
-    sPart[threadIdx.x] = acc;
-    __syncthreads();
-    if (sl == 0 && in) {
-        double a2 = sPart[lane];
-        for (int q = 1; q < TT_RED_THREADS / 64; ++q) a2 += sPart[64 * q + lane];
-        R.Dj[d * R.sO + (size_t)jI * N + x] = a2;
+        tr_combine(sPart, acc, w, lane, tot);
+        if (w == 0) {
+#pragma unroll
+            for (int u = 0; u < TT_RED_CT; ++u) {
+                const int lx = t0 + 64 * u + lane;
+                if (lx < nX) R.Dj[d * R.sO + (size_t)jI * N + xs + lx] = tot[u];
+            }
+        }
     }
 }
 
-// kind 1: Jt totals of one row k of a class pair, 64 columns: the partial blocks of every first index above (k, l)
-__device__ __forceinline__ void tr_jt_block(const TRArgs &R, int d, int rowid, int tile, double *sPart)
+// kind 1, one workgroup per row k of a class pair: the Jt totals of the row = the partial blocks of every first index above (k, l); the
+// waves share the first indices.
+__device__ __forceinline__ void tr_jt_block(const TRArgs &R, const TPairI *__restrict__ pairs, int d, int rowid, int w, int lane, double *sPart)
 {
-    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
     int p = 0, row = rowid;
-    while (p + 1 < R.npair && row >= R.tab[TVT_CSIZE + R.tab[TVT_PA + p]]) { row -= R.tab[TVT_CSIZE + R.tab[TVT_PA + p]]; ++p; }     // (wave-uniform walk over <= 10 pairs)
+    while (p + 1 < R.npair && row >= R.tab[TVT_CSIZE + R.tab[TVT_PA + p]]) { row -= R.tab[TVT_CSIZE + R.tab[TVT_PA + p]]; ++p; }
     const int a = R.tab[TVT_PA + p], b = R.tab[TVT_PB + p];
     const bool tri = a == b;
-    const int lc = 64 * tile + lane;
-    const int nb = R.tab[TVT_CSIZE + b];
-    if (64 * tile >= nb) return;
+    const int nb = R.tab[TVT_CSIZE + b], pitch = R.tab[TVT_PMPITCH + p];
+    const int ncols = tri ? row + 1 : nb;
     const double *Jt = R.Jt + d * R.sJt;
-    double acc = 0.0;
-    for (int iI = sl; iI < R.N; iI += TT_RED_THREADS / 64) {
-        const TPairI P = R.pairs[(size_t)iI * 10 + p];
-        if (P.first_task < 0 || row >= P.nk) continue;
-        if (lc < (tri ? row + 1 : P.nl)) {
-            const double *src = Jt + P.jt_base + (long long)row * P.jt_pitch + lc;
-            for (int part = 0; part < P.nparts; ++part) acc += src[part * P.jt_part_stride];
-        }
-    }
-    sPart[threadIdx.x] = acc;
-    __syncthreads();
-    if (sl == 0 && lc < R.tab[TVT_PMPITCH + p]) {
-        double a2 = sPart[lane];
-        for (int q = 1; q < TT_RED_THREADS / 64; ++q) a2 += sPart[64 * q + lane];
-        R.JtTot[(size_t)d * R.pm_len + R.tab[TVT_PMOFF + p] + (size_t)row * R.tab[TVT_PMPITCH + p] + lc] = a2;
-    }
-}
-
-// kind 2: D[i][x] and Jd[i][j] for one i: the per-task outputs of the tasks of i (creation order)
-__device__ __forceinline__ void tr_gather_block(const TRArgs &R, int d, int iI)
-{
-    const int N = R.N;
-    for (int x = threadIdx.x; x < N; x += TT_RED_THREADS) {
-        const int cX = R.clsI[x], lx = x - R.tab[TVT_CSTART + cX];
-        double di = 0.0, jd = 0.0;
-        for (int q = R.itask_ptr[iI]; q < R.itask_ptr[iI + 1]; ++q) {
-            const TTask &t = R.tasks[R.itasks[q]];
-            if (cX == t.a && lx >= t.k0 && lx < t.k0 + t.nks)
-                for (int w = 0; w < t.nw; ++w) di += R.DIk[d * R.sDIk + (size_t)(t.di_base + w) * 64 + (lx - t.k0)];
-            if (cX == t.b) {
-                const int w = lx / TT_LB - t.lb0;
-                if (w >= 0 && w < t.nw) di += R.DIl[d * R.sDIl + (size_t)(t.di_base + w) * 16 + (lx & (TT_LB - 1))];
+    for (int t0 = 0; t0 < pitch; t0 += 64 * TT_RED_CT) {
+        double acc[TT_RED_CT], tot[TT_RED_CT];
+#pragma unroll
+        for (int u = 0; u < TT_RED_CT; ++u) acc[u] = 0.0;
+        if (t0 < ncols)
+            for (int iI = w; iI < R.N; iI += TT_RED_WAVES) {
+                const TPairI P = pairs[(size_t)iI * 10 + p];
+                if (P.first_task < 0 || row >= P.nk) continue;
+                const double *src = Jt + P.jt_base + (long long)row * P.jt_pitch;
+                const int lim = tri ? row + 1 : P.nl;
+                for (int part = 0; part < P.nparts; ++part) {
+#pragma unroll
+                    for (int u = 0; u < TT_RED_CT; ++u) {
+                        const int lc = t0 + 64 * u + lane;
+                        if (lc < lim) acc[u] += src[lc];
+                    }
+                    src += P.jt_part_stride;
+                }
             }
-            if (x >= t.j0 && x < t.j0 + t.nj)
-                for (int w = 0; w < t.nw; ++w) jd += R.Jd[d * R.sJd + t.jd_base + (size_t)w * t.nj + (x - t.j0)];
+        tr_combine(sPart, acc, w, lane, tot);
+        if (w == 0) {
+#pragma unroll
+            for (int u = 0; u < TT_RED_CT; ++u) {
+                const int lc = t0 + 64 * u + lane;
+                if (lc < pitch) R.JtTot[(size_t)d * R.pm_len + R.tab[TVT_PMOFF + p] + (size_t)row * pitch + lc] = tot[u];
+            }
         }
-        R.Di[d * R.sO + (size_t)iI * N + x] = di;
-        R.JD[d * R.sO + (size_t)iI * N + x] = jd;
     }
 }
 
-__global__ __launch_bounds__(TT_RED_THREADS) void jk_tile_reduce_kernel(TRArgs R)
+// kind 2, one workgroup per i: D[i][x] and Jd[i][j] from the per-task outputs of the tasks of i.  Wave w takes every fourth task (creation
+// order) and adds into its own copy of the two output rows in LDS; the copies are added in fixed order.
+__device__ __forceinline__ void tr_gather_block(const TRArgs &R, const TTask *__restrict__ tasks, int d, int iI, double *sAcc)
 {
-    __shared__ double sPart[TT_RED_THREADS];
     const int N = R.N;
-    const int n0 = N * R.xtiles, n1 = R.jt_rows * R.xtiles, n2 = N;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    double *aD = sAcc + (size_t)w * 2 * N, *aJ = aD + N;
+    for (int x = lane; x < 2 * N; x += 64) aD[x] = 0.0;
+    for (int q = R.itask_ptr[iI] + w; q < R.itask_ptr[iI + 1]; q += TT_RED_WAVES) {
+        const TTask *t = tasks + R.itasks[q];
+        const int nw = t->nw, nks = t->nks, nj = t->nj, di = t->di_base, jd = t->jd_base;
+        if (lane < nks) {                                                   // D[i][k]
+            double v = 0.0;
+            for (int u = 0; u < nw; ++u) v += R.DIk[d * R.sDIk + (size_t)(di + u) * 64 + lane];
+            aD[t->kbase + t->k0 + lane] += v;
+        }
+        {                                                                   // D[i][l]: lane = (wave of the task, column of its block)
+            const int u = lane >> 4, lc = TT_LB * (t->lb0 + u) + (lane & 15);
+            if (u < nw && lc < t->ncol) aD[t->lbase + lc] += R.DIl[d * R.sDIl + (size_t)(di + u) * 16 + (lane & 15)];
+        }
+        if (lane < nj) {                                                    // Jd[i][j]
+            double v = 0.0;
+            for (int u = 0; u < nw; ++u) v += R.Jd[d * R.sJd + jd + (size_t)u * nj + lane];
+            aJ[t->j0 + lane] += v;
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < N; x += TT_RED_THREADS) {
+        double dd = 0.0, jj = 0.0;
+        for (int u = 0; u < TT_RED_WAVES; ++u) { dd += sAcc[(size_t)u * 2 * N + x]; jj += sAcc[(size_t)u * 2 * N + N + x]; }
+        R.Di[d * R.sO + (size_t)iI * N + x] = dd;
+        R.JD[d * R.sO + (size_t)iI * N + x] = jj;
+    }
+}
+
+__global__ __launch_bounds__(TT_RED_THREADS) void jk_tile_reduce_kernel(const TTask *__restrict__ tasks, const TPairI *__restrict__ pairs,
+                                                                         const TRunI *__restrict__ runs, const int *__restrict__ jlist, TRArgs R)
+{
+    extern __shared__ double sAcc[];                                       // [waves][D row N | J row N] (gather) / [waves][64 TT_RED_CT] (the others)
+    const int N = R.N;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n2 = N, n0 = 4 * N, n1 = R.jt_rows;                          // gather first: its workgroups run longest
     int b = blockIdx.x;
     const int d = b / (n0 + n1 + n2);
     b -= d * (n0 + n1 + n2);
-    if (b < n0) {
-        // 64-column tiles of the internal index space that do not straddle a class: tile t of class X starts at cstart[X] + 64 t'
-        const int jI = b / R.xtiles, tl = b % R.xtiles;
-        int X0 = -1, cnt = 0;
-        for (int c = 0; c < 4 && X0 < 0; ++c) {
-            const int nt = (R.tab[TVT_CSIZE + c] + 63) / 64;
-            if (tl < cnt + nt) X0 = R.tab[TVT_CSTART + c] + 64 * (tl - cnt);
-            cnt += nt;
-        }
-        if (X0 >= 0) tr_dj_block(R, d, jI, X0, sPart);
-    } else if (b < n0 + n1) {
-        b -= n0;
-        tr_jt_block(R, d, b / R.xtiles, b % R.xtiles, sPart);
-    } else
-        tr_gather_block(R, d, b - n0 - n1);
+    if (b < n2)
+        tr_gather_block(R, tasks, d, N - 1 - b, sAcc);                     // (the last first indices have the most tasks)
+    else if (b < n2 + n0)
+        tr_dj_block(R, pairs, runs, jlist, d, (b - n2) >> 2, (b - n2) & 3, w, lane, sAcc);
+    else
+        tr_jt_block(R, pairs, d, b - n2 - n0, w, lane, sAcc);
 }
 
 // Original indices (x, y): K = D + D2^T with D = Dj + Di + ED + EDT^T (D2 = D for a symmetric density; a general one: D = D(P^T), D2 = D(P));

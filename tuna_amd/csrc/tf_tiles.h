@@ -65,6 +65,29 @@ TT_HD int tt_row_off(bool tri, int ks, int lb, int r, int nl)          // start 
     const int d0 = TT_KS * ks - TT_LB * lb;
     return tt_triF(d0 + r) - tt_triF(d0);
 }
+// Inside a block of 16 rows the values are NOT row-major: the Fock kernel loads a piece straight into the A-operand layout of
+// v_mfma_f64_16x16x4 (lane = 16 kk + m: row m, columns 4 kk + 2 h .. + 1 with load h), and a quarter wave -- 16 lanes, the unit the
+// memory pipeline coalesces -- would touch 16 different lines of a row-major tile.  The block is therefore stored chunk by chunk: for
+// h = 0, 1 and kk = 0 .. 3 the column pair c0 = 4 kk + 2 h of every row that has it (a triangle's first rows are shorter), row after
+// row: what a quarter wave loads is one contiguous run (256 bytes of a full block, whose eight chunks are 2 KB in load order).  Same
+// doubles as row-major.  r: row of the stored strip; c: column of the block (0 .. 15).
+TT_HD int tt_elem_off(bool tri, int ks, int lb, int r, int c, int nks, int nl)
+{
+    const int r0 = r & ~15, m = r - r0, nr = tt_min(16, nks - r0);
+    const int base = tt_row_off(tri, ks, lb, r0, nl);
+    const int d0 = TT_KS * ks + r0 - TT_LB * lb;                       // triangle: diagonal distance of the block's first row
+    const int rl = tri ? 0 : tt_pad2(tt_min(TT_LB, nl - TT_LB * lb)); // rectangle: padded row length
+    const int c0 = c & ~1;
+    int off = base;
+    for (int h = 0; h < 2; ++h)
+        for (int kq = 0; kq < 4; ++kq) {
+            const int cc = 4 * kq + 2 * h;
+            const int m0 = tri ? tt_max(0, cc - d0) : (cc < rl ? 0 : 16);   // first row of the block that has the pair cc
+            if (cc == c0) return off + 2 * (m - m0) + (c - c0);
+            off += 2 * tt_max(0, nr - m0);
+        }
+    return off;
+}
 TT_HD int tt_piece_len(bool tri, int ks, int lb, int nks, int nl)      // doubles of the piece, a multiple of 16 (128 bytes)
 {
     return (tt_row_off(tri, ks, lb, nks, nl) + 15) & ~15;
@@ -186,5 +209,5 @@ TT_HD long long tt_elem_addr(const TView &V, const int *clsI, int iI, int jI, in
     const int ch = lb / w, wv = lb - ch * w;
     const int before = tri ? ks * (ks + 1) / 2 : ks * nch;                 // chunks of the (full) strips in front
     const TTask *Rg = V.regions + (size_t)P.first_task + (size_t)part * P.tasks_per_part + before + ch;
-    return Rg->base + (long long)s * Rg->slice + Rg->woff[wv] + tt_row_off(tri, ks, lb, kr - TT_KS * ks, P.nl) + (lc - TT_LB * lb);
+    return Rg->base + (long long)s * Rg->slice + Rg->woff[wv] + tt_elem_off(tri, ks, lb, kr - TT_KS * ks, lc - TT_LB * lb, tt_min(TT_KS, P.nk - TT_KS * ks), P.nl);
 }
