@@ -198,6 +198,39 @@ def test_synthetic_series_properties(engine, n_sph):
     assert abs(J1[i, j] - np.sum(M * P1)) < 1e-10 * scale
 
 
+def test_fock_rows_at_the_benched_size_against_sampled_tensor_rows(engine):
+    """N = 400, the tensor bench.py times: 24 elements each of J and K -- AOs of all four parity classes, the first and last AOs, both
+    triangles -- against a direct contraction of sampled tensor rows with the reference's index strings (scf:70 "ijkl,kl->ij": J_ab =
+    sum_kl (ab|kl) P_kl; scf:42 "ilkj,kl->ij": K_ab = sum_kl (al|kb) P_kl), for the one-density pass and for the fused two-density pass.
+    (The tensor itself is pinned at this size by test_bench_workload_tensor_against_oracle.)"""
+    n_sph = 400
+    counts = mol.synthetic_counts(n_sph)
+    atoms = mol.make_atoms(["AR", "AR"], 7.1)
+    aos = mol.expand_cartesian_aos(mol.build_shells(atoms, {18: mol.even_tempered_basis(*counts)}))
+    engine.set_basis(aos).build_eri(True)
+    N = engine.N
+    rng = np.random.default_rng(17)
+    A = rng.standard_normal((2, N, N))
+    P = A + A.transpose(0, 2, 1)
+    J1, K1 = engine.fock_jk(P[0])
+    J2, K2 = engine.fock_jk(P)                                            # both densities in one pass
+    assert np.array_equal(J2[0], J1) or np.abs(J2[0] - J1).max() < 1e-11 * np.abs(J1).max()
+    picks = [(0, 0), (N - 1, N - 1), (N - 1, 0), (0, N - 1), (N // 2, N // 2 - 1), (199, 200), (200, 199), (399, 200)]
+    while len(picks) < 24:
+        a, b = (int(x) for x in rng.integers(0, N, size=2))
+        picks.append((a, b))
+    kk, ll = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    kk, ll = kk.reshape(-1).astype(np.int32), ll.reshape(-1).astype(np.int32)
+    sJ, sK = np.abs(J1).max(), np.abs(K1).max()
+    for (a, b) in picks:
+        ia, ib = np.full(N * N, a, dtype=np.int32), np.full(N * N, b, dtype=np.int32)
+        Mj = engine.sample_eri(np.stack([ia, ib, kk, ll], axis=1)).reshape(N, N)       # (ab|kl)
+        Mk = engine.sample_eri(np.stack([ia, ll, kk, ib], axis=1)).reshape(N, N)       # (al|kb) at [k][l]
+        for d, (J, K) in enumerate(((J1, K1), (J2[1], K2[1]))):
+            assert abs(J[a, b] - np.sum(Mj * P[d])) < 1e-10 * sJ, (a, b, d)
+            assert abs(K[a, b] - np.sum(Mk * P[d])) < 1e-10 * sK, (a, b, d)
+
+
 def test_multi_chunk_contraction_against_the_reference_einsums(engine):
     """The contraction itself where a parity class is wider than one 64-column chunk (N = 200: 81 / 48 / 48 / 23 AOs per class, so the
     tasks of jk_packed_kernel come in several chunks per class -- no golden system reaches that): the dense copy of the GPU tensor (pinned

@@ -177,17 +177,22 @@ struct tf_ctx {
     tft::TaskList tsub1;                 // the one-density task list when its strips are shorter than the stored ones (TF_TILE_KSUB)
     int ksub1 = TT_KS;
     TView tv{};
-    struct TileList {                    // device copy of a tft::TaskList
+    struct TileList {                    // device copy of a tft::TaskList + the partial-sum buffers of its passes
         TTask *d_tasks = nullptr;
         TPairI *d_pairs = nullptr;
         TRunI *d_runs = nullptr;
         int *d_itask_ptr = nullptr, *d_itasks = nullptr;
         int n_tasks = 0, bucket[TT_W + 1] = {0, 0, 0, 0, 0}, ksub = TT_KS, n_di = 0;
         long long dj_len = 0, jd_len = 0, jt_len = 0;
-    } tl1;
+        double *DJ = nullptr, *Jt = nullptr, *Jd = nullptr, *DIk = nullptr, *DIl = nullptr;
+        int nd_cap = 0;                  // densities the buffers are sized for
+    } tl1, tlw;                          // one density per pass (strips of ksub1 rows); 4 / 8 densities per pass (strips of 16 rows: built at first use)
+    tft::TaskList tsubw;
+    tft::ClassInfo tclass;               // what the list builder needs again for tlw
+    std::vector<std::pair<int, int>> trows;
     int *d_jlist_ptr = nullptr, *d_jlist = nullptr, *d_tvtab = nullptr;
-    double *t_X = nullptr, *t_Pm = nullptr, *t_DJ = nullptr, *t_Jt = nullptr, *t_Jd = nullptr, *t_DIk = nullptr, *t_DIl = nullptr;
-    double *t_out = nullptr;             // [2 passes][Dj, Di, ED, EDT, JD, EJ][N][N]
+    double *t_X = nullptr, *t_Pm = nullptr;   // [8][N][N] internal densities, [8] pair matrices
+    double *t_out = nullptr;             // [6: Dj, Di, ED, EDT, JD, EJ][densities of the pass][N][N]; two such sets (the two passes of a general density)
     double *t_JtTot = nullptr;
     std::vector<void *> tile_allocs;
     size_t tile_lds_set = 48 * 1024;     // dynamic LDS limit requested for the tiles layout's edge / reduce kernels
@@ -261,6 +266,10 @@ static int upload(tf_ctx *ctx, const std::vector<T> &h, T **d, bool track = true
     return TF_OK;
 }
 
+extern "C++" {
+static int tile_list_upload(tf_ctx *ctx, const tft::TaskList &TL, bool own_shapes, tf_ctx::TileList &D);
+}
+
 static void free_eri(tf_ctx *ctx)
 {
     (void)hipDeviceSynchronize();               // (the freed blocks are recycled at once: nothing queued earlier may still use them)
@@ -280,10 +289,10 @@ static void free_eri(tf_ctx *ctx)
     ctx->layout_allocs.clear();
     for (void *p : ctx->tile_allocs) (void)tf_free(p);
     ctx->tile_allocs.clear();
-    ctx->tl1 = tf_ctx::TileList();
+    ctx->tl1 = tf_ctx::TileList(); ctx->tlw = tf_ctx::TileList();
     ctx->tv = TView{};
     ctx->d_jlist_ptr = ctx->d_jlist = ctx->d_tvtab = nullptr;
-    ctx->t_X = ctx->t_Pm = ctx->t_DJ = ctx->t_Jt = ctx->t_Jd = ctx->t_DIk = ctx->t_DIl = ctx->t_out = ctx->t_JtTot = nullptr;
+    ctx->t_X = ctx->t_Pm = ctx->t_out = ctx->t_JtTot = nullptr;
     if (ctx->d_rowsec) { (void)tf_free(ctx->d_rowsec); ctx->d_rowsec = nullptr; }
     ctx->bl = BLayout{};
     ctx->d_class_rows = nullptr; ctx->d_row_pos = nullptr; ctx->d_row_ij = nullptr; ctx->d_rowmap = nullptr; ctx->d_Jrow = nullptr; ctx->d_Kp = nullptr;
@@ -827,7 +836,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     // layout: packed (8-fold unique, tf_jkpacked.hip.h) unless asked otherwise
     int layout = ctx->layout_req;
     if (const char *e = getenv("TF_ERI_LAYOUT")) layout = (e[0] == 't') ? 2 : ((e[0] == 'p') ? 1 : (e[0] == 'r' ? 0 : layout));
-    if (layout < 0) layout = 2;
+    if (layout < 0) layout = 1;                                       // (tiles: opt-in -- measured slower than packed at N = 400)
     ctx->layout = layout;
     // packed: the symmetry-unique, parity-allowed values (layouts 1 and 2: the generation and its slab are the same); tiles: stored
     // j-innermost in (i, class pair, strip, chunk) regions (tf_tiles.h) instead of row by row (tf_jkpacked.hip.h)
@@ -929,6 +938,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         std::vector<std::pair<int, int>> rows_ij(row_ij.size());
         for (size_t r = 0; r < row_ij.size(); ++r) rows_ij[r] = {H.sigma[row_ij[r].x], H.sigma[row_ij[r].y]};
         static const int part_steps = std::min(TT_STEPS_MAX, getenv("TF_TILE_PART_STEPS") ? std::max(1, atoi(getenv("TF_TILE_PART_STEPS"))) : TT_STEPS_MAX);
+        ctx->tclass = C; ctx->trows = rows_ij;
         std::string e = tft::build(C, rows_ij, part_steps, ctx->tiles);
         if (!e.empty()) TF_FAIL(ctx, TF_EINVAL, "%s", e.c_str());
         static const int ksub_env = getenv("TF_TILE_KSUB") ? atoi(getenv("TF_TILE_KSUB")) : TT_KS;
@@ -1125,13 +1135,8 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                 if (!rc3) ctx->tile_allocs.push_back(*d);
                 return rc3;
             };
-            tf_ctx::TileList &D = ctx->tl1;
-            if (ctx->ksub1 != TT_KS && ((rc2 = up_t(TL.pairs, &D.d_pairs)) || (rc2 = up_t(TL.runs, &D.d_runs)))) return rc2;   // (the shapes of the DJ vectors differ)
-            if ((rc2 = up_t(TL.tasks, &D.d_tasks)) || (rc2 = up_t(TL.itask_ptr, &D.d_itask_ptr)) || (rc2 = up_t(TL.itasks, &D.d_itasks)) ||
-                (rc2 = up_t(TT.jlist_ptr, &ctx->d_jlist_ptr)) || (rc2 = up_t(TT.jlist, &ctx->d_jlist)))
+            if ((rc2 = tile_list_upload(ctx, TL, ctx->ksub1 != TT_KS, ctx->tl1)) || (rc2 = up_t(TT.jlist_ptr, &ctx->d_jlist_ptr)) || (rc2 = up_t(TT.jlist, &ctx->d_jlist)))
                 return rc2;
-            D.n_tasks = (int)TL.tasks.size(); D.ksub = TL.ksub; D.n_di = TL.n_di; D.dj_len = TL.dj_len; D.jd_len = TL.jd_len; D.jt_len = TL.jt_len;
-            for (int b = 0; b <= TT_W; ++b) D.bucket[b] = TL.bucket[b];
             return TF_OK;
         }
         if ((rc2 = build_jk_tables(JKShape<1>::RB, ctx->jkt[0])) || (rc2 = build_jk_tables(JKShape<2>::RB, ctx->jkt[1]))) return rc2;
@@ -2351,11 +2356,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             if (zero) HIPCHK(ctx, hipMemset(*p, 0, std::max<size_t>(1, doubles) * sizeof(double)));
             return TF_OK;
         };
-        if ((rc = alloc_t(&ctx->t_X, nn, false)) || (rc = alloc_t(&ctx->t_Pm, pml, true)) || (rc = alloc_t(&ctx->t_DJ, (size_t)D.dj_len, false)) ||
-            (rc = alloc_t(&ctx->t_Jt, (size_t)D.jt_len, false)) || (rc = alloc_t(&ctx->t_Jd, (size_t)D.jd_len, false)) ||
-            (rc = alloc_t(&ctx->t_DIk, (size_t)D.n_di * 64, false)) || (rc = alloc_t(&ctx->t_DIl, (size_t)D.n_di * 16, false)) ||
-            (rc = alloc_t(&ctx->t_out, 2 * 6 * nn, true)) || (rc = alloc_t(&ctx->t_JtTot, pml, true)))
+        if ((rc = alloc_t(&ctx->t_X, 8 * nn, false)) || (rc = alloc_t(&ctx->t_Pm, 8 * pml, true)) || (rc = alloc_t(&ctx->t_out, 2 * 6 * 8 * nn, true)) ||
+            (rc = alloc_t(&ctx->t_JtTot, 8 * pml, true)))
             return rc;
+        (void)D;
     } else if (packed) {
         // everything sized for a two-density pass (second density behind the first)
         const size_t npr = (size_t)std::max<long long>(1, H.NPtot);    // padded pair index space
@@ -2383,9 +2387,10 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     } else
         HIPCHK(ctx, tf_malloc((void **)&ctx->d_Kp, 2 * std::max<size_t>(1, (size_t)ctx->n_rows) * 2 * ld * sizeof(double)));
     HIPCHK(ctx, tf_malloc((void **)&ctx->d_Ppad, 2 * (size_t)N * ld * sizeof(double)));
-    HIPCHK(ctx, tf_malloc((void **)&ctx->d_J, 2 * nn * sizeof(double)));
-    HIPCHK(ctx, tf_malloc((void **)&ctx->d_K, 2 * nn * sizeof(double)));
-    HIPCHK(ctx, tf_malloc((void **)&ctx->d_P, 2 * nn * sizeof(double)));
+    const size_t npass = tiles ? 8 : 2;                             // densities of one call of tf_fock_jk that go through the tensor together
+    HIPCHK(ctx, tf_malloc((void **)&ctx->d_J, npass * nn * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&ctx->d_K, npass * nn * sizeof(double)));
+    HIPCHK(ctx, tf_malloc((void **)&ctx->d_P, npass * nn * sizeof(double)));
     DBG("build_eri done");
     ctx->have_eri = true;
     return TF_OK;
@@ -2611,98 +2616,171 @@ static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double
     return TF_OK;
 }
 
-// Fock build from the tiles layout (tf_jktile.hip.h): per density pack -> jk_tile_kernel (one launch per workgroup size) beside
-// jk_edge_kernel -> jk_tile_reduce_kernel -> jk_tile_final_kernel.  A non-symmetric density takes two passes (K = D(P^T) + D(P)^T).
-static int launch_jk_tiles(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st, const int *nonsym)
+// Fock build from the tiles layout (tf_jktile.hip.h): pack -> jk_tile_kernel beside jk_edge_kernel -> jk_tile_reduce_kernel ->
+// jk_tile_final_kernel.  One density per pass (a non-symmetric one: two passes, K = D(P^T) + D(P)^T), or -- symmetric densities only --
+// up to eight per pass: densities = columns of the B operands of the matrix-core products (ND = 4 or 8; fewer: zero columns).
+extern "C++" {
+// the partial-sum buffers of a list for nd densities per pass
+static int tile_list_buffers(tf_ctx *ctx, tf_ctx::TileList &D, int nd)
+{
+    if (D.nd_cap >= nd) return TF_OK;
+    auto alloc_t = [&](double **p, size_t doubles) -> int {
+        HIPCHK(ctx, tf_malloc((void **)p, std::max<size_t>(1, doubles) * sizeof(double)));
+        ctx->tile_allocs.push_back(*p);
+        return TF_OK;
+    };
+    int rc;
+    if ((rc = alloc_t(&D.DJ, (size_t)D.dj_len * nd)) || (rc = alloc_t(&D.Jt, (size_t)D.jt_len * nd)) || (rc = alloc_t(&D.Jd, (size_t)D.jd_len * nd)) ||
+        (rc = alloc_t(&D.DIk, (size_t)D.n_di * 64 * nd)) || (rc = alloc_t(&D.DIl, (size_t)D.n_di * 16 * nd)))
+        return rc;
+    D.nd_cap = nd;
+    return TF_OK;
+}
+// device copy of a task list
+static int tile_list_upload(tf_ctx *ctx, const tft::TaskList &TL, bool own_shapes, tf_ctx::TileList &D)
+{
+    auto up_t = [&](const auto &h, auto **d) -> int {
+        int rc3 = upload(ctx, h, d, false);
+        if (!rc3) ctx->tile_allocs.push_back(*d);
+        return rc3;
+    };
+    int rc;
+    if (own_shapes && ((rc = up_t(TL.pairs, &D.d_pairs)) || (rc = up_t(TL.runs, &D.d_runs)))) return rc;   // (the shapes of the DJ vectors differ with the strip height)
+    if ((rc = up_t(TL.tasks, &D.d_tasks)) || (rc = up_t(TL.itask_ptr, &D.d_itask_ptr)) || (rc = up_t(TL.itasks, &D.d_itasks))) return rc;
+    D.n_tasks = (int)TL.tasks.size(); D.ksub = TL.ksub; D.n_di = TL.n_di; D.dj_len = TL.dj_len; D.jd_len = TL.jd_len; D.jt_len = TL.jt_len;
+    for (int b = 0; b <= TT_W; ++b) D.bucket[b] = TL.bucket[b];
+    return TF_OK;
+}
+
+// one pass over the tensor for the ND densities in ctx->t_X / t_Pm (packed by the caller); `out`: [6][ND][N][N]
+template <int ND>
+static int jk_tiles_pass(tf_ctx *ctx, tf_ctx::TileList &D, hipStream_t st, double *out)
 {
     const int N = ctx->N;
     const size_t nn = (size_t)N * N;
-    const tf_ctx::TileList &D = ctx->tl1;
     const tft::Tables &TT = ctx->tiles;
-    const dim3 gN((unsigned)((nn + 255) / 256)), b256(256);
+    int rc = tile_list_buffers(ctx, D, ND);
+    if (rc) return rc;
     int jt_rows = 0;
     for (int p = 0; p < TT.npair; ++p) jt_rows += ctx->hl.csize[TT.pa[p]];
+    const size_t edge_lds = (size_t)(2 + 3 * TT_EDGE_WAVES) * N * sizeof(double), red_lds = std::max((size_t)2 * TT_RED_WAVES * N, (size_t)TT_RED_WAVES * 64 * TT_RED_CT) * sizeof(double);
+    if (std::max(edge_lds, red_lds) > ctx->tile_lds_set) {                // (beyond the default 64 KB per workgroup: N > 580)
+        if (std::max(edge_lds, red_lds) > (size_t)160 * 1024 - 1024) TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the LDS rows of the tiles layout's reductions", N);
+        const int want = (int)std::max(edge_lds, red_lds);
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_edge_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_edge_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_edge_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_tile_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        ctx->tile_lds_set = (size_t)want;
+    }
+    TJArgs A{};
+    A.DJ = D.DJ; A.Jt = D.Jt; A.Jd = D.Jd; A.DIk = D.DIk; A.DIl = D.DIl; A.sJt = (size_t)D.jt_len; A.sDIk = (size_t)D.n_di * 64; A.sDIl = (size_t)D.n_di * 16;
+    A.N = N; A.pm_len = TT.pm_len;
+    TEArgs E{};
+    E.edge_base = TT.edge_base; E.N = N; E.tab = ctx->d_tvtab; E.EJ = out + 5 * ND * nn; E.ED = out + 2 * ND * nn; E.EDT = out + 3 * ND * nn; E.sE = nn;
+    const bool fork = ctx->have_streams && getenv("TF_JK_SERIAL") == nullptr;
+    if (D.n_tasks > 0) {
+        hipEvent_t ev_after = nullptr;
+        if (ctx->prof_jk) {
+            if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { ctx->prof_ev.push_back(a); ctx->prof_ev.push_back(b); }
+            }
+            if (ctx->prof_used + 2 <= ctx->prof_ev.size()) {
+                (void)hipEventRecord(ctx->prof_ev[ctx->prof_used], st);
+                ev_after = ctx->prof_ev[ctx->prof_used + 1];
+                ctx->prof_used += 2;
+            }
+        }
+        if (fork) (void)hipEventRecord(ctx->sev[0], st);
+        // ONE launch of full-size workgroups over all tasks (measured at N = 400: 1.57 ms against 1.82 for one launch per workgroup size
+        // on side streams -- loads only); the idle waves of the narrower tasks wait in the task's barriers
+        static const int pf_env = getenv("TF_TILE_PF") ? atoi(getenv("TF_TILE_PF")) : 2;
+        const dim3 grid((unsigned)D.n_tasks), block(64 * TT_W);
+#define TF_TJ_LAUNCH(NDV, MBV, PFV) hipLaunchKernelGGL((jk_tile_kernel<NDV, MBV, PFV>), grid, block, 0, st, ctx->d_eri, D.d_tasks, ctx->t_X, ctx->t_Pm, A)
+        if constexpr (ND == 1) {
+            if (D.ksub == 16) { if (pf_env == 1) TF_TJ_LAUNCH(1, 1, 1); else TF_TJ_LAUNCH(1, 1, 2); }
+            else if (D.ksub == 32) { if (pf_env == 1) TF_TJ_LAUNCH(1, 2, 1); else TF_TJ_LAUNCH(1, 2, 2); }
+            else TF_TJ_LAUNCH(1, 4, 1);
+        } else {
+            if (D.ksub != 16) TF_FAIL(ctx, TF_EINVAL, "tiles layout: the wide pass needs the list of 16-row strips");
+            if (pf_env == 1) TF_TJ_LAUNCH(ND, 1, 1); else TF_TJ_LAUNCH(ND, 1, 2);
+        }
+#undef TF_TJ_LAUNCH
+        if (ev_after) (void)hipEventRecord(ev_after, st);
+    }
+    {
+        // the edge elements beside the tile launch
+        hipStream_t ls = st;
+        if (fork && D.n_tasks > 0) { ls = ctx->streams[1]; (void)hipStreamWaitEvent(ls, ctx->sev[0], 0); }
+        hipLaunchKernelGGL((jk_edge_kernel<ND>), dim3((unsigned)N, (unsigned)ND), dim3(64 * TT_EDGE_WAVES), edge_lds, ls, ctx->d_eri, ctx->t_X, D.d_runs, E);
+        if (ls != st) { (void)hipEventRecord(ctx->sev[1], ls); (void)hipStreamWaitEvent(st, ctx->sev[1], 0); }
+    }
+    TRArgs R{};
+    R.itask_ptr = D.d_itask_ptr; R.itasks = D.d_itasks; R.jlist_ptr = ctx->d_jlist_ptr; R.clsI = ctx->bl.clsI;
+    R.DJ = D.DJ; R.Jt = D.Jt; R.Jd = D.Jd; R.DIk = D.DIk; R.DIl = D.DIl; R.T = ctx->d_eri; R.X = ctx->t_X;
+    R.sJt = A.sJt; R.sDIk = A.sDIk; R.sDIl = A.sDIl; R.sO = nn;
+    R.Dj = out; R.Di = out + (size_t)ND * nn; R.JD = out + (size_t)4 * ND * nn; R.JtTot = ctx->t_JtTot;
+    R.edge_base = TT.edge_base; R.N = N; R.ksub = D.ksub; R.npair = TT.npair; R.nd = ND; R.pm_len = TT.pm_len; R.tab = ctx->d_tvtab;
+    R.jt_rows = jt_rows;
+    const unsigned nblk = (unsigned)ND * (unsigned)(5 * N + jt_rows);
+    hipLaunchKernelGGL(jk_tile_reduce_kernel, dim3(nblk), dim3(TT_RED_THREADS), red_lds, st, D.d_tasks, D.d_pairs, D.d_runs, ctx->d_jlist, R);
+    return TF_OK;
+}
+}  // extern "C++"
+
+static int launch_jk_tiles(tf_ctx *ctx, int nd, const double *const *dP, double *const *dJ, double *const *dK, hipStream_t st, const int *nonsym)
+{
+    const int N = ctx->N;
+    const size_t nn = (size_t)N * N, pml = (size_t)std::max(1, ctx->tiles.pm_len);
+    const dim3 gN((unsigned)((nn + 255) / 256)), b256(256);
+    auto final_launch = [&](const double *o0, const double *o1, int ndp, int d, const double *jtt, double *J, double *K) {
+        TFArgs F{};                                                          // out sets: [6][ndp][N][N]; D of the first pass, D2 of the last
+        F.Dj = o0 + (size_t)(0 * ndp + d) * nn; F.Di = o0 + (size_t)(1 * ndp + d) * nn; F.ED = o0 + (size_t)(2 * ndp + d) * nn; F.EDT = o0 + (size_t)(3 * ndp + d) * nn;
+        F.Dj2 = o1 + (size_t)(0 * ndp + d) * nn; F.Di2 = o1 + (size_t)(1 * ndp + d) * nn; F.ED2 = o1 + (size_t)(2 * ndp + d) * nn; F.EDT2 = o1 + (size_t)(3 * ndp + d) * nn;
+        F.JD = o1 + (size_t)(4 * ndp + d) * nn; F.EJ = o1 + (size_t)(5 * ndp + d) * nn; F.JtTot = jtt; F.tab = ctx->d_tvtab;
+        hipLaunchKernelGGL(jk_tile_final_kernel, gN, b256, 0, st, F, ctx->bl, J, K);
+    };
+    bool any_general = false;
+    for (int d = 0; d < nd; ++d) any_general = any_general || (nonsym && nonsym[d]);
+    static const int wide_min = getenv("TF_TILE_WIDE_MIN") ? atoi(getenv("TF_TILE_WIDE_MIN")) : 2;     // fewest densities that go through the wide pass
+    if (nd >= wide_min && nd >= 2 && !any_general) {
+        // the list of 16-row strips (one row block per wave: the registers hold ND accumulator sets), built at first use
+        if (!ctx->tlw.d_tasks) {
+            static const int part_steps = std::min(TT_STEPS_MAX, getenv("TF_TILE_PART_STEPS") ? std::max(1, atoi(getenv("TF_TILE_PART_STEPS"))) : TT_STEPS_MAX);
+            const tft::TaskList *TL = &ctx->tsubw;
+            if (ctx->ksub1 == 16) TL = &ctx->tsub1;
+            else {
+                const std::string e = tft::build_list(ctx->tclass, ctx->tiles, ctx->trows, 16, part_steps, ctx->tsubw);
+                if (!e.empty()) TF_FAIL(ctx, TF_EINVAL, "%s", e.c_str());
+            }
+            int rc = tile_list_upload(ctx, *TL, true, ctx->tlw);
+            if (rc) return rc;
+        }
+        for (int d0 = 0; d0 < nd;) {
+            const int left = nd - d0, ndp = left > 4 ? 8 : 4, n = std::min(left, ndp);
+            for (int d = 0; d < n; ++d)
+                hipLaunchKernelGGL(pack_density_tiles_kernel, gN, b256, 0, st, dP[d0 + d], ctx->bl, ctx->tv, 0, ctx->t_X + (size_t)d * nn, ctx->t_Pm + (size_t)d * pml);
+            if (n < ndp) {                                                   // empty columns
+                HIPCHK(ctx, hipMemsetAsync(ctx->t_X + (size_t)n * nn, 0, (size_t)(ndp - n) * nn * sizeof(double), st));
+                HIPCHK(ctx, hipMemsetAsync(ctx->t_Pm + (size_t)n * pml, 0, (size_t)(ndp - n) * pml * sizeof(double), st));
+            }
+            int rc = ndp == 8 ? jk_tiles_pass<8>(ctx, ctx->tlw, st, ctx->t_out) : jk_tiles_pass<4>(ctx, ctx->tlw, st, ctx->t_out);
+            if (rc) return rc;
+            for (int d = 0; d < n; ++d) final_launch(ctx->t_out, ctx->t_out, ndp, d, ctx->t_JtTot + (size_t)d * pml, dJ[d0 + d], dK[d0 + d]);
+            d0 += n;
+        }
+        return TF_OK;
+    }
     for (int d = 0; d < nd; ++d) {
         const bool general = nonsym && nonsym[d];
         for (int pass = 0; pass < (general ? 2 : 1); ++pass) {
-            double *out = ctx->t_out + (size_t)pass * 6 * nn;              // Dj, Di, ED, EDT, JD, EJ of this pass
+            double *out = ctx->t_out + (size_t)pass * 6 * nn;
             hipLaunchKernelGGL(pack_density_tiles_kernel, gN, b256, 0, st, dP[d], ctx->bl, ctx->tv, (general && pass == 0) ? 1 : 0, ctx->t_X, ctx->t_Pm);
-            const size_t edge_lds = (size_t)(2 + 3 * TT_EDGE_WAVES) * N * sizeof(double), red_lds = std::max((size_t)2 * TT_RED_WAVES * N, (size_t)TT_RED_WAVES * 64 * TT_RED_CT) * sizeof(double);
-            if (std::max(edge_lds, red_lds) > ctx->tile_lds_set) {                                // (beyond the default 64 KB per workgroup: N > 580)
-                if (std::max(edge_lds, red_lds) > (size_t)160 * 1024 - 1024) TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the LDS rows of the tiles layout's reductions", N);
-                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_edge_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(edge_lds, red_lds)));
-                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_tile_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(edge_lds, red_lds)));
-                ctx->tile_lds_set = std::max(edge_lds, red_lds);
-            }
-            TJArgs A{};
-            A.DJ = ctx->t_DJ; A.Jt = ctx->t_Jt; A.Jd = ctx->t_Jd; A.DIk = ctx->t_DIk; A.DIl = ctx->t_DIl; A.N = N; A.pm_len = TT.pm_len;
-            TEArgs E{};
-            E.edge_base = TT.edge_base; E.N = N; E.tab = ctx->d_tvtab; E.EJ = out + 5 * nn; E.ED = out + 2 * nn; E.EDT = out + 3 * nn; E.sE = 0;
-            if (D.n_tasks > 0) {
-                hipEvent_t ev_after = nullptr;
-                if (ctx->prof_jk) {
-                    if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
-                        hipEvent_t a, b;
-                        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { ctx->prof_ev.push_back(a); ctx->prof_ev.push_back(b); }
-                    }
-                    if (ctx->prof_used + 2 <= ctx->prof_ev.size()) {
-                        (void)hipEventRecord(ctx->prof_ev[ctx->prof_used], st);
-                        ev_after = ctx->prof_ev[ctx->prof_used + 1];
-                        ctx->prof_used += 2;
-                    }
-                }
-                static const bool serial = getenv("TF_JK_SERIAL") != nullptr;
-                static const int one_launch_below = getenv("TF_JK_ONE_LAUNCH") ? atoi(getenv("TF_JK_ONE_LAUNCH")) : 1 << 30;   // (measured at N = 400: one launch of full-size workgroups 1.57 ms, four launches side by side 1.82 -- loads only)
-                int n_launch = 0;
-                for (int b = 0; b < TT_W; ++b) n_launch += D.bucket[b + 1] > D.bucket[b] ? 1 : 0;
-                const bool one_launch = n_launch > 1 && D.n_tasks < one_launch_below;
-                const bool fork = !serial && ctx->have_streams;
-                if (fork) (void)hipEventRecord(ctx->sev[0], st);
-                int side = 0;
-                bool first = true;
-                static const int pf_env = getenv("TF_TILE_PF") ? atoi(getenv("TF_TILE_PF")) : 2;
-                auto launch_tiles = [&](int t0, int nt, int nwv, hipStream_t ls) {
-#define TF_TJ_LAUNCH(MBV, PFV) hipLaunchKernelGGL((jk_tile_kernel<1, MBV, PFV>), dim3((unsigned)nt), dim3(64 * nwv), 0, ls, ctx->d_eri, D.d_tasks + t0, ctx->t_X, ctx->t_Pm, A)
-                    if (D.ksub == 16) { if (pf_env == 1) TF_TJ_LAUNCH(1, 1); else if (pf_env == 4) TF_TJ_LAUNCH(1, 4); else TF_TJ_LAUNCH(1, 2); }
-                    else if (D.ksub == 32) { if (pf_env == 1) TF_TJ_LAUNCH(2, 1); else TF_TJ_LAUNCH(2, 2); }
-                    else { if (pf_env == 1) TF_TJ_LAUNCH(4, 1); else TF_TJ_LAUNCH(4, 2); }
-#undef TF_TJ_LAUNCH
-                };
-                if (one_launch) launch_tiles(0, D.n_tasks, TT_W, st);
-                for (int b = 0; b < TT_W && !one_launch; ++b) {
-                    const int t0 = D.bucket[b], t1 = D.bucket[b + 1];
-                    if (t1 <= t0) continue;
-                    hipStream_t ls = st;
-                    if (fork && !first) { ++side; ls = ctx->streams[side]; (void)hipStreamWaitEvent(ls, ctx->sev[0], 0); }
-                    first = false;
-                    launch_tiles(t0, t1 - t0, TT_W - b, ls);
-                    if (ls != st) { (void)hipEventRecord(ctx->sev[side], ls); (void)hipStreamWaitEvent(st, ctx->sev[side], 0); }
-                }
-                if (ev_after) (void)hipEventRecord(ev_after, st);
-                // the edge elements beside the tile launches
-                {
-                    hipStream_t ls = st;
-                    if (fork) { ++side; ls = ctx->streams[side]; (void)hipStreamWaitEvent(ls, ctx->sev[0], 0); }
-                    hipLaunchKernelGGL((jk_edge_kernel<1>), dim3((unsigned)N), dim3(64 * TT_EDGE_WAVES), edge_lds, ls, ctx->d_eri, ctx->t_X, ctx->tl1.d_runs, E);
-                    if (ls != st) { (void)hipEventRecord(ctx->sev[side], ls); (void)hipStreamWaitEvent(st, ctx->sev[side], 0); }
-                }
-            } else
-                hipLaunchKernelGGL((jk_edge_kernel<1>), dim3((unsigned)N), dim3(64 * TT_EDGE_WAVES), edge_lds, st, ctx->d_eri, ctx->t_X, ctx->tl1.d_runs, E);
-            TRArgs R{};
-            R.itask_ptr = D.d_itask_ptr; R.itasks = D.d_itasks; R.jlist_ptr = ctx->d_jlist_ptr; R.clsI = ctx->bl.clsI;
-            R.DJ = ctx->t_DJ; R.Jt = ctx->t_Jt; R.Jd = ctx->t_Jd; R.DIk = ctx->t_DIk; R.DIl = ctx->t_DIl; R.T = ctx->d_eri; R.X = ctx->t_X;
-            R.Dj = out; R.Di = out + nn; R.JD = out + 4 * nn; R.JtTot = ctx->t_JtTot;
-            R.edge_base = TT.edge_base; R.N = N; R.ksub = D.ksub; R.npair = TT.npair; R.nd = 1; R.pm_len = TT.pm_len; R.tab = ctx->d_tvtab;
-            R.jt_rows = jt_rows;
-            const unsigned nblk = (unsigned)(5 * N + jt_rows);
-            hipLaunchKernelGGL(jk_tile_reduce_kernel, dim3(nblk), dim3(TT_RED_THREADS), red_lds, st, D.d_tasks, D.d_pairs, D.d_runs, ctx->d_jlist, R);
+            int rc = jk_tiles_pass<1>(ctx, ctx->tl1, st, out);
+            if (rc) return rc;
             if (general && pass == 0) continue;
-            const double *o0 = ctx->t_out, *o1 = out;                        // D of the first pass, D2 of the last
-            TFArgs F{};
-            F.Dj = o0; F.Di = o0 + nn; F.ED = o0 + 2 * nn; F.EDT = o0 + 3 * nn;
-            F.Dj2 = o1; F.Di2 = o1 + nn; F.ED2 = o1 + 2 * nn; F.EDT2 = o1 + 3 * nn;
-            F.JD = o1 + 4 * nn; F.EJ = o1 + 5 * nn; F.JtTot = ctx->t_JtTot; F.tab = ctx->d_tvtab;
-            hipLaunchKernelGGL(jk_tile_final_kernel, gN, b256, 0, st, F, ctx->bl, dJ[d], dK[d]);
+            final_launch(ctx->t_out, out, 1, 0, ctx->t_JtTot, dJ[d], dK[d]);
         }
     }
     return TF_OK;
@@ -2883,10 +2961,11 @@ int tf_fock_jk_device(tf_ctx *ctx, int n_dens, const double *dP, double *dJ, dou
     if (n_dens < 1 || !dP || !dJ || !dK) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nn = (size_t)ctx->N * ctx->N;
-    for (int d = 0; d < n_dens; d += 2) {                       // densities go through the tensor two at a time
-        const int nd = std::min(2, n_dens - d);
-        const double *p[2] = {dP + d * nn, dP + (d + nd - 1) * nn};
-        double *j[2] = {dJ + d * nn, dJ + (d + nd - 1) * nn}, *k[2] = {dK + d * nn, dK + (d + nd - 1) * nn};
+    const int chunk = ctx->layout == 2 ? 8 : 2;                  // densities per pass over the tensor: two (packed / rows), up to eight (tiles)
+    for (int d = 0; d < n_dens; d += chunk) {
+        const int nd = std::min(chunk, n_dens - d);
+        const double *p[8]; double *j[8], *k[8];
+        for (int q = 0; q < 8; ++q) { const int dq = d + std::min(q, nd - 1); p[q] = dP + dq * nn; j[q] = dJ + dq * nn; k[q] = dK + dq * nn; }
         int rc = launch_jk(ctx, nd, p, j, k, (hipStream_t)stream);
         if (rc) return rc;
     }
@@ -2900,12 +2979,13 @@ int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K)
     if (n_dens < 1 || !P || !J || !K) TF_FAIL(ctx, TF_EINVAL, "tf_fock_jk: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t nn = (size_t)ctx->N * ctx->N;
-    for (int d = 0; d < n_dens; d += 2) {
-        const int nd = std::min(2, n_dens - d);
+    const int chunk = ctx->layout == 2 ? 8 : 2;
+    for (int d = 0; d < n_dens; d += chunk) {
+        const int nd = std::min(chunk, n_dens - d);
         HIPCHK(ctx, hipMemcpy(ctx->d_P, P + d * nn, nd * nn * sizeof(double), hipMemcpyHostToDevice));
-        const double *p[2] = {ctx->d_P, ctx->d_P + (nd - 1) * nn};
-        double *j[2] = {ctx->d_J, ctx->d_J + (nd - 1) * nn}, *k[2] = {ctx->d_K, ctx->d_K + (nd - 1) * nn};
-        int nonsym[2] = {0, 0};                                  // the packed layout needs a second pass for a non-symmetric density
+        const double *p[8]; double *j[8], *k[8];
+        for (int q = 0; q < 8; ++q) { const int dq = std::min(q, nd - 1); p[q] = ctx->d_P + dq * nn; j[q] = ctx->d_J + dq * nn; k[q] = ctx->d_K + dq * nn; }
+        int nonsym[8] = {0, 0, 0, 0, 0, 0, 0, 0};                // the packed / tiles layouts need a second pass for a non-symmetric density
         const int N = ctx->N;
         for (int q = 0; q < nd; ++q) {
             const double *Pq = P + (d + q) * nn;

@@ -176,8 +176,8 @@ __global__ void pack_density_tiles_kernel(const double *__restrict__ P, BLayout 
 
 // ---- the Fock kernel ------------------------------------------------------------------------------------------------------------
 struct TJArgs {
-    double *DJ, *Jt, *Jd, *DIk, *DIl;
-    size_t sDJ, sJt, sJd, sDIk, sDIl;   // strides between the densities of a pass
+    double *DJ, *Jt, *Jd, *DIk, *DIl;   // DJ and Jd: density-minor ([index][ND]: written at every step); the others: one plane per density
+    size_t sJt, sDIk, sDIl;             // strides between the densities of a pass
     int N, pm_len;
 };
 
@@ -203,15 +203,21 @@ __device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, dou
 #define TT_STEPS_MAX 48
 #endif
 #define TT_STEPS_MAX_DOC                          // steps of a task at most (tf_tiles_host.h: part_steps): its density rows are staged in LDS once
+#define TT_TRP 17
 template <int ND, int MB>
 struct TJLds {
-    double slots[TT_KB * TT_W * ND * 64];
-    double2 pp[TT_W][ND][MB * 2][64];
-    double jdl[TT_W][ND][TT_KB][64];             // Jd: the lanes' partial sums of a block's steps (summed over the wave four steps at a time)
+    static constexpr bool STAGE = ND <= 2;       // one or two densities: their rows of every step and the Jd weights live in LDS; four and
+                                                 // more: the rows come through the prefetch ring (lanes = densities), the weights sit in registers
+    double slots[TT_KB * TT_W * ND * 16 * MB];   // row sums of a block's steps: [step][wave][density][row]
+    double2 pp[STAGE ? TT_W : 1][STAGE ? ND : 1][MB * 2][STAGE ? 64 : 1];
+    double jdl[STAGE ? TT_W : 1][STAGE ? ND : 1][TT_KB][STAGE ? 64 : 1];   // Jd: the lanes' partial sums of a block's steps (summed over the wave four steps at a time)
+    double tr[ND > 1 ? TT_W : 1][ND > 1 ? MB : 1][ND > 1 ? 16 * TT_TRP : 1];   // (ND > 1) a wave's 16 x 16 blocks of the current slice, [k][l] (pitch TT_TRP: odd, no bank conflicts; one buffer per
+                                                 // block: a single one serialises the blocks on the LDS round trip -- 2.1 -> 2.9 ms): written
+                                                 // from the A-operand registers, read back transposed (lane = column l) for the sums over k
     // the density rows of ALL steps of the task, staged by the whole workgroup in the prologue (nothing is loaded for them inside the loop:
     // a wait for such a load would drain the prefetched slices): P_d[j][k] of the task's rows, P_d[j][l] of its column blocks, Pp_d[ij]
-    double pk[ND][TT_STEPS_MAX][16 * MB];
-    double pl[ND][TT_STEPS_MAX][TT_W * TT_LB];
+    double pk[STAGE ? ND : 1][STAGE ? TT_STEPS_MAX : 1][16 * MB];
+    double pl[STAGE ? ND : 1][STAGE ? TT_STEPS_MAX : 1][TT_W * TT_LB];
     double pij[ND][TT_STEPS_MAX];
 };
 
@@ -235,7 +241,6 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
     const size_t nn = (size_t)N * N;
     // ---- per-lane constants
     unsigned offA[MB], offB[MB];
-    double pik[ND][MB];
     int rdiag[MB];
     bool rv[MB];
 #pragma unroll
@@ -247,80 +252,111 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
         const int nst = tt_min(TT_KS, TJ_U(tp->nk) - TT_KS * ks);          // rows of the STORED strip (the chunk order inside a block of 16 rows depends on it)
         offA[mb] = (4 * kk < rl) ? 8u * (unsigned)(woffw + tt_elem_off(tri, ks, lb, rs, 4 * kk, nst, tnl)) : TF_BUF_OOB;
         offB[mb] = (4 * kk + 2 < rl) ? 8u * (unsigned)(woffw + tt_elem_off(tri, ks, lb, rs, 4 * kk + 2, nst, tnl)) : TF_BUF_OOB;
-        const int kI = kbase + k0 + r;
         rdiag[mb] = (k0 + r) - (TT_LB * lb + 4 * kk);                    // the register of this lane that holds k == l (triangles)
-#pragma unroll
-        for (int d = 0; d < ND; ++d) pik[d][mb] = rv[mb] ? X[d * nn + (size_t)iI * N + kI] : 0.0;
     }
     const int lcol0 = TT_LB * lb + 4 * kk;                                 // loc of the lane's first column
     // buffer descriptors: the task's region of the tensor; its DJ vectors (row of step s at s * dj_len); this wave's Jd values
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(T + tbase), 0, (int)min((long long)nj * slice * 8, 0x7fffffffLL), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdj = __builtin_amdgcn_make_buffer_rsrc(A.DJ + dj_base, 0, (int)min((long long)nj * dj_len * 8, 0x7fffffffLL), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rjd = __builtin_amdgcn_make_buffer_rsrc(A.Jd + jd_base + (size_t)w * nj, 0, nj * 8, 0x00020000);
-    const unsigned st_l = ((m & 3) == 0) ? 8u * (unsigned)(dj_loffw + 4 * kk + (m >> 2)) : TF_BUF_OOB;        // column sums: lanes m = 0, 4, 8, 12 of every row
-    const int krel = 16 * (lane >> 4) + ((lane >> 2) & 3) + 4 * (lane & 3);
-    const unsigned st_k = (krel < nks && (lane >> 4) < MB) ? 8u * (unsigned)(dj_koff + krel) : TF_BUF_OOB;       // merged row sums: one lane per row
-    const unsigned st_jd = ((lane & 15) == 0) ? 8u * (unsigned)(lane >> 4) : TF_BUF_OOB;
+    constexpr bool R4V = ND == 1;                                           // the column sums on the vector unit (one density) or the matrix core
+    const __amdgpu_buffer_rsrc_t rdj = __builtin_amdgcn_make_buffer_rsrc(A.DJ + dj_base * ND, 0, (int)min((long long)nj * dj_len * ND * 8, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rjd = __builtin_amdgcn_make_buffer_rsrc(A.Jd + ((size_t)jd_base + (size_t)w * nj) * ND, 0, nj * ND * 8, 0x00020000);
+    const unsigned st_l = R4V ? (((m & 3) == 0) ? 8u * (unsigned)(dj_loffw + 4 * kk + (m >> 2)) : TF_BUF_OOB)   // one density: lanes m = 0, 4, 8, 12 of every row
+                              : ((m < ND) ? 8u * (unsigned)((dj_loffw + kk) * ND + m) : TF_BUF_OOB);            // lane (density m, row kk), registers q: rows kk + 4 q
+    const unsigned st_jd = ((lane & 15) == 0) ? 8u * (unsigned)((lane >> 4) * ND) : TF_BUF_OOB;
+    // Column sums D_d[j][l] = sum_k m P_d[i][k].  One density: lane-local products and a transposing butterfly over the 16 lanes of a DPP row
+    // (measured at N = 400: 2.2 ms against 2.9 through the matrix core, whose LDS round trip per block the single density does not pay
+    // for); several: on the matrix core from the transposed blocks (lane = (column d, row group g), K index 4 q + g), B operand below.
+    double pik[R4V ? MB : 1];
+#pragma unroll
+    for (int mb = 0; mb < (R4V ? MB : 1); ++mb) pik[mb] = (R4V && rv[mb]) ? X[(size_t)iI * N + kbase + k0 + 16 * mb + m] : 0.0;
+    double b4[MB][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * mb + 4 * q + kk;
+            b4[mb][q] = (active && m < ND && r < nks) ? X[(size_t)(m < ND ? m : 0) * nn + (size_t)iI * N + kbase + k0 + r] : 0.0;
+        }
     // B operand of the row sums: column d = P_d[i][l] (lanes m == d), zero elsewhere
     double b1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) b1[r] = (active && m < ND && lcol0 + r < ncol) ? X[(size_t)(m < ND ? m : 0) * nn + (size_t)iI * N + lbase + lcol0 + r] : 0.0;
-    // weights of Jd: Pp_d(k, l) of the lane's elements, kept in LDS (pad columns of the pair matrices are zero)
+    // weights of Jd: Pp_d(k, l) of the lane's elements (pad columns of the pair matrices are zero): in LDS, or in registers (ND >= 4)
+    constexpr bool STAGE = TJLds<ND, MB>::STAGE;
+    double ppr[STAGE ? 1 : ND][MB][4];
     if (active) {
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const double *src = Pm + (size_t)d * A.pm_len + pm_off + (size_t)(k0 + 16 * mb + m) * pm_pitch + lcol0;
-                S.pp[w][d][2 * mb][lane] = (rv[mb] && lcol0 < pm_pitch) ? *reinterpret_cast<const double2 *>(src) : make_double2(0.0, 0.0);
-                S.pp[w][d][2 * mb + 1][lane] = (rv[mb] && lcol0 + 2 < pm_pitch) ? *reinterpret_cast<const double2 *>(src + 2) : make_double2(0.0, 0.0);
+                const double2 q0 = (rv[mb] && lcol0 < pm_pitch) ? *reinterpret_cast<const double2 *>(src) : make_double2(0.0, 0.0);
+                const double2 q1 = (rv[mb] && lcol0 + 2 < pm_pitch) ? *reinterpret_cast<const double2 *>(src + 2) : make_double2(0.0, 0.0);
+                if constexpr (STAGE) { S.pp[w][d][2 * mb][lane] = q0; S.pp[w][d][2 * mb + 1][lane] = q1; }
+                else { ppr[d][mb][0] = q0.x; ppr[d][mb][1] = q0.y; ppr[d][mb][2] = q1.x; ppr[d][mb][3] = q1.y; }
             }
-    }
-    // accumulators
-    double jt[ND][MB][4], x5[ND][4], x2[ND][MB];
+    } else if constexpr (!STAGE) {
 #pragma unroll
-    for (int d = 0; d < ND; ++d) {
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ppr[d][mb][r] = 0.0;
+    }
+    // accumulators.  D_d[i][k] and D_d[i][l] -- sums over the steps -- are lane-local multiply-adds for one or two densities (M25 false)
+    // and two more products on the matrix core (columns = densities, accumulated over the steps) for four and more.
+    constexpr bool M25 = ND >= 4;
+    double jt[ND][MB][4], x5[M25 ? 1 : ND][4], x2[M25 ? 1 : ND][MB];
+    tt_v4d acc2[MB], acc5 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc2[mb] = tt_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int d = 0; d < (M25 ? 1 : ND); ++d) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) x5[d][r] = 0.0;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            x2[d][mb] = 0.0;
+        for (int mb = 0; mb < MB; ++mb) x2[d][mb] = 0.0;
+    }
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) jt[d][mb][r] = 0.0;
-        }
-    }
-    // the density rows of the task's steps -> LDS (all threads of the workgroup; the barrier in front of the loop follows).  All loads of a
-    // thread are issued before its first LDS store (a loop of load - wait - store was 10 us of a 40 us task).
+    // the density rows of the task's steps -> LDS (all threads of the workgroup; the barrier in front of the loop follows), a group of
+    // loads in flight per thread (a loop of load - wait - store was 10 us of a 40 us task).
     {
         const int nthr = (int)blockDim.x, tid = (int)threadIdx.x;
         constexpr int G = 8;                                                // loads in flight per thread
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             const double *Xd = X + d * nn;
-            for (int e0 = tid; e0 < nj * 16 * MB; e0 += G * nthr) {
-                double v[G];
+            if constexpr (STAGE) {
+                for (int e0 = tid; e0 < nj * 16 * MB; e0 += G * nthr) {
+                    double v[G];
 #pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int e = e0 + u * nthr, sq = e / (16 * MB), x = e - sq * (16 * MB);
-                    v[u] = (sq < nj && x < nks) ? Xd[(size_t)(j0 + sq) * N + kbase + k0 + x] : 0.0;
+                    for (int u = 0; u < G; ++u) {
+                        const int e = e0 + u * nthr, sq = e / (16 * MB), x = e - sq * (16 * MB);
+                        v[u] = (sq < nj && x < nks) ? Xd[(size_t)(j0 + sq) * N + kbase + k0 + x] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        const int e = e0 + u * nthr;
+                        if (e < nj * 16 * MB) (&S.pk[d][0][0])[e] = v[u];
+                    }
                 }
+                for (int e0 = tid; e0 < nj * TT_W * TT_LB; e0 += G * nthr) {
+                    double v[G];
 #pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int e = e0 + u * nthr;
-                    if (e < nj * 16 * MB) (&S.pk[d][0][0])[e] = v[u];
-                }
-            }
-            for (int e0 = tid; e0 < nj * TT_W * TT_LB; e0 += G * nthr) {
-                double v[G];
+                    for (int u = 0; u < G; ++u) {
+                        const int e = e0 + u * nthr, sq = e / (TT_W * TT_LB), x = e - sq * (TT_W * TT_LB), lc = TT_LB * lb0 + x;
+                        v[u] = (sq < nj && lc < ncol) ? Xd[(size_t)(j0 + sq) * N + lbase + lc] : 0.0;
+                    }
 #pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int e = e0 + u * nthr, sq = e / (TT_W * TT_LB), x = e - sq * (TT_W * TT_LB), lc = TT_LB * lb0 + x;
-                    v[u] = (sq < nj && lc < ncol) ? Xd[(size_t)(j0 + sq) * N + lbase + lc] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int e = e0 + u * nthr;
-                    if (e < nj * TT_W * TT_LB) (&S.pl[d][0][0])[e] = v[u];
+                    for (int u = 0; u < G; ++u) {
+                        const int e = e0 + u * nthr;
+                        if (e < nj * TT_W * TT_LB) (&S.pl[d][0][0])[e] = v[u];
+                    }
                 }
             }
             if (tid < nj) {
@@ -330,6 +366,30 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
             }
         }
     }
+    // ND >= 4: the B operands of the sums over the steps -- P_d[j][l] of the wave's columns, P_d[j][k] of its rows, d = lane & 15 -- come
+    // through the ring with the slices (loads of the lanes m < ND; a step beyond the last: out of range = zeros)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(X), 0, (int)min((long long)ND * N * N * 8, 0x7fffffffLL), 0x00020000);
+    const unsigned ax_l0 = (active && m < ND && lcol0 < ncol) ? 8u * (unsigned)(m * N * N + lbase + lcol0) : TF_BUF_OOB;
+    const unsigned ax_l1 = (active && m < ND && lcol0 + 2 < ncol) ? 8u * (unsigned)(m * N * N + lbase + lcol0 + 2) : TF_BUF_OOB;
+    unsigned ax_k[MB][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * mb + 4 * q + kk;
+            ax_k[mb][q] = (active && m < ND && r < nks) ? 8u * (unsigned)(m * N * N + kbase + k0 + r) : TF_BUF_OOB;
+        }
+    struct TJAux { double2 l[2]; double k[MB][4]; };
+    auto load_aux = [&](TJAux &Q, int s) {                                   // (s >= nj: nothing)
+        const unsigned so = 8u * (unsigned)((j0 + min(s, nj - 1)) * N);
+        const bool ok = s < nj;
+        Q.l[0] = buf_load2<0>(rx, ok ? ax_l0 : TF_BUF_OOB, so);
+        Q.l[1] = buf_load2<0>(rx, ok ? ax_l1 : TF_BUF_OOB, so);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Q.k[mb][q] = buf_load1<0>(rx, ok ? ax_k[mb][q] : TF_BUF_OOB, so);
+    };
     // The wave's pieces of the next PF slices live in a ring of PF register sets: the loads of row block mb of step s + PF are issued as
     // soon as row block mb of step s has been consumed (the last steps re-load the last slice: no branch, no copies between the sets).
     auto load_mb = [&](double2 (&B)[MB][2], int mb, int s) {
@@ -337,91 +397,150 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
         B[mb][0] = buf_load2<2>(rt, offA[mb], so);
         B[mb][1] = buf_load2<2>(rt, offB[mb], so);
     };
-    auto step = [&](double2 (&B)[MB][2], int s, int kq) {
+    auto step = [&](double2 (&B)[MB][2], TJAux &Q, int s, int kq) {
         const bool self = self_last && s == nj - 1;
         const int sc = min(s, nj - 1);                                      // (every step of a block runs -- those beyond the last on the last step's
         const double live = s < nj ? 1.0 : 0.0;                             // data with zero weights, their stores out of range: a branch around a
         const int snext = min(s + PF, nj - 1);                              // step would make the ring a set of copies)
-        double ppij[ND], pjl[ND][4], pjk[ND][MB];
+        double ppij[ND], pjl[M25 ? 1 : ND][4], pjk[M25 ? 1 : ND][MB], b2[4];
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            ppij[d] = live * S.pij[d][sc];
-            const double2 q0 = *reinterpret_cast<const double2 *>(&S.pl[d][sc][TT_LB * w + 4 * kk]), q1 = *reinterpret_cast<const double2 *>(&S.pl[d][sc][TT_LB * w + 4 * kk + 2]);
-            pjl[d][0] = live * q0.x; pjl[d][1] = live * q0.y; pjl[d][2] = live * q1.x; pjl[d][3] = live * q1.y;
+        for (int d = 0; d < ND; ++d) ppij[d] = live * S.pij[d][sc];
+        if constexpr (M25) {
+            // B operand of D_d[i][k] += sum_l m P_d[j][l]: column d = lanes m == d (from the ring)
+            b2[0] = Q.l[0].x; b2[1] = Q.l[0].y; b2[2] = Q.l[1].x; b2[3] = Q.l[1].y;
+        } else {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) pjk[d][mb] = live * S.pk[d][sc][16 * mb + m];
+            for (int d = 0; d < ND; ++d) {
+                const double2 q0 = *reinterpret_cast<const double2 *>(&S.pl[d][sc][TT_LB * w + 4 * kk]), q1 = *reinterpret_cast<const double2 *>(&S.pl[d][sc][TT_LB * w + 4 * kk + 2]);
+                pjl[d][0] = live * q0.x; pjl[d][1] = live * q0.y; pjl[d][2] = live * q1.x; pjl[d][3] = live * q1.y;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) pjk[d][mb] = live * S.pk[d][sc][16 * mb + m];
+            }
         }
-        double t4[ND][4], jd[ND];
+        double jd[ND];
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            jd[d] = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t4[d][r] = 0.0;
-        }
+        for (int d = 0; d < ND; ++d) jd[d] = 0.0;
         tt_v4d accs[MB];
+        tt_v4d acc4 = {0.0, 0.0, 0.0, 0.0};                                 // column sums of the step: rows l, columns d
+        double t4[4] = {0.0, 0.0, 0.0, 0.0};
+        double *trw = &S.tr[R4V ? 0 : w][0][0];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const double tv[4] = {B[mb][0].x, B[mb][0].y, B[mb][1].x, B[mb][1].y};
+            // the block into LDS, [k = m][l]: the lane's two column pairs
+            if constexpr (!R4V) {
+                double *dst = trw + mb * (16 * TT_TRP) + m * TT_TRP + 4 * kk;
+                dst[0] = tv[0]; dst[1] = tv[1]; dst[2] = tv[2]; dst[3] = tv[3];
+            }
             tt_v4d acc = {0.0, 0.0, 0.0, 0.0};
 #ifndef TJ_ABL_NOMFMA                    // (TJ_ABL_*: timing experiments only, wrong results -- tools/build_variant.sh)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[r], b1[r], acc, 0, 0, 0);
 #endif
             accs[mb] = acc;
+            if constexpr (M25) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[r], b2[r], acc2[mb], 0, 0, 0);
+            }
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
-                const double2 w0 = S.pp[w][d][2 * mb][lane], w1 = S.pp[w][d][2 * mb + 1][lane];
-                const double ppv[4] = {w0.x, w0.y, w1.x, w1.y};
+                double ppv[4];
+                if constexpr (STAGE) {
+                    const double2 w0 = S.pp[w][d][2 * mb][lane], w1 = S.pp[w][d][2 * mb + 1][lane];
+                    ppv[0] = w0.x; ppv[1] = w0.y; ppv[2] = w1.x; ppv[3] = w1.y;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ppv[r] = ppr[d][mb][r];
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double tm = tv[r];
-                    const double to = (DIAG && r == rdiag[mb]) ? 0.0 : tm;          // without the diagonal k == l
 #ifdef TJ_ABL_NOVALU
                     jd[d] += tm;
 #else
                     jt[d][mb][r] += tm * ppij[d];
                     jd[d] += tm * ppv[r];
-                    x2[d][mb] += tm * pjl[d][r];
-                    x5[d][r] += to * pjk[d][mb];
-                    t4[d][r] += to * pik[d][mb];
+                    if constexpr (!M25) {
+                        const double to = (DIAG && r == rdiag[mb]) ? 0.0 : tm;      // without the diagonal k == l
+                        x2[d][mb] += tm * pjl[d][r];
+                        x5[d][r] += to * pjk[d][mb];
+                        if constexpr (R4V) t4[r] += to * pik[mb];
+                    }
 #endif
                 }
             }
+            // the block back, transposed: lane (column l = m, row group kk) holds the rows k = 4 q + kk -- the A operand of the sums over k
+#ifndef TJ_ABL_NOR4
+            if constexpr (!R4V) {
+                const double *src = trw + mb * (16 * TT_TRP) + kk * TT_TRP + m;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double tw = src[4 * q * TT_TRP];
+                    if (DIAG && (k0 + 16 * mb + 4 * q + kk) == (TT_LB * lb + m)) tw = 0.0;      // without the diagonal k == l
+                    acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(tw, b4[mb][q], acc4, 0, 0, 0);
+                    if constexpr (M25) {                                    // D_d[i][l] += sum_k m P_d[j][k]: B column d = lanes m == d, K index 4 q + kk
+                        acc5 = __builtin_amdgcn_mfma_f64_16x16x4f64(tw, Q.k[mb][q], acc5, 0, 0, 0);
+                    }
+                }
+            }
+#endif
             // the slice of step s + PF into the registers this row block has just been read from (issued behind their last use: the
             // ring positions stay the same physical registers around the loop -- no copies, no wait for the loads in flight)
             __builtin_amdgcn_sched_barrier(0);
             load_mb(B, mb, snext);
             __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int d = 0; d < ND; ++d) S.jdl[w][d][kq][lane] = jd[d];
-        // column sums D_d[j][l]: over the 16 rows of the lane's DPP row; lane m then holds column 4 kk + (m >> 2)
-        const unsigned srow = (self || s >= nj) ? TF_BUF_OOB : (unsigned)s * (unsigned)dj_len * 8u;     // (the row (i, i) takes no D[j][.] terms)
-#ifndef TJ_ABL_NOR4
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const double cs = row_sum4(t4[d][0], t4[d][1], t4[d][2], t4[d][3]);
-            buf_store1<0>(d == 0 ? rdj : __builtin_amdgcn_make_buffer_rsrc(A.DJ + d * A.sDJ + dj_base, 0, (int)min((long long)nj * dj_len * 8, 0x7fffffffLL), 0x00020000),
-                          st_l, srow, cs);
+        if constexpr (M25) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_aux(Q, s + PF);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (STAGE) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d) S.jdl[w][d][kq][lane] = jd[d];
+        } else {
+            // Jd of the step: the wave totals of the ND densities together; density-minor store
+            double v;
+            if constexpr (ND == 4) v = wave_sum4(jd[0], jd[1], jd[2], jd[3]);          // lane L: density L >> 4
+            else { const double v8[8] = {jd[0], jd[1], jd[2], jd[3], jd[4 % ND], jd[5 % ND], jd[6 % ND], jd[7 % ND]}; v = wave_sum8(v8); }   // lane L: density L >> 3
+            constexpr int SH = ND == 4 ? 4 : 3;
+            const bool own = (lane & ((1 << SH) - 1)) == 0 && s < nj;
+            buf_store1<0>(rjd, own ? 8u * (unsigned)(lane >> SH) : TF_BUF_OOB, (unsigned)(min(s, nj - 1) * ND * 8), v);
+        }
+        // column sums D_d[j][l]: column d of acc4 = lanes m == d, rows l = kk + 4 q
+        {
+            // (the row (i, i) takes no D[j][.] terms; a step beyond the last stores nothing.  Dropped through the LANE offset: the scalar
+            // offset of a buffer access is not range-checked)
+            const unsigned lo = (self || s >= nj) ? TF_BUF_OOB : st_l;
+            const unsigned srow = (unsigned)min(s, nj - 1) * (unsigned)dj_len * (unsigned)(8 * ND);
+#ifndef TJ_ABL_NOR4
+            if constexpr (R4V) buf_store1<0>(rdj, lo, srow, row_sum4(t4[0], t4[1], t4[2], t4[3]));   // lane m holds column 4 kk + (m >> 2)
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) buf_store1<0>(rdj, lo, srow + (unsigned)(32 * ND * q), acc4[q]);
+            }
 #endif
+        }
         // row sums D_d[j][k]: column d of the result tiles = lanes m == d, rows kk + 4 q (written behind the vector work: the matrix
         // core has long delivered)
         if (m < ND) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                double *sl = S.slots + ((size_t)(kq * TT_W + w) * ND + m) * 64 + mb * 16 + kk * 4;
+                double *sl = S.slots + ((size_t)(kq * TT_W + w) * ND + m) * (16 * MB) + mb * 16 + kk * 4;
                 *reinterpret_cast<double2 *>(sl) = make_double2(accs[mb][0], accs[mb][1]);
                 *reinterpret_cast<double2 *>(sl + 2) = make_double2(accs[mb][2], accs[mb][3]);
             }
         }
     };
     double2 R[PF][MB][2];
+    TJAux RQ[PF];
     if (active) {
 #pragma unroll
-        for (int q = 0; q < PF; ++q)
+        for (int q = 0; q < PF; ++q) {
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) load_mb(R[q], mb, min(q, nj - 1));
+            if constexpr (M25) load_aux(RQ[q], q);
+        }
     }
     __syncthreads();                                                       // the density rows and the Jd weights are in place
     for (int sb = 0; sb < nj; sb += TT_KB) {
@@ -431,14 +550,14 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
 #pragma unroll 1
             for (int kq0 = 0; kq0 < TT_KB; kq0 += PF) {
 #pragma unroll
-                for (int q = 0; q < PF; ++q) step(R[q], sb + kq0 + q, kq0 + q);
+                for (int q = 0; q < PF; ++q) step(R[q], RQ[q], sb + kq0 + q, kq0 + q);
             }
             // Jd of the steps sb .. sb + 3: the wave totals of four values together (steps beyond the last: out of the buffer's range)
+            if constexpr (STAGE)
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const double v = wave_sum4(S.jdl[w][d][0][lane], S.jdl[w][d][1][lane], S.jdl[w][d][2][lane], S.jdl[w][d][3][lane]);
-                buf_store1<0>(d == 0 ? rjd : __builtin_amdgcn_make_buffer_rsrc(A.Jd + d * A.sJd + jd_base + (size_t)w * nj, 0, nj * 8, 0x00020000), st_jd,
-                              (unsigned)sb * 8u, v);
+                buf_store1<0>(rjd, ((lane & 15) == 0 && sb + (lane >> 4) < nj) ? st_jd : TF_BUF_OOB, (unsigned)((sb * ND + d) * 8), v);
             }
         }
 #ifndef TJ_ABL_NOMERGE
@@ -449,12 +568,13 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
             const int s = sb + kq;
             if (s >= nj) break;
             const bool self = self_last && s == nj - 1;
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                double v = S.slots[((size_t)(kq * TT_W) * ND + d) * 64 + lane];
-                for (int u = 1; u < tnw; ++u) v += S.slots[((size_t)(kq * TT_W + u) * ND + d) * 64 + lane];
-                buf_store1<0>(d == 0 ? rdj : __builtin_amdgcn_make_buffer_rsrc(A.DJ + d * A.sDJ + dj_base, 0, (int)min((long long)nj * dj_len * 8, 0x7fffffffLL), 0x00020000),
-                              st_k, self ? TF_BUF_OOB : (unsigned)s * (unsigned)dj_len * 8u, v);
+            // the 16 MB rows x ND densities of the step, density-minor as they are stored: element e = row ND + d
+            for (int e = lane; e < 16 * MB * ND; e += 64) {
+                const int row = e / ND, d = e - row * ND;                  // row: position in the slots = mb 16 + kk 4 + q  <->  strip row mb 16 + kk + 4 q
+                double v = S.slots[((size_t)(kq * TT_W) * ND + d) * (16 * MB) + row];
+                for (int u = 1; u < tnw; ++u) v += S.slots[((size_t)(kq * TT_W + u) * ND + d) * (16 * MB) + row];
+                const int krel = 16 * (row >> 4) + ((row >> 2) & 3) + 4 * (row & 3);
+                buf_store1<0>(rdj, (krel < nks && !self) ? 8u * (unsigned)((dj_koff + krel) * ND + d) : TF_BUF_OOB, (unsigned)s * (unsigned)dj_len * (unsigned)(8 * ND), v);
             }
         }
 #ifndef TJ_ABL_NOMERGE
@@ -471,14 +591,26 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
             if (rv[mb] && lcol0 < jt_pitch) *reinterpret_cast<double2 *>(dst) = make_double2(jt[d][mb][0], jt[d][mb][1]);
             if (rv[mb] && lcol0 + 2 < jt_pitch) *reinterpret_cast<double2 *>(dst + 2) = make_double2(jt[d][mb][2], jt[d][mb][3]);
         }
-        const double cs = row_sum4(x5[d][0], x5[d][1], x5[d][2], x5[d][3]);   // D[i][l]: over the rows
-        if ((m & 3) == 0) A.DIl[d * A.sDIl + (size_t)(di_base + w) * 16 + 4 * kk + (m >> 2)] = cs;
+        if constexpr (!M25) {
+            const double cs = row_sum4(x5[d][0], x5[d][1], x5[d][2], x5[d][3]);   // D[i][l]: over the rows
+            if ((m & 3) == 0) A.DIl[d * A.sDIl + (size_t)(di_base + w) * 16 + 4 * kk + (m >> 2)] = cs;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {                                   // D[i][k]: over the four lane groups
-            double v = x2[d][mb];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (kk == 0) A.DIk[d * A.sDIk + (size_t)(di_base + w) * 64 + 16 * mb + m] = v;
+            for (int mb = 0; mb < MB; ++mb) {                               // D[i][k]: over the four lane groups
+                double v = x2[d][mb];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (kk == 0) A.DIk[d * A.sDIk + (size_t)(di_base + w) * 64 + 16 * mb + m] = v;
+            }
+        }
+    }
+    if constexpr (M25) {                                                    // column d of the result tiles = lanes m == d, rows kk + 4 q
+        if (m < ND) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                A.DIl[m * A.sDIl + (size_t)(di_base + w) * 16 + kk + 4 * q] = acc5[q];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) A.DIk[m * A.sDIk + (size_t)(di_base + w) * 64 + 16 * mb + kk + 4 * q] = acc2[mb][q];
+            }
         }
     }
 }
@@ -486,7 +618,7 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
 // One workgroup per task; blockDim = 64 x (waves of the launch's bucket: >= the task's column blocks).  MB = row blocks of 16 of a
 // task's strip (4: strips of 64 rows, one density; fewer for the passes over several densities: tf_tiles.h, `ksub`).
 template <int ND, int MB, int PF>
-__global__ __launch_bounds__(64 * TT_W, (MB >= 4 ? 1 : (MB == 1 && PF <= 2 ? 3 : 2))) void jk_tile_kernel(const double *__restrict__ T, const TTask *__restrict__ tasks,
+__global__ __launch_bounds__(64 * TT_W, (ND >= 8 || MB >= 4) ? 1 : 2) void jk_tile_kernel(const double *__restrict__ T, const TTask *__restrict__ tasks,
                                                                             const double *__restrict__ X, const double *__restrict__ Pm, TJArgs A)
 {
     static_assert(TT_KB == 4 && TT_KB % PF == 0, "the ring position of a step must be a compile-time constant");
@@ -522,7 +654,8 @@ __global__ __launch_bounds__(64 * TT_EDGE_WAVES) void jk_edge_kernel(const doubl
     const size_t nn = (size_t)N * N;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *Xi = sE, *Xti = sE + N, *accJ = sE + 2 * N + (size_t)w * 3 * N, *accD = accJ + N, *accT = accD + N;
-    for (int d = 0; d < ND; ++d) {
+    {
+        const int d = blockIdx.y;                                           // grid (N, densities of the pass)
         const double *Xd = X + d * nn;
         for (int x = threadIdx.x; x < N; x += blockDim.x) { Xi[x] = Xd[(size_t)iI * N + x]; Xti[x] = Xd[(size_t)x * N + iI]; }
         for (int x = lane; x < 3 * N; x += 64) accJ[x] = 0.0;
@@ -573,7 +706,7 @@ struct TRArgs {
     const int *itask_ptr, *itasks, *jlist_ptr;
     const int *clsI;
     const double *DJ, *Jt, *Jd, *DIk, *DIl, *T, *X;
-    size_t sDJ, sJt, sJd, sDIk, sDIl, sO;
+    size_t sJt, sDIk, sDIl, sO;                 // (DJ and Jd are density-minor: [index][nd])
     double *Dj, *Di, *JtTot, *JD; // Dj[j][x], Di[i][x], JD[i][j]: [N][N] internal; JtTot: pair matrices
     long long edge_base;
     int N, ksub, npair, nd, pm_len;
@@ -610,7 +743,8 @@ __device__ __forceinline__ void tr_dj_block(const TRArgs &R, const TPairI *__res
     const int cj = R.clsI[jI];
     const int xs = R.tab[TVT_CSTART + cX], nX = R.tab[TVT_CSIZE + cX];
     const int lj = jI - R.tab[TVT_CSTART + cj];
-    const double *DJ = R.DJ + d * R.sDJ;
+    const double *DJ = R.DJ + d;                                           // density-minor
+    const int nd = R.nd;
     const double *Xd = R.X + (size_t)d * N * N;
     for (int t0 = 0; t0 < nX; t0 += 64 * TT_RED_CT) {
         double acc[TT_RED_CT], tot[TT_RED_CT];
@@ -622,7 +756,7 @@ __device__ __forceinline__ void tr_dj_block(const TRArgs &R, const TPairI *__res
             const int p = R.tab[TVT_PID + cX * 4 + (cX ^ c)];
             const TPairI P = pairs[(size_t)iI * 10 + p];
             const TRunI Rn = runs[(size_t)iI * 4 + cj];
-            const double *vec = DJ + Rn.dj_base + (long long)(jI - Rn.j0) * Rn.dj_len;
+            const double *vec = DJ + (Rn.dj_base + (long long)(jI - Rn.j0) * Rn.dj_len) * nd;
             const int a = R.tab[TVT_PA + p], b = R.tab[TVT_PB + p];
             const bool tri = a == b, have = P.first_task >= 0;
             const long long l0 = Rn.j0 - R.tab[TVT_CSTART + cj];
@@ -636,13 +770,13 @@ __device__ __forceinline__ void tr_dj_block(const TRArgs &R, const TPairI *__res
                     const int ks = lx / TT_KS, nst = min(TT_KS, P.nk - TT_KS * ks);
                     int nch, wv;
                     tt_chunks(tt_nlb(tri, ks, P.nk, P.nl), &nch, &wv);
-                    const double *src = vec + P.dj_k + tt_dj_koff(tri, ks, P.nl) + (lx - TT_KS * ks);
-                    for (int ch = 0; ch < nch; ++ch) v += src[ch * nst];
+                    const double *src = vec + (size_t)(P.dj_k + tt_dj_koff(tri, ks, P.nl) + (lx - TT_KS * ks)) * nd;
+                    for (int ch = 0; ch < nch; ++ch) v += src[(size_t)ch * nst * nd];
                 }
                 if (have && cX == b && lx < P.nl) {                       // x as a column index l: the sub-strips that reach its block
                     const int lb = lx / TT_LB, ns = (P.nk + R.ksub - 1) / R.ksub, f = tt_dj_first_sub(tri, lb, R.ksub);
-                    const double *src = vec + P.dj_l + tt_dj_loff(tri, lb, P.nk, R.ksub) + (lx - TT_LB * lb);
-                    for (int s2 = f; s2 < ns; ++s2) v += src[(s2 - f) * TT_LB];
+                    const double *src = vec + (size_t)(P.dj_l + tt_dj_loff(tri, lb, P.nk, R.ksub) + (lx - TT_LB * lb)) * nd;
+                    for (int s2 = f; s2 < ns; ++s2) v += src[(size_t)(s2 - f) * TT_LB * nd];
                 }
                 if (cX == cj && lx <= lj) v += (lx == lj ? 0.5 : 1.0) * Ee[lx] * xii;   // edge: D[j][l] += w (ij|il) P[i][i]
                 acc[u] += v;
@@ -722,7 +856,7 @@ __device__ __forceinline__ void tr_gather_block(const TRArgs &R, const TTask *__
         }
         if (lane < nj) {                                                    // Jd[i][j]
             double v = 0.0;
-            for (int u = 0; u < nw; ++u) v += R.Jd[d * R.sJd + jd + (size_t)u * nj + lane];
+            for (int u = 0; u < nw; ++u) v += R.Jd[((size_t)jd + (size_t)u * nj + lane) * R.nd + d];
             aJ[t->j0 + lane] += v;
         }
     }
