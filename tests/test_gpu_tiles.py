@@ -28,15 +28,17 @@ def test_tiles_tensor_and_fock_matrices_against_reference_golden(engine, golden,
     atoms = mol.make_atoms(["N", "N"], R_N2)
     aos = mol.expand_cartesian_aos(mol.build_shells(atoms, basis))
     try:
-        engine.set_basis(aos).build_eri(False, layout="tiles")
+        engine.set_basis(aos).build_eri(False, layout="tiles")               # Cartesian tensor (CARTHARM)
         assert engine.eri_storage()["layout"] == "tiles"
-        idx, val = z["eri_idx"].astype(np.int32), z["eri_val"]
-        got = engine.sample_eri(idx)
-        assert np.abs(got - val).max() < 1e-12
+        assert np.abs(engine.sample_eri(z["eri_idx"].astype(np.int32)) - z["eri_val"]).max() < 1e-12
+        engine.build_eri(True, layout="tiles")                               # real spherical harmonics: the reference's default
+        assert np.abs(engine.sample_eri(z["eri_sph_idx"].astype(np.int32)) - z["eri_sph_val"]).max() < 1e-12
+        Es = engine.copy_eri()
+        assert abs(np.sqrt(np.sum(Es * Es)) - z["eri_sph_fro"]) < 1e-10 * z["eri_sph_fro"]
         P = z["P_rand"]
+        assert P.shape == (engine.N, engine.N)
         J, K = engine.fock_jk(P)
-        assert np.abs(J - z["J_rand"]).max() < 1e-10 * np.abs(z["J_rand"]).max()
-        assert np.abs(K - z["K_rand"]).max() < 1e-10 * np.abs(z["K_rand"]).max()
+        assert np.abs(J - z["J_rand"]).max() < 1e-10 and np.abs(K - z["K_rand"]).max() < 1e-10
     finally:
         _reset(engine)
 
