@@ -147,7 +147,7 @@ class Engine:
     def fock_jk(self, P: np.ndarray):
         """J, K for one [N,N] or several [n,N,N] densities (host buffers).  Partial sums when world > 1."""
         P = f64(P)
-        if P.ndim not in (2, 3) or P.shape[-1] != self.N or P.shape[-2] != self.N:
+        if self._L.tf_eri_layout(self._ctx) >= 0 and (P.ndim not in (2, 3) or P.shape[-1] != self.N or P.shape[-2] != self.N):   # (no tensor yet: the library reports that)
             raise ValueError(f"fock_jk: densities must be [{self.N},{self.N}] or [n,{self.N},{self.N}], got {P.shape}")
         nd = 1 if P.ndim == 2 else P.shape[0]
         J, K = np.zeros_like(P), np.zeros_like(P)
