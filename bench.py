@@ -164,8 +164,8 @@ def pmc_traffic(workload: str, world: int, layout: str, stored_bytes: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)   # 100 timed builds after 10 warm-ups
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=os.environ.get("TUNA_BENCH_WORKLOAD", "synth-400"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scf", action="store_true")
@@ -239,9 +239,16 @@ def main():
             dist.all_reduce(h, **kw)
             t.copy_(h)
 
+    # The exchange step of a sharded build: inside the library (tf_comm_init: an RCCL communicator of the ranks, ncclAllReduce of J and K
+    # issued by tf_fock_jk_device on the same stream, no host callback); TUNA_BENCH_TORCH_ALLREDUCE=1 or a gloo rehearsal: torch.distributed.
+    in_library = world > 1 and backend == "nccl" and os.environ.get("TUNA_BENCH_TORCH_ALLREDUCE") is None
+    if in_library:
+        from tuna_amd import distributed as tdist
+        tdist.attach_rccl(eng)
+
     def step():
         eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), nd, stream)
-        if world > 1:
+        if world > 1 and not in_library:
             allreduce(dJK)
 
     for _ in range(args.warmup):

@@ -139,6 +139,19 @@ int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K);
 typedef int (*tf_allreduce_fn)(void *user, double *device_buf, int64_t count, void *stream);
 int tf_set_allreduce(tf_ctx *ctx, tf_allreduce_fn fn, void *user);
 
+/* The exchange step inside the library: an RCCL communicator of the ranks that share the tensor (one process per GPU; RCCL over xGMI).
+ * Rank 0 calls tf_comm_unique_id and hands the TF_COMM_ID_BYTES bytes to the other ranks by any means (tuna_amd: torch.distributed's
+ * store); then EVERY rank calls tf_comm_init (collective).  From then on the native cycles, tf_ao_to_mo / tf_mp2_rhf and
+ * tf_fock_jk_device complete their partial sums with ncclAllReduce on the library's (or the caller's) stream -- no host callback per
+ * Fock build; a hook registered with tf_set_allreduce is ignored while a communicator is attached.  librccl is loaded at the first call
+ * (dlopen): processes that never shard do not pay for it.  The reference has no counterpart. */
+#define TF_COMM_ID_BYTES 128
+int tf_comm_unique_id(void *id_out);
+int tf_comm_init(tf_ctx *ctx, const void *id, int comm_rank, int comm_size);
+int tf_comm_destroy(tf_ctx *ctx);
+/* 1 when a communicator is attached: tf_fock_jk_device then returns J and K summed over the ranks. */
+int tf_comm_attached(const tf_ctx *ctx);
+
 /* Same with device pointers, asynchronous on `stream` (a hipStream_t, may be NULL for the
  * default stream).  Inputs already in HBM; nothing is synchronised or copied.  With the packed
  * layout the densities must be symmetric here (every SCF density is); tf_fock_jk itself also

@@ -225,8 +225,15 @@ def _nccl_single_rank(rank, port, ret):
             partial = dJK.cpu().numpy().copy()
             dist.all_reduce(dJK)                                        # what bench.py --gpus N issues per build
             after = dJK.cpu().numpy()
-            # the native cycle: every Fock build of it calls the hook (ncclAllReduce on the staging buffer, status word, agreement vector)
-            tdist.attach_allreduce(eng)
+            # the exchange step INSIDE the library (tf_comm_init: librccl loaded by the library, ncclAllReduce issued by allreduce_jk on the
+            # build's stream -- no Python frame per build): first on the Fock build itself ...
+            tdist.attach_rccl(eng)
+            assert eng.comm_attached()
+            eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            inlib = dJK.cpu().numpy().copy()
+            assert np.array_equal(inlib, partial), "the sum over a one-rank communicator is the rank's own partial sums"
+            # ... then in the native cycle: every Fock build of it all-reduces [J;K] and the agreement vector through the communicator
             xyz, chg, org = atom_arrays(atoms)
             S, T, V, _, _ = eng.one_electron(xyz, chg, org, spherical=True)
             X, _, _ = eng.orthogonaliser(S)
@@ -246,7 +253,8 @@ def _nccl_single_rank(rank, port, ret):
 
 
 def test_rccl_branch_of_the_exchange_step_runs_on_a_single_rank_group():
-    """The `nccl` (= RCCL) branches -- bench.py's all-reduce of [J;K] and the hook of the native cycles -- executed on hardware."""
+    """The RCCL branches -- bench.py's torch all-reduce of [J;K], and the library's own communicator (tf_comm_init: the exchange step of
+    tf_fock_jk_device and of the native cycles without a host callback) -- executed on hardware."""
     import torch.multiprocessing as mp
     with mp.Manager() as mgr:
         ret = mgr.dict()
@@ -255,7 +263,7 @@ def test_rccl_branch_of_the_exchange_step_runs_on_a_single_rank_group():
     diff, scale, outcome, backend, finite = res[0]
     assert backend == "nccl" and finite
     assert diff == 0.0 and scale > 0.0                               # the sum over a one-rank communicator is the rank's own partial sums
-    # the native cycle went through the hook (ncclAllReduce of [J;K] + status word, then of the agreement vector); its agreement test then
+    # the native cycle went through the communicator (ncclAllReduce of [J;K], then of the agreement vector); its agreement test then
     # notices, correctly, that the one-rank group sums ONE rank's decision values where the context expects the sum over two
     assert outcome[0] == "error" and "disagree on a control decision" in outcome[1], outcome
 

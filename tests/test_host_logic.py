@@ -261,3 +261,16 @@ def test_lockstep_cycles_on_a_cpu_stand_in():
         np.testing.assert_allclose(r["table"][:, 1], ref["table"][:, 1], atol=1e-10)
         total_iterations += r["n_iter"]
     assert eri.n_builds == max(r["n_iter"] for r in res) < total_iterations
+
+
+def test_public_header_is_valid_c():
+    """include/tunafock.h is the C ABI a maintainer binds (cgo / ctypes / JNI): it must compile as C, not only as the C++ the library is
+    built from"""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    hdr = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "tunafock.h")
+    r = subprocess.run([cc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

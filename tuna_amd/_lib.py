@@ -45,7 +45,8 @@ EXPORTS = ["tf_create", "tf_destroy", "tf_last_error", "tf_version", "tf_normali
            "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf", "tf_scf_uhf",
            "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts", "tf_shard_plan", "tf_jk_profile",
            "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_ao_to_mo", "tf_mp2_rhf", "tf_dft_setup", "tf_dft_vxc",
-           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs", "tf_packed_pad", "tf_eri_flops", "tf_segment_pad", "tf_set_allreduce", "tf_scf_rhf_batch"]
+           "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs", "tf_packed_pad", "tf_eri_flops", "tf_segment_pad", "tf_set_allreduce", "tf_scf_rhf_batch",
+           "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_comm_attached"]
 
 _lib = None
 
@@ -87,6 +88,10 @@ def lib():
     L.tf_eri_flops.restype = ci; L.tf_eri_flops.argtypes = [vp, vp]
     L.tf_segment_pad.restype = ci; L.tf_segment_pad.argtypes = []
     L.tf_set_allreduce.restype = ci; L.tf_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.tf_comm_unique_id.restype = ci; L.tf_comm_unique_id.argtypes = [vp]
+    L.tf_comm_init.restype = ci; L.tf_comm_init.argtypes = [vp, vp, ci, ci]
+    L.tf_comm_destroy.restype = ci; L.tf_comm_destroy.argtypes = [vp]
+    L.tf_comm_attached.restype = ci; L.tf_comm_attached.argtypes = [vp]
     L.tf_copy_eri.restype = ci; L.tf_copy_eri.argtypes = [vp, vp]
     L.tf_sample_eri.restype = ci; L.tf_sample_eri.argtypes = [vp, C.c_int64, vp, vp]
     L.tf_eri_element.restype = ci; L.tf_eri_element.argtypes = [vp, vp, vp, vp, vp, vp, dp]

@@ -9,6 +9,7 @@
 #include <array>
 #include <cstring>
 #include <condition_variable>
+#include <dlfcn.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -200,6 +201,7 @@ struct tf_ctx {
     bool prof_jk = false;
     std::vector<hipEvent_t> prof_ev;     // pairs (before, after) around the row kernel, on the launch stream
     size_t prof_used = 0;
+    void *comm = nullptr;                 // RCCL communicator of the ranks that share the tensor (tf_comm_init): the exchange step without a host callback
     tf_allreduce_fn allreduce = nullptr;  // completes partial [J;K] over the ranks of a sharded tensor (tf_set_allreduce)
     void *allreduce_user = nullptr;
     double *d_jkstage = nullptr;          // [2][nd][N][N] staging buffer of that exchange step
@@ -263,6 +265,51 @@ static int upload(tf_ctx *ctx, const std::vector<T> &h, T **d, bool track = true
     HIPCHK(ctx, tf_malloc((void **)d, bytes));
     if (track) ctx->basis_allocs.push_back(*d);
     if (!h.empty()) HIPCHK(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return TF_OK;
+}
+
+// ---- RCCL, loaded on demand (include/tunafock.h: tf_comm_*) ------------------------------------------------------------------------
+namespace tfrccl {
+typedef struct { char internal[128]; } UniqueId;                // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+typedef int (*GetUniqueId_t)(UniqueId *);
+typedef int (*CommInitRank_t)(void **, int, UniqueId, int);
+typedef int (*CommDestroy_t)(void *);
+typedef int (*AllReduce_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*Group_t)(void);
+typedef const char *(*GetErrorString_t)(int);
+static std::mutex mu;
+static void *handle = nullptr;
+static GetUniqueId_t GetUniqueId = nullptr;
+static CommInitRank_t CommInitRank = nullptr;
+static CommDestroy_t CommDestroy = nullptr;
+static AllReduce_t AllReduce = nullptr;
+static Group_t GroupStart = nullptr, GroupEnd = nullptr;
+static GetErrorString_t GetErrorString = nullptr;
+enum { kFloat64 = 8, kSum = 0 };                                   // ncclFloat64, ncclSum
+static bool load(std::string &err)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    if (handle) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (handle) break;
+    }
+    if (!handle) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
+    GetUniqueId = (GetUniqueId_t)dlsym(handle, "ncclGetUniqueId"); CommInitRank = (CommInitRank_t)dlsym(handle, "ncclCommInitRank");
+    CommDestroy = (CommDestroy_t)dlsym(handle, "ncclCommDestroy"); AllReduce = (AllReduce_t)dlsym(handle, "ncclAllReduce");
+    GroupStart = (Group_t)dlsym(handle, "ncclGroupStart"); GroupEnd = (Group_t)dlsym(handle, "ncclGroupEnd");
+    GetErrorString = (GetErrorString_t)dlsym(handle, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd) { err = "librccl lacks an expected symbol"; dlclose(handle); handle = nullptr; return false; }
+    return true;
+}
+static std::string errstr(int code) { return GetErrorString ? std::string(GetErrorString(code)) : ("code " + std::to_string(code)); }
+}  // namespace tfrccl
+
+// sum over the ranks of the attached communicator, in place, on stream st
+static int comm_allreduce(tf_ctx *ctx, double *buf, size_t count, hipStream_t st)
+{
+    const int rc = tfrccl::AllReduce(buf, buf, count, tfrccl::kFloat64, tfrccl::kSum, ctx->comm, st);
+    if (rc) TF_FAIL(ctx, TF_ENODEVICE, "ncclAllReduce failed: %s", tfrccl::errstr(rc).c_str());
     return TF_OK;
 }
 
@@ -617,6 +664,7 @@ void tf_destroy(tf_ctx *ctx)
     for (int k = 0; k < 3; ++k)
         if (ctx->scr[k]) (void)tf_free(ctx->scr[k]);
     if (ctx->mo_pool) (void)tf_free(ctx->mo_pool);
+    if (ctx->comm) { (void)hipDeviceSynchronize(); (void)tfrccl::CommDestroy(ctx->comm); ctx->comm = nullptr; }
     if (ctx->d_jkstage) (void)tf_free(ctx->d_jkstage);
     if (ctx->d_agree) (void)tf_free(ctx->d_agree);
     if (ctx->d_lrec) (void)tf_free(ctx->d_lrec);
@@ -2860,8 +2908,21 @@ static int launch_jk(tf_ctx *ctx, int nd, const double *const *dP, double *const
 static int allreduce_jk(tf_ctx *ctx, int nd, double *const *dJ, double *const *dK, hipStream_t st)
 {
     if (ctx->world == 1) return TF_OK;
+    if (ctx->comm) {
+        // in the library: ncclAllReduce of J and of K where they lie, one group, on the build's stream (no staging copy, no status word: a
+        // failed rank fails the collective for every rank)
+        const size_t nn1 = (size_t)ctx->N * ctx->N;
+        int grc = tfrccl::GroupStart();
+        for (int d = 0; d < nd && !grc; ++d) {
+            grc = tfrccl::AllReduce(dJ[d], dJ[d], nn1, tfrccl::kFloat64, tfrccl::kSum, ctx->comm, st);
+            if (!grc) grc = tfrccl::AllReduce(dK[d], dK[d], nn1, tfrccl::kFloat64, tfrccl::kSum, ctx->comm, st);
+        }
+        const int erc = tfrccl::GroupEnd();
+        if (grc || erc) TF_FAIL(ctx, TF_ENODEVICE, "ncclAllReduce of [J;K] failed: %s", tfrccl::errstr(grc ? grc : erc).c_str());
+        return TF_OK;
+    }
     if (!ctx->allreduce)
-        TF_FAIL(ctx, TF_EINVAL, "the tensor is sharded over %d ranks: register the all-reduce of the partial [J;K] with tf_set_allreduce", ctx->world);
+        TF_FAIL(ctx, TF_EINVAL, "the tensor is sharded over %d ranks: attach an RCCL communicator (tf_comm_init) or register the all-reduce of the partial [J;K] with tf_set_allreduce", ctx->world);
     const size_t nn = (size_t)ctx->N * ctx->N, need = 2 * (size_t)nd * nn;
     // one slot beyond the payload carries a status word through the same collective: a rank whose exchange step failed locally (the
     // hook sets it) makes the sum non-zero on EVERY rank, so that all of them return an error instead of some waiting in a collective
@@ -2894,14 +2955,16 @@ static int allreduce_jk(tf_ctx *ctx, int nd, double *const *dJ, double *const *d
 // waiting in the next collective.
 static int agree_over_ranks(tf_ctx *ctx, const double *vals, int n, std::string &msg)
 {
-    if (ctx->world == 1 || !ctx->allreduce) return TF_OK;
+    if (ctx->world == 1 || (!ctx->allreduce && !ctx->comm)) return TF_OK;
     if (n > 7) n = 7;
     double h[16] = {0};
     h[0] = 1.0;
     for (int k = 0; k < n; ++k) { h[1 + k] = vals[k]; h[8 + k] = vals[k] * vals[k]; }
     if (!ctx->d_agree && tf_malloc((void **)&ctx->d_agree, 16 * sizeof(double)) != hipSuccess) { msg = "hipMalloc failed (agree buffer)"; return TF_ENOMEM; }
     if (hipMemcpy(ctx->d_agree, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) { msg = "hipMemcpy failed (agree buffer)"; return TF_ENODEVICE; }
-    const int rc = ctx->allreduce(ctx->allreduce_user, ctx->d_agree, 16, nullptr);
+    int rc;
+    if (ctx->comm) { rc = comm_allreduce(ctx, ctx->d_agree, 16, nullptr); if (rc) { msg = ctx->err; return rc; } }
+    else rc = ctx->allreduce(ctx->allreduce_user, ctx->d_agree, 16, nullptr);
     if (rc) { msg = "the registered all-reduce failed (code " + std::to_string(rc) + ")"; return TF_ENODEVICE; }
     double s[16];
     if (hipMemcpy(s, ctx->d_agree, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) { msg = "hipMemcpy failed (agree buffer)"; return TF_ENODEVICE; }
@@ -2954,6 +3017,48 @@ int tf_set_allreduce(tf_ctx *ctx, tf_allreduce_fn fn, void *user)
     return TF_OK;
 }
 
+int tf_comm_unique_id(void *id_out)
+{
+    if (!id_out) return TF_EINVAL;
+    std::string err;
+    if (!tfrccl::load(err)) { g_create_error = err; return TF_ENODEVICE; }
+    tfrccl::UniqueId id;
+    const int rc = tfrccl::GetUniqueId(&id);
+    if (rc) { g_create_error = "ncclGetUniqueId failed: " + tfrccl::errstr(rc); return TF_ENODEVICE; }
+    std::memcpy(id_out, &id, sizeof(id));
+    return TF_OK;
+}
+
+int tf_comm_init(tf_ctx *ctx, const void *id, int comm_rank, int comm_size)
+{
+    if (!ctx || !id || comm_size < 1 || comm_rank < 0 || comm_rank >= comm_size) return TF_EINVAL;
+    std::string err;
+    if (!tfrccl::load(err)) TF_FAIL(ctx, TF_ENODEVICE, "%s", err.c_str());
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm) { (void)tfrccl::CommDestroy(ctx->comm); ctx->comm = nullptr; }
+    tfrccl::UniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    void *comm = nullptr;
+    const int rc = tfrccl::CommInitRank(&comm, comm_size, uid, comm_rank);
+    if (rc) TF_FAIL(ctx, TF_ENODEVICE, "ncclCommInitRank failed: %s", tfrccl::errstr(rc).c_str());
+    ctx->comm = comm;
+    return TF_OK;
+}
+
+int tf_comm_destroy(tf_ctx *ctx)
+{
+    if (!ctx) return TF_EINVAL;
+    if (ctx->comm) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        (void)tfrccl::CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    return TF_OK;
+}
+
+int tf_comm_attached(const tf_ctx *ctx) { return (ctx && ctx->comm) ? 1 : 0; }
+
 int tf_fock_jk_device(tf_ctx *ctx, int n_dens, const double *dP, double *dJ, double *dK, void *stream)
 {
     if (!ctx) return TF_EINVAL;
@@ -2968,6 +3073,7 @@ int tf_fock_jk_device(tf_ctx *ctx, int n_dens, const double *dP, double *dJ, dou
         for (int q = 0; q < 8; ++q) { const int dq = d + std::min(q, nd - 1); p[q] = dP + dq * nn; j[q] = dJ + dq * nn; k[q] = dK + dq * nn; }
         int rc = launch_jk(ctx, nd, p, j, k, (hipStream_t)stream);
         if (rc) return rc;
+        if (ctx->comm && ctx->world > 1 && (rc = allreduce_jk(ctx, nd, j, k, (hipStream_t)stream))) return rc;   // in the library, on the same stream
     }
     return TF_OK;
 }
@@ -3187,8 +3293,8 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     std::string msg;
     int rc = tfscf::ensure(ctx->scf, N, 6, msg);
     if (rc) { ctx->err = msg; return rc; }
-    if (ctx->world > 1 && !ctx->allreduce)
-        TF_FAIL(ctx, TF_EINVAL, "AO->MO transformation of a sharded tensor (world > 1) needs the all-reduce hook (tf_set_allreduce)");
+    if (ctx->world > 1 && !ctx->allreduce && !ctx->comm)
+        TF_FAIL(ctx, TF_EINVAL, "AO->MO transformation of a sharded tensor (world > 1) needs an RCCL communicator (tf_comm_init) or the all-reduce hook (tf_set_allreduce)");
     const bool packed = ctx->layout >= 1, tiles = ctx->layout == 2;
     double *dC[4] = {nullptr, nullptr, nullptr, nullptr}, *dG[2] = {nullptr, nullptr};
     const double *hC[4] = {C1, C2, C3, C4};
@@ -3206,7 +3312,7 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
         if (tf_malloc((void **)&dC[k], (size_t)N * nk[k] * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
         if (hipMemcpy(dC[k], hC[k], (size_t)N * nk[k] * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation: copy failed");
     }
-    if (tf_malloc((void **)d_out, total * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");
+    if (tf_malloc((void **)d_out, (total + 1) * sizeof(double)) != hipSuccess) return fail(TF_ENOMEM, "AO->MO transformation: out of device memory");   // (+ 1: the status word of the hook's exchange)
     // the short index first: a ket coefficient matrix of at most 32 columns (the occupied orbitals of (ia|jb)) goes through the hand-written
     // first quarter on the packed segments (tfmp2::mo_q1_kernel); TF_MO_Q1=0 keeps the expanded-block path (A/B, tests)
     const char *q1env = getenv("TF_MO_Q1");
@@ -3259,8 +3365,17 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
     }
     if (ctx->world > 1) {                                   // every rank transformed its own rows: the sum is the tensor
         if (hipDeviceSynchronize() != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation failed on the device");
-        const int arc = ctx->allreduce(ctx->allreduce_user, *d_out, (long long)total, nullptr);
-        if (arc) return fail(TF_ENODEVICE, "AO->MO transformation: the all-reduce hook failed (code " + std::to_string(arc) + ")");
+        if (ctx->comm) {
+            if (comm_allreduce(ctx, *d_out, total, nullptr)) return fail(TF_ENODEVICE, ctx->err);
+        } else {
+            // the hook sums a buffer whose LAST element is a status word: a rank whose staging failed sends zeros and sets it
+            if (hipMemset(*d_out + total, 0, sizeof(double)) != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation: memset failed");
+            const int arc = ctx->allreduce(ctx->allreduce_user, *d_out, (long long)(total + 1), nullptr);
+            if (arc) return fail(TF_ENODEVICE, "AO->MO transformation: the all-reduce hook failed (code " + std::to_string(arc) + ")");
+            double status = 0.0;
+            if (hipMemcpy(&status, *d_out + total, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation: copy failed");
+            if (status != 0.0) return fail(TF_ENODEVICE, "AO->MO transformation: the exchange step failed on a rank: every rank stops");
+        }
     }
     if (hipDeviceSynchronize() != hipSuccess) return fail(TF_ENODEVICE, "AO->MO transformation failed on the device");
     cleanup();

@@ -157,6 +157,21 @@ def attach_allreduce(engine, group=None):
     return engine
 
 
+def attach_rccl(engine, group=None):
+    """The exchange step INSIDE the library (tf_comm_init): one RCCL communicator over the ranks of `group` (torch.distributed is used
+    once, to hand rank 0's unique id to the others); afterwards every Fock build of the native cycles, tf_fock_jk_device and the AO->MO
+    transformation issue ncclAllReduce themselves on the library's stream -- no Python frame per build."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        raise _lib.TunaError("attach_rccl: torch.distributed is not initialised (one process per GPU)")
+    rank, size = dist.get_rank(group), dist.get_world_size(group)
+    box = [type(engine).comm_unique_id() if rank == 0 else None]
+    if size > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init(box[0], rank, size)
+    return engine
+
+
 class ShardedFock:
     """Fock builds over a sharded tensor: engine.fock_jk_device on this rank's rows + ONE all-reduce of the stacked [J;K];
     one [N,N] density or several [n,N,N] (a UHF build passes alpha and beta)."""
@@ -185,7 +200,9 @@ class ShardedFock:
         dP.copy_(torch.from_numpy(Pn))
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self.engine.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), Pn.shape[0], stream)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.engine.comm_attached():                    # summed over the ranks inside the library (tf_comm_init)
+            out = dJK.cpu().numpy()
+        elif dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             if dist.get_backend() == "nccl":
                 dist.all_reduce(dJK)
                 out = dJK.cpu().numpy()

@@ -249,6 +249,28 @@ class Engine:
         o.n_atom_ao[1] = n_atom_ao[1] if len(n_atom_ao) > 1 else 0
         return o
 
+    def comm_init(self, uid: bytes, comm_rank: int, comm_size: int):
+        """tf_comm_init: attaches an RCCL communicator (collective over the ranks that share the tensor); uid = the 128 bytes rank 0 got
+        from Engine.comm_unique_id()."""
+        buf = C.create_string_buffer(bytes(uid), 128)
+        self._check(self._L.tf_comm_init(self._ctx, buf, int(comm_rank), int(comm_size)))
+        return self
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        L = _lib.lib()
+        buf = C.create_string_buffer(128)
+        rc = L.tf_comm_unique_id(buf)
+        if rc != 0:
+            raise TunaError(L.tf_last_error(None).decode(), rc)
+        return buf.raw
+
+    def comm_attached(self) -> bool:
+        return bool(self._L.tf_comm_attached(self._ctx))
+
+    def comm_destroy(self):
+        self._check(self._L.tf_comm_destroy(self._ctx))
+
     def set_allreduce(self, hook):
         """tf_set_allreduce: hook(user, device_ptr, count, stream) -> 0 sums `count` doubles at `device_ptr` over the ranks that share
         the tensor (tuna_amd.distributed.attach_allreduce builds it on torch.distributed); None removes it."""
