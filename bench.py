@@ -342,7 +342,7 @@ def main():
     # SCF wall time, the second half of the metric: collective when the tensor is sharded (every rank runs the native cycle on its
     # rows; one all-reduce of the partial [J;K] per Fock build through torch.distributed / RCCL), so every rank takes part
     if not args.no_scf:
-        if world > 1:
+        if world > 1 and not eng.comm_attached():
             from tuna_amd import distributed as tdist
             tdist.attach_allreduce(eng)
         # (an exception in a leg must not cost the headline line: it is reported in the leg's place.  With several ranks a leg that
@@ -484,7 +484,7 @@ def scf_leg(eng, args, rank=0, world=1, allreduce=None):
 
     def one_build():
         eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), 1, stream)
-        if world > 1:
+        if world > 1 and not eng.comm_attached():
             allreduce(dJK)
     for _ in range(5):
         one_build()
