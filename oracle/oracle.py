@@ -5,8 +5,9 @@ the compiled *unmodified* reference engine from oracle/_ref/ (see oracle/build_r
 tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
 product package (tuna_amd/) never does.
 
-Parity status: PINNED against the reference engine and its golden vectors
-(tests/test_oracle_vs_reference.py, tests/golden/).
+Parity status: PINNED against the reference engine and its golden vectors (tests/test_oracle.py:
+test_oracle_matches_compiled_reference_on_random_basis runs the compiled engine of oracle/_ref beside the
+restatement where /root/reference exists; the other tests replay tests/golden/, which that engine produced).
 """
 from __future__ import annotations
 

@@ -6,7 +6,7 @@
  * z-axis diatomics.  It is the checker for the HIP path: only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks every function here
+ * Parity status: PINNED.  tests/test_oracle.py checks every function here
  * against the compiled, unmodified reference engine (oracle/_ref, built by
  * oracle/build_ref.sh from the sources where they lie) and against the golden vectors
  * that engine produced (tests/golden/).

@@ -274,3 +274,21 @@ def test_public_header_is_valid_c():
     hdr = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "tunafock.h")
     r = subprocess.run([cc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", hdr], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_custom_criteria_are_applied_over_the_derivative_driven_preset():
+    """tuna_calc.py:473-494: the named criteria are chosen first -- DIPOLE without LOOSE..EXTREME means tight, POLAR / HYPER extreme -- and
+    ECONV / RMSDP / MAXDP / DIISERR then overwrite single entries of that set."""
+    from tuna_amd import energy as en
+    def conv(line):
+        _, method, basis, _, _, params = en.parse_input(line)
+        return en.interpret_keywords(params, en.Calculation("SPE", "HF", basis)).SCF_conv
+    base = "SPE : H H 0.74 : HF STO-3G :"
+    assert conv(base) == en.SCF_CONVERGENCE["medium"]
+    c = conv(base + " DIPOLE ECONV 3e-7")
+    assert c["delta_E"] == 3e-7 and {k: v for k, v in c.items() if k != "delta_E"} == {k: v for k, v in en.SCF_CONVERGENCE["tight"].items() if k != "delta_E"}
+    c = conv(base + " POLAR MAXDP 1e-5 DIISERR 2e-6")
+    ext = en.SCF_CONVERGENCE["extreme"]
+    assert c["max_DP"] == 1e-5 and c["commutator"] == 2e-6 and c["delta_E"] == ext["delta_E"] and c["RMS_DP"] == ext["RMS_DP"]
+    c = conv(base + " HYPER LOOSE RMSDP 1e-4")                        # an explicit preset wins over the derivative-driven one
+    assert c["RMS_DP"] == 1e-4 and c["delta_E"] == en.SCF_CONVERGENCE["loose"]["delta_E"]

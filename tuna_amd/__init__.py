@@ -15,8 +15,10 @@ import os as _os
 # of one queue run one after the other, each as long as its slowest workgroup.  A tensor build of a contracted basis set issues ~70
 # launches of very different lengths on 8 streams: with 16 queues Ar2/cc-pVQZ's ERI kernels take 8.7 ms instead of 14.7.
 # The runtime reads the variable when it initialises, so it has to be in the environment before the first HIP call of the process --
-# importing this package before torch touches the GPU is enough; an explicit setting of the caller is left alone.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# importing this package before torch touches the GPU is enough; an explicit setting of the caller is left alone.  It is a setting of
+# the whole process (torch and RCCL see it too): TUNA_NO_HWQ=1 opts out, and the library itself never touches the environment.
+if not _os.environ.get("TUNA_NO_HWQ"):
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def cpu_quota() -> int:

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <dlfcn.h>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -49,9 +50,37 @@ static size_t cached_bytes = 0;
 static const size_t MAX_BLOCK = (size_t)64 << 20, MAX_CACHED = (size_t)1 << 30;
 static const bool off = getenv("TF_ALLOC_CACHE") && getenv("TF_ALLOC_CACHE")[0] == '0';
 static size_t size_class(size_t b) { size_t c = 512; while (c < b) c <<= 1; return c; }
+// Hands every cached block back to the runtime (after a device-wide synchronisation: a kernel of an earlier call may still read one).
+// Called when the runtime is out of memory -- the cache must never be the reason a build fails -- and by tf_destroy of the last context.
+static void trim()
+{
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_blocks.empty()) return;
+    int dev0 = 0;
+    (void)hipGetDevice(&dev0);
+    for (auto &kv : free_blocks) {
+        (void)hipSetDevice(kv.second.dev);
+        (void)hipDeviceSynchronize();
+        (void)::hipFree(kv.second.p);
+    }
+    (void)hipSetDevice(dev0);
+    free_blocks.clear();
+    cached_bytes = 0;
+}
+static size_t cached() { std::lock_guard<std::mutex> lk(mu); return cached_bytes; }
+static hipError_t raw_malloc(void **p, size_t bytes)
+{
+    hipError_t e = ::hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && cached() > 0) {
+        (void)hipGetLastError();
+        trim();
+        e = ::hipMalloc(p, bytes);
+    }
+    return e;
+}
 static hipError_t cmalloc(void **p, size_t bytes)
 {
-    if (off || bytes > MAX_BLOCK) return ::hipMalloc(p, bytes);
+    if (off || bytes > MAX_BLOCK) return raw_malloc(p, bytes);
     int dev = 0;
     (void)hipGetDevice(&dev);
     const size_t c = size_class(bytes);
@@ -67,7 +96,7 @@ static hipError_t cmalloc(void **p, size_t bytes)
                 return hipSuccess;
             }
     }
-    hipError_t e = ::hipMalloc(p, c);
+    hipError_t e = raw_malloc(p, c);
     if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*p] = std::make_pair(c, dev); }
     return e;
 }
@@ -99,6 +128,7 @@ static inline hipError_t tf_free(void *p) { return tfcache::cfree(p); }
 using namespace tfk;
 
 static std::string g_create_error;
+static std::atomic<int> g_live_contexts{0};
 static const bool g_dbg = getenv("TF_DEBUG") != nullptr;
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define DBG(...) do { if (g_dbg) { fprintf(stderr, "[tf %.6f] ", now_s()); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
@@ -625,9 +655,9 @@ int tf_shard_plan(int n_blocks, const int64_t *weight, int world, int32_t *owner
 
 tf_ctx *tf_create(int device, int rank, int world)
 {
-    // more hardware queues for the concurrent launches of the tensor build (effective if this is the first HIP call of the process;
-    // the Python package and INTEGRATION.md say the same); a setting of the host application is left alone
-    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // (GPU_MAX_HW_QUEUES -- more hardware queues for the concurrent launches of the tensor build -- belongs to the HOST application: it has
+    // to be in the environment before the first HIP call of the process, and setenv from a library is not safe beside a threaded host's
+    // getenv.  INTEGRATION.md recommends 16; the Python package sets it on import unless TUNA_NO_HWQ is set.)
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -644,6 +674,7 @@ tf_ctx *tf_create(int device, int rank, int world)
     }
     tf_ctx *ctx = new tf_ctx();
     ctx->device = device; ctx->rank = rank; ctx->world = world;
+    ++g_live_contexts;
     return ctx;
 }
 
@@ -672,6 +703,7 @@ void tf_destroy(tf_ctx *ctx)
     if (ctx->d_gtab) (void)tf_free(ctx->d_gtab);
     ctx->arena1e.release();
     delete ctx;
+    if (--g_live_contexts == 0) tfcache::trim();      // the last context of the process: the cached blocks go back to the runtime
 }
 
 const char *tf_last_error(const tf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -2968,6 +3000,8 @@ static int agree_over_ranks(tf_ctx *ctx, const double *vals, int n, std::string 
     if (rc) { msg = "the registered all-reduce failed (code " + std::to_string(rc) + ")"; return TF_ENODEVICE; }
     double s[16];
     if (hipMemcpy(s, ctx->d_agree, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess) { msg = "hipMemcpy failed (agree buffer)"; return TF_ENODEVICE; }
+    // slot 15 is the status word of the hook's convention (distributed.py: a rank whose staging failed adds 1 to the last element)
+    if (s[15] != 0.0) { msg = "the exchange of the agreement vector failed on at least one rank"; return TF_ENODEVICE; }
     const double w = (double)ctx->world;
     bool same = s[0] == w;
     // all equal <=> sum of squares == (sum)^2 / world (small integers and flags: exact in double precision)
@@ -3322,7 +3356,7 @@ static int mo_transform_device(tf_ctx *ctx, const double *C1, int n1, const doub
         if (q1_allowed && nk[c] <= 32 && nk[a] <= 32 && (size_t)N * ((nk[a] + 1) & ~1) * sizeof(double) + (size_t)N * sizeof(int) <= ((size_t)150 << 10)) {
             const size_t need = tfmp2::q1_pool_doubles(N, ctx->n_rows, nk[a], nk[b], nk[c], nk[d]) * sizeof(double);
             size_t free_b = 0, total_b = 0;
-            const bool fits = need <= ctx->mo_pool_bytes || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) <= free_b + ctx->mo_pool_bytes);
+            const bool fits = need <= ctx->mo_pool_bytes || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need + ((size_t)2 << 30) <= free_b + ctx->mo_pool_bytes + tfcache::cached());
             if (fits) {
                 if (need > ctx->mo_pool_bytes) {
                     if (ctx->mo_pool) { (void)tf_free(ctx->mo_pool); ctx->mo_pool = nullptr; ctx->mo_pool_bytes = 0; }
@@ -3450,7 +3484,7 @@ extern "C++" {
 struct ShardedCycleGuard {
     tf_ctx *ctx;
     bool on;
-    explicit ShardedCycleGuard(tf_ctx *c) : ctx(c), on(c->world > 1 && c->allreduce) {
+    explicit ShardedCycleGuard(tf_ctx *c) : ctx(c), on(c->world > 1 && (c->allreduce || c->comm)) {
         if (!on) { ctx->scf.agree = nullptr; return; }
         ctx->scf.agree = [c](const double *v, int nv, std::string &m) { return agree_over_ranks(c, v, nv, m); };
         if (ctx->scf.blas) (void)rocblas_set_atomics_mode(ctx->scf.blas, rocblas_atomics_not_allowed);

@@ -722,7 +722,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
                    const double *X, const double *P0, double E0, int n_occ, double V_NN, const JKFn &jk, int world,
                    tf_scf_result &out, std::string &msg, const XCFn &xc = XCFn())
 {
-    // world > 1: the J/K hook completes the partial sums of this rank's tensor rows with the registered all-reduce (tf_set_allreduce);
+    // world > 1: the J/K hook completes the partial sums of this rank's tensor rows with the communicator (tf_comm_init) or the registered all-reduce (tf_set_allreduce);
     // every rank then runs the O(N^3) steps redundantly on identical data
     (void)world;
     if (o.max_diis > TF_MAX_DIIS) { msg = "tf_scf_rhf: at most 64 DIIS matrices are held by the native cycle"; return TF_EINVAL; }

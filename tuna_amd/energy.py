@@ -163,6 +163,13 @@ def interpret_keywords(params, calc: Calculation) -> Calculation:
             pass                                             # (SCFGUESS: the reference's default guess path, calc:405-421 -- reproduced by default)
         else:
             raise TunaError(f"Keyword \"{p}\" is not supported on the GPU hot path (SCF keywords only)")
+    # calc:473-494: first the named criteria -- a derivative request without LOOSE..EXTREME tightens them (polarisabilities: extreme,
+    # dipole: tight) -- then ECONV / RMSDP / MAXDP / DIISERR are applied over whichever set was chosen
+    if not any(p in params for p in ("LOOSE", "MEDIUM", "TIGHT", "EXTREME")):
+        if calc.polarisability or calc.hyperpolarisability:
+            calc.SCF_conv = SCF_CONVERGENCE["extreme"]
+        elif calc.dipole:
+            calc.SCF_conv = SCF_CONVERGENCE["tight"]
     if custom:
         calc.SCF_conv = dict(calc.SCF_conv, **custom)
     return calc
@@ -311,9 +318,4 @@ def run(input_line: str, silent: bool = True, engine: Engine | None = None, log=
         calc.reference = "UHF"
     if method in dft_mod.FUNCTIONALS:
         calc.functional = method
-    if not any(p in params for p in ("LOOSE", "MEDIUM", "TIGHT", "EXTREME")):      # calc:473-485: derivative requests tighten the SCF
-        if calc.polarisability or calc.hyperpolarisability:
-            calc.SCF_conv = SCF_CONVERGENCE["extreme"]
-        elif calc.dipole:
-            calc.SCF_conv = SCF_CONVERGENCE["tight"]
     return calculate_energy(symbols, R, calc, engine, silent, log)
