@@ -52,14 +52,21 @@ def build_workload(name: str):
     return atoms, shells, mol.expand_cartesian_aos(shells), nocc, desc
 
 
-def _time_fock_einsums(Ns: int, budget_s: float, max_n: int = 200):
-    """seconds per J+K build with the reference's einsum strings on a dense random Ns^4 tensor"""
+def _time_fock_einsums(Ns: int, budget_s: float, max_n: int = 200, warm: bool = True):
+    """seconds per J+K build with the reference's einsum strings on a dense Ns^4 tensor of random values"""
     from oracle import scf_oracle as so
     rng = np.random.default_rng(0)
-    T = rng.standard_normal((Ns, Ns, Ns, Ns))
+    if Ns <= 128:
+        T = rng.standard_normal((Ns, Ns, Ns, Ns))
+    else:                                       # (GBs of normal deviates cost more than the builds: one random slab, rescaled per first index)
+        slab = rng.standard_normal((Ns, Ns, Ns))
+        T = np.empty((Ns, Ns, Ns, Ns))
+        for i in range(Ns):
+            np.multiply(slab, 1.0 + 0.37 * np.sin(i), out=T[i])
     A = rng.standard_normal((Ns, Ns))
     P = A + A.T
-    so.coulomb(P, T); so.exchange(P, T)
+    if warm:
+        so.coulomb(P, T); so.exchange(P, T)
     t0 = time.perf_counter()
     n = 0
     while True:
@@ -73,9 +80,10 @@ def _time_fock_einsums(Ns: int, budget_s: float, max_n: int = 200):
 
 def cpu_baseline_fock(N_workload: int, budget_s: float = 9.0):
     """The reference's CPU Fock build -- np.einsum("ijkl,kl->ij") + np.einsum("ilkj,kl->ij"), optimize=True
-    (scf:70, scf:42, restated in oracle/scf_oracle.py) -- timed on BOUNDED dense sample tensors (96^4 and 144^4: the second size
-    shows how far the N^4 scaling to the workload size holds) with all the CPUs this process may use, and at TUNA's default of 4
-    threads (tuna_calc.py:153)."""
+    (scf:70, scf:42, restated in oracle/scf_oracle.py) -- timed DIRECTLY on dense tensors of two real sizes: N = 118 (Ar2/cc-pVQZ,
+    BASELINE.json configs[2]; 1.6 GB) and N = 200 (12.8 GB, two builds), with all the CPUs this process may use; `value` is the
+    N = 200 time scaled by (N/200)^4 to the workload (a factor 16 at N = 400, whose dense tensor -- 205 GB -- no host einsum can hold
+    twice).  A 96^4 sample with many builds and TUNA's default of 4 threads (tuna_calc.py:153) are reported beside it."""
     import tuna_amd
     # BLAS threads = the CPUs this process may use (cgroup quota): more threads than that only spin and get the process throttled
     threads = tuna_amd.cpu_quota()
@@ -84,10 +92,15 @@ def cpu_baseline_fock(N_workload: int, budget_s: float = 9.0):
     except Exception:
         threadpool_limits = None
     Ns = min(N_workload, 96)
-    Ns2 = min(N_workload, 144)
+    sizes = [n for n in (118, 200) if n <= N_workload] or [N_workload]
     pool = threadpool_limits(limits=threads) if threadpool_limits else None
-    per_build, n = _time_fock_einsums(Ns, budget_s)
-    per_build2, n2 = _time_fock_einsums(Ns2, 0.6 * budget_s, 12) if Ns2 > Ns else (per_build, n)
+    per_build, n = _time_fock_einsums(Ns, 0.5 * budget_s)
+    direct = []
+    for nd_ in sizes:
+        pb, nb = _time_fock_einsums(nd_, budget_s if nd_ <= 128 else 2.0 * budget_s, 12 if nd_ <= 128 else 2, warm=nd_ <= 128)
+        direct.append({"n": nd_, "builds": nb, "ms_per_build": pb * 1e3, "dense_tensor_GB": 8.0 * nd_ ** 4 / 1e9,
+                       "scaled_seconds_per_build_at_workload_size": pb * (N_workload / nd_) ** 4,
+                       "ratio_to_96_sample": pb * (N_workload / nd_) ** 4 / (per_build * (N_workload / Ns) ** 4)})
     if pool is not None:
         pool.restore_original_limits()
     pool = threadpool_limits(limits=min(4, threads)) if threadpool_limits else None
@@ -95,16 +108,17 @@ def cpu_baseline_fock(N_workload: int, budget_s: float = 9.0):
     if pool is not None:
         pool.restore_original_limits()
         tuna_amd.limit_host_threads()
-    scaled = per_build * (N_workload / Ns) ** 4
-    scaled2 = per_build2 * (N_workload / Ns2) ** 4
+    big = direct[-1]
+    scaled = big["scaled_seconds_per_build_at_workload_size"]
     return {"value": 1.0 / scaled, "unit": "Fock builds/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} J+K builds with the reference einsum strings on a dense random {Ns}^4 f64 tensor "
-                      f"({per_build * 1e3:.1f} ms each), scaled by (N/{Ns})^4 to N = {N_workload}",
+            "sample": f"{big['builds']} J+K builds with the reference einsum strings on a dense {big['n']}^4 f64 tensor of random values "
+                      f"({big['ms_per_build']:.0f} ms each, timed directly), scaled by (N/{big['n']})^4 to N = {N_workload}",
             "seconds_per_build_at_workload_size": scaled,
-            "second_sample": {"n": Ns2, "builds": n2, "ms_per_build": per_build2 * 1e3, "scaled_seconds_per_build_at_workload_size": scaled2,
-                              "ratio_to_first_sample": scaled2 / scaled,
-                              "note": "ratio 1 = perfect N^4 scaling between the two sample sizes; above 1 the strided exchange einsum is "
-                                      "losing cache locality, so the N^4 extrapolation from the first sample flatters the CPU"},
+            "direct": direct,
+            "sample_96": {"n": Ns, "builds": n, "ms_per_build": per_build * 1e3,
+                          "scaled_seconds_per_build_at_workload_size": per_build * (N_workload / Ns) ** 4,
+                          "note": "ratio_to_96_sample above 1 in `direct` = the strided exchange einsum loses cache locality as N grows: "
+                                  "an N^4 extrapolation from a small sample flatters the CPU (rounds 1-3 quoted that one)"},
             "tuna_default_4_threads": {"threads": int(min(4, threads)), "builds": n4, "ms_per_build_sample": per_build4 * 1e3,
                                        "value": 1.0 / (per_build4 * (N_workload / Ns) ** 4), "unit": "Fock builds/s"}}
 
@@ -131,7 +145,7 @@ def cpu_baseline_eri(aos, limit_s: float = 20.0):
     return {"seconds": t_all, "kind": kind, "cores": cores, "seconds_1_thread": t_one, "speedup_over_1_thread": t_one / t_all}
 
 
-JK_KERNEL = {"packed": "jk_packed_kernel", "rows": "tfk::jk_rows_kernel"}
+JK_KERNEL = {"packed": "jk_packed_kernel", "rows": "tfk::jk_rows_kernel", "tiles": "jk_tile_kernel"}
 
 
 def pmc_traffic(workload: str, world: int, layout: str, stored_bytes: float):
@@ -161,6 +175,32 @@ def pmc_traffic(workload: str, world: int, layout: str, stored_bytes: float):
     return None, None, None
 
 
+def pmc_eri_valu(workload: str, cart_kernel_s: float):
+    """EXECUTED vector work of the Cartesian ERI kernels (eri_*; the slab transforms are excluded) from the committed rocprofv3 PMC pass of
+    a tensor build of the same workload: wave-level VALU instructions per build (SQ_INSTS_VALU) and the share of the chip's VALU issue
+    slots they fill during this run's ERI kernel time -- a wave64 instruction occupies its SIMD's 16-lane FP64 pipe for 4 cycles, 1024
+    SIMDs at 2.4 GHz (MI355X_MICROARCH.md).  Unlike `nominal_flops` this counts what the kernels execute, not the reference's loop nest."""
+    for rnd in ("r04", "r03"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_eri_{workload.replace('-', '')}.json")
+        try:
+            d = json.load(open(path))
+            builds = float(d["_meta"]["builds"])
+            fam = {k: v for k, v in d.items() if k.startswith("eri_")}
+            insts = sum(v["SQ_INSTS_VALU"] for v in fam.values()) / builds
+            busy = sum(v.get("SQ_BUSY_CYCLES", 0.0) for v in fam.values())
+            active = sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in fam.values())
+            return {"valu_wave_instructions_per_build": insts,
+                    "valu_issue_utilisation": insts * 4.0 / (1024 * 2.4e9 * max(cart_kernel_s, 1e-12)),
+                    "lds_wave_instructions_per_build": sum(v["SQ_INSTS_LDS"] for v in fam.values()) / builds,
+                    "salu_wave_instructions_per_build": sum(v["SQ_INSTS_SALU"] for v in fam.values()) / builds,
+                    "profile": os.path.relpath(path, ROOT), "profile_meta": d["_meta"],
+                    "note": "valu_issue_utilisation = VALU wave instructions of the profiled build x 4 cycles / (1024 SIMDs x 2.4 GHz x the ERI "
+                            "kernel seconds of THIS run); the kernels run concurrently on 8 streams, so kernel seconds are the device-busy span"}
+        except Exception:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,7 +211,7 @@ def main():
     ap.add_argument("--no-scf", action="store_true")
     ap.add_argument("--n-dens", type=int, choices=[1, 2, 4, 8, 16], default=1,
                     help="densities per step (2 = a UHF build: alpha and beta in one pass; 4, 8, 16 = a finite-field batch: pairs of densities per pass)")
-    ap.add_argument("--layout", choices=["packed", "rows"], default="packed", help="ERI storage layout (tunafock.h: tf_set_eri_layout)")
+    ap.add_argument("--layout", choices=["packed", "rows", "tiles"], default="packed", help="ERI storage layout (tunafock.h: tf_set_eri_layout)")
     args = ap.parse_args()
 
     import torch
@@ -292,7 +332,10 @@ def main():
         storage = {"packed": "parity-blocked 8-fold symmetry-unique values of the spherical tensor: row (i>=j) keeps the pairs (k>=l) <= (i,j) "
                              "whose x/y reflection parity class equals that of (i,j) -- the others are exact zeros (pyx:1324-1327) -- f64, "
                              "units of 8 interleaved rows, sharded by (ij) shell pair over ranks",
-                   "rows": "rows (i>=j) x full (k,l) of the spherical tensor, f64, sharded by (ij) shell pair over ranks"}[layout]
+                   "rows": "rows (i>=j) x full (k,l) of the spherical tensor, f64, sharded by (ij) shell pair over ranks",
+                   "tiles": "the same 8-fold unique, parity-blocked values arranged for v_mfma_f64_16x16x4: per first index i and class pair, "
+                            "(k,l) rectangles / triangles below i in strips of 64 x 16-column blocks, second index innermost (tf_tiles.h); "
+                            "opt-in (DESIGN.md section 4.1b: slower than `packed` at N = 400)"}[layout]
         out = {
             "metric": "Fock builds/sec (J+K from the HBM-resident ERI tensor, one density) + SCF wall time",
             "value": args.steps / elapsed, "unit": "Fock builds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -333,6 +376,7 @@ def main():
                           "gflops": (eri_t["nominal_flops"] / max(eri_t["cart_kernel_s"], 1e-12) / 1e9) if eri_t.get("nominal_flops") else None,
                           "frac_of_fp64_vector_peak": (eri_t["nominal_flops"] / max(eri_t["cart_kernel_s"], 1e-12) / FP64_VECTOR_PEAK_FLOPS)
                           if eri_t.get("nominal_flops") else None,
+                          "executed": pmc_eri_valu(args.workload, eri_t["cart_kernel_s"]),
                           "flops_note": "nominal_flops = the reference algorithm's count for the quartets evaluated (SURVEY 8d(ii): per primitive AO "
                                         "quartet 8 x inner terms of the loop nest pyx:1179-1217 + 6 (L+1) + 3 (L+1)^2 / 2 + 60), divided by the time of "
                                         "the ERI kernels; the kernels factorise the sum per shell quartet and execute fewer operations than that",

@@ -283,6 +283,12 @@ int tf_segment_pad(void);
  * (0 = rocsolver dsyevd, 1 = dsyev, 2 = dsyevj); instrumentation only. */
 int tf_eigh_probe(tf_ctx *ctx, int n, int variant, int reps, double *seconds);
 
+/* Counters of the context's eigensolver paths since tf_create (instrumentation, tests): out[0] solves by eigenvector refinement,
+ * out[1] refinement steps, out[2] refinements that fell back to a full eigensolve, out[3] eigensolves done block by block
+ * (the x/y parity classes of a diatomic solved together, tf_scf.hip.h: eigh_blocked), out[4] eigensolves where the matrix did not
+ * have the block structure and the full matrix was solved. */
+int tf_eigh_stats(tf_ctx *ctx, int64_t out[5]);
+
 /* HIP-event timing of the dominant kernel of the Fock build (the row pass over the stored tensor), recorded on
  * the stream each build is launched on.  enable: start (and reset) / stop collecting; read: synchronises the
  * recorded events, returns their summed duration and the number of launches, and resets. */

@@ -233,3 +233,41 @@ def test_electric_field_term_of_the_fock_matrix(engine, reference):
     mu = float(np.sum(res[0.0].P * Dz))
     assert abs(mu) > 1e-2                                           # (electronic dipole about the centre of mass: not zero by symmetry)
     assert abs(slope - mu) < 2e-6
+
+
+def test_symmetry_blocked_eigensolve_and_its_refusal():
+    """tf_scf.hip.h: eigh_blocked -- the x/y parity classes of a diatomic are solved as one batch of small problems when (and only when)
+    the matrix has no element connecting two classes.  scf:222-250 for both cases: the same orbital energies as LAPACK on the full matrix,
+    S-orthonormal orbitals that solve F C = S C eps; a dipole field along x couples the classes and must take the full solve."""
+    from conftest import atom_arrays, make_system
+    from tuna_amd.engine import Engine
+    atoms, shells, aos, nocc = make_system("c3_ar2_ccpvqz")
+    with Engine(0) as eng:
+        eng.set_basis(aos).build_eri(True)
+        N = eng.N
+        assert N > 64
+        xyz, chg, org = atom_arrays(atoms)
+        S, T, V, D, _ = eng.one_electron(xyz, chg, org, spherical=True)
+        s0 = eng.eigh_stats()
+        X, smin, _ = eng.orthogonaliser(S)
+        s1 = eng.eigh_stats()
+        assert s1["blocked_solves"] == s0["blocked_solves"] + 1            # S itself is block diagonal
+        assert np.abs(X @ S @ X - np.eye(N)).max() < 1e-10
+        F = T + V
+
+        def check(Fm):
+            eps, Cm = eng.diagonalise(Fm, X)
+            ref = np.linalg.eigvalsh(0.5 * (X.T @ Fm @ X + (X.T @ Fm @ X).T))
+            assert np.abs(eps - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+            assert np.all(np.diff(eps) >= 0)
+            assert np.abs(Cm.T @ S @ Cm - np.eye(N)).max() < 1e-10
+            assert np.abs(Fm @ Cm - S @ Cm * eps).max() < 1e-8 * max(1.0, np.abs(ref).max())
+        check(F)
+        s2 = eng.eigh_stats()
+        assert s2["blocked_solves"] == s1["blocked_solves"] + 1 and s2["blocked_declined"] == s1["blocked_declined"]
+        check(F + 0.01 * D[2])                                             # a field along z keeps the classes apart
+        s3 = eng.eigh_stats()
+        assert s3["blocked_solves"] == s2["blocked_solves"] + 1
+        check(F + 0.01 * D[0])                                             # a field along x does not: full solve
+        s4 = eng.eigh_stats()
+        assert s4["blocked_solves"] == s3["blocked_solves"] and s4["blocked_declined"] == s3["blocked_declined"] + 1

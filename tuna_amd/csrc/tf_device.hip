@@ -3220,12 +3220,21 @@ int tf_eri_element(tf_ctx *ctx, const double *origin, const int32_t *lmn, const 
 
 // ---- SCF --------------------------------------------------------------------------------------------
 
+// The parity class of every output AO of the current build, offered to the eigensolvers of a workspace (tfscf::eigh_blocked verifies on
+// every call that the matrix really has the block structure, so a vector that does not fit the problem only costs the test).
+static void offer_symmetry(tf_ctx *ctx, tfscf::Workspace &w, int n)
+{
+    static const std::vector<int> none;
+    tfscf::set_symmetry(w, (ctx->have_eri && (int)ctx->hl.cls.size() == n) ? ctx->hl.cls : none);
+}
+
 int tf_orthogonaliser(tf_ctx *ctx, int n, const double *S, double *X, double *S_inv, double *smallest_eig)
 {
     if (!ctx) return TF_EINVAL;
     if (n < 1 || !S || !X) TF_FAIL(ctx, TF_EINVAL, "tf_orthogonaliser: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::string msg;
+    offer_symmetry(ctx, ctx->scf, n);
     int rc = tfscf::orthogonaliser(ctx->scf, n, S, X, S_inv, smallest_eig, msg);
     if (rc) ctx->err = msg;
     return rc;
@@ -3237,6 +3246,7 @@ int tf_diagonalise(tf_ctx *ctx, int n, const double *F, const double *X, double 
     if (n < 1 || !F || !X || !eps || !C) TF_FAIL(ctx, TF_EINVAL, "tf_diagonalise: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::string msg;
+    offer_symmetry(ctx, ctx->scf, n);
     int rc = tfscf::diagonalise(ctx->scf, n, F, X, eps, C, msg);
     if (rc) ctx->err = msg;
     return rc;
@@ -3477,6 +3487,14 @@ int tf_eigh_probe(tf_ctx *ctx, int n, int variant, int reps, double *seconds)
     return rc;
 }
 
+int tf_eigh_stats(tf_ctx *ctx, int64_t out[5])
+{
+    if (!ctx || !out) return TF_EINVAL;
+    const tfscf::Workspace &w = ctx->scf;
+    out[0] = w.ref_solves; out[1] = w.ref_steps; out[2] = w.ref_fallbacks; out[3] = w.sym_solves; out[4] = w.sym_declined;
+    return TF_OK;
+}
+
 extern "C++" {
 // A native cycle on a sharded tensor: every rank must take the same decisions from the same data.  For the duration of the cycle the
 // control decisions are agreed over the ranks (agree_over_ranks) and rocBLAS runs without atomics (bitwise reproducible GEMMs; not
@@ -3516,6 +3534,7 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
         xc = [&](const double *dP, double *dV, double *o3) { return tfdft::vxc(ctx->scf.blas, ctx->grid, dP, dV, o3, msg); };
     }
     ShardedCycleGuard guard(ctx);
+    offer_symmetry(ctx, ctx->scf, ctx->N);
     int rc = tfscf::run_rhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0, E0, n_occ, V_NN, jk, ctx->world, *out, msg, xc);
     if (rc && !msg.empty()) ctx->err = msg;
     return rc;
@@ -3614,6 +3633,7 @@ int tf_scf_rhf_batch(tf_ctx *ctx, int n_cycles, const tf_scf_opts *opts, const d
             hipStream_t st = serial_streams ? nullptr : pool[(size_t)c % pool.size()];
             tfscf::t_stream = st;
             auto jk = [&](const double *dP, double *dJ, double *dK, hipStream_t s2) { return ls.fock(dP, dJ, dK, s2); };
+            offer_symmetry(ctx, *ctx->scf_batch[(size_t)c], ctx->N);
             rcs[(size_t)c] = tfscf::run_rhf(*ctx->scf_batch[(size_t)c], ctx->N, *opts, S, T, V, Fext ? Fext[c] : nullptr, X, P0[c], E0[c], n_occ, V_NN, jk, 1,
                                              out[c], msgs[(size_t)c], tfscf::XCFn());
             (void)hipStreamSynchronize(st);
@@ -3653,6 +3673,7 @@ int tf_scf_uhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
     tfscf::UhfOut uo;
     for (int sp = 0; sp < 2; ++sp) { uo.P[sp] = out->P_spin[sp]; uo.C[sp] = out->C_spin[sp]; uo.eps[sp] = out->eps_spin[sp]; uo.F[sp] = out->F_spin[sp]; }
     ShardedCycleGuard guard(ctx);
+    offer_symmetry(ctx, ctx->scf, ctx->N);
     int rc = tfscf::run_uhf(ctx->scf, ctx->N, *opts, S, T, V, Fext, X, P0_alpha, P0_beta, E0, n_alpha, n_beta, V_NN, jk2, ctx->world,
                             out->common, uo, msg);
     if (rc && !msg.empty()) ctx->err = msg;

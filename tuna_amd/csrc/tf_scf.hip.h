@@ -70,6 +70,15 @@ struct Workspace {
     size_t ref_alt_cap = 0;
     int ref_alt_n = 0;
     std::vector<hipEvent_t> tev;     // timing events, read after the cycle (no synchronisation inside it)
+    // Symmetry blocks (eigh_blocked): class of every basis function (set_symmetry; empty = none known), the functions of each class
+    std::vector<int> sym_cls;
+    int sym_n = 0, sym_nb = 0, sym_mmax = 0;   // matrix size the tables were built for, classes present, largest class
+    int sym_m[4] = {0, 0, 0, 0};
+    int *sym_idx = nullptr;          // device [4][mmax]: original index of member t of block b (-1: padding); then cls[n]
+    double *sym_buf = nullptr;       // device: [nb][mmax][mmax] blocks, [nb][mmax] values, [nb][mmax] work, 2 doubles of the cross-class test
+    int *sym_src = nullptr;          // device [n]: block * mmax + member of the eigenvalue of global rank r
+    rocblas_int *sym_info = nullptr; // device [4]
+    long long sym_solves = 0, sym_declined = 0;
 };
 
 inline void release(Workspace &w)
@@ -88,6 +97,10 @@ inline void release(Workspace &w)
     if (w.h_pin) (void)hipHostFree(w.h_pin);
     if (w.ev_pin) (void)hipEventDestroy(w.ev_pin);
     for (hipEvent_t e : w.tev) (void)hipEventDestroy(e);
+    if (w.sym_idx) (void)hipFree(w.sym_idx);
+    if (w.sym_buf) (void)hipFree(w.sym_buf);
+    if (w.sym_src) (void)hipFree(w.sym_src);
+    if (w.sym_info) (void)hipFree(w.sym_info);
     w = Workspace();
 }
 
@@ -316,6 +329,135 @@ inline rocblas_status gemm_rm(rocblas_handle h, bool tA, bool tB, int n, double 
                          tA ? rocblas_operation_transpose : rocblas_operation_none, n, n, n, &alpha, B, n, A, n, &beta, C, n);
 }
 
+// ---- symmetry-blocked eigensolve ----------------------------------------------------------------------------------------------
+// A diatomic on the z axis keeps the reflections x -> -x and y -> -y: every AO is even or odd under each (four classes, the same ones
+// the packed tensor layout is blocked by), S, X = S^-1/2, the core Hamiltonian and a field along z do not connect different classes,
+// and J, K of a class-diagonal density are class-diagonal again ((ij|kl) vanishes unless the four parities multiply to even,
+// pyx:1324-1327).  The matrices the cycle diagonalises are then block diagonal after a permutation: at N = 400 blocks of
+// 162 / 96 / 96 / 46 instead of 400, which rocsolver_dsyevd_strided_batched solves together in the time of the largest one
+// (3.3 ms against 10.8 ms for the full matrix, `tools/gpu_eigh_blocks.py`).  Nothing is assumed: every call first measures the largest
+// element that connects two classes (k_blk_cross) and declines -- the caller then solves the full matrix -- unless it is below
+// 1e-14 of the largest element (a field along x, a symmetry-broken density or a basis without the structure end up there).
+// Blocks are padded to the largest one with a decoupled diagonal far above the spectrum; the eigenvalues of all blocks are ranked
+// together (ties by block, then by position: a stable sort) and the vectors scattered back to the full basis.
+inline void set_symmetry(Workspace &w, const std::vector<int> &cls) { if (cls != w.sym_cls) { w.sym_cls = cls; w.sym_n = 0; } }
+
+__global__ void k_blk_cross(const double *__restrict__ A, const int *__restrict__ cls, int n, unsigned long long *__restrict__ out)
+{
+    __shared__ double sa[256], sx[256];
+    double all = 0.0, cross = 0.0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)n * n; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
+        const double v = fabs(A[e]);
+        all = fmax(all, v);
+        if (cls[i] != cls[j]) cross = fmax(cross, v);
+    }
+    sa[threadIdx.x] = all; sx[threadIdx.x] = cross;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { sa[threadIdx.x] = fmax(sa[threadIdx.x], sa[threadIdx.x + st]); sx[threadIdx.x] = fmax(sx[threadIdx.x], sx[threadIdx.x + st]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {          // non-negative doubles order like their bit patterns (a NaN ends up above everything: declined)
+        atomicMax(out, (unsigned long long)__double_as_longlong(sa[0]));
+        atomicMax(out + 1, (unsigned long long)__double_as_longlong(sx[0]));
+    }
+}
+
+// B[b][r][c] = A[idx[b][r]][idx[b][c]] (symmetrised), padding: a decoupled diagonal `big + r`
+__global__ void k_blk_gather(const double *__restrict__ A, const int *__restrict__ idx, int n, int mmax, double big, double *__restrict__ B)
+{
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= mmax * mmax) return;
+    const int r = e / mmax, c = e - r * mmax;
+    const int i = idx[b * mmax + r], j = idx[b * mmax + c];
+    double v;
+    if (i >= 0 && j >= 0) v = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]);
+    else v = (r == c) ? big + (double)r : 0.0;
+    B[((size_t)b * mmax + r) * mmax + c] = v;
+}
+
+// global ranks of the eigenvalues of all blocks (padding excluded): vals[rank] = value, src[rank] = b * mmax + t; single block of 1024
+__global__ void k_blk_rank(const double *__restrict__ D, const int *__restrict__ idx, int nb, int mmax, double *__restrict__ vals, int *__restrict__ src)
+{
+    // member t of block b is real iff idx[b][t] >= 0 (members come first); the padded problems return their values ascending, so the
+    // real ones are the first m_b of each block
+    const int tot = nb * mmax;
+    for (int q = threadIdx.x; q < tot; q += blockDim.x) {
+        if (idx[q] < 0) continue;
+        const double d = D[q];
+        int rank = 0;
+        for (int p = 0; p < tot; ++p) {
+            if (idx[p] < 0) continue;
+            const double dp = D[p];
+            rank += (dp < d || (dp == d && p < q)) ? 1 : 0;
+        }
+        vals[rank] = d;
+        src[rank] = q;
+    }
+}
+
+// W[rank][:] = eigenvector `src[rank]` of its block, scattered to the full basis (zero outside the block); one workgroup per row
+__global__ void k_blk_scatter(const double *__restrict__ B, const int *__restrict__ idx, const int *__restrict__ src, int n, int mmax,
+                              double *__restrict__ W)
+{
+    const int r = blockIdx.x;
+    const int q = src[r], b = q / mmax, t = q - b * mmax;
+    double *row = W + (size_t)r * n;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) row[c] = 0.0;
+    __syncthreads();
+    const double *v = B + ((size_t)b * mmax + t) * mmax;          // row t of the block in row-major terms = column t for rocSOLVER
+    for (int c = threadIdx.x; c < mmax; c += blockDim.x) {
+        const int i = idx[b * mmax + c];
+        if (i >= 0) row[i] = v[c];
+    }
+}
+
+// TF_OK: solved (W rows = eigenvectors, vals ascending).  TF_EINVAL with an empty msg: declined, the caller solves the full matrix.
+inline int eigh_blocked(Workspace &w, int n, double *W, double *vals, std::string &msg)
+{
+    static const bool off = getenv("TF_EIGH_BLOCKS") && getenv("TF_EIGH_BLOCKS")[0] == '0';
+    if (off || (int)w.sym_cls.size() != n || n <= 64) return TF_EINVAL;
+    if (w.sym_n != n) {                                            // tables for this class vector
+        int m[4] = {0, 0, 0, 0};
+        for (int c : w.sym_cls) { if (c < 0 || c > 3) return TF_EINVAL; ++m[c]; }
+        int nb = 0, mmax = 0, blk_of[4] = {-1, -1, -1, -1};
+        for (int c = 0; c < 4; ++c) if (m[c] > 0) { blk_of[c] = nb; w.sym_m[nb] = m[c]; ++nb; mmax = std::max(mmax, m[c]); }
+        w.sym_nb = nb; w.sym_mmax = mmax; w.sym_n = n;
+        if (w.sym_idx) (void)hipFree(w.sym_idx);
+        if (w.sym_buf) (void)hipFree(w.sym_buf);
+        if (w.sym_src) (void)hipFree(w.sym_src);
+        w.sym_idx = nullptr; w.sym_buf = nullptr; w.sym_src = nullptr;
+        std::vector<int> idx((size_t)4 * mmax + n, -1);
+        int fill[4] = {0, 0, 0, 0};
+        for (int i = 0; i < n; ++i) { const int b = blk_of[w.sym_cls[i]]; idx[(size_t)b * mmax + fill[b]++] = i; idx[(size_t)4 * mmax + i] = w.sym_cls[i]; }
+        TFS_HIP(hipMalloc((void **)&w.sym_idx, idx.size() * sizeof(int)));
+        TFS_HIP(tfs_memcpy(w.sym_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        TFS_HIP(hipMalloc((void **)&w.sym_buf, ((size_t)nb * mmax * mmax + 2 * (size_t)nb * mmax + 2) * sizeof(double)));
+        TFS_HIP(hipMalloc((void **)&w.sym_src, (size_t)n * sizeof(int)));
+        if (!w.sym_info) TFS_HIP(hipMalloc((void **)&w.sym_info, 4 * sizeof(rocblas_int)));
+    }
+    const int nb = w.sym_nb, mmax = w.sym_mmax;
+    if (nb < 2 || 4 * mmax > 3 * n) return TF_EINVAL;             // one class holds (nearly) everything: nothing to gain
+    double *B = w.sym_buf, *D = B + (size_t)nb * mmax * mmax, *E = D + (size_t)nb * mmax;
+    unsigned long long *flag = (unsigned long long *)(E + (size_t)nb * mmax);
+    const int *cls = w.sym_idx + (size_t)4 * mmax;
+    TFS_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(double), TFS_ST));
+    hipLaunchKernelGGL(k_blk_cross, dim3(std::min(256, (n * n + 255) / 256)), dim3(256), 0, TFS_ST, W, cls, n, flag);
+    double h[2];
+    TFS_HIP(tfs_memcpy(h, flag, sizeof(h), hipMemcpyDeviceToHost));
+    if (!(h[1] <= 1e-14 * h[0]) || !std::isfinite(h[0])) { ++w.sym_declined; return TF_EINVAL; }
+    const int g = (mmax * mmax + 255) / 256;
+    hipLaunchKernelGGL(k_blk_gather, dim3(g, nb), dim3(256), 0, TFS_ST, W, w.sym_idx, n, mmax, 4.0 * h[0] * n + 1.0, B);
+    TFS_BLAS(rocsolver_dsyevd_strided_batched(w.blas, rocblas_evect_original, rocblas_fill_upper, mmax, B, mmax, (rocblas_stride)mmax * mmax,
+                                              D, mmax, E, mmax, w.sym_info, nb));
+    hipLaunchKernelGGL(k_blk_rank, dim3(1), dim3(1024), 0, TFS_ST, D, w.sym_idx, nb, mmax, vals, w.sym_src);
+    hipLaunchKernelGGL(k_blk_scatter, dim3(n), dim3(128), 0, TFS_ST, B, w.sym_idx, w.sym_src, n, mmax, W);
+    ++w.sym_solves;
+    return TF_OK;
+}
+
 // Symmetric eigenproblem: W (in: symmetric matrix, out: row k = eigenvector k in row-major terms), vals ascending.
 // n <= 64: single-launch in-LDS Jacobi (tf_jacobi.hip.h; measured 0.06/0.23/0.96 ms at n = 10/28/60 against 0.24/0.67/1.22 ms
 // for dsyevd); larger: rocsolver_dsyevd (faster from n ~ 70 on).  TF_EIGH=rocsolver|jacobi overrides.
@@ -345,6 +487,12 @@ inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, st
             return TF_OK;
         }
         if (e != hipSuccess) { msg = std::string("Jacobi eigensolver launch failed: ") + hipGetErrorString(e); return TF_ENODEVICE; }
+    }
+    if (!force_rocsolver) {                                        // the symmetry blocks of a diatomic, solved together (declines if there are none)
+        std::string bmsg;
+        const int rb = eigh_blocked(w, n, W, vals, bmsg);
+        if (rb == TF_OK) return TF_OK;
+        if (!bmsg.empty()) { msg = bmsg; return rb; }
     }
     TFS_BLAS(rocsolver_dsyevd(w.blas, rocblas_evect_original, rocblas_fill_upper, n, W, n, vals, work_e, w.d_info));
     return TF_OK;
@@ -695,6 +843,17 @@ inline int eigh_probe(Workspace &w, int n, int variant, int reps, double *second
             else
                 TFS_BLAS(rocsolver_dsyevx(w.blas, rocblas_evect_original, rocblas_erange_index, rocblas_fill_upper, n, A, n, 0.0, 0.0, 1, k, 0.0, nev,
                                           vals, V, n, (rocblas_int *)(base_ifail(w, n)), (rocblas_int *)(w.d_scal + 40)));
+        }
+        else if (variant == 8 || variant == 9) {                  // a batch of four n x n problems in one call (the symmetry blocks of a diatomic)
+            // pool: A0 | A | V | vals... : four matrices need 4 nn doubles from A on (ensure() gave 6 nn + vectors): copy A into 4 slots
+            if (n > 256) { msg = "probe variant 8: n <= 256"; return TF_EINVAL; }
+            double *B = w.pool + nn;                              // 4 matrices of n x n behind A0 (A, V and the tail of the pool)
+            for (int q = 1; q < 4; ++q) TFS_HIP(tfs_memcpy(B + q * nn, A0, nn * sizeof(double), hipMemcpyDeviceToDevice));
+            double *vb = w.pool + 5 * nn, *eb = vb + 4 * n;       // needs 5 nn + 8 n doubles <= 6 nn + ... for n >= 8
+            if (variant == 8)
+                TFS_BLAS(rocsolver_dsyevd_strided_batched(w.blas, rocblas_evect_original, rocblas_fill_upper, n, B, n, (rocblas_stride)nn, vb, n, eb, n, w.d_info, 4));
+            else
+                TFS_BLAS(rocsolver_dsyevdj_strided_batched(w.blas, rocblas_evect_original, rocblas_fill_upper, n, B, n, (rocblas_stride)nn, vb, n, w.d_info, 4));
         }
         else if (variant == 6) TFS_BLAS(rocsolver_dsyevdj(w.blas, rocblas_evect_original, rocblas_fill_upper, n, A, n, vals, w.d_info));
         else if (variant == 7) {                                  // four n x n GEMMs: the cost of one eigenvector refinement step

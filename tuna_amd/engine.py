@@ -232,6 +232,13 @@ class Engine:
         self._check(self._L.tf_diagonalise(self._ctx, n, ptr(F), ptr(X), ptr(eps), ptr(Cm)))
         return eps, Cm
 
+    def eigh_stats(self):
+        """Counters of the eigensolver paths of this engine's workspace (tunafock.h: tf_eigh_stats)."""
+        import ctypes as C
+        out = (C.c_int64 * 5)()
+        self._check(self._L.tf_eigh_stats(self._ctx, out))
+        return dict(zip(("refined_solves", "refinement_steps", "refinement_fallbacks", "blocked_solves", "blocked_declined"), (int(v) for v in out)))
+
     def _scf_opts(self, *, conv="medium", max_iter=100, diis=True, max_diis=6, damping="dynamic", damping_factor=0.0, max_damping=0.7,
                   hfx=1.0, n_atom_ao=None):
         N = self.N
