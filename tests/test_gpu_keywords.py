@@ -3,6 +3,7 @@ reference's own cycle with the fields those keywords set (tests/golden/keyword_r
 import json
 import os
 
+import numpy as np
 import pytest
 
 from conftest import GOLD
@@ -20,9 +21,17 @@ def test_keyword_against_the_reference_run(system, case):
     out = run(f"{LINES[system]} {g['keywords']}")
     loose = case in ("base", "ez", "ex_ez", "egz", "egx_egy", "conv")        # MEDIUM thresholds (or looser): energies agree as far as the trajectories do
     assert abs(out.energy - g["energy"]) < (1e-8 if not loose else 2e-8), (out.energy, g["energy"])
-    # (EXTREME thresholds sit in the rounding noise of the last iterations -- |dE| hovers around 1e-11 for three iterations of the
-    # reference's own DIIS 12 run -- so the count may differ by one or two there; the energies agree to 1e-8 regardless)
-    assert abs(out.n_iterations - g["iterations"]) <= (0 if loose else 2)
+    # EXTREME runs stop on |dE| < 1e-11 alone -- the other three criteria are met two to three iterations earlier (tools/
+    # gpu_iteration_counts.py prints both tables) -- and by then dE is what DIIS extrapolation over 10-12 nearly collinear error vectors
+    # leaves of the rounding differences between the two Fock builds: in the reference's own HF/6-31G run |dE| reads 1.9e-11, 3.8e-11,
+    # 8.3e-12 over its last three iterations.  Measured: CO/cc-pVDZ stops on the reference's iteration in both runs, HF/6-31G one
+    # later (DIIS 10) and two earlier (DIIS 12).  Until that plateau the tables agree:
+    assert abs(out.n_iterations - g["iterations"]) <= (0 if loose or system == "co_ccpvdz" else 2)
+    ref_table, table = np.asarray(g["table"]), np.asarray(out.table)
+    n_common = min(len(ref_table), len(table)) - 3
+    assert np.abs(table[:n_common, 1] - ref_table[:n_common, 1]).max() < 1e-8          # energies, iteration by iteration
+    big = ref_table[:n_common, 5] > 1e-7
+    assert np.abs(table[:n_common, 5][big] / ref_table[:n_common, 5][big] - 1.0).max() < 1e-2   # DIIS error norms above the noise
     assert abs(out.electric_field_energy + out.electric_field_gradient_energy - g["field_energy"] - g["field_gradient_energy"]) < 1e-8
 
 

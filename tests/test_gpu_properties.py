@@ -82,7 +82,10 @@ def test_lockstep_cycles_equal_cycles_run_one_by_one(engine):
     one_by_one = props.FieldEnergies(molecule, calc, integrals, V_NN, X, guess, batched=False)
     Ea, Eb = together.energies(fields), one_by_one.energies(fields)
     assert np.abs(np.array(Ea) - np.array(Eb)).max() < 1e-9
-    assert abs(together.iterations - one_by_one.iterations) <= len(fields)          # same trajectories, cycle by cycle
+    # same trajectories, cycle by cycle.  The counts are not identical: a lockstep iteration builds its Fock matrices two densities per
+    # pass (jk_packed_kernel<2>: another order of the same sums than the one-density pass), and a cycle whose |dE| sits on the EXTREME
+    # threshold of 1e-11 then stops an iteration earlier or later -- measured: one cycle of the eight, by one (tools/gpu_iteration_counts.py)
+    assert abs(together.iterations - one_by_one.iterations) <= 2
     # a field along x mixes AOs of different x parity: the density leaves the block structure of the zero-field problem
     assert abs(Ea[4] - Ea[7]) < 1e-9 and abs(Ea[5] - Ea[6]) < 1e-9                  # E(+x) = E(-x) by symmetry
     # the same batch inside the library (tf_scf_rhf_batch: the native cycle per field on its own host thread and workspace, the Fock
@@ -91,7 +94,7 @@ def test_lockstep_cycles_equal_cycles_run_one_by_one(engine):
     b0 = integrals.ERI_AO.n_builds
     Ec = native.energies(fields)
     assert np.abs(np.array(Ec) - np.array(Eb)).max() < 1e-9
-    assert abs(native.iterations - one_by_one.iterations) <= len(fields)            # the same native cycle, only scheduled together
+    assert abs(native.iterations - one_by_one.iterations) <= 2                      # the same native cycle, only scheduled together
     assert integrals.ERI_AO.n_builds - b0 <= (one_by_one.iterations + 1) // 2 + len(fields)   # passes over the tensor: two densities each
     # an odd number of cycles (the last pass of an iteration carries one density) and a single one
     Ed = props.FieldEnergies(molecule, calc, integrals, V_NN, X, guess, batched="native").energies(fields[:3])
