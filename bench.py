@@ -157,7 +157,7 @@ def pmc_traffic(workload: str, world: int, layout: str, stored_bytes: float):
     run's (another layout or padding) is not used.  Returns (bytes, file, meta) or (None, None, None)."""
     if world != 1:
         return None, None, None
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload.replace('-', '')}_{layout}.json")
         try:
             d = json.load(open(path))

@@ -100,6 +100,7 @@ static hipError_t cmalloc(void **p, size_t bytes)
     if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*p] = std::make_pair(c, dev); }
     return e;
 }
+static thread_local bool bypass = false;     // set while blocks are released after a failed synchronisation: straight back to the runtime
 static hipError_t cfree(void *p)
 {
     if (!p) return hipSuccess;
@@ -110,7 +111,7 @@ static hipError_t cfree(void *p)
             const size_t c = it->second.first;
             const int dev = it->second.second;
             live.erase(it);
-            if (cached_bytes + c <= MAX_CACHED) {
+            if (!bypass && cached_bytes + c <= MAX_CACHED) {
                 free_blocks.emplace(c, Block{p, dev});
                 cached_bytes += c;
                 return hipSuccess;
@@ -347,9 +348,27 @@ extern "C++" {
 static int tile_list_upload(tf_ctx *ctx, const tft::TaskList &TL, bool own_shapes, tf_ctx::TileList &D);
 }
 
+// The blocks freed by free_eri / free_basis are recycled at once (tfcache): nothing queued earlier may still use them, hence the
+// synchronisation.  If it FAILS the device is in an error state: the error is kept for the caller (tf_last_error), the cache is emptied
+// and the blocks of this call go straight back to the runtime instead of being handed out again.
+struct DrainedFree {
+    bool ok;
+    DrainedFree(tf_ctx *ctx, const char *what)
+    {
+        const hipError_t e = hipDeviceSynchronize();
+        ok = e == hipSuccess;
+        if (!ok) {
+            ctx->err = std::string(what) + ": hipDeviceSynchronize failed before buffers were released (" + hipGetErrorString(e) + ")";
+            tfcache::trim();
+            tfcache::bypass = true;
+        }
+    }
+    ~DrainedFree() { tfcache::bypass = false; }
+};
+
 static void free_eri(tf_ctx *ctx)
 {
-    (void)hipDeviceSynchronize();               // (the freed blocks are recycled at once: nothing queued earlier may still use them)
+    DrainedFree drained(ctx, "free_eri");
     for (void *p : {(void *)ctx->d_class_rows, (void *)ctx->d_row_pos, (void *)ctx->d_row_ij, (void *)ctx->d_rowmap, (void *)ctx->d_Jrow, (void *)ctx->d_Kp,
                     (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_Psym,
                     (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ, (void *)ctx->d_Jt, (void *)ctx->d_D})
@@ -382,7 +401,7 @@ static void free_eri(tf_ctx *ctx)
 
 static void free_basis(tf_ctx *ctx)
 {
-    (void)hipDeviceSynchronize();
+    DrainedFree drained(ctx, "free_basis");
     for (void *p : ctx->basis_allocs) (void)tf_free(p);
     ctx->basis_allocs.clear();
     for (void *p : {(void *)ctx->d_csr_ptr, (void *)ctx->d_csr_idx, (void *)ctx->d_csr_val})

@@ -107,33 +107,8 @@ __global__ __launch_bounds__(256) void xform_bra_store_tiles(const double *__res
     eri[ad] = s;
 }
 
-// The stored part of local rows as symmetric matrices, for the GEMM-shaped consumers (AO->MO): the tiles counterparts of
-// unpack_own_rows_kernel / unpack_own_rows_blocked_kernel (tf_jkpacked.hip.h).
-__global__ void unpack_own_rows_tiles_kernel(const double *__restrict__ eri, TView V, BLayout L, const int2 *__restrict__ row_ij, long long r0, int ld,
-                                             double *__restrict__ out)
-{
-    const long long r = r0 + blockIdx.y;
-    const int2 ij = row_ij[r];
-    const int wi = L.ao[ij.x], wj = L.ao[ij.y];
-    const int c = ao_cls(wi) ^ ao_cls(wj), iI = ao_sigma(L, wi), jI = ao_sigma(L, wj), lamj = ao_loc(wj);
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= bl_np(L, c)) return;
-    const int kI = L.gk[bl_gbase(L, c) + x / TF_SEG_PAD];
-    const int a = L.clsI[kI];
-    const KInfo ki = L.kinfo[(size_t)c * L.N + kI];
-    const int lam = x - bl_fullsec(L, c, a) - ki.offA;
-    if (lam >= ki.cnt || kI - bl_cstart(L, a) >= L.cntA[(size_t)a * L.N + iI] || (kI == iI && lam > lamj)) return;
-    const int lI = bl_cstart(L, a ^ c) + lam;
-    const long long ad = tt_elem_addr(V, L.clsI, iI, jI, kI, lI);
-    if (ad < 0) return;
-    double v = eri[ad];
-    if (kI == iI && lam == lamj) v *= 0.5;
-    const int k = L.origI[kI], l = L.origI[lI];
-    double *__restrict__ o = out + (size_t)blockIdx.y * L.N * ld;
-    o[(size_t)k * ld + l] = v;
-    o[(size_t)l * ld + k] = v;
-}
-
+// The stored part of local rows as symmetric matrices, for the GEMM-shaped consumers (AO->MO): the tiles counterpart of
+// unpack_own_rows_blocked_kernel (tf_jkpacked.hip.h).
 __global__ void unpack_own_rows_blocked_tiles_kernel(const double *__restrict__ eri, TView V, BLayout L, const int2 *__restrict__ row_ij,
                                                      const int *__restrict__ rows, int c, RowBlocks RBk, double *__restrict__ out)
 {
