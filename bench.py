@@ -437,11 +437,23 @@ def scf_on_workload(eng, atoms, shells, nocc, desc):
             P0 = 0.5 * (P0 + P0.T)
             t1 = time.perf_counter()
             nao = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
-            r = eng.scf_rhf(S, T, V, P0, float(np.sum(P0 * (T + V))), nocc, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping="none",
-                            n_atom_ao=nao, max_iter=200)
+            # The core guess of this Ar2-like system cuts through its near-degenerate n = 3 shell (2.4e-6 Eh between the last occupied
+            # and the first empty orbital), so the undamped cycle is sensitive to the last digits of the guess: the same code has taken
+            # 18 or 24 iterations or none at all depending on the eigensolver's rounding.  Undamped first (the configuration of rounds
+            # 1-3); if that does not converge, the reference's default dynamic damping -- and the line says which one ran.
+            damping = "none"
+            try:
+                r = eng.scf_rhf(S, T, V, P0, float(np.sum(P0 * (T + V))), nocc, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping=damping,
+                                n_atom_ao=nao, max_iter=100)
+            except TunaError:
+                damping = "dynamic (the undamped cycle did not converge from this core guess)"
+                t1 = time.perf_counter()
+                r = eng.scf_rhf(S, T, V, P0, float(np.sum(P0 * (T + V))), nocc, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping="dynamic",
+                                n_atom_ao=nao, max_iter=200)
             t2 = time.perf_counter()
             orbitals = (r["C"], r["epsilons"])
-            best = {"energy_Eh": r["energy"], "iterations": r["n_iter"], "setup_wall_s": t1 - t0, "scf_wall_s": t2 - t1,
+            best = {"energy_Eh": r["energy"], "iterations": r["n_iter"], "damping": damping, "eigensolver_paths": eng.eigh_stats(),
+                    "setup_wall_s": t1 - t0, "scf_wall_s": t2 - t1,
                     "ms_per_iteration": 1e3 * (t2 - t1) / r["n_iter"], "fock_kernels_ms_per_iteration": 1e3 * r["fock_seconds"] / r["n_iter"],
                     "eigen_ms_per_iteration": 1e3 * r["eig_seconds"] / r["n_iter"], "smallest_overlap_eigenvalue": smin}
         res.update(best)

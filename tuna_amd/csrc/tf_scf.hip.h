@@ -338,33 +338,43 @@ inline rocblas_status gemm_rm(rocblas_handle h, bool tA, bool tB, int n, double 
 // (3.3 ms against 10.8 ms for the full matrix, `tools/gpu_eigh_blocks.py`).  Nothing is assumed: every call first measures the largest
 // element that connects two classes (k_blk_cross) and declines -- the caller then solves the full matrix -- unless it is below
 // 1e-14 of the largest element (a field along x, a symmetry-broken density or a basis without the structure end up there).
-// Blocks are padded to the largest one with a decoupled diagonal far above the spectrum; the eigenvalues of all blocks are ranked
+// Blocks are padded to the largest one with a decoupled diagonal JUST above the spectrum (1.01 x the Gershgorin bound: a padding value
+// of n x max|a| -- 10^3 times the norm -- cost that factor in absolute accuracy, which the near-degenerate g/u pairs of a stretched
+// diatomic cannot afford: 6e-7 in the core-guess orbital energies at N = 400); the eigenvalues of all blocks are ranked
 // together (ties by block, then by position: a stable sort) and the vectors scattered back to the full basis.
 inline void set_symmetry(Workspace &w, const std::vector<int> &cls) { if (cls != w.sym_cls) { w.sym_cls = cls; w.sym_n = 0; } }
 
+// out[0] = max |a_ij|, out[1] = max |a_ij| over pairs of different classes, out[2] = max_i sum_j |a_ij| (Gershgorin: no eigenvalue lies
+// outside [-out[2], out[2]]); one workgroup per row.  Non-negative doubles order like their bit patterns (a NaN ends up above
+// everything: declined).
 __global__ void k_blk_cross(const double *__restrict__ A, const int *__restrict__ cls, int n, unsigned long long *__restrict__ out)
 {
-    __shared__ double sa[256], sx[256];
-    double all = 0.0, cross = 0.0;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)n * n; e += (size_t)gridDim.x * 256) {
-        const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
-        const double v = fabs(A[e]);
+    __shared__ double sa[256], sx[256], ss[256];
+    const int i = blockIdx.x, ci = cls[i];
+    double all = 0.0, cross = 0.0, sum = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const double v = fabs(A[(size_t)i * n + j]);
         all = fmax(all, v);
-        if (cls[i] != cls[j]) cross = fmax(cross, v);
+        sum += v;
+        if (cls[j] != ci) cross = fmax(cross, v);
     }
-    sa[threadIdx.x] = all; sx[threadIdx.x] = cross;
+    sa[threadIdx.x] = all; sx[threadIdx.x] = cross; ss[threadIdx.x] = sum;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) { sa[threadIdx.x] = fmax(sa[threadIdx.x], sa[threadIdx.x + st]); sx[threadIdx.x] = fmax(sx[threadIdx.x], sx[threadIdx.x + st]); }
+        if (threadIdx.x < st) {
+            sa[threadIdx.x] = fmax(sa[threadIdx.x], sa[threadIdx.x + st]); sx[threadIdx.x] = fmax(sx[threadIdx.x], sx[threadIdx.x + st]);
+            ss[threadIdx.x] += ss[threadIdx.x + st];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {          // non-negative doubles order like their bit patterns (a NaN ends up above everything: declined)
+    if (threadIdx.x == 0) {
         atomicMax(out, (unsigned long long)__double_as_longlong(sa[0]));
         atomicMax(out + 1, (unsigned long long)__double_as_longlong(sx[0]));
+        atomicMax(out + 2, (unsigned long long)__double_as_longlong(ss[0]));
     }
 }
 
-// B[b][r][c] = A[idx[b][r]][idx[b][c]] (symmetrised), padding: a decoupled diagonal `big + r`
+// B[b][r][c] = A[idx[b][r]][idx[b][c]] (symmetrised), padding: a decoupled diagonal `big`
 __global__ void k_blk_gather(const double *__restrict__ A, const int *__restrict__ idx, int n, int mmax, double big, double *__restrict__ B)
 {
     const int b = blockIdx.y;
@@ -374,7 +384,7 @@ __global__ void k_blk_gather(const double *__restrict__ A, const int *__restrict
     const int i = idx[b * mmax + r], j = idx[b * mmax + c];
     double v;
     if (i >= 0 && j >= 0) v = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]);
-    else v = (r == c) ? big + (double)r : 0.0;
+    else v = (r == c) ? big : 0.0;
     B[((size_t)b * mmax + r) * mmax + c] = v;
 }
 
@@ -434,7 +444,7 @@ inline int eigh_blocked(Workspace &w, int n, double *W, double *vals, std::strin
         for (int i = 0; i < n; ++i) { const int b = blk_of[w.sym_cls[i]]; idx[(size_t)b * mmax + fill[b]++] = i; idx[(size_t)4 * mmax + i] = w.sym_cls[i]; }
         TFS_HIP(hipMalloc((void **)&w.sym_idx, idx.size() * sizeof(int)));
         TFS_HIP(tfs_memcpy(w.sym_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
-        TFS_HIP(hipMalloc((void **)&w.sym_buf, ((size_t)nb * mmax * mmax + 2 * (size_t)nb * mmax + 2) * sizeof(double)));
+        TFS_HIP(hipMalloc((void **)&w.sym_buf, ((size_t)nb * mmax * mmax + 2 * (size_t)nb * mmax + 4) * sizeof(double)));
         TFS_HIP(hipMalloc((void **)&w.sym_src, (size_t)n * sizeof(int)));
         if (!w.sym_info) TFS_HIP(hipMalloc((void **)&w.sym_info, 4 * sizeof(rocblas_int)));
     }
@@ -443,13 +453,13 @@ inline int eigh_blocked(Workspace &w, int n, double *W, double *vals, std::strin
     double *B = w.sym_buf, *D = B + (size_t)nb * mmax * mmax, *E = D + (size_t)nb * mmax;
     unsigned long long *flag = (unsigned long long *)(E + (size_t)nb * mmax);
     const int *cls = w.sym_idx + (size_t)4 * mmax;
-    TFS_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(double), TFS_ST));
-    hipLaunchKernelGGL(k_blk_cross, dim3(std::min(256, (n * n + 255) / 256)), dim3(256), 0, TFS_ST, W, cls, n, flag);
-    double h[2];
+    TFS_HIP(hipMemsetAsync(flag, 0, 3 * sizeof(double), TFS_ST));
+    hipLaunchKernelGGL(k_blk_cross, dim3(n), dim3(256), 0, TFS_ST, W, cls, n, flag);
+    double h[3];
     TFS_HIP(tfs_memcpy(h, flag, sizeof(h), hipMemcpyDeviceToHost));
-    if (!(h[1] <= 1e-14 * h[0]) || !std::isfinite(h[0])) { ++w.sym_declined; return TF_EINVAL; }
+    if (!(h[1] <= 1e-14 * h[0]) || !std::isfinite(h[0]) || !std::isfinite(h[2])) { ++w.sym_declined; return TF_EINVAL; }
     const int g = (mmax * mmax + 255) / 256;
-    hipLaunchKernelGGL(k_blk_gather, dim3(g, nb), dim3(256), 0, TFS_ST, W, w.sym_idx, n, mmax, 4.0 * h[0] * n + 1.0, B);
+    hipLaunchKernelGGL(k_blk_gather, dim3(g, nb), dim3(256), 0, TFS_ST, W, w.sym_idx, n, mmax, 1.01 * h[2] + 1e-300, B);
     TFS_BLAS(rocsolver_dsyevd_strided_batched(w.blas, rocblas_evect_original, rocblas_fill_upper, mmax, B, mmax, (rocblas_stride)mmax * mmax,
                                               D, mmax, E, mmax, w.sym_info, nb));
     hipLaunchKernelGGL(k_blk_rank, dim3(1), dim3(1024), 0, TFS_ST, D, w.sym_idx, nb, mmax, vals, w.sym_src);
