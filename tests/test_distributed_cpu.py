@@ -100,6 +100,22 @@ def test_two_rank_sharded_fock_build(tag, layout):
     assert abs(res[0][2] - res[1][2]) <= 0.1 * res[0][3] + slack    # and the plan balances the stored values
 
 
+def test_eight_rank_sharded_fock_build():
+    """The world size the driver's scaling run uses, rehearsed over gloo on the CPU: eight ranks each contract the rows the plan gives them
+    (packed layout, N2/cc-pVDZ), one all-reduce of [J;K] completes them on every rank (scf:42, scf:70 for the sums)."""
+    world = 8
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, "n2_ccpvdz", "packed", ret), nprocs=world, join=True)
+        res = dict(ret)
+    assert set(res) == set(range(world))
+    for rank, (eJ, eK, mine, total) in res.items():
+        assert eJ < 1e-11 and eK < 1e-11
+    assert sum(v[2] for v in res.values()) == res[0][3]           # every row has exactly one owner
+    assert min(v[2] for v in res.values()) > 0                    # and every rank has work
+
+
 @pytest.mark.parametrize("layout", ["packed", "rows"])
 def test_shard_plan_deterministic_and_consistent_with_rows(layout):
     _, shells, _, _ = make_system("c3_ar2_ccpvqz")

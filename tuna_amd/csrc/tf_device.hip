@@ -2762,14 +2762,16 @@ static int jk_tiles_pass(tf_ctx *ctx, tf_ctx::TileList &D, hipStream_t st, doubl
     if (rc) return rc;
     int jt_rows = 0;
     for (int p = 0; p < TT.npair; ++p) jt_rows += ctx->hl.csize[TT.pa[p]];
-    const size_t edge_lds = (size_t)(2 + 3 * TT_EDGE_WAVES) * N * sizeof(double), red_lds = std::max((size_t)2 * TT_RED_WAVES * N, (size_t)TT_RED_WAVES * 64 * TT_RED_CT) * sizeof(double);
+    const size_t edge_lds = (size_t)(2 + 3 * TT_EDGE_WAVES) * N * sizeof(double), red_lds = std::max((size_t)2 * TT_RED_WAVES * N, (size_t)TT_RED_WAVES * 64 * std::max(TT_RED_CT, ND)) * sizeof(double);
     if (std::max(edge_lds, red_lds) > ctx->tile_lds_set) {                // (beyond the default 64 KB per workgroup: N > 580)
         if (std::max(edge_lds, red_lds) > (size_t)160 * 1024 - 1024) TF_FAIL(ctx, TF_EINVAL, "N = %d exceeds the LDS rows of the tiles layout's reductions", N);
         const int want = (int)std::max(edge_lds, red_lds);
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_edge_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_edge_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_edge_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_tile_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_tile_reduce_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_tile_reduce_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jk_tile_reduce_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
         ctx->tile_lds_set = (size_t)want;
     }
     TJArgs A{};
@@ -2822,8 +2824,8 @@ static int jk_tiles_pass(tf_ctx *ctx, tf_ctx::TileList &D, hipStream_t st, doubl
     R.Dj = out; R.Di = out + (size_t)ND * nn; R.JD = out + (size_t)4 * ND * nn; R.JtTot = ctx->t_JtTot;
     R.edge_base = TT.edge_base; R.N = N; R.ksub = D.ksub; R.npair = TT.npair; R.nd = ND; R.pm_len = TT.pm_len; R.tab = ctx->d_tvtab;
     R.jt_rows = jt_rows;
-    const unsigned nblk = (unsigned)ND * (unsigned)(5 * N + jt_rows);
-    hipLaunchKernelGGL(jk_tile_reduce_kernel, dim3(nblk), dim3(TT_RED_THREADS), red_lds, st, D.d_tasks, D.d_pairs, D.d_runs, ctx->d_jlist, R);
+    const unsigned nblk = ND == 1 ? (unsigned)(5 * N + jt_rows) : (unsigned)(4 * N) + (unsigned)ND * (unsigned)(N + jt_rows);
+    hipLaunchKernelGGL(jk_tile_reduce_kernel<ND>, dim3(nblk), dim3(TT_RED_THREADS), red_lds, st, D.d_tasks, D.d_pairs, D.d_runs, ctx->d_jlist, R);
     return TF_OK;
 }
 }  // extern "C++"

@@ -768,6 +768,77 @@ __device__ __forceinline__ void tr_dj_block(const TRArgs &R, const TPairI *__res
     }
 }
 
+// kind 0 of a wide pass: ALL densities of the pass in one workgroup.  The DJ vectors are density-minor ([index][ND]: what the tile kernel's
+// merge writes with one store per lane), so a lane reads the ND values of its element as one or two 32-byte loads; a workgroup per
+// density would fetch every 64-byte sector ND times (measured: 1.0 ms of reduction per density at ND = 8 against 0.5 ms at ND = 1).
+template <int ND>
+__device__ __forceinline__ void tr_dj_block_wide(const TRArgs &R, const TPairI *__restrict__ pairs, const TRunI *__restrict__ runs,
+                                                 const int *__restrict__ jlist, int jI, int cX, int w, int lane, double *sPart)
+{
+    static_assert(ND == 4 || ND == 8, "densities of a wide pass");
+    const int N = R.N;
+    const size_t nn = (size_t)N * N;
+    const int cj = R.clsI[jI];
+    const int xs = R.tab[TVT_CSTART + cX], nX = R.tab[TVT_CSIZE + cX];
+    const int lj = jI - R.tab[TVT_CSTART + cj];
+    auto add = [](double (&v)[ND], const double *__restrict__ src) {
+#pragma unroll
+        for (int h = 0; h < ND / 4; ++h) {
+            const tt_v4d t = *reinterpret_cast<const tt_v4d *>(src + 4 * h);
+            v[4 * h] += t.x; v[4 * h + 1] += t.y; v[4 * h + 2] += t.z; v[4 * h + 3] += t.w;
+        }
+    };
+    for (int t0 = 0; t0 < nX; t0 += 64) {
+        const int lx = t0 + lane;
+        double acc[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) acc[d] = 0.0;
+        for (int q = R.jlist_ptr[jI] + w; q < R.jlist_ptr[jI + 1]; q += TT_RED_WAVES) {
+            const int iI = jlist[q];
+            const int c = R.clsI[iI] ^ cj;
+            const int p = R.tab[TVT_PID + cX * 4 + (cX ^ c)];
+            const TPairI P = pairs[(size_t)iI * 10 + p];
+            const TRunI Rn = runs[(size_t)iI * 4 + cj];
+            const double *vec = R.DJ + (Rn.dj_base + (long long)(jI - Rn.j0) * Rn.dj_len) * ND;
+            const int a = R.tab[TVT_PA + p], b = R.tab[TVT_PB + p];
+            const bool tri = a == b, have = P.first_task >= 0;
+            const long long l0 = Rn.j0 - R.tab[TVT_CSTART + cj];
+            const double *Ee = R.T + R.edge_base + Rn.e_base + (long long)lj * (lj + 1) / 2 - l0 * (l0 + 1) / 2;
+            double v[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) v[d] = 0.0;
+            if (have && cX == a && lx < P.nk) {                           // x as a row index k: the chunks of its stored strip
+                const int ks = lx / TT_KS, nst = min(TT_KS, P.nk - TT_KS * ks);
+                int nch, wv;
+                tt_chunks(tt_nlb(tri, ks, P.nk, P.nl), &nch, &wv);
+                const double *src = vec + (size_t)(P.dj_k + tt_dj_koff(tri, ks, P.nl) + (lx - TT_KS * ks)) * ND;
+                for (int ch = 0; ch < nch; ++ch) add(v, src + (size_t)ch * nst * ND);
+            }
+            if (have && cX == b && lx < P.nl) {                           // x as a column index l: the sub-strips that reach its block
+                const int lb = lx / TT_LB, ns = (P.nk + R.ksub - 1) / R.ksub, f = tt_dj_first_sub(tri, lb, R.ksub);
+                const double *src = vec + (size_t)(P.dj_l + tt_dj_loff(tri, lb, P.nk, R.ksub) + (lx - TT_LB * lb)) * ND;
+                for (int s2 = f; s2 < ns; ++s2) add(v, src + (size_t)(s2 - f) * TT_LB * ND);
+            }
+            if (cX == cj && lx <= lj) {                                   // edge: D[j][l] += w (ij|il) P[i][i]
+                const double e = (lx == lj ? 0.5 : 1.0) * Ee[lx];
+#pragma unroll
+                for (int d = 0; d < ND; ++d) v[d] += e * R.X[(size_t)d * nn + (size_t)iI * N + iI];
+            }
+#pragma unroll
+            for (int d = 0; d < ND; ++d) acc[d] += v[d];
+        }
+#pragma unroll
+        for (int d = 0; d < ND; ++d) sPart[((size_t)w * ND + d) * 64 + lane] = acc[d];
+        __syncthreads();
+        for (int d = w; d < ND; d += TT_RED_WAVES) {                      // wave d adds the partial rows of density d in fixed order
+            double t = 0.0;
+            for (int q2 = 0; q2 < TT_RED_WAVES; ++q2) t += sPart[((size_t)q2 * ND + d) * 64 + lane];
+            if (lx < nX) R.Dj[d * R.sO + (size_t)jI * N + xs + lx] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // kind 1, one workgroup per row k of a class pair: the Jt totals of the row = the partial blocks of every first index above (k, l); the
 // waves share the first indices.
 __device__ __forceinline__ void tr_jt_block(const TRArgs &R, const TPairI *__restrict__ pairs, int d, int rowid, int w, int lane, double *sPart)
@@ -844,6 +915,9 @@ __device__ __forceinline__ void tr_gather_block(const TRArgs &R, const TTask *__
     }
 }
 
+// NDW = 1: one density after the other (block index = density x kinds); NDW = 4 / 8 (a wide pass): the D[j][.] blocks take all densities
+// together and come first (they run longest), the gather and Jt blocks follow density by density.
+template <int NDW>
 __global__ __launch_bounds__(TT_RED_THREADS) void jk_tile_reduce_kernel(const TTask *__restrict__ tasks, const TPairI *__restrict__ pairs,
                                                                          const TRunI *__restrict__ runs, const int *__restrict__ jlist, TRArgs R)
 {
@@ -852,14 +926,25 @@ __global__ __launch_bounds__(TT_RED_THREADS) void jk_tile_reduce_kernel(const TT
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int n2 = N, n0 = 4 * N, n1 = R.jt_rows;                          // gather first: its workgroups run longest
     int b = blockIdx.x;
-    const int d = b / (n0 + n1 + n2);
-    b -= d * (n0 + n1 + n2);
-    if (b < n2)
-        tr_gather_block(R, tasks, d, N - 1 - b, sAcc);                     // (the last first indices have the most tasks)
-    else if (b < n2 + n0)
-        tr_dj_block(R, pairs, runs, jlist, d, (b - n2) >> 2, (b - n2) & 3, w, lane, sAcc);
-    else
-        tr_jt_block(R, pairs, d, b - n2 - n0, w, lane, sAcc);
+    if constexpr (NDW == 1) {
+        const int d = b / (n0 + n1 + n2);
+        b -= d * (n0 + n1 + n2);
+        if (b < n2)
+            tr_gather_block(R, tasks, d, N - 1 - b, sAcc);                 // (the last first indices have the most tasks)
+        else if (b < n2 + n0)
+            tr_dj_block(R, pairs, runs, jlist, d, (b - n2) >> 2, (b - n2) & 3, w, lane, sAcc);
+        else
+            tr_jt_block(R, pairs, d, b - n2 - n0, w, lane, sAcc);
+    } else {
+        if (b < n0) { tr_dj_block_wide<NDW>(R, pairs, runs, jlist, b >> 2, b & 3, w, lane, sAcc); return; }
+        b -= n0;
+        const int d = b / (n1 + n2);
+        b -= d * (n1 + n2);
+        if (b < n2)
+            tr_gather_block(R, tasks, d, N - 1 - b, sAcc);
+        else
+            tr_jt_block(R, pairs, d, b - n2, w, lane, sAcc);
+    }
 }
 
 // Original indices (x, y): K = D + D2^T with D = Dj + Di + ED + EDT^T (D2 = D for a symmetric density; a general one: D = D(P^T), D2 = D(P));
