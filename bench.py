@@ -201,6 +201,26 @@ def pmc_eri_valu(workload: str, cart_kernel_s: float):
     return None
 
 
+def pmc_mfma(workload: str, nd: int, kernel_avg_s: float):
+    """Matrix-core use of the tiles layout's wide Fock pass (densities = B-operand columns of v_mfma_f64_16x16x4_f64) from the committed
+    PMC pass of the same workload: MFMA instructions per launch, the share of the chip's SIMD cycles the matrix pipes are busy during this
+    run's kernel time (SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per instruction; 1024 SIMDs, 2.4 GHz), and the share of those that works on
+    real columns (densities per pass / 16)."""
+    path = os.path.join(ROOT, "profiles", f"r04_pmc_{workload.replace('-', '')}_tiles_wide.json")
+    try:
+        d = json.load(open(path))
+        per_pass = min(nd, 8)
+        key = "jk_tile_kernel<8, 1, 2>" if per_pass > 4 else "jk_tile_kernel<4, 1, 2>"
+        k = [v for name, v in d.items() if key in name][0]
+        val = lambda c: k[c]["mean"] if isinstance(k[c], dict) else k[c]
+        busy = val("SQ_VALU_MFMA_BUSY_CYCLES") / (max(kernel_avg_s, 1e-12) * 2.4e9 * 1024)
+        return {"kernel": key, "mfma_instructions_per_launch": val("SQ_INSTS_MFMA"), "cycles_per_instruction": val("SQ_VALU_MFMA_BUSY_CYCLES") / val("SQ_INSTS_MFMA"),
+                "matrix_pipe_busy_fraction": busy, "useful_column_fraction": per_pass / 16.0, "useful_busy_fraction": busy * per_pass / 16.0,
+                "valu_wave_instructions_per_launch": val("SQ_INSTS_VALU"), "profile": os.path.relpath(path, ROOT), "profile_meta": d.get("_meta")}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,7 +370,8 @@ def main():
             "per_density": {"n_densities": nd, "fock_matrices_per_s": nd * args.steps / elapsed,
                             "executed_fp64_tflops": 12.0 * (stored_bytes / 8.0) * nd * args.steps / elapsed / 1e12,
                             "frac_of_fp64_peak": 12.0 * (stored_bytes / 8.0) * nd * args.steps / elapsed / FP64_VECTOR_PEAK_FLOPS,
-                            "passes_over_the_tensor_per_step": (nd + 1) // 2},
+                            "passes_over_the_tensor_per_step": (nd + 7) // 8 if layout == "tiles" else (nd + 1) // 2,
+                            "mfma": pmc_mfma(args.workload, nd, kernel_avg_s) if layout == "tiles" and nd >= 2 else None},
             # roofline of the dominant kernel on PHYSICAL bytes (a fraction of the 8 TB/s HBM peak, <= 1); the reference's dense 8 N^4
             # bytes per build that the same launch stands for are reported separately
             "roofline": {"bound": "hbm", "kernel": JK_KERNEL[layout], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,5 +1,6 @@
 """GPU: wall time of the eight field evaluations of a polarisability (tuna_amd/properties.py), cycles in lockstep with batched Fock
-builds (host-orchestrated) against eight native cycles one after the other.  usage: python tools/gpu_field_timing.py"""
+builds (host-orchestrated) against eight native cycles one after the other.  usage: python tools/gpu_field_timing.py [native-only]
+(TF_ERI_LAYOUT=t: on the tiles layout, whose lockstep iterations send all eight densities through the tensor in one wide pass)"""
 import os, sys, time, types
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -24,7 +25,8 @@ def case(eng, atoms, shells, aos, nocc, label, conv):
     V_NN = mol.nuclear_repulsion(atoms)
     h = props.SECOND_ELEC_DERIVATIVE_STEP
     fields = [[0, 0, 2 * h], [0, 0, h], [0, 0, -h], [0, 0, -2 * h], [2 * h, 0, 0], [h, 0, 0], [-h, 0, 0], [-2 * h, 0, 0]]
-    for batched in ("native", True, False, "native", False):
+    modes = ("native", "native", False) if "native-only" in sys.argv else ("native", True, False, "native", False)
+    for batched in modes:
         fe = props.FieldEnergies(molecule, calc, integrals, V_NN, X, (P0, P0 / 2, P0 / 2, E0), batched=batched)
         b0 = integrals.ERI_AO.n_builds
         t0 = time.perf_counter(); E = fe.energies(fields); dt = time.perf_counter() - t0

@@ -1,8 +1,9 @@
 #!/usr/bin/env bash
 # GPU box: PMC passes over a short run of tools/gpu_tiles_perf.py (one pass per counter group; kernel-trace only, as the pool requires),
-# summarised by tools/pmc_summary.py into gpurun_out/pmc_<tag>.json.   usage: tools/gpu_pmc_tiles.sh TAG [workload]
+# summarised by tools/pmc_summary.py into gpurun_out/pmc_<tag>.json.   usage: tools/gpu_pmc_tiles.sh TAG [workload] [script = gpu_tiles_perf.py]
+# (script gpu_tiles_nd.py: the wide passes over 4 and 8 densities)
 set -uo pipefail
-TAG="$1"; WL="${2:-synth-400}"
+TAG="$1"; WL="${2:-synth-400}"; SCRIPT="${3:-gpu_tiles_perf.py}"
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 cd /tmp && export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out/pmc_$TAG"
@@ -11,7 +12,7 @@ i=0
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$OUT/p$i" -- python3 "$ROOT/tools/gpu_tiles_perf.py" "$WL" 3 > "$OUT/p$i.log" 2>&1 || echo "pass $i ($group) failed" >> "$OUT/fail.log"
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$OUT/p$i" -- python3 "$ROOT/tools/$SCRIPT" "$WL" 3 > "$OUT/p$i.log" 2>&1 || echo "pass $i ($group) failed" >> "$OUT/fail.log"
 done <<'GROUPS'
 FETCH_SIZE
 WRITE_SIZE

@@ -3583,10 +3583,12 @@ struct LockstepJK {
     void build_locked(hipStream_t st)               // on the stream of the cycle that arrived last; the others wait for its event
     {
         int rc = TF_OK;
-        for (int q = 0; q < waiting && rc == TF_OK; q += 2) {
-            const int nd = (q + 1 < waiting) ? 2 : 1;
-            const double *p[2] = {req[q].dP, req[q + nd - 1].dP};
-            double *j[2] = {req[q].dJ, req[q + nd - 1].dJ}, *k[2] = {req[q].dK, req[q + nd - 1].dK};
+        const int cap = ctx->layout == 2 ? 8 : 2;   // densities per pass over the tensor: the tiles layout's wide pass takes eight, the packed kernel two
+        for (int q = 0; q < waiting && rc == TF_OK; q += cap) {
+            const int nd = std::min(cap, waiting - q);
+            const double *p[8];
+            double *j[8], *k[8];
+            for (int d = 0; d < nd; ++d) { p[d] = req[q + d].dP; j[d] = req[q + d].dJ; k[d] = req[q + d].dK; }
             rc = launch_jk(ctx, nd, p, j, k, st, nullptr);
             ++passes; builds += nd;
         }
