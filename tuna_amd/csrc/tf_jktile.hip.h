@@ -592,8 +592,10 @@ __device__ __forceinline__ void tj_run(const double *__restrict__ T, const doubl
 
 // One workgroup per task; blockDim = 64 x (waves of the launch's bucket: >= the task's column blocks).  MB = row blocks of 16 of a
 // task's strip (4: strips of 64 rows, one density; fewer for the passes over several densities: tf_tiles.h, `ksub`).
+// (eight densities: 256 VGPRs + 61 AGPRs, one wave per SIMD.  Compiled for two -- 28 spilled registers with a one-slot ring, 331 with
+// two -- the kernel takes 9.2 / 18.8 ms against 8.6: occupancy is not what it lacks)
 template <int ND, int MB, int PF>
-__global__ __launch_bounds__(64 * TT_W, (ND >= 8 || MB >= 4) ? 1 : 2) void jk_tile_kernel(const double *__restrict__ T, const TTask *__restrict__ tasks,
+__global__ __launch_bounds__(64 * TT_W, (MB >= 4) ? 1 : (ND >= 8 ? 1 : 2)) void jk_tile_kernel(const double *__restrict__ T, const TTask *__restrict__ tasks,
                                                                             const double *__restrict__ X, const double *__restrict__ Pm, TJArgs A)
 {
     static_assert(TT_KB == 4 && TT_KB % PF == 0, "the ring position of a step must be a compile-time constant");
