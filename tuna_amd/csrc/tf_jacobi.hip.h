@@ -30,8 +30,21 @@ template <bool V_IN_LDS>
 __global__ __launch_bounds__(TFJ_THREADS) void jacobi_eigh_kernel(int n, double *__restrict__ W /* in: A, out: eigenvector rows */,
                                                                   double *__restrict__ vals, double *__restrict__ Vg /* n*n scratch */,
                                                                   const double *__restrict__ V0, double *__restrict__ Vkeep,
-                                                                  int max_sweeps, int *__restrict__ info)
+                                                                  int max_sweeps, int *__restrict__ info,
+                                                                  const int *__restrict__ sizes = nullptr, long long stride = 0, int vstride = 0)
 {
+    // a batch (the symmetry blocks of a matrix, tf_scf.hip.h: eigh_blocked): workgroup b solves the sizes[b] x sizes[b] matrix at
+    // W + b stride (compact: leading dimension sizes[b]); values at vals + b vstride, info[b]
+    if (sizes) {
+        const long long off = (long long)blockIdx.x * stride;
+        n = sizes[blockIdx.x];
+        W += off; vals += (size_t)blockIdx.x * vstride;
+        if (Vg) Vg += off;
+        if (V0) V0 += off;
+        if (Vkeep) Vkeep += off;
+        if (info) info += blockIdx.x;
+        if (n < 1) return;
+    }
     extern __shared__ double sm[];
     const int lda = n | 1;
     double *sA = sm;
@@ -196,6 +209,22 @@ inline bool launch(int n, double *W, double *vals, double *Vscratch, int *info, 
     } else
         hipLaunchKernelGGL(jacobi_eigh_kernel<false>, dim3(1), dim3(TFJ_THREADS), lds_bytes(n, false), st, n, W, vals, Vscratch,
                            (const double *)nullptr, Vkeep, 40, info);
+    *err = hipGetLastError();
+    return *err == hipSuccess;
+}
+
+// a batch of nb problems of at most mmax <= 64 rows each in one launch (eigenvectors in LDS; warm start per block as above)
+inline bool launch_batch(int nb, int mmax, const int *d_sizes, double *W, long long stride, double *vals, int vstride, int *info,
+                         hipStream_t st, hipError_t *err, const double *V0 = nullptr, double *Vkeep = nullptr)
+{
+    if (nb < 1 || mmax < 1 || mmax > 64) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)jacobi_eigh_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(jacobi_eigh_kernel<true>, dim3(nb), dim3(TFJ_THREADS), lds_bytes(mmax, true, V0 != nullptr), st, mmax, W, vals,
+                       (double *)nullptr, V0, Vkeep, 40, info, d_sizes, stride, vstride);
     *err = hipGetLastError();
     return *err == hipSuccess;
 }

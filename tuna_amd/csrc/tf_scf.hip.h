@@ -78,6 +78,8 @@ struct Workspace {
     double *sym_buf = nullptr;       // device: [nb][mmax][mmax] blocks, [nb][mmax] values, [nb][mmax] work, 2 doubles of the cross-class test
     int *sym_src = nullptr;          // device [n]: block * mmax + member of the eigenvalue of global rank r
     rocblas_int *sym_info = nullptr; // device [4]
+    double *sym_prev = nullptr;      // device [nb][mmax][mmax]: block eigenvectors of the previous solve (warm start of the batched Jacobi)
+    int sym_prev_n = 0;              // 0 = none
     long long sym_solves = 0, sym_declined = 0;
 };
 
@@ -101,6 +103,7 @@ inline void release(Workspace &w)
     if (w.sym_buf) (void)hipFree(w.sym_buf);
     if (w.sym_src) (void)hipFree(w.sym_src);
     if (w.sym_info) (void)hipFree(w.sym_info);
+    if (w.sym_prev) (void)hipFree(w.sym_prev);
     w = Workspace();
 }
 
@@ -374,14 +377,20 @@ __global__ void k_blk_cross(const double *__restrict__ A, const int *__restrict_
     }
 }
 
-// B[b][r][c] = A[idx[b][r]][idx[b][c]] (symmetrised), padding: a decoupled diagonal `big`
-__global__ void k_blk_gather(const double *__restrict__ A, const int *__restrict__ idx, int n, int mmax, double big, double *__restrict__ B)
+// B[b][r][c] = A[idx[b][r]][idx[b][c]] (symmetrised).  sizes == nullptr: every block padded to mmax x mmax with a decoupled diagonal `big`
+// (rocSOLVER's batched solver wants one size); sizes given: compact blocks, leading dimension sizes[b] (the batched Jacobi kernel)
+__global__ void k_blk_gather(const double *__restrict__ A, const int *__restrict__ idx, int n, int mmax, double big, double *__restrict__ B,
+                             const int *__restrict__ sizes)
 {
     const int b = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= mmax * mmax) return;
     const int r = e / mmax, c = e - r * mmax;
     const int i = idx[b * mmax + r], j = idx[b * mmax + c];
+    if (sizes) {
+        if (i >= 0 && j >= 0) B[(size_t)b * mmax * mmax + (size_t)r * sizes[b] + c] = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]);
+        return;
+    }
     double v;
     if (i >= 0 && j >= 0) v = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]);
     else v = (r == c) ? big : 0.0;
@@ -410,14 +419,14 @@ __global__ void k_blk_rank(const double *__restrict__ D, const int *__restrict__
 
 // W[rank][:] = eigenvector `src[rank]` of its block, scattered to the full basis (zero outside the block); one workgroup per row
 __global__ void k_blk_scatter(const double *__restrict__ B, const int *__restrict__ idx, const int *__restrict__ src, int n, int mmax,
-                              double *__restrict__ W)
+                              double *__restrict__ W, const int *__restrict__ sizes)
 {
     const int r = blockIdx.x;
     const int q = src[r], b = q / mmax, t = q - b * mmax;
     double *row = W + (size_t)r * n;
     for (int c = threadIdx.x; c < n; c += blockDim.x) row[c] = 0.0;
     __syncthreads();
-    const double *v = B + ((size_t)b * mmax + t) * mmax;          // row t of the block in row-major terms = column t for rocSOLVER
+    const double *v = B + (size_t)b * mmax * mmax + (size_t)t * (sizes ? sizes[b] : mmax);   // row t of the block in row-major terms = column t for rocSOLVER
     for (int c = threadIdx.x; c < mmax; c += blockDim.x) {
         const int i = idx[b * mmax + c];
         if (i >= 0) row[i] = v[c];
@@ -428,7 +437,8 @@ __global__ void k_blk_scatter(const double *__restrict__ B, const int *__restric
 inline int eigh_blocked(Workspace &w, int n, double *W, double *vals, std::string &msg)
 {
     static const bool off = getenv("TF_EIGH_BLOCKS") && getenv("TF_EIGH_BLOCKS")[0] == '0';
-    if (off || (int)w.sym_cls.size() != n || n <= 64) return TF_EINVAL;
+    static const int nmin = getenv("TF_EIGH_BLOCKS_NMIN") ? atoi(getenv("TF_EIGH_BLOCKS_NMIN")) : 40;   // below: one in-LDS Jacobi of the whole matrix is as fast
+    if (off || (int)w.sym_cls.size() != n || n < nmin) return TF_EINVAL;
     if (w.sym_n != n) {                                            // tables for this class vector
         int m[4] = {0, 0, 0, 0};
         for (int c : w.sym_cls) { if (c < 0 || c > 3) return TF_EINVAL; ++m[c]; }
@@ -439,9 +449,13 @@ inline int eigh_blocked(Workspace &w, int n, double *W, double *vals, std::strin
         if (w.sym_buf) (void)hipFree(w.sym_buf);
         if (w.sym_src) (void)hipFree(w.sym_src);
         w.sym_idx = nullptr; w.sym_buf = nullptr; w.sym_src = nullptr;
-        std::vector<int> idx((size_t)4 * mmax + n, -1);
+        std::vector<int> idx((size_t)4 * mmax + n + 4, -1);         // members of the blocks | class of every function | block sizes
         int fill[4] = {0, 0, 0, 0};
         for (int i = 0; i < n; ++i) { const int b = blk_of[w.sym_cls[i]]; idx[(size_t)b * mmax + fill[b]++] = i; idx[(size_t)4 * mmax + i] = w.sym_cls[i]; }
+        for (int b = 0; b < 4; ++b) idx[(size_t)4 * mmax + n + b] = b < nb ? w.sym_m[b] : 0;
+        w.sym_prev_n = 0;
+        if (w.sym_prev) { (void)hipFree(w.sym_prev); w.sym_prev = nullptr; }
+        if (mmax <= 64) TFS_HIP(hipMalloc((void **)&w.sym_prev, (size_t)nb * mmax * mmax * sizeof(double)));
         TFS_HIP(hipMalloc((void **)&w.sym_idx, idx.size() * sizeof(int)));
         TFS_HIP(tfs_memcpy(w.sym_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
         TFS_HIP(hipMalloc((void **)&w.sym_buf, ((size_t)nb * mmax * mmax + 2 * (size_t)nb * mmax + 4) * sizeof(double)));
@@ -459,11 +473,27 @@ inline int eigh_blocked(Workspace &w, int n, double *W, double *vals, std::strin
     TFS_HIP(tfs_memcpy(h, flag, sizeof(h), hipMemcpyDeviceToHost));
     if (!(h[1] <= 1e-14 * h[0]) || !std::isfinite(h[0]) || !std::isfinite(h[2])) { ++w.sym_declined; return TF_EINVAL; }
     const int g = (mmax * mmax + 255) / 256;
-    hipLaunchKernelGGL(k_blk_gather, dim3(g, nb), dim3(256), 0, TFS_ST, W, w.sym_idx, n, mmax, 1.01 * h[2] + 1e-300, B);
-    TFS_BLAS(rocsolver_dsyevd_strided_batched(w.blas, rocblas_evect_original, rocblas_fill_upper, mmax, B, mmax, (rocblas_stride)mmax * mmax,
-                                              D, mmax, E, mmax, w.sym_info, nb));
+    const int *sizes = nullptr;
+    if (mmax <= 64) {
+        // every block fits the in-LDS Jacobi kernel (tf_jacobi.hip.h): one launch, a workgroup per block, compact blocks, warm-started
+        // from the block eigenvectors of the previous solve of the cycle (N2/cc-pVTZ: 60 = 26 + 14 + 14 + 6)
+        static const bool no_warm = getenv("TF_EIGH_COLD") != nullptr;
+        sizes = w.sym_idx + (size_t)4 * mmax + n;
+        hipLaunchKernelGGL(k_blk_gather, dim3(g, nb), dim3(256), 0, TFS_ST, W, w.sym_idx, n, mmax, 0.0, B, sizes);
+        const double *V0 = (w.warm_ok && !no_warm && w.sym_prev_n == n) ? w.sym_prev : nullptr;
+        hipError_t e = hipSuccess;
+        if (!tfjac::launch_batch(nb, mmax, sizes, B, (long long)mmax * mmax, D, mmax, (int *)w.sym_info, TFS_ST, &e, V0, w.warm_ok ? w.sym_prev : nullptr)) {
+            msg = std::string("batched Jacobi eigensolver launch failed: ") + hipGetErrorString(e);
+            return TF_ENODEVICE;
+        }
+        w.sym_prev_n = w.warm_ok ? n : 0;
+    } else {
+        hipLaunchKernelGGL(k_blk_gather, dim3(g, nb), dim3(256), 0, TFS_ST, W, w.sym_idx, n, mmax, 1.01 * h[2] + 1e-300, B, sizes);
+        TFS_BLAS(rocsolver_dsyevd_strided_batched(w.blas, rocblas_evect_original, rocblas_fill_upper, mmax, B, mmax, (rocblas_stride)mmax * mmax,
+                                                  D, mmax, E, mmax, w.sym_info, nb));
+    }
     hipLaunchKernelGGL(k_blk_rank, dim3(1), dim3(1024), 0, TFS_ST, D, w.sym_idx, nb, mmax, vals, w.sym_src);
-    hipLaunchKernelGGL(k_blk_scatter, dim3(n), dim3(128), 0, TFS_ST, B, w.sym_idx, w.sym_src, n, mmax, W);
+    hipLaunchKernelGGL(k_blk_scatter, dim3(n), dim3(128), 0, TFS_ST, B, w.sym_idx, w.sym_src, n, mmax, W, sizes);
     ++w.sym_solves;
     return TF_OK;
 }
@@ -476,6 +506,12 @@ inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, st
     static const bool force_rocsolver = getenv("TF_EIGH") && std::string(getenv("TF_EIGH")) == "rocsolver";
     static const bool force_jacobi = getenv("TF_EIGH") && std::string(getenv("TF_EIGH")) == "jacobi";
     static const int jac_nmax = getenv("TF_JACOBI_NMAX") ? std::min(TFJ_NMAX, std::max(2, atoi(getenv("TF_JACOBI_NMAX")))) : 64;
+    if (!force_rocsolver && !force_jacobi) {                       // the symmetry blocks of a diatomic, solved together (declines if there are none)
+        std::string bmsg;
+        const int rb = eigh_blocked(w, n, W, vals, bmsg);
+        if (rb == TF_OK) return TF_OK;
+        if (!bmsg.empty()) { msg = bmsg; return rb; }
+    }
     if (!force_rocsolver && n >= 2 && n <= (force_jacobi ? TFJ_NMAX : jac_nmax)) {
         if (w.jac_cap < (size_t)n * n) {
             if (w.jac_scratch) (void)hipFree(w.jac_scratch);
@@ -497,12 +533,6 @@ inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, st
             return TF_OK;
         }
         if (e != hipSuccess) { msg = std::string("Jacobi eigensolver launch failed: ") + hipGetErrorString(e); return TF_ENODEVICE; }
-    }
-    if (!force_rocsolver) {                                        // the symmetry blocks of a diatomic, solved together (declines if there are none)
-        std::string bmsg;
-        const int rb = eigh_blocked(w, n, W, vals, bmsg);
-        if (rb == TF_OK) return TF_OK;
-        if (!bmsg.empty()) { msg = bmsg; return rb; }
     }
     TFS_BLAS(rocsolver_dsyevd(w.blas, rocblas_evect_original, rocblas_fill_upper, n, W, n, vals, work_e, w.d_info));
     return TF_OK;
