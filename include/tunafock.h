@@ -289,6 +289,12 @@ int tf_eigh_probe(tf_ctx *ctx, int n, int variant, int reps, double *seconds);
  * have the block structure and the full matrix was solved. */
 int tf_eigh_stats(tf_ctx *ctx, int64_t out[5]);
 
+/* Fock builds of the native cycles on the packed layout since tf_create: out[0] builds that went over the shorter task list of a
+ * class-diagonal density (no element between AOs of different x/y parity: every product of the skipped tasks is an exact zero,
+ * J and K are bit for bit those of the full list), out[1] builds whose density was not and took the full list.  Builds through
+ * tf_fock_jk / tf_fock_jk_device always take the full list (no test, no read-back). */
+int tf_jk_path_stats(tf_ctx *ctx, int64_t out[2]);
+
 /* HIP-event timing of the dominant kernel of the Fock build (the row pass over the stored tensor), recorded on
  * the stream each build is launched on.  enable: start (and reset) / stop collecting; read: synchronises the
  * recorded events, returns their summed duration and the number of launches, and resets. */

@@ -273,3 +273,59 @@ def test_symmetry_blocked_eigensolve_and_its_refusal():
         check(F + 0.01 * D[0])                                             # a field along x does not: full solve
         s4 = eng.eigh_stats()
         assert s4["blocked_solves"] == s3["blocked_solves"] and s4["blocked_declined"] == s3["blocked_declined"] + 1
+
+
+@pytest.mark.parametrize("kind", ["rhf", "uhf"])
+def test_class_diagonal_task_list_gives_the_same_bits(kind):
+    """tf_device.hip: launch_jk_packed -- the native cycles send class-diagonal densities (no element between AOs of different x/y parity)
+    over a shorter task list; the skipped products are exact zeros, so the whole cycle (scf:1072-1154 / 1165-1281) must come out bit for
+    bit as with the full list (TF_JK_CLASS_DIAGONAL=0), and the counters must show that the shorter list was really taken."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from conftest import atom_arrays, make_system, make_uhf_system
+from tuna_amd import molecule as mol
+from tuna_amd.engine import Engine
+from oracle import scf_oracle as so
+kind = %r
+with Engine(0) as eng:
+    if kind == "rhf":
+        atoms, shells, aos, nocc = make_system("c3_ar2_ccpvqz")
+    else:
+        atoms, shells, aos, na, nb = make_uhf_system("o2_triplet_ccpvdz")
+    eng.set_basis(aos).build_eri(True)
+    xyz, chg, org = atom_arrays(atoms)
+    S, T, V, _, _ = eng.one_electron(xyz, chg, org, spherical=True)
+    X, _, _ = eng.orthogonaliser(S)
+    nao = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
+    if kind == "rhf":
+        _, C0 = eng.diagonalise(T + V, X)
+        P0 = 2.0 * C0[:, :nocc] @ C0[:, :nocc].T; P0 = 0.5 * (P0 + P0.T)
+        r = eng.scf_rhf(S, T, V, P0, float(np.sum(P0 * (T + V))), nocc, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping="dynamic", n_atom_ao=nao)
+        mats = [r["P"], r["F"]]
+    else:
+        _, C0 = eng.diagonalise(T + V, X)
+        Pa = C0[:, :na] @ C0[:, :na].T; Pb = C0[:, :nb] @ C0[:, :nb].T
+        E0 = float(np.sum((Pa + Pb) * (T + V)))
+        r = eng.scf_uhf(S, T, V, 0.5 * (Pa + Pa.T), 0.5 * (Pb + Pb.T), E0, na, nb, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping="dynamic", n_atom_ao=nao)
+        mats = [r["P_spin"][0], r["P_spin"][1]]
+    print(json.dumps({"E": float(r["energy"]).hex(), "n_iter": int(r["n_iter"]), "table": [float(x).hex() for x in np.asarray(r["table"])[:r["n_iter"], 1]],
+                      "sums": [float(np.abs(m).sum()).hex() for m in mats], "paths": eng.jk_path_stats()}))
+''' % (os.path.join(os.path.dirname(__file__), ".."), os.path.dirname(__file__), kind)
+    res = {}
+    for mode in ("short", "full"):
+        env = dict(os.environ)
+        env.pop("TF_JK_CLASS_DIAGONAL", None)
+        if mode == "full":
+            env["TF_JK_CLASS_DIAGONAL"] = "0"
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+    a, b = res["short"], res["full"]
+    assert a["paths"]["class_diagonal_passes"] >= a["n_iter"] - 2 and b["paths"]["class_diagonal_passes"] == 0
+    assert a["E"] == b["E"] and a["n_iter"] == b["n_iter"] and a["table"] == b["table"] and a["sums"] == b["sums"]

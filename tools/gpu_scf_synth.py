@@ -30,4 +30,4 @@ for rep in range(reps):
     t5 = time.perf_counter()
     it = r["n_iter"]
     print(f"synth-{eng.N} rep{rep}: eri {t1-t0:.3f} s, 1e {t2-t1:.3f}, ortho {t3-t2:.3f} (min S eig {smin:.2e}), scf {t5-t4:.3f} s = {it} iterations x "
-          f"{1e3*(t5-t4)/it:.2f} ms [fock kernels {1e3*r['fock_seconds']/it:.2f} ms/it, eigen {1e3*r['eig_seconds']/it:.2f} ms/it]  E = {r['energy']:.8f}")
+          f"{1e3*(t5-t4)/it:.2f} ms [fock kernels {1e3*r['fock_seconds']/it:.2f} ms/it, eigen {1e3*r['eig_seconds']/it:.2f} ms/it]  E = {r['energy']:.8f}  {eng.jk_path_stats()}")

@@ -44,7 +44,7 @@ EXPORTS = ["tf_create", "tf_destroy", "tf_last_error", "tf_version", "tf_normali
            "tf_dims", "tf_get_sph_matrix", "tf_one_electron", "tf_cross_overlap", "tf_build_eri", "tf_eri_storage",
            "tf_copy_eri", "tf_sample_eri", "tf_eri_element", "tf_fock_jk", "tf_fock_jk_device", "tf_scf_rhf", "tf_scf_uhf",
            "tf_orthogonaliser", "tf_eri_timings", "tf_eri_counts", "tf_shard_plan", "tf_jk_profile",
-           "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_eigh_stats", "tf_ao_to_mo", "tf_mp2_rhf", "tf_dft_setup", "tf_dft_vxc",
+           "tf_jk_profile_read", "tf_diagonalise", "tf_eigh_probe", "tf_eigh_stats", "tf_jk_path_stats", "tf_ao_to_mo", "tf_mp2_rhf", "tf_dft_setup", "tf_dft_vxc",
            "tf_dft_clear", "tf_set_eri_layout", "tf_eri_layout", "tf_shard_plan_pairs", "tf_packed_pad", "tf_eri_flops", "tf_segment_pad", "tf_set_allreduce", "tf_scf_rhf_batch",
            "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_comm_attached"]
 
@@ -115,6 +115,7 @@ def lib():
     L.tf_dft_clear.restype = ci; L.tf_dft_clear.argtypes = [vp]
     L.tf_eigh_probe.restype = ci; L.tf_eigh_probe.argtypes = [vp, ci, ci, ci, dp]
     L.tf_eigh_stats.restype = ci; L.tf_eigh_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.tf_jk_path_stats.restype = ci; L.tf_jk_path_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.tf_jk_profile.restype = ci; L.tf_jk_profile.argtypes = [vp, ci]
     L.tf_jk_profile_read.restype = ci; L.tf_jk_profile_read.argtypes = [vp, dp, lp]
     _lib = L

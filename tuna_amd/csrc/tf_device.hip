@@ -200,10 +200,21 @@ struct tf_ctx {
         int *d_gfirst = nullptr;        // [2][N]: first / one-past-last group with i == a
         int n_groups = 0, n_tasks = 0, n_supers = 0, nseg = 1;
         int bucket[4] = {0, 0, 0, 0};   // tasks [bucket[b], bucket[b + 1]) run with 4, 2, 1 waves per workgroup (b = 0, 1, 2)
+        // the tasks a CLASS-DIAGONAL density needs (same order, same buckets): a row (i, j) of class c != 0 only meets P[j][l], P[j][k],
+        // P[i][k], P[i][l] and the pair densities of class 0 -- every product of a task whose column class is neither i's nor j's is zero
+        JKTask *d_tasks_cd = nullptr;
+        int n_tasks_cd = 0, bucket_cd[4] = {0, 0, 0, 0};
         long long ypart_len = 0;
         JKJtPlan jp{};
     } jkt[2];
     double *d_Psym = nullptr, *d_Pp = nullptr, *d_ypart = nullptr, *d_DI = nullptr, *d_DJ = nullptr, *d_Jt = nullptr, *d_D = nullptr;
+    // second set of partial-sum buffers for passes over the class-diagonal task list (the entries its skipped tasks would write stay
+    // zero, which the reductions rely on); allocated at the first such pass.  cd_bytes: sizes of d_Jrow, d_ypart, d_DI, d_DJ
+    double *cd_Jrow = nullptr, *cd_ypart = nullptr, *cd_DI = nullptr, *cd_DJ = nullptr;
+    size_t cd_bytes[4] = {0, 0, 0, 0};
+    unsigned long long *d_cdflag = nullptr;       // device word: largest |P| between AOs of different classes (bit pattern), per build
+    bool jk_try_class_diagonal = false;           // set by the SCF cycles around their Fock builds (their densities usually are)
+    long long jk_cd_passes = 0, jk_cd_declined = 0;
     // tiles layout (tf_tiles.h, tf_jktile.hip.h): host tables, their device copies and the partial-sum buffers of the Fock kernel
     tft::Tables tiles;
     tft::TaskList tsub1;                 // the one-density task list when its strips are shorter than the stored ones (TF_TILE_KSUB)
@@ -373,8 +384,11 @@ static void free_eri(tf_ctx *ctx)
                     (void *)ctx->d_Ppad, (void *)ctx->d_J, (void *)ctx->d_K, (void *)ctx->d_P, (void *)ctx->d_rowoff, (void *)ctx->d_Psym,
                     (void *)ctx->d_Pp, (void *)ctx->d_ypart, (void *)ctx->d_DI, (void *)ctx->d_DJ, (void *)ctx->d_Jt, (void *)ctx->d_D})
         if (p) (void)tf_free(p);
+    for (void *p : {(void *)ctx->cd_Jrow, (void *)ctx->cd_ypart, (void *)ctx->cd_DI, (void *)ctx->cd_DJ, (void *)ctx->d_cdflag})
+        if (p) (void)tf_free(p);
+    ctx->cd_Jrow = ctx->cd_ypart = ctx->cd_DI = ctx->cd_DJ = nullptr; ctx->d_cdflag = nullptr;
     for (auto &t : ctx->jkt) {
-        for (void *p : {(void *)t.d_groups, (void *)t.d_tasks, (void *)t.d_supers, (void *)t.d_gfirst})
+        for (void *p : {(void *)t.d_groups, (void *)t.d_tasks, (void *)t.d_supers, (void *)t.d_gfirst, (void *)t.d_tasks_cd})
             if (p) (void)tf_free(p);
         t = tf_ctx::JKTables();
     }
@@ -1170,9 +1184,34 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
             if (T.bucket[2] < T.bucket[1]) T.bucket[1] = T.bucket[2];
             tasks.swap(sorted);
         }
+        // the class-diagonal list: the same tasks in the same order without those whose column class is neither i's nor j's
+        std::vector<JKTask> tasks_cd;
+        tasks_cd.reserve(tasks.size());
+        for (int b = 0; b < 4; ++b) T.bucket_cd[b] = 0;
+        for (size_t t = 0; t < tasks.size(); ++t) {
+            for (int b = 1; b < 4; ++b) if ((int)t == T.bucket[b]) T.bucket_cd[b] = (int)tasks_cd.size();
+            const JKSuper &sg = supers[tasks[t].super];
+            const int ci = H.clsI[sg.i], cj = ci ^ sg.c, cb = H.chunk_cls[tasks[t].w];
+            if (sg.c == 0 || cb == ci || cb == cj) tasks_cd.push_back(tasks[t]);
+        }
+        for (int b = 1; b < 4; ++b) if (T.bucket[b] == (int)tasks.size()) T.bucket_cd[b] = (int)tasks_cd.size();
+        T.n_tasks_cd = (int)tasks_cd.size();
+        {
+            long long st_all = 0, st_cd = 0;                       // wave steps of the two lists (what a pass costs)
+            for (size_t t = 0; t < tasks.size(); ++t) {
+                const JKSuper &sg = supers[tasks[t].super];
+                const int ci = H.clsI[sg.i], cj = ci ^ sg.c, cb = H.chunk_cls[tasks[t].w];
+                const int walk = H.ke(cb ^ sg.c, sg.i) - H.kap0[(size_t)sg.c * H.NW + tasks[t].w];
+                const long long stp = (long long)std::min(H.KS, walk - tasks[t].part * H.KS) * ((sg.ng + TF_JKP_GPW - 1) / TF_JKP_GPW);
+                st_all += stp;
+                if (sg.c == 0 || cb == ci || cb == cj) st_cd += stp;
+            }
+            DBG("J/K tasks: %zu (class-diagonal list: %zu), wave steps %lld (%lld)", tasks.size(), tasks_cd.size(), st_all, st_cd);
+        }
         int rc2;
         if ((rc2 = upload(ctx, groups, &T.d_groups, false)) || (rc2 = upload(ctx, gfirst, &T.d_gfirst, false)) ||
-            (rc2 = upload(ctx, tasks, &T.d_tasks, false)) || (rc2 = upload(ctx, supers, &T.d_supers, false)))
+            (rc2 = upload(ctx, tasks, &T.d_tasks, false)) || (rc2 = upload(ctx, supers, &T.d_supers, false)) ||
+            (rc2 = upload(ctx, tasks_cd, &T.d_tasks_cd, false)))
             return rc2;
         T.n_groups = (int)groups.size(); T.n_tasks = (int)tasks.size(); T.n_supers = (int)supers.size();
         T.nseg = std::max(1, std::min(TF_JKP_SEG, T.n_supers / 128));
@@ -2443,6 +2482,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     const size_t nn = (size_t)N * N;
     // (sized for two densities per pass)
     const int NWjk = packed ? std::max(1, H.NW) * H.MP : 1;         // column chunks of jk_packed_kernel x parts of a walk
+    ctx->cd_bytes[0] = 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double);
     HIPCHK(ctx, tf_malloc((void **)&ctx->d_Jrow, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     HIPCHK(ctx, hipMemset(ctx->d_Jrow, 0, 2 * (size_t)std::max(1, NWjk) * std::max<size_t>(1, (size_t)ctx->n_rows) * sizeof(double)));
     if (tiles) {
@@ -2476,6 +2516,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         const size_t per_g = (size_t)N * H.MP + H.RS, nr1 = std::max<size_t>(1, (size_t)ctx->n_rows);
         const size_t di_doubles = ((size_t)std::max(1, ctx->jkt[0].n_groups) + 2 * (size_t)std::max(1, ctx->jkt[1].n_groups)) * per_g;
         const size_t dj_doubles = 3 * nr1 * per_g;
+        ctx->cd_bytes[1] = std::max<size_t>(1, ny) * sizeof(double); ctx->cd_bytes[2] = di_doubles * sizeof(double); ctx->cd_bytes[3] = dj_doubles * sizeof(double);
         HIPCHK(ctx, tf_malloc((void **)&ctx->d_DI, di_doubles * sizeof(double)));
         HIPCHK(ctx, tf_malloc((void **)&ctx->d_DJ, dj_doubles * sizeof(double)));
         HIPCHK(ctx, hipMemset(ctx->d_DI, 0, di_doubles * sizeof(double)));
@@ -2592,7 +2633,7 @@ int tf_sample_eri(tf_ctx *ctx, int64_t n_idx, const int32_t *idx, double *values
 // reductions; dDout[d]: the D matrix of density d.  Tables: set ND - 1.
 extern "C++" {
 template <int ND>
-static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
+static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout, bool cd = false)
 {
     const BLayout &L = ctx->bl;
     const int N = ctx->N, NW = L.NW;
@@ -2608,10 +2649,15 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
     S.DIc = MP * S.planeI; S.DIr = ng * (size_t)L.RS; S.DJc = MP * S.planeJ; S.DJr = nrows * (size_t)L.RS;
     // region of this pass type inside the partial buffers (tf_build_eri: [one-density pass | two-density pass])
     const size_t per_g = (size_t)N * MP + L.RS;
-    double *DI0 = ctx->d_DI + (ND == 2 ? (size_t)std::max(1, ctx->jkt[0].n_groups) * per_g : 0);
-    double *DJ0 = ctx->d_DJ + (ND == 2 ? nrows * per_g : 0);
+    // cd: the class-diagonal task list with its own partial-sum buffers (launch_jk_packed decides)
+    double *const pJrow = cd ? ctx->cd_Jrow : ctx->d_Jrow, *const pY = cd ? ctx->cd_ypart : ctx->d_ypart;
+    const JKTask *const tasks = cd ? T.d_tasks_cd : T.d_tasks;
+    const int n_tasks = cd ? T.n_tasks_cd : T.n_tasks;
+    const int *const bucket = cd ? T.bucket_cd : T.bucket;
+    double *DI0 = (cd ? ctx->cd_DI : ctx->d_DI) + (ND == 2 ? (size_t)std::max(1, ctx->jkt[0].n_groups) * per_g : 0);
+    double *DJ0 = (cd ? ctx->cd_DJ : ctx->d_DJ) + (ND == 2 ? nrows * per_g : 0);
     double *DIc = DI0, *DIr = DI0 + ND * S.DIc, *DJc = DJ0, *DJr = DJ0 + ND * S.DJc;
-    if (T.n_tasks > 0) {
+    if (n_tasks > 0) {
         hipEvent_t ev_after = nullptr;
         if (ctx->prof_jk) {
             if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
@@ -2628,7 +2674,7 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
         // their ramp-up and tail overlap the big one (fork / join on events; TF_JK_SERIAL=1: all on the caller's stream)
         static const bool serial = getenv("TF_JK_SERIAL") != nullptr;
         int n_launch = 0;
-        for (int b = 0; b < 3; ++b) n_launch += (T.bucket[b + 1] > T.bucket[b] && (TF_JKP_W >> b) >= 1) ? 1 : 0;
+        for (int b = 0; b < 3; ++b) n_launch += (bucket[b + 1] > bucket[b] && (TF_JKP_W >> b) >= 1) ? 1 : 0;
         // Few tasks (small tensors: N2/cc-pVTZ has 1 400): ONE launch of full-size workgroups over all of them -- the idle waves of the
         // narrower tasks cost nothing on a chip the build cannot fill, two launches and the fork / join events of the side streams do
         // (a Fock build at N = 60 is ~90 us of launches, not of work)
@@ -2638,16 +2684,16 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
         // (a rank of several only when its super-groups are full -- the whole-shell plan: >= 24 rows per super-group on average; 0.382 -> 0.363 ms
         // per local build on 8 ranks.  Under the segment plan a rank's super-groups hold a few rows each: see above.)
         const bool full_supers = T.n_supers > 0 && ctx->n_rows >= 24LL * T.n_supers;
-        const bool one_launch = n_launch > 1 && T.n_tasks < one_launch_below && (ctx->world == 1 || full_supers);
+        const bool one_launch = n_launch > 1 && n_tasks < one_launch_below && (ctx->world == 1 || full_supers);
         const bool fork = !serial && !one_launch && ctx->have_streams && n_launch > 1;
         if (fork) (void)hipEventRecord(ctx->sev[0], st);
         int side = 0;
         bool first = true;
         if (one_launch)
-            hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)T.n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, T.d_groups,
-                               T.d_supers, T.d_tasks, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+            hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)n_tasks), dim3(64 * TF_JKP_W), 0, st, ctx->d_eri, T.d_groups,
+                               T.d_supers, tasks, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, pJrow, pY, DIc, DIr, DJc, DJr, S);
         for (int b = 0; b < 3 && !one_launch; ++b) {
-            const int t0 = T.bucket[b], t1 = T.bucket[b + 1];
+            const int t0 = bucket[b], t1 = bucket[b + 1];
             if (!(t1 > t0 && (TF_JKP_W >> b) >= 1)) continue;
             hipStream_t ls = st;
             if (fork && !first) {
@@ -2657,7 +2703,7 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
             }
             first = false;
             hipLaunchKernelGGL((jk_packed_kernel<ND>), dim3((unsigned)(t1 - t0)), dim3(64 * (TF_JKP_W >> b)), 0, ls, ctx->d_eri, T.d_groups,
-                               T.d_supers, T.d_tasks + t0, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, ctx->d_Jrow, ctx->d_ypart, DIc, DIr, DJc, DJr, S);
+                               T.d_supers, tasks + t0, L, L.kinfo, ctx->d_Psym, ctx->d_Pp, pJrow, pY, DIc, DIr, DJc, DJr, S);
             if (ls != st) {
                 (void)hipEventRecord(ctx->sev[side], ls);
                 (void)hipStreamWaitEvent(st, ctx->sev[side], 0);
@@ -2666,7 +2712,7 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout)
         if (ev_after) (void)hipEventRecord(ev_after, st);
     }
     JKReduce R{};
-    R.ypart = ctx->d_ypart; R.sy = S.y; R.supers = T.d_supers; R.MC = ctx->hl.MC; R.MP = MP; R.planeI = S.planeI; R.planeJ = S.planeJ; R.nseg = T.nseg; R.jp = T.jp;
+    R.ypart = pY; R.sy = S.y; R.supers = T.d_supers; R.MC = ctx->hl.MC; R.MP = MP; R.planeI = S.planeI; R.planeJ = S.planeJ; R.nseg = T.nseg; R.jp = T.jp;
     R.Jt = ctx->d_Jt; R.sJt = (size_t)T.nseg * npr;
     R.DIc = DIc; R.sDIc = S.DIc; R.DIr = DIr; R.sDIr = S.DIr; R.DJc = DJc; R.sDJc = S.DJc; R.DJr = DJr; R.sDJr = S.DJr;
     R.gfirst = T.d_gfirst; R.jptr = ctx->d_jptr; R.jrows = ctx->d_jrows; R.row_ij = ctx->d_row_ij; R.xorder = ctx->d_xorder;
@@ -2687,16 +2733,54 @@ static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double
     const size_t nn = (size_t)N * N, npr = (size_t)L.NPtot, nrows = (size_t)std::max<long long>(1, ctx->n_rows);
     const dim3 gN((N * N + 255) / 256), b256(256);
     static const bool no_fuse = getenv("TF_JK_NOFUSE") != nullptr;
+    // Class-diagonal densities (what an SCF cycle of a diatomic without a transverse field produces: no element between AOs of
+    // different x/y parity) need a quarter fewer tasks -- see JKTables::d_tasks_cd.  Only when the caller expects them (the native cycles
+    // set jk_try_class_diagonal: the test costs a small kernel and one 16-byte read-back per call) and only when no density of the call
+    // has an element between two classes above 1e-14 of its largest element -- the threshold under which the blocked eigensolver
+    // (tf_scf.hip.h) already treats such elements as zero.  With exact zeros there (densities built from class-pure orbitals) the skipped
+    // products are exact zeros and J, K come out bit for bit the same; DIIS mixtures that carry 1e-16 of a host-made guess differ by that.
+    bool cd = false;
+    {
+        static const bool cd_off = getenv("TF_JK_CLASS_DIAGONAL") && getenv("TF_JK_CLASS_DIAGONAL")[0] == '0';
+        bool any_general = false;
+        for (int d = 0; d < nd; ++d) any_general = any_general || (nonsym && nonsym[d]);
+        if (ctx->jk_try_class_diagonal && !cd_off && !any_general && ctx->jkt[0].n_tasks_cd < ctx->jkt[0].n_tasks) {
+            if (!ctx->d_cdflag) HIPCHK(ctx, tf_malloc((void **)&ctx->d_cdflag, 2 * sizeof(unsigned long long)));
+            cd = true;
+            for (int d = 0; d < nd && cd; ++d) {                   // (per density: the threshold is relative to ITS largest element)
+                HIPCHK(ctx, hipMemsetAsync(ctx->d_cdflag, 0, 2 * sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(class_cross_max_kernel, dim3((unsigned)N), dim3(256), 0, st, dP[d], L, ctx->d_cdflag);
+                double h[2] = {0.0, 1.0};
+                HIPCHK(ctx, hipMemcpyAsync(h, ctx->d_cdflag, sizeof(h), hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                cd = std::isfinite(h[0]) && h[0] < 1e299 && h[1] <= 1e-14 * h[0];
+            }
+            if (cd && !ctx->cd_Jrow) {                             // the second set of partial-sum buffers: zeroed once, like the first
+                double **bufs[4] = {&ctx->cd_Jrow, &ctx->cd_ypart, &ctx->cd_DI, &ctx->cd_DJ};
+                for (int q = 0; q < 4; ++q) {
+                    if (tf_malloc((void **)bufs[q], ctx->cd_bytes[q]) != hipSuccess) {     // no room: the full list then
+                        (void)hipGetLastError();
+                        for (int u = 0; u < q; ++u) { (void)tf_free(*bufs[u]); *bufs[u] = nullptr; }
+                        cd = false;
+                        break;
+                    }
+                    HIPCHK(ctx, hipMemsetAsync(*bufs[q], 0, ctx->cd_bytes[q], st));
+                }
+            }
+            if (cd) ++ctx->jk_cd_passes; else ++ctx->jk_cd_declined;
+        }
+    }
+    double *const pJrow = cd ? ctx->cd_Jrow : ctx->d_Jrow;
     if (nd == 2 && !no_fuse && !(nonsym && (nonsym[0] || nonsym[1]))) {
         // two symmetric densities (UHF alpha / beta): one pass over the tensor, groups of 4 rows x 2 densities
         for (int d = 0; d < 2; ++d)
             hipLaunchKernelGGL(pack_density_kernel, gN, b256, 0, st, dP[d], L, 0, ctx->d_Psym + d * nn, ctx->d_Pp + d * npr);
         double *dD[2] = {ctx->d_D, ctx->d_D + nn};
-        int rc = jk_packed_pass<2>(ctx, st, dD);
+        int rc = jk_packed_pass<2>(ctx, st, dD, cd);
         if (rc) return rc;
         const int nseg = ctx->jkt[1].nseg;
         for (int d = 0; d < 2; ++d)
-            hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, dD[d], dD[d], ctx->d_Jrow + d * ctx->hl.MP * nrows * NW, nrows * NW,
+            hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, dD[d], dD[d], pJrow + d * ctx->hl.MP * nrows * NW, nrows * NW,
                                ctx->hl.KS, ctx->hl.MP, ctx->d_Jt + (size_t)d * nseg * npr, nseg, ctx->d_rowmap, L, dJ[d], dK[d]);
         return TF_OK;
     }
@@ -2706,10 +2790,10 @@ static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double
         double *dD = (pass == 0) ? ctx->d_D : ctx->d_D + nn;
         hipLaunchKernelGGL(pack_density_kernel, gN, b256, 0, st, dP[d], L, (general && pass == 0) ? 1 : 0, ctx->d_Psym, ctx->d_Pp);
         double *dDp[1] = {dD};
-        int rc = jk_packed_pass<1>(ctx, st, dDp);
+        int rc = jk_packed_pass<1>(ctx, st, dDp, cd);
         if (rc) return rc;
         if (general && pass == 0) continue;
-        hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, ctx->d_D, dD, ctx->d_Jrow, nrows * NW, ctx->hl.KS, ctx->hl.MP, ctx->d_Jt,
+        hipLaunchKernelGGL(jk_packed_final_kernel, gN, b256, 0, st, ctx->d_D, dD, pJrow, nrows * NW, ctx->hl.KS, ctx->hl.MP, ctx->d_Jt,
                            ctx->jkt[0].nseg, ctx->d_rowmap, L, dJ[d], dK[d]);
       }
     return TF_OK;
@@ -3508,6 +3592,13 @@ int tf_eigh_probe(tf_ctx *ctx, int n, int variant, int reps, double *seconds)
     return rc;
 }
 
+int tf_jk_path_stats(tf_ctx *ctx, int64_t out[2])
+{
+    if (!ctx || !out) return TF_EINVAL;
+    out[0] = ctx->jk_cd_passes; out[1] = ctx->jk_cd_declined;
+    return TF_OK;
+}
+
 int tf_eigh_stats(tf_ctx *ctx, int64_t out[5])
 {
     if (!ctx || !out) return TF_EINVAL;
@@ -3546,7 +3637,9 @@ int tf_scf_rhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
     auto jk = [&](const double *dP, double *dJ, double *dK, hipStream_t st) {
         const double *p[2] = {dP, dP};
         double *j[2] = {dJ, dJ}, *k[2] = {dK, dK};
+        ctx->jk_try_class_diagonal = true;                          // (a cycle's densities are class-diagonal unless a field along x / y mixes the classes)
         int rcj = launch_jk(ctx, 1, p, j, k, st);
+        ctx->jk_try_class_diagonal = false;
         return rcj ? rcj : allreduce_jk(ctx, 1, j, k, st);
     };
     tfscf::XCFn xc;
@@ -3589,7 +3682,9 @@ struct LockstepJK {
             const double *p[8];
             double *j[8], *k[8];
             for (int d = 0; d < nd; ++d) { p[d] = req[q + d].dP; j[d] = req[q + d].dJ; k[d] = req[q + d].dK; }
+            ctx->jk_try_class_diagonal = true;                      // (under the mutex of the batch: one pass at a time)
             rc = launch_jk(ctx, nd, p, j, k, st, nullptr);
+            ctx->jk_try_class_diagonal = false;
             ++passes; builds += nd;
         }
         if (hipEventRecord(ev[generation & 1], st) != hipSuccess && rc == TF_OK) rc = TF_ENODEVICE;
@@ -3690,7 +3785,9 @@ int tf_scf_uhf(tf_ctx *ctx, const tf_scf_opts *opts, const double *S, const doub
     auto jk2 = [&](const double *dPa, const double *dPb, double *dJa, double *dJb, double *dKa, double *dKb, hipStream_t st) {
         const double *p[2] = {dPa, dPb};
         double *j[2] = {dJa, dJb}, *k[2] = {dKa, dKb};
+        ctx->jk_try_class_diagonal = true;
         int rcj = launch_jk(ctx, 2, p, j, k, st);
+        ctx->jk_try_class_diagonal = false;
         return rcj ? rcj : allreduce_jk(ctx, 2, j, k, st);
     };
     tfscf::UhfOut uo;

@@ -192,6 +192,31 @@ __global__ void pack_density_kernel(const double *__restrict__ P, BLayout L, int
     }
 }
 
+// out[0] = largest |P[k][l]| of all, out[1] = largest |P[k][l]| between AOs of different x/y parity classes (ORIGINAL indices, one
+// workgroup per row), as bit patterns of non-negative doubles merged with atomicMax (a NaN counts as a huge cross element).
+__global__ void class_cross_max_kernel(const double *__restrict__ P, BLayout L, unsigned long long *__restrict__ out)
+{
+    __shared__ double sa[256], sx[256];
+    const int N = L.N, k = blockIdx.x, ck = ao_cls(L.ao[k]);
+    double all = 0.0, cross = 0.0;
+    for (int l = threadIdx.x; l < N; l += 256) {
+        double v = fabs(P[(size_t)k * N + l]);
+        if (v != v) v = 1e300;
+        all = fmax(all, v);
+        if (ao_cls(L.ao[l]) != ck) cross = fmax(cross, v);
+    }
+    sa[threadIdx.x] = all; sx[threadIdx.x] = cross;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { sa[threadIdx.x] = fmax(sa[threadIdx.x], sa[threadIdx.x + st]); sx[threadIdx.x] = fmax(sx[threadIdx.x], sx[threadIdx.x + st]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(out, (unsigned long long)__double_as_longlong(sa[0]));
+        if (sx[0] != 0.0) atomicMax(out + 1, (unsigned long long)__double_as_longlong(sx[0]));
+    }
+}
+
 // The kernel handles ND = 1 or 2 densities per pass.  Its eight "virtual rows" v = d * RB + r are RB = 8 / ND tensor rows times
 // ND densities: the loads of a tensor row are shared by the densities, all per-row state is indexed by v.  Arrays of the second
 // density follow those of the first at the strides given in JKWave.

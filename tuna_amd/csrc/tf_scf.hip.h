@@ -78,6 +78,8 @@ struct Workspace {
     double *sym_buf = nullptr;       // device: [nb][mmax][mmax] blocks, [nb][mmax] values, [nb][mmax] work, 2 doubles of the cross-class test
     int *sym_src = nullptr;          // device [n]: block * mmax + member of the eigenvalue of global rank r
     rocblas_int *sym_info = nullptr; // device [4]
+    bool sym_last_blocked = false;   // the last eigh() went block by block: sym_src names the block of every eigenvector it returned
+    int ref_vcls_n = 0, ref_alt_vcls_n = 0;   // n when the refinement's vectors carry block labels (tail of ref_buf), else 0
     double *sym_prev = nullptr;      // device [nb][mmax][mmax]: block eigenvectors of the previous solve (warm start of the batched Jacobi)
     int sym_prev_n = 0;              // 0 = none
     long long sym_solves = 0, sym_declined = 0;
@@ -433,6 +435,13 @@ __global__ void k_blk_scatter(const double *__restrict__ B, const int *__restric
     }
 }
 
+// block of the eigenvector of global rank r
+__global__ void k_blk_labels(const int *__restrict__ src, int mmax, int n, int *__restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = src[r] / mmax;
+}
+
 // TF_OK: solved (W rows = eigenvectors, vals ascending).  TF_EINVAL with an empty msg: declined, the caller solves the full matrix.
 inline int eigh_blocked(Workspace &w, int n, double *W, double *vals, std::string &msg)
 {
@@ -495,6 +504,7 @@ inline int eigh_blocked(Workspace &w, int n, double *W, double *vals, std::strin
     hipLaunchKernelGGL(k_blk_rank, dim3(1), dim3(1024), 0, TFS_ST, D, w.sym_idx, nb, mmax, vals, w.sym_src);
     hipLaunchKernelGGL(k_blk_scatter, dim3(n), dim3(128), 0, TFS_ST, B, w.sym_idx, w.sym_src, n, mmax, W, sizes);
     ++w.sym_solves;
+    w.sym_last_blocked = true;
     return TF_OK;
 }
 
@@ -506,6 +516,7 @@ inline int eigh(Workspace &w, int n, double *W, double *vals, double *work_e, st
     static const bool force_rocsolver = getenv("TF_EIGH") && std::string(getenv("TF_EIGH")) == "rocsolver";
     static const bool force_jacobi = getenv("TF_EIGH") && std::string(getenv("TF_EIGH")) == "jacobi";
     static const int jac_nmax = getenv("TF_JACOBI_NMAX") ? std::min(TFJ_NMAX, std::max(2, atoi(getenv("TF_JACOBI_NMAX")))) : 64;
+    w.sym_last_blocked = false;
     if (!force_rocsolver && !force_jacobi) {                       // the symmetry blocks of a diatomic, solved together (declines if there are none)
         std::string bmsg;
         const int rb = eigh_blocked(w, n, W, vals, bmsg);
@@ -581,13 +592,18 @@ __global__ void k_ref_diag(const double *__restrict__ S, int n, int n_occ, doubl
 }
 
 // E (row-major, antisymmetric) and per block: max |e_ij| over all pairs, and over the occupied-virtual pairs
+// vcls (optional): block label of every vector (the exact solve they come from went block by block over the parity classes).  Vectors
+// of different blocks are never rotated into each other: what couples them is rounding residue of the class-diagonal problem (the
+// blocked solver dropped the same elements), and vectors that stay class-pure give densities with exact zeros between the classes,
+// which the Fock build then exploits (tf_device.hip: the class-diagonal task list).  A coupling that is NOT residue (> 1e-6 as a rotation)
+// is reported as a rotation of 1: the caller falls back to an exact solve, which will decline the blocks.
 __global__ void k_ref_E(const double *__restrict__ S, const double *__restrict__ lam, const double *__restrict__ wocc, int n,
-                        double *__restrict__ E, double *__restrict__ blockmax)
+                        double *__restrict__ E, double *__restrict__ blockmax, const int *__restrict__ vcls)
 {
     __shared__ double sm[256], so[256];
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0.0;
-    bool ov = false;
+    bool ov = false, cross_bad = false;
     if (e < n * n) {
         const int i = e / n, j = e - i * n;
         if (i != j) {
@@ -595,10 +611,14 @@ __global__ void k_ref_E(const double *__restrict__ S, const double *__restrict__
             const double dl = lam[j] - lam[i];
             ov = wocc[i] != wocc[j];
             if (ov || (fabs(sij) <= TF_REF_INTRA * fabs(dl) && fabs(dl) > TF_REF_CLUSTER)) v = sij / dl;
+            if (vcls && vcls[i] != vcls[j]) {
+                cross_bad = ov && fabs(v) > 1e-6;
+                v = 0.0;
+            }
         }
         E[e] = v;
     }
-    sm[threadIdx.x] = fabs(v); so[threadIdx.x] = ov ? fabs(v) : 0.0;
+    sm[threadIdx.x] = cross_bad ? 1.0 : fabs(v); so[threadIdx.x] = cross_bad ? 1.0 : (ov ? fabs(v) : 0.0);
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
         if (threadIdx.x < st) { sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + st]); so[threadIdx.x] = fmax(so[threadIdx.x], so[threadIdx.x + st]); }
@@ -616,7 +636,7 @@ __global__ void k_scale_rows(const double *__restrict__ X, const double *__restr
 
 inline int ref_ensure(Workspace &w, int n, std::string &msg)
 {
-    const size_t need = 6 * (size_t)n * n + 2 * (size_t)n + 2 * (((size_t)n * n + 255) / 256) + 8;
+    const size_t need = 6 * (size_t)n * n + 3 * (size_t)n + 2 * (((size_t)n * n + 255) / 256) + 8;   // (+ n: block labels of the vectors)
     if (need > w.ref_cap) {
         if (w.ref_buf) (void)hipFree(w.ref_buf);
         w.ref_buf = nullptr; w.ref_cap = 0; w.ref_n = 0;
@@ -644,6 +664,7 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
     double *X = w.ref_buf, *Xn = X + nn, *G = Xn + nn, *Y = G + nn, *S = Y + nn, *E = S + nn;
     double *lam = E + nn, *wocc = lam + n, *bmax = wocc + n;
     const int g = (int)((nn + 255) / 256);
+    const int *vcls = (w.ref_vcls_n == n) ? reinterpret_cast<const int *>(w.ref_buf + 6 * nn + 2 * (size_t)n + 2 * (size_t)g + 8) : nullptr;
     // X <- (3/2 I - 1/2 G) X with G = X X^T (rows are the vectors)
     auto orthonormalise = [&]() -> int {
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, X, X, 0.0, G));
@@ -664,7 +685,7 @@ inline int ref_refine(Workspace &w, int n, int n_occ, const double *A, double **
         TFS_BLAS(gemm_rm(w.blas, false, false, n, 1.0, X, A, 0.0, Y));         // rows A x_i
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Y, X, 0.0, S));          // S = X^T A X
         hipLaunchKernelGGL(k_ref_diag, dim3(1), dim3(1024), 0, TFS_ST, S, n, n_occ, lam, wocc, bmax + 2 * (size_t)g);
-        hipLaunchKernelGGL(k_ref_E, dim3(g), dim3(256), 0, TFS_ST, S, lam, wocc, n, E, bmax);
+        hipLaunchKernelGGL(k_ref_E, dim3(g), dim3(256), 0, TFS_ST, S, lam, wocc, n, E, bmax, vcls);
         TFS_HIP(hipMemcpyAsync(w.h_pin, bmax, npin * sizeof(double), hipMemcpyDeviceToHost, TFS_ST));
         TFS_HIP(hipEventRecord(w.ev_pin, TFS_ST));
         TFS_HIP(hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
@@ -751,6 +772,13 @@ inline int ref_store(Workspace &w, int n, const double *V, std::string &msg)
     if (rc) return rc;
     TFS_HIP(hipMemcpyAsync(w.ref_buf, V, (size_t)n * n * sizeof(double), hipMemcpyDeviceToDevice, TFS_ST));
     w.ref_n = n;
+    w.ref_vcls_n = 0;
+    if (w.sym_last_blocked && w.sym_n == n && w.sym_src) {         // V are the vectors of the blocked solve just done: keep their block labels
+        const size_t nn = (size_t)n * n, g = (nn + 255) / 256;
+        int *vcls = reinterpret_cast<int *>(w.ref_buf + 6 * nn + 2 * (size_t)n + 2 * g + 8);
+        hipLaunchKernelGGL(k_blk_labels, dim3((n + 255) / 256), dim3(256), 0, TFS_ST, w.sym_src, w.sym_mmax, n, vcls);
+        w.ref_vcls_n = n;
+    }
     return TF_OK;
 }
 
@@ -1319,9 +1347,9 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         Workspace &w; bool on;
         SpinSlot(Workspace &ws, bool o_) : w(ws), on(o_) { swap(); }
         ~SpinSlot() { swap(); }
-        void swap() { if (on) { std::swap(w.ref_buf, w.ref_alt_buf); std::swap(w.ref_cap, w.ref_alt_cap); std::swap(w.ref_n, w.ref_alt_n); } }
+        void swap() { if (on) { std::swap(w.ref_buf, w.ref_alt_buf); std::swap(w.ref_cap, w.ref_alt_cap); std::swap(w.ref_n, w.ref_alt_n); std::swap(w.ref_vcls_n, w.ref_alt_vcls_n); } }
     };
-    w.ref_n = 0; w.ref_alt_n = 0;
+    w.ref_n = 0; w.ref_alt_n = 0; w.ref_vcls_n = 0; w.ref_alt_vcls_n = 0;
     w.warm_ok = false; w.jac_prev_n = 0;          // two alternating spins: no warm start for the (rare) Jacobi solves
     bool orbitals_current[2] = {false, false}, orbitals_final[2] = {false, false};
     // diagonalise F_s (AO) -> P_s = C_occ C_occ^T symmetrised (one electron per orbital, scf:1227-1228)
@@ -1539,7 +1567,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         if (uo.eps[sp]) TFS_HIP(tfs_memcpy(uo.eps[sp], vals, n * sizeof(double), hipMemcpyDeviceToHost));
         if (uo.C[sp]) TFS_HIP(tfs_memcpy(uo.C[sp], dC, nn * sizeof(double), hipMemcpyDeviceToHost));
     }
-    w.ref_n = 0; w.ref_alt_n = 0;
+    w.ref_n = 0; w.ref_alt_n = 0; w.ref_vcls_n = 0; w.ref_alt_vcls_n = 0;
     TFS_HIP(tfs_sync());
     for (const auto &sp : spans) {
         float ms = 0.f;

@@ -239,6 +239,13 @@ class Engine:
         self._check(self._L.tf_eigh_stats(self._ctx, out))
         return dict(zip(("refined_solves", "refinement_steps", "refinement_fallbacks", "blocked_solves", "blocked_declined"), (int(v) for v in out)))
 
+    def jk_path_stats(self):
+        """Fock builds of the native cycles over the class-diagonal task list / over the full list (tunafock.h: tf_jk_path_stats)."""
+        import ctypes as C
+        out = (C.c_int64 * 2)()
+        self._check(self._L.tf_jk_path_stats(self._ctx, out))
+        return {"class_diagonal_passes": int(out[0]), "full_passes_after_test": int(out[1])}
+
     def _scf_opts(self, *, conv="medium", max_iter=100, diis=True, max_diis=6, damping="dynamic", damping_factor=0.0, max_damping=0.7,
                   hfx=1.0, n_atom_ao=None):
         N = self.N
