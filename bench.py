@@ -473,7 +473,7 @@ def scf_on_workload(eng, atoms, shells, nocc, desc):
                                 n_atom_ao=nao, max_iter=200)
             t2 = time.perf_counter()
             orbitals = (r["C"], r["epsilons"])
-            best = {"energy_Eh": r["energy"], "iterations": r["n_iter"], "damping": damping, "eigensolver_paths": eng.eigh_stats(),
+            best = {"energy_Eh": r["energy"], "iterations": r["n_iter"], "damping": damping, "eigensolver_paths": eng.eigh_stats(), "fock_paths": eng.jk_path_stats(),
                     "setup_wall_s": t1 - t0, "scf_wall_s": t2 - t1,
                     "ms_per_iteration": 1e3 * (t2 - t1) / r["n_iter"], "fock_kernels_ms_per_iteration": 1e3 * r["fock_seconds"] / r["n_iter"],
                     "eigen_ms_per_iteration": 1e3 * r["eig_seconds"] / r["n_iter"], "smallest_overlap_eigenvalue": smin}

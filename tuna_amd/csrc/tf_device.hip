@@ -2744,7 +2744,9 @@ static int launch_jk_packed(tf_ctx *ctx, int nd, const double *const *dP, double
         static const bool cd_off = getenv("TF_JK_CLASS_DIAGONAL") && getenv("TF_JK_CLASS_DIAGONAL")[0] == '0';
         bool any_general = false;
         for (int d = 0; d < nd; ++d) any_general = any_general || (nonsym && nonsym[d]);
-        if (ctx->jk_try_class_diagonal && !cd_off && !any_general && ctx->jkt[0].n_tasks_cd < ctx->jkt[0].n_tasks) {
+        // (the test is a kernel and a read-back, ~30 us: a build of a small tensor takes less than that in all -- N2/cc-pVTZ 70 us)
+        static const int cd_nmin = getenv("TF_JK_CD_NMIN") ? atoi(getenv("TF_JK_CD_NMIN")) : 160;
+        if (ctx->jk_try_class_diagonal && !cd_off && !any_general && N >= cd_nmin && ctx->jkt[0].n_tasks_cd < ctx->jkt[0].n_tasks) {
             if (!ctx->d_cdflag) HIPCHK(ctx, tf_malloc((void **)&ctx->d_cdflag, 2 * sizeof(unsigned long long)));
             cd = true;
             for (int d = 0; d < nd && cd; ++d) {                   // (per density: the threshold is relative to ITS largest element)
