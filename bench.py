@@ -304,7 +304,19 @@ def main():
     in_library = world > 1 and backend == "nccl" and os.environ.get("TUNA_BENCH_TORCH_ALLREDUCE") is None
     if in_library:
         from tuna_amd import distributed as tdist
-        tdist.attach_rccl(eng)
+        try:
+            tdist.attach_rccl(eng)
+            ok_comm = 1.0
+        except Exception as e:                                # (librccl not loadable on this box, ...): the torch all-reduce then -- on EVERY rank
+            ok_comm = 0.0
+            if rank == 0:
+                print(f"bench.py: in-library RCCL communicator not available ({type(e).__name__}: {e}); using torch.distributed", file=sys.stderr)
+        flag = torch.tensor([ok_comm], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) == 0.0:
+            if eng.comm_attached():
+                eng.comm_destroy()
+            in_library = False
 
     def step():
         eng.fock_jk_device(dP.data_ptr(), dJK[0].data_ptr(), dJK[1].data_ptr(), nd, stream)
@@ -363,7 +375,7 @@ def main():
             "dtype": "f64", "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL: gloo, ranks sharing cards -- not a measurement)",
             "config": {"workload": f"{args.workload}: {desc}", "n_ao_spherical": N, "n_ao_cartesian": eng.n_cart,
                        "n_shells": eng.n_shell, "n_densities": nd, "layout": layout, "storage": storage,
-                       "stored_bytes_per_gpu": stored_bytes, "parallelism": f"ij-row shards x{world} + RCCL all-reduce of [J;K]" if world > 1 else "1 GPU",
+                       "stored_bytes_per_gpu": stored_bytes, "parallelism": (f"ij-row shards x{world} + RCCL all-reduce of [J;K] " + ("issued by the library (tf_comm_init)" if in_library else "through torch.distributed")) if world > 1 else "1 GPU",
                        "result_ok": ok},
             # all densities of a step: Fock matrices per second, and the executed FP64 rate -- six multiply-adds per stored value and
             # density (tf_jkpacked.hip.h) -- against the FP64 peak (78.6 TFLOP/s; vector and matrix cores run FP64 at the same rate on CDNA4)
