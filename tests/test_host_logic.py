@@ -292,3 +292,20 @@ def test_custom_criteria_are_applied_over_the_derivative_driven_preset():
     assert c["max_DP"] == 1e-5 and c["commutator"] == 2e-6 and c["delta_E"] == ext["delta_E"] and c["RMS_DP"] == ext["RMS_DP"]
     c = conv(base + " HYPER LOOSE RMSDP 1e-4")                        # an explicit preset wins over the derivative-driven one
     assert c["RMS_DP"] == 1e-4 and c["delta_E"] == en.SCF_CONVERGENCE["loose"]["delta_E"]
+
+
+def test_bench_reads_the_committed_profiles_of_this_round():
+    """bench.py turns committed rocprofv3 PMC summaries into roofline.traffic, eri_build.executed and per_density.mfma: the files it
+    looks for must exist, carry `_meta`, and give sane figures (MI355X_MICROARCH.md: FETCH_SIZE x 2 + WRITE_SIZE; 64 cycles per
+    v_mfma_f64_16x16x4)."""
+    import json
+    import bench
+    root = os.path.join(os.path.dirname(__file__), "..")
+    meta = json.load(open(os.path.join(root, "profiles", "r04_pmc_synth400_packed.json")))["_meta"]
+    traffic, src, m = bench.pmc_traffic("synth-400", 1, "packed", meta["stored_bytes"])
+    assert src == "profiles/r04_pmc_synth400_packed.json" and 1.0 < traffic / meta["stored_bytes"] < 1.5
+    ex = bench.pmc_eri_valu("synth-400", 0.027)
+    assert ex["profile"] == "profiles/r04_pmc_eri_synth400.json" and 0.2 < ex["valu_issue_utilisation"] < 0.8
+    mf = bench.pmc_mfma("synth-400", 8, 8.6e-3)
+    assert mf["cycles_per_instruction"] == 64.0 and 0.1 < mf["matrix_pipe_busy_fraction"] < 0.4 and mf["useful_column_fraction"] == 0.5
+    assert bench.pmc_mfma("synth-400", 4, 5.0e-3)["kernel"] == "jk_tile_kernel<4, 1, 2>"
