@@ -1196,7 +1196,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
         for (int b = 1; b < 4; ++b) if (T.bucket[b] == (int)tasks.size()) T.bucket_cd[b] = (int)tasks_cd.size();
         T.n_tasks_cd = (int)tasks_cd.size();
-        {
+        if (g_dbg) {
             long long st_all = 0, st_cd = 0;                       // wave steps of the two lists (what a pass costs)
             for (size_t t = 0; t < tasks.size(); ++t) {
                 const JKSuper &sg = supers[tasks[t].super];
