@@ -275,7 +275,7 @@ def test_symmetry_blocked_eigensolve_and_its_refusal():
         assert s4["blocked_solves"] == s3["blocked_solves"] and s4["blocked_declined"] == s3["blocked_declined"] + 1
 
 
-@pytest.mark.parametrize("kind", ["rhf", "uhf"])
+@pytest.mark.parametrize("kind", ["rhf", "uhf", "mixed"])
 def test_class_diagonal_task_list_gives_the_same_bits(kind):
     """tf_device.hip: launch_jk_packed -- the native cycles send class-diagonal densities (no element between AOs of different x/y parity)
     over a shorter task list; the skipped products are exact zeros, so the whole cycle (scf:1072-1154 / 1165-1281) must come out bit for
@@ -294,7 +294,7 @@ from tuna_amd.engine import Engine
 from oracle import scf_oracle as so
 kind = %r
 with Engine(0) as eng:
-    if kind == "rhf":
+    if kind in ("rhf", "mixed"):
         atoms, shells, aos, nocc = make_system("c3_ar2_ccpvqz")
     else:
         atoms, shells, aos, na, nb = make_uhf_system("o2_triplet_ccpvdz")
@@ -303,7 +303,16 @@ with Engine(0) as eng:
     S, T, V, _, _ = eng.one_electron(xyz, chg, org, spherical=True)
     X, _, _ = eng.orthogonaliser(S)
     nao = [sum(s.n_sph for s in shells if s.atom == a) for a in range(len(atoms))]
-    if kind == "rhf":
+    if kind == "mixed":
+        # a two-density cycle, then a one-density cycle on the same context: the partial sums of the two pass types are laid out
+        # differently, and the slots a skipped task leaves alone must not hold what the other pass type wrote there
+        _, C0 = eng.diagonalise(T + V, X)
+        Ph = C0[:, :nocc] @ C0[:, :nocc].T; Ph = 0.5 * (Ph + Ph.T)
+        ru = eng.scf_uhf(S, T, V, Ph, Ph, float(np.sum(2 * Ph * (T + V))), nocc, nocc, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping="dynamic", n_atom_ao=nao)
+        r = eng.scf_rhf(S, T, V, 2 * Ph, float(np.sum(2 * Ph * (T + V))), nocc, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping="dynamic", n_atom_ao=nao)
+        assert abs(ru["energy"] - r["energy"]) < 1e-8
+        mats = [r["P"], r["F"], ru["P_spin"][0]]
+    elif kind == "rhf":
         _, C0 = eng.diagonalise(T + V, X)
         P0 = 2.0 * C0[:, :nocc] @ C0[:, :nocc].T; P0 = 0.5 * (P0 + P0.T)
         r = eng.scf_rhf(S, T, V, P0, float(np.sum(P0 * (T + V))), nocc, mol.nuclear_repulsion(atoms), X=X, conv="tight", damping="dynamic", n_atom_ao=nao)

@@ -2516,7 +2516,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         const size_t per_g = (size_t)N * H.MP + H.RS, nr1 = std::max<size_t>(1, (size_t)ctx->n_rows);
         const size_t di_doubles = ((size_t)std::max(1, ctx->jkt[0].n_groups) + 2 * (size_t)std::max(1, ctx->jkt[1].n_groups)) * per_g;
         const size_t dj_doubles = 3 * nr1 * per_g;
-        ctx->cd_bytes[1] = std::max<size_t>(1, ny) * sizeof(double); ctx->cd_bytes[2] = di_doubles * sizeof(double); ctx->cd_bytes[3] = dj_doubles * sizeof(double);
+        ctx->cd_bytes[1] = std::max<size_t>(1, (size_t)ctx->jkt[0].ypart_len + 2 * (size_t)ctx->jkt[1].ypart_len) * sizeof(double); ctx->cd_bytes[2] = di_doubles * sizeof(double); ctx->cd_bytes[3] = dj_doubles * sizeof(double);
         HIPCHK(ctx, tf_malloc((void **)&ctx->d_DI, di_doubles * sizeof(double)));
         HIPCHK(ctx, tf_malloc((void **)&ctx->d_DJ, dj_doubles * sizeof(double)));
         HIPCHK(ctx, hipMemset(ctx->d_DI, 0, di_doubles * sizeof(double)));
@@ -2650,7 +2650,10 @@ static int jk_packed_pass(tf_ctx *ctx, hipStream_t st, double *const *dDout, boo
     // region of this pass type inside the partial buffers (tf_build_eri: [one-density pass | two-density pass])
     const size_t per_g = (size_t)N * MP + L.RS;
     // cd: the class-diagonal task list with its own partial-sum buffers (launch_jk_packed decides)
-    double *const pJrow = cd ? ctx->cd_Jrow : ctx->d_Jrow, *const pY = cd ? ctx->cd_ypart : ctx->d_ypart;
+    // (the Jt partials of the two pass types are laid out by their own super-groups: in the general buffer every pass overwrites what it
+    // reads, in the class-diagonal buffer the slots of skipped tasks must STAY zero -- each pass type has its own region there)
+    double *const pJrow = cd ? ctx->cd_Jrow : ctx->d_Jrow;
+    double *const pY = cd ? ctx->cd_ypart + (ND == 2 ? (size_t)std::max<long long>(0, ctx->jkt[0].ypart_len) : 0) : ctx->d_ypart;
     const JKTask *const tasks = cd ? T.d_tasks_cd : T.d_tasks;
     const int n_tasks = cd ? T.n_tasks_cd : T.n_tasks;
     const int *const bucket = cd ? T.bucket_cd : T.bucket;
