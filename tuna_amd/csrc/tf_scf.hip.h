@@ -1075,8 +1075,8 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     std::vector<double> B((size_t)max_diis * max_diis, 0.0);
     int n_hist = 0;
     w.warm_ok = true;                 // successive Fock matrices are close: warm-start the Jacobi solver from the last eigenvectors
-    w.jac_prev_n = 0;
-    struct WarmGuard { Workspace &w; ~WarmGuard() { w.warm_ok = false; w.jac_prev_n = 0; } } warm_guard{w};
+    w.jac_prev_n = 0; w.sym_prev_n = 0;   // (no warm start across cycles: a cycle's result must not depend on what the context solved before)
+    struct WarmGuard { Workspace &w; ~WarmGuard() { w.warm_ok = false; w.jac_prev_n = 0; w.sym_prev_n = 0; } } warm_guard{w};
     double E = E0, E_old = E0, commutator = 1.0;
     double comps[7] = {0, 0, 0, 0, 0, 0, 0};
     out.fock_seconds = 0; out.eig_seconds = 0; out.n_iter = 0; out.converged = 0;
@@ -1350,7 +1350,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         void swap() { if (on) { std::swap(w.ref_buf, w.ref_alt_buf); std::swap(w.ref_cap, w.ref_alt_cap); std::swap(w.ref_n, w.ref_alt_n); std::swap(w.ref_vcls_n, w.ref_alt_vcls_n); } }
     };
     w.ref_n = 0; w.ref_alt_n = 0; w.ref_vcls_n = 0; w.ref_alt_vcls_n = 0;
-    w.warm_ok = false; w.jac_prev_n = 0;          // two alternating spins: no warm start for the (rare) Jacobi solves
+    w.warm_ok = false; w.jac_prev_n = 0; w.sym_prev_n = 0;          // two alternating spins: no warm start for the (rare) Jacobi solves
     bool orbitals_current[2] = {false, false}, orbitals_final[2] = {false, false};
     // diagonalise F_s (AO) -> P_s = C_occ C_occ^T symmetrised (one electron per orbital, scf:1227-1228)
     auto diag_density = [&](int sp, const double *Fao, double *Pout) -> int {
