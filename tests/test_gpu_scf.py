@@ -339,3 +339,69 @@ with Engine(0) as eng:
     a, b = res["short"], res["full"]
     assert a["paths"]["class_diagonal_passes"] >= a["n_iter"] - 2 and b["paths"]["class_diagonal_passes"] == 0
     assert a["E"] == b["E"] and a["n_iter"] == b["n_iter"] and a["table"] == b["table"] and a["sums"] == b["sums"]
+
+
+def test_mixed_sequence_on_one_context_equals_the_plain_paths():
+    """A context used the way a finite-field property run uses it -- restricted cycle, lockstep batch with fields along z and x (pairs of
+    densities per pass), restricted cycle with a field, unrestricted cycle, a Fock build through the public entry -- at a size where the
+    class-diagonal task list, the blocked eigensolver and the block labels of the refinement are all active (synthetic 176-AO Ar2-like
+    system; scf:1072-1281 for the cycles, energy:315-540 for the batch).  Every energy must equal the one of the same sequence with those
+    paths switched off (TF_JK_CLASS_DIAGONAL=0 TF_EIGH_BLOCKS=0) to 1e-9: nothing may leak from one call into the next."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import bench
+from tuna_amd import molecule as mol
+from tuna_amd.engine import Engine
+atoms, shells, aos, nocc, desc = bench.build_workload("synth-176")
+with Engine(0) as eng:
+    eng.set_basis(aos).build_eri(True)
+    N = eng.N
+    xyz, chg = [a.origin for a in atoms], [float(a.charge) for a in atoms]
+    S, T, V, D, Q = eng.one_electron(xyz, chg, [0.0, 0.0, 0.5 * atoms[-1].origin[2]], spherical=True)
+    X, _, _ = eng.orthogonaliser(S)
+    _, C0 = eng.diagonalise(T + V, X)
+    P0 = 2.0 * C0[:, :nocc] @ C0[:, :nocc].T; P0 = 0.5 * (P0 + P0.T)
+    E0 = float(np.sum(P0 * (T + V)))
+    nao = [sum(s.n_sph for s in shells if s.atom == a) for a in range(2)]
+    VNN = mol.nuclear_repulsion(atoms)
+    kw = dict(X=X, conv="tight", damping="dynamic", n_atom_ao=nao, max_iter=200)
+    out = {}
+    out["rhf"] = eng.scf_rhf(S, T, V, P0, E0, nocc, VNN, **kw)["energy"]
+    h = 0.002
+    fields = [h * D[2], -h * D[2], h * D[0], -h * D[0]]
+    rb = eng.scf_rhf_batch(S, T, V, [P0] * 4, [E0] * 4, nocc, VNN, Fexts=fields, **kw)
+    out["batch"] = [r["energy"] for r in rb]
+    out["rhf_z"] = eng.scf_rhf(S, T, V, P0, E0, nocc, VNN, Fext=fields[0], **kw)["energy"]
+    out["rhf_x"] = eng.scf_rhf(S, T, V, P0, E0, nocc, VNN, Fext=fields[2], **kw)["energy"]
+    out["uhf"] = eng.scf_uhf(S, T, V, P0 / 2, P0 / 2, E0, nocc, nocc, VNN, **kw)["energy"]
+    out["rhf_again"] = eng.scf_rhf(S, T, V, P0, E0, nocc, VNN, **kw)["energy"]
+    A = np.random.default_rng(5).standard_normal((N, N)); Pr = A + A.T
+    J, K = eng.fock_jk(Pr[None])
+    out["jk"] = [float(np.abs(J).sum()), float(np.abs(K).sum())]
+    out["paths"] = eng.jk_path_stats(); out["eigh"] = eng.eigh_stats(); out["N"] = N
+    print(json.dumps(out))
+''' % (os.path.join(os.path.dirname(__file__), ".."),)
+    res = {}
+    for mode in ("round4", "plain"):
+        env = dict(os.environ)
+        for k in ("TF_JK_CLASS_DIAGONAL", "TF_EIGH_BLOCKS"):
+            env.pop(k, None)
+        if mode == "plain":
+            env["TF_JK_CLASS_DIAGONAL"] = "0"; env["TF_EIGH_BLOCKS"] = "0"
+        o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert o.returncode == 0, o.stderr[-2000:]
+        res[mode] = json.loads(o.stdout.strip().splitlines()[-1])
+    a, b = res["round4"], res["plain"]
+    assert a["N"] >= 160 and a["paths"]["class_diagonal_passes"] > 20 and a["eigh"]["blocked_solves"] > 5
+    assert b["paths"]["class_diagonal_passes"] == 0 and b["eigh"]["blocked_solves"] == 0
+    for key in ("rhf", "rhf_z", "rhf_x", "uhf", "rhf_again"):
+        assert abs(a[key] - b[key]) < 1e-9, (key, a[key], b[key])
+    assert np.abs(np.array(a["batch"]) - np.array(b["batch"])).max() < 1e-9
+    assert abs(a["rhf"] - a["rhf_again"]) < 1e-10 and abs(a["uhf"] - a["rhf"]) < 1e-8
+    assert abs(a["batch"][0] - a["rhf_z"]) < 1e-9 and abs(a["batch"][2] - a["rhf_x"]) < 1e-9 and abs(a["batch"][2] - a["batch"][3]) < 1e-9
+    assert np.allclose(a["jk"], b["jk"], rtol=1e-13, atol=0)
