@@ -98,3 +98,35 @@ def test_tiles_at_the_benched_size(engine):
         assert np.abs(Jt - Jp).max() < 1e-11 * np.abs(Jp).max() and np.abs(Kt - Kp).max() < 1e-11 * np.abs(Kp).max()
     finally:
         _reset(engine)
+
+
+def test_lockstep_batch_on_the_tiles_layout_takes_the_wide_pass(engine):
+    """tf_scf_rhf_batch on a tiles tensor sends all densities of an iteration through ONE wide pass (up to eight as B-operand columns of
+    the matrix-core products): the same energies as the batch on the packed tensor (pairs of densities per pass) and as single cycles,
+    in a quarter of the passes (energy:315-540 for what the batch stands for; scf:1072-1154 for each cycle)."""
+    import bench
+    atoms, shells, aos, nocc, _ = bench.build_workload("synth-176")      # (the smallest of the series whose cycles converge from the core guess)
+    try:
+        xyz, chg = [a.origin for a in atoms], [float(a.charge) for a in atoms]
+        res = {}
+        for layout in ("packed", "tiles"):
+            engine.set_basis(aos).build_eri(True, layout=layout)
+            S, T, V, D, _ = engine.one_electron(xyz, chg, [0.0, 0.0, 0.5 * atoms[-1].origin[2]], spherical=True)
+            X, _, _ = engine.orthogonaliser(S)
+            _, C0 = engine.diagonalise(T + V, X)
+            P0 = 2.0 * C0[:, :nocc] @ C0[:, :nocc].T
+            P0 = 0.5 * (P0 + P0.T)
+            E0 = float(np.sum(P0 * (T + V)))
+            nao = [sum(s.n_sph for s in shells if s.atom == a) for a in range(2)]
+            h = 0.002
+            fields = [h * D[2], -h * D[2], h * D[0], -h * D[0], 2 * h * D[2], 2 * h * D[0]]
+            kw = dict(X=X, conv="tight", damping="dynamic", n_atom_ao=nao, max_iter=200)
+            rb = engine.scf_rhf_batch(S, T, V, [P0] * len(fields), [E0] * len(fields), nocc, mol.nuclear_repulsion(atoms), Fexts=fields, **kw)
+            single = engine.scf_rhf(S, T, V, P0, E0, nocc, mol.nuclear_repulsion(atoms), Fext=fields[2], **kw)
+            res[layout] = ([r["energy"] for r in rb], single["energy"], max(r["n_iter"] for r in rb), rb[0].get("passes"))
+        Ep, Et = np.array(res["packed"][0]), np.array(res["tiles"][0])
+        assert np.abs(Ep - Et).max() < 1e-9
+        assert abs(res["tiles"][1] - Et[2]) < 1e-9 and abs(res["packed"][1] - Ep[2]) < 1e-9
+        assert abs(Et[2] - Et[3]) < 1e-9                                      # E(+x) = E(-x)
+    finally:
+        _reset(engine)
