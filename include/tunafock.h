@@ -129,7 +129,8 @@ int tf_eri_element(tf_ctx *ctx, const double *origin, const int32_t *lmn, const 
 
 /* J_ij = sum_kl (ij|kl) P_kl ;  K_ij = sum_kl (il|kj) P_kl  for n_dens densities, host buffers
  * [n_dens,N,N].  With world > 1 the result is this rank's PARTIAL J and K (sum over ranks =
- * full matrices); the caller all-reduces (RCCL) -- see tuna_amd/distributed.py. */
+ * full matrices) and the caller all-reduces -- unless a communicator is attached (tf_comm_init
+ * below): then the library has summed them over the ranks already. */
 int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K);
 /* N > 1 ranks: every rank holds the tensor rows of its bra shell pairs, a Fock build gives partial J and K,
  * and ONE all-reduce of the stacked [J;K] completes them.  The native SCF cycles (tf_scf_rhf / tf_scf_uhf) call this hook once per

@@ -3245,6 +3245,7 @@ int tf_fock_jk(tf_ctx *ctx, int n_dens, const double *P, double *J, double *K)
         }
         int rc = launch_jk(ctx, nd, p, j, k, 0, nonsym);
         if (rc) return rc;
+        if (ctx->comm && ctx->world > 1 && (rc = allreduce_jk(ctx, nd, j, k, 0))) return rc;     // a communicator is attached: the sums over the ranks
         HIPCHK(ctx, hipMemcpy(J + d * nn, ctx->d_J, nd * nn * sizeof(double), hipMemcpyDeviceToHost));
         HIPCHK(ctx, hipMemcpy(K + d * nn, ctx->d_K, nd * nn * sizeof(double), hipMemcpyDeviceToHost));
     }

@@ -145,7 +145,8 @@ class Engine:
 
     # ---- Fock build --------------------------------------------------------------------------
     def fock_jk(self, P: np.ndarray):
-        """J, K for one [N,N] or several [n,N,N] densities (host buffers).  Partial sums when world > 1."""
+        """J, K for one [N,N] or several [n,N,N] densities (host buffers).  Partial sums when world > 1, unless a communicator is
+        attached (comm_init): then the library has summed them over the ranks."""
         P = f64(P)
         if self._L.tf_eri_layout(self._ctx) >= 0 and (P.ndim not in (2, 3) or P.shape[-1] != self.N or P.shape[-2] != self.N):   # (no tensor yet: the library reports that)
             raise ValueError(f"fock_jk: densities must be [{self.N},{self.N}] or [n,{self.N},{self.N}], got {P.shape}")
