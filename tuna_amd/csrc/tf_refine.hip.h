@@ -66,8 +66,18 @@ __device__ __forceinline__ void mm_tile(double *C, const double *A, const double
 __global__ __launch_bounds__(TFR_THREADS) void refine_lds_kernel(int n, int n_occ, const double *__restrict__ A, double *__restrict__ X,
                                                                  double *__restrict__ lam_out, double *__restrict__ wocc_out, int max_steps,
                                                                  int *__restrict__ status, const double *__restrict__ Fao,
-                                                                 const double *__restrict__ Xo, double *__restrict__ Pout, double occ)
+                                                                 const double *__restrict__ Xo, double *__restrict__ Pout, double occ,
+                                                                 const int *__restrict__ sizes = nullptr, const int *__restrict__ noccs = nullptr,
+                                                                 long long stride = 0, int vstride = 0)
 {
+    // a batch (the symmetry blocks of a larger matrix, tf_scf.hip.h: ref_refine_blocks): workgroup b refines the sizes[b] vectors of
+    // block b (compact, leading dimension sizes[b]) against its block of A, with noccs[b] of them occupied; status[2 b], [2 b + 1]
+    if (sizes) {
+        const long long off = (long long)blockIdx.x * stride;
+        n = sizes[blockIdx.x]; n_occ = noccs[blockIdx.x];
+        A += off; X += off; lam_out += (size_t)blockIdx.x * vstride; wocc_out += (size_t)blockIdx.x * vstride; status += 2 * blockIdx.x;
+        if (n < 1) { if (threadIdx.x == 0) { status[0] = 1; status[1] = 0; } return; }
+    }
     extern __shared__ double sm[];
     const int np = tfr_np(n), ns = tfr_stride(np);
     double *sX = sm, *sA = sX + np * ns, *sT1 = sA + np * ns, *sT2 = sT1 + np * ns;
@@ -323,6 +333,22 @@ inline bool launch(int n, int n_occ, const double *A, double *X, double *lam, do
         attr_set = true;
     }
     hipLaunchKernelGGL(refine_lds_kernel, dim3(1), dim3(TFR_THREADS), lds_bytes(n), st, n, n_occ, A, X, lam, wocc, 12, status, Fao, Xo, Pout, occ);
+    *err = hipGetLastError();
+    return *err == hipSuccess;
+}
+
+// a batch of nb blocks of at most mmax <= 64 vectors each in one launch (non-fused form)
+inline bool launch_batch(int nb, int mmax, const int *d_sizes, const int *d_noccs, const double *A, double *X, long long stride, double *lam,
+                         double *wocc, int vstride, int *status, hipStream_t st, hipError_t *err)
+{
+    static bool attr_set = false;
+    if (nb < 1 || mmax < 1 || mmax > TFR_NMAX) return false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)refine_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(refine_lds_kernel, dim3(nb), dim3(TFR_THREADS), lds_bytes(mmax), st, mmax, 0, A, X, lam, wocc, 12, status,
+                       (const double *)nullptr, (const double *)nullptr, (double *)nullptr, 2.0, d_sizes, d_noccs, stride, vstride);
     *err = hipGetLastError();
     return *err == hipSuccess;
 }

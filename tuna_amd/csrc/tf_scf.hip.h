@@ -78,6 +78,12 @@ struct Workspace {
     double *sym_buf = nullptr;       // device: [nb][mmax][mmax] blocks, [nb][mmax] values, [nb][mmax] work, 2 doubles of the cross-class test
     int *sym_src = nullptr;          // device [n]: block * mmax + member of the eigenvalue of global rank r
     rocblas_int *sym_info = nullptr; // device [4]
+    // blocked refinement (ref_refine_blocks): every block <= 64 vectors -- the in-LDS refinement kernel on all blocks in one launch
+    double *blk_X = nullptr, *blk_alt_X = nullptr;   // device [nb][mmax][mmax] compact: the blocks' current vectors (second slot: the other spin)
+    int *blk_ints = nullptr;         // device: noccs[4] | status[4][2] | combined[2] | .. | noccs[4] of the other slot at 16
+    int blk_ref_n = 0, blk_alt_ref_n = 0;            // n when blk_X / noccs are valid, else 0
+    int blk_nocc_off = 0, blk_alt_nocc_off = 16;     // where this slot's noccs[4] live in blk_ints
+    long long blk_solves = 0, blk_fallbacks = 0;
     bool sym_last_blocked = false;   // the last eigh() went block by block: sym_src names the block of every eigenvector it returned
     int ref_vcls_n = 0, ref_alt_vcls_n = 0;   // n when the refinement's vectors carry block labels (tail of ref_buf), else 0
     double *sym_prev = nullptr;      // device [nb][mmax][mmax]: block eigenvectors of the previous solve (warm start of the batched Jacobi)
@@ -106,6 +112,9 @@ inline void release(Workspace &w)
     if (w.sym_src) (void)hipFree(w.sym_src);
     if (w.sym_info) (void)hipFree(w.sym_info);
     if (w.sym_prev) (void)hipFree(w.sym_prev);
+    if (w.blk_X) (void)hipFree(w.blk_X);
+    if (w.blk_alt_X) (void)hipFree(w.blk_alt_X);
+    if (w.blk_ints) (void)hipFree(w.blk_ints);
     w = Workspace();
 }
 
@@ -462,8 +471,10 @@ inline int eigh_blocked(Workspace &w, int n, double *W, double *vals, std::strin
         int fill[4] = {0, 0, 0, 0};
         for (int i = 0; i < n; ++i) { const int b = blk_of[w.sym_cls[i]]; idx[(size_t)b * mmax + fill[b]++] = i; idx[(size_t)4 * mmax + i] = w.sym_cls[i]; }
         for (int b = 0; b < 4; ++b) idx[(size_t)4 * mmax + n + b] = b < nb ? w.sym_m[b] : 0;
-        w.sym_prev_n = 0;
+        w.sym_prev_n = 0; w.blk_ref_n = 0; w.blk_alt_ref_n = 0;
         if (w.sym_prev) { (void)hipFree(w.sym_prev); w.sym_prev = nullptr; }
+        if (w.blk_X) { (void)hipFree(w.blk_X); w.blk_X = nullptr; }
+        if (w.blk_alt_X) { (void)hipFree(w.blk_alt_X); w.blk_alt_X = nullptr; }
         if (mmax <= 64) TFS_HIP(hipMalloc((void **)&w.sym_prev, (size_t)nb * mmax * mmax * sizeof(double)));
         TFS_HIP(hipMalloc((void **)&w.sym_idx, idx.size() * sizeof(int)));
         TFS_HIP(tfs_memcpy(w.sym_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -766,7 +777,98 @@ inline int ref_density_lds(Workspace &w, int n, int n_occ, const double *Fao, co
 }
 
 // after a real eigensolve: rows of V (row-major, as eigh() leaves them) become the refinement start
-inline int ref_store(Workspace &w, int n, const double *V, std::string &msg)
+// ---- refinement block by block (64 < n, every parity block <= 64 vectors: cc-pVQZ-size molecules) ---------------------------------
+// The exact solves of such a matrix already run as one batched launch of the in-LDS Jacobi kernel over its blocks (eigh_blocked); the
+// refinement does the same with the in-LDS refinement kernel (tf_refine.hip.h): a workgroup per block, its vectors and its block of A in
+// LDS, the five products of a step on the matrix core -- one launch and one status read per solve instead of five rocBLAS GEMMs, two
+// kernels and a read-back per STEP at the full dimension.  Each block keeps the number of occupied vectors the last exact solve gave it;
+// after the launch the global aufbau order is verified (highest occupied value of all blocks below the lowest empty one), else -- or if
+// a block did not converge, or A has an element between two classes -- the caller diagonalises.
+__global__ void k_blk_noccs(const int *__restrict__ src, int mmax, int n_occ, int *__restrict__ noccs)
+{
+    __shared__ int cnt[4];
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < n_occ; r += blockDim.x) atomicAdd(&cnt[src[r] / mmax], 1);
+    __syncthreads();
+    if (threadIdx.x < 4) noccs[threadIdx.x] = cnt[threadIdx.x];
+}
+
+// combined[0] = 1 iff every block converged and the occupied values of all blocks lie below all empty ones; combined[1] = most steps
+__global__ void k_blk_ref_finish(const int *__restrict__ sizes, const int *__restrict__ status, const double *__restrict__ lam,
+                                 const double *__restrict__ wocc, int nb, int mmax, int *__restrict__ combined)
+{
+    __shared__ double sh[256], sl[256];
+    double homo = -1e300, lumo = 1e300;
+    for (int q = threadIdx.x; q < nb * mmax; q += 256) {
+        const int b = q / mmax, t = q - b * mmax;
+        if (t >= sizes[b]) continue;
+        if (wocc[q] != 0.0) homo = fmax(homo, lam[q]); else lumo = fmin(lumo, lam[q]);
+    }
+    sh[threadIdx.x] = homo; sl[threadIdx.x] = lumo;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + st]); sl[threadIdx.x] = fmin(sl[threadIdx.x], sl[threadIdx.x + st]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int ok = (sh[0] < sl[0]) ? 1 : 0, steps = 0;
+        for (int b = 0; b < nb; ++b) { ok = ok && status[2 * b]; steps = max(steps, status[2 * b + 1]); }
+        combined[0] = ok; combined[1] = steps;
+    }
+}
+
+// rows of the occupied vectors of all blocks in the full basis (block after block; the others zero): what ref_refine hands back
+__global__ void k_blk_xocc(const double *__restrict__ Xb, const double *__restrict__ wocc, const int *__restrict__ idx, const int *__restrict__ sizes,
+                           int n, int mmax, double *__restrict__ out)
+{
+    int r = blockIdx.x, b = 0;
+    while (b < 3 && r >= sizes[b]) { r -= sizes[b]; ++b; }
+    double *row = out + (size_t)blockIdx.x * n;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) row[c] = 0.0;
+    __syncthreads();
+    const double wv = wocc[b * mmax + r];
+    if (wv == 0.0) return;
+    const int m = sizes[b];
+    const double *v = Xb + (size_t)b * mmax * mmax + (size_t)r * m;
+    for (int c = threadIdx.x; c < m; c += blockDim.x) row[idx[b * mmax + c]] = wv * v[c];
+}
+
+inline int ref_refine_blocks(Workspace &w, int n, const double *A, double **Xocc, std::string &msg)
+{
+    if (w.blk_ref_n != n || !w.blk_X || w.sym_n != n || w.sym_mmax > TFR_NMAX || !w.ref_buf) return TF_ELINALG;
+    const int nb = w.sym_nb, mmax = w.sym_mmax;
+    double *B = w.sym_buf, *D = B + (size_t)nb * mmax * mmax, *E = D + (size_t)nb * mmax;
+    unsigned long long *flag = (unsigned long long *)(E + (size_t)nb * mmax);
+    const int *cls = w.sym_idx + (size_t)4 * mmax, *sizes = cls + n;
+    int *noccs = w.blk_ints + w.blk_nocc_off, *status = w.blk_ints + 4, *combined = w.blk_ints + 12;
+    ++w.ref_solves; ++w.blk_solves;
+    TFS_HIP(hipMemsetAsync(flag, 0, 3 * sizeof(double), TFS_ST));
+    hipLaunchKernelGGL(k_blk_cross, dim3(n), dim3(256), 0, TFS_ST, A, cls, n, flag);
+    hipLaunchKernelGGL(k_blk_gather, dim3((mmax * mmax + 255) / 256, nb), dim3(256), 0, TFS_ST, A, w.sym_idx, n, mmax, 0.0, B, sizes);
+    hipError_t e = hipSuccess;
+    if (!tfref::launch_batch(nb, mmax, sizes, noccs, B, w.blk_X, (long long)mmax * mmax, D, E, mmax, status, TFS_ST, &e)) {
+        if (e != hipSuccess) { msg = std::string("blocked refinement kernel launch failed: ") + hipGetErrorString(e); return TF_ENODEVICE; }
+        return TF_ELINALG;
+    }
+    hipLaunchKernelGGL(k_blk_ref_finish, dim3(1), dim3(256), 0, TFS_ST, sizes, status, D, E, nb, mmax, combined);
+    double *Xw = w.ref_buf + 2 * (size_t)n * n;
+    hipLaunchKernelGGL(k_blk_xocc, dim3(n), dim3(64), 0, TFS_ST, w.blk_X, E, w.sym_idx, sizes, n, mmax, Xw);
+    int h[2] = {0, 0};
+    double hf[3] = {0.0, 1.0, 0.0};
+    TFS_HIP(tfs_memcpy(h, combined, sizeof(h), hipMemcpyDeviceToHost));
+    TFS_HIP(tfs_memcpy(hf, flag, sizeof(hf), hipMemcpyDeviceToHost));
+    static const bool dbg = getenv("TF_DEBUG") != nullptr;
+    const bool diag_ok = std::isfinite(hf[0]) && hf[1] <= 1e-14 * hf[0];
+    if (dbg) fprintf(stderr, "[tf refine/blocks] n %d (%d blocks <= %d): %s after %d steps%s\n", n, nb, mmax, h[0] ? "converged" : "NOT converged", h[1],
+                     diag_ok ? "" : ", matrix not class-diagonal");
+    if (!h[0] || !diag_ok) { ++w.ref_fallbacks; ++w.blk_fallbacks; w.blk_ref_n = 0; w.ref_n = 0; return TF_ELINALG; }
+    w.ref_steps += h[1];
+    *Xocc = Xw;
+    return TF_OK;
+}
+
+inline int ref_store(Workspace &w, int n, const double *V, std::string &msg, int n_occ = -1)
 {
     int rc = ref_ensure(w, n, msg);
     if (rc) return rc;
@@ -778,6 +880,17 @@ inline int ref_store(Workspace &w, int n, const double *V, std::string &msg)
         int *vcls = reinterpret_cast<int *>(w.ref_buf + 6 * nn + 2 * (size_t)n + 2 * g + 8);
         hipLaunchKernelGGL(k_blk_labels, dim3((n + 255) / 256), dim3(256), 0, TFS_ST, w.sym_src, w.sym_mmax, n, vcls);
         w.ref_vcls_n = n;
+    }
+    // every block fits the in-LDS refinement kernel: keep the blocks' vectors (still in the solver's buffer) and their occupations
+    static const bool blk_off = getenv("TF_REFINE_BLOCKS") && getenv("TF_REFINE_BLOCKS")[0] == '0';
+    w.blk_ref_n = 0;
+    if (!blk_off && n_occ > 0 && n > TFR_NMAX && w.sym_last_blocked && w.sym_n == n && w.sym_mmax <= TFR_NMAX && w.sym_src) {
+        const size_t bytes = (size_t)w.sym_nb * w.sym_mmax * w.sym_mmax * sizeof(double);
+        if (!w.blk_X) TFS_HIP(hipMalloc((void **)&w.blk_X, bytes));
+        if (!w.blk_ints) TFS_HIP(hipMalloc((void **)&w.blk_ints, 32 * sizeof(int)));
+        TFS_HIP(hipMemcpyAsync(w.blk_X, w.sym_buf, bytes, hipMemcpyDeviceToDevice, TFS_ST));
+        hipLaunchKernelGGL(k_blk_noccs, dim3(1), dim3(64), 0, TFS_ST, w.sym_src, w.sym_mmax, n_occ, w.blk_ints + w.blk_nocc_off);
+        w.blk_ref_n = n;
     }
     return TF_OK;
 }
@@ -1016,7 +1129,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
     static const bool no_refine = getenv("TF_EIGH") != nullptr;
     const bool refining = !no_refine && n >= 2 && n_occ > 0 && n_occ < n;
     bool orbitals_current = false, orbitals_final = false;
-    w.ref_n = 0;
+    w.ref_n = 0; w.blk_ref_n = 0;
     static const bool no_fused = getenv("TF_REFINE_UNFUSED") != nullptr;
     auto diag_density = [&](const double *Fao, double *Pout) -> int {
         if (refining && !no_fused && n <= TFR_NMAX && w.ref_n == n && !getenv("TF_REFINE_CHECK")) {
@@ -1035,7 +1148,8 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         if (refining && w.ref_n == n) {
             double *Xocc = nullptr;
             std::string rmsg;
-            const int rr = (n <= TFR_NMAX) ? ref_refine_lds(w, n, n_occ, dW, &Xocc, rmsg) : ref_refine(w, n, n_occ, dW, &Xocc, rmsg);
+            const int rr = (n <= TFR_NMAX) ? ref_refine_lds(w, n, n_occ, dW, &Xocc, rmsg)
+                         : (w.blk_ref_n == n)  ? ref_refine_blocks(w, n, dW, &Xocc, rmsg) : ref_refine(w, n, n_occ, dW, &Xocc, rmsg);
             if (rr == TF_OK) {
                 const double two = 2.0, zero = 0.0;
                 TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Xocc, dX, 0.0, t1));    // rows: occupied orbitals in the AO basis (others 0)
@@ -1061,7 +1175,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         }
         int r = eigh(w, n, dW, vals, ework, msg);
         if (r) return r;
-        if (refining) { r = ref_store(w, n, dW, msg); if (r) return r; }
+        if (refining) { r = ref_store(w, n, dW, msg, n_occ); if (r) return r; }
         span_end(te);
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));      // C = X V   (dW rows = eigenvectors)
         const double two = 2.0, zero = 0.0;
@@ -1252,7 +1366,7 @@ inline int run_rhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         if (out.eps) TFS_HIP(tfs_memcpy(out.eps, vals, n * sizeof(double), hipMemcpyDeviceToHost));
         if (out.C) TFS_HIP(tfs_memcpy(out.C, dC, nn * sizeof(double), hipMemcpyDeviceToHost));
     }
-    w.ref_n = 0;
+    w.ref_n = 0; w.blk_ref_n = 0;
     TFS_HIP(tfs_sync());
     for (const auto &sp : spans) {
         float ms = 0.f;
@@ -1347,9 +1461,10 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         Workspace &w; bool on;
         SpinSlot(Workspace &ws, bool o_) : w(ws), on(o_) { swap(); }
         ~SpinSlot() { swap(); }
-        void swap() { if (on) { std::swap(w.ref_buf, w.ref_alt_buf); std::swap(w.ref_cap, w.ref_alt_cap); std::swap(w.ref_n, w.ref_alt_n); std::swap(w.ref_vcls_n, w.ref_alt_vcls_n); } }
+        void swap() { if (on) { std::swap(w.ref_buf, w.ref_alt_buf); std::swap(w.ref_cap, w.ref_alt_cap); std::swap(w.ref_n, w.ref_alt_n); std::swap(w.ref_vcls_n, w.ref_alt_vcls_n);
+                                 std::swap(w.blk_X, w.blk_alt_X); std::swap(w.blk_ref_n, w.blk_alt_ref_n); std::swap(w.blk_nocc_off, w.blk_alt_nocc_off); } }
     };
-    w.ref_n = 0; w.ref_alt_n = 0; w.ref_vcls_n = 0; w.ref_alt_vcls_n = 0;
+    w.ref_n = 0; w.ref_alt_n = 0; w.ref_vcls_n = 0; w.ref_alt_vcls_n = 0; w.blk_ref_n = 0; w.blk_alt_ref_n = 0;
     w.warm_ok = false; w.jac_prev_n = 0; w.sym_prev_n = 0;          // two alternating spins: no warm start for the (rare) Jacobi solves
     bool orbitals_current[2] = {false, false}, orbitals_final[2] = {false, false};
     // diagonalise F_s (AO) -> P_s = C_occ C_occ^T symmetrised (one electron per orbital, scf:1227-1228)
@@ -1376,7 +1491,8 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         if (refining && w.ref_n == n) {
             double *Xocc = nullptr;
             std::string rmsg;
-            const int rr = (n <= TFR_NMAX) ? ref_refine_lds(w, n, no, dW, &Xocc, rmsg) : ref_refine(w, n, no, dW, &Xocc, rmsg);
+            const int rr = (n <= TFR_NMAX) ? ref_refine_lds(w, n, no, dW, &Xocc, rmsg)
+                         : (w.blk_ref_n == n)  ? ref_refine_blocks(w, n, dW, &Xocc, rmsg) : ref_refine(w, n, no, dW, &Xocc, rmsg);
             if (rr == TF_OK) {
                 TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, Xocc, dX, 0.0, t1));
                 TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, t1, n, t1, n, &zero, t2, n));
@@ -1388,7 +1504,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         }
         int r = eigh(w, n, dW, vals, ework, msg);
         if (r) return r;
-        if (refining) { r = ref_store(w, n, dW, msg); if (r) return r; }
+        if (refining) { r = ref_store(w, n, dW, msg, no); if (r) return r; }
         span_end(te);
         TFS_BLAS(gemm_rm(w.blas, false, true, n, 1.0, dX, dW, 0.0, dC));
         TFS_BLAS(rocblas_dgemm(w.blas, rocblas_operation_transpose, rocblas_operation_none, n, n, no, &one, dC, n, dC, n, &zero, t1, n));
@@ -1567,7 +1683,7 @@ inline int run_uhf(Workspace &w, int n, const tf_scf_opts &o, const double *S, c
         if (uo.eps[sp]) TFS_HIP(tfs_memcpy(uo.eps[sp], vals, n * sizeof(double), hipMemcpyDeviceToHost));
         if (uo.C[sp]) TFS_HIP(tfs_memcpy(uo.C[sp], dC, nn * sizeof(double), hipMemcpyDeviceToHost));
     }
-    w.ref_n = 0; w.ref_alt_n = 0; w.ref_vcls_n = 0; w.ref_alt_vcls_n = 0;
+    w.ref_n = 0; w.ref_alt_n = 0; w.ref_vcls_n = 0; w.ref_alt_vcls_n = 0; w.blk_ref_n = 0; w.blk_alt_ref_n = 0;
     TFS_HIP(tfs_sync());
     for (const auto &sp : spans) {
         float ms = 0.f;
