@@ -405,3 +405,31 @@ with Engine(0) as eng:
     assert abs(a["rhf"] - a["rhf_again"]) < 1e-10 and abs(a["uhf"] - a["rhf"]) < 1e-8
     assert abs(a["batch"][0] - a["rhf_z"]) < 1e-9 and abs(a["batch"][2] - a["rhf_x"]) < 1e-9 and abs(a["batch"][2] - a["batch"][3]) < 1e-9
     assert np.allclose(a["jk"], b["jk"], rtol=1e-13, atol=0)
+
+
+def test_blocked_refinement_of_an_unrestricted_cycle():
+    """64 < n with parity blocks <= 64 (NO doublet / cc-pVQZ, N = 110): the densities of both spins come from the in-LDS refinement kernel
+    run on all blocks in one launch (tf_scf.hip.h: ref_refine_blocks, one slot per spin); the cycle (scf:1165-1281) must reproduce the
+    run with the GEMM refinement at the full dimension (TF_REFINE_BLOCKS=0) and the one with every solve exact (TF_EIGH=rocsolver)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+from tuna_amd.energy import run
+out = run("SPE : N O 1.151 : UHF CC-PVQZ : ML 2")
+print(json.dumps({"E": out.energy, "n": out.n_iterations}))
+''' % (os.path.join(os.path.dirname(__file__), ".."),)
+    res = {}
+    for mode, var in (("blocks", None), ("gemm", ("TF_REFINE_BLOCKS", "0")), ("exact", ("TF_EIGH", "rocsolver"))):
+        env = dict(os.environ)
+        env.pop("TF_REFINE_BLOCKS", None); env.pop("TF_EIGH", None)
+        if var:
+            env[var[0]] = var[1]
+        o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert o.returncode == 0, o.stderr[-2000:]
+        res[mode] = json.loads(o.stdout.strip().splitlines()[-1])
+    assert abs(res["blocks"]["E"] - res["exact"]["E"]) < 1e-9 and abs(res["gemm"]["E"] - res["exact"]["E"]) < 1e-9
+    assert abs(res["blocks"]["n"] - res["exact"]["n"]) <= 2
