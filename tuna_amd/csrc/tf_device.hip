@@ -1734,6 +1734,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         }
     };
 
+    DBG("stage: small-problem groups");
     // Small problems: per slab one launch per (bra group, ket group), each mixing the classes of its groups (LDS carved by the
     // capacities the groups need).  bra_host: the slab's bra pairs (sorted by group).
     static const bool old_generic = getenv("TF_ERI_GENERIC_OLD") != nullptr;
@@ -1770,6 +1771,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         g.maxLp1 = g.maxLp + 1;
         return g;
     };
+    DBG("stage: carve-outs");
     // LDS carve-out of the launch (bra group gb, ket group gk), from the largest angular momenta / contraction depths of the groups
     CFCaps gcaps[NGRP][NGRP];
     bool gcaps_fit[NGRP][NGRP], gcaps_gtab[NGRP][NGRP];
@@ -1890,6 +1892,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         lrecs_host = recs;
         return TF_OK;
     };
+    DBG("stage: launch lambda defined");
     // One launch per (bra group, ket group) with work.  A process has few hardware queues (4 by default) and the launches of one
     // queue run one after the other, each as long as its slowest workgroup: the launches are spread over NQ streams by estimated
     // cost (heaviest first, always onto the least loaded stream) instead of round-robin over all of them.
@@ -2023,6 +2026,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     };
     if (!per_class) make_caps();
     if ((rc = make_lrecs(!per_class))) return rc;
+    DBG("stage: team tables");
     // ---- team kernels (tf_eri_team.hip.h): the uncontracted classes of the per-class mode, packed layout.  Per pair class the ket
     // pair transform (Cartesian component pairs -> output pairs inside each x/y parity class, normalisation ratios folded in), per
     // shell pair the slab offsets of its output pairs.
@@ -2157,6 +2161,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     long long slab_no = 0;
     std::vector<hipEvent_t> tev;                                   // 4 timing events per slab, read at the end
     std::vector<hipEvent_t> tev2;                                  // 2 per slab around the task-list team kernels (they count as ERI kernels)
+    DBG("stage: teamc tables");
     // ---- small-problem mode with team kernels (eri_teamc_kernel): class records per (bra class, ket class), created on demand; tasks
     // per slab.  A quartet belongs to that kernel when both pair sums are <= TF_TEAM_LMAX and it has <= teamc_pqmax primitive quartets;
     // eri_cfact_kernel skips exactly those (CFCaps::team_lmax / team_pqmax).
@@ -2201,6 +2206,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
     TClass *d_tcs = nullptr; TeamTask *d_tasks = nullptr;
     size_t d_tcs_cap = 0, d_tasks_cap = 0;
     size_t cursor = 0;
+    DBG("stage: slab loop");
     while (cursor < mine_sorted.size()) {
         std::vector<int> bra; std::vector<long long> braoff; std::vector<OutRow> outs;
         std::vector<OutRowP> outsP;
