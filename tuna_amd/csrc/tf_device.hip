@@ -1865,23 +1865,22 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
                         nb = std::min(nb, std::min(c.capG / r.gsz, c.capXZ / r.xz));
                     }
                 r.nb_cap = std::max(nb, 1);
+                // entry e of the G table = ((cc (Ld + 1) + d) Lab1 + v) nM + n, of the X / Z tables = (((a2 (Lb + 1) + b2) (Lc + 1) + cc) (Ld + 1) + d) nM + m
+                // (nested loops in that order: a cc-pVQZ basis has 625 tuples and 6e5 entries -- with a division chain per entry this was
+                // 2 ms of every tensor build)
                 r.tupG_off = (int)tup.size();
-                for (int e = 0; e < r.gsz; ++e) {
-                    const int n = e % r.nM;
-                    int q = e / r.nM;
-                    const int v = q % Lab1; q /= Lab1;
-                    const int d = q % (Ld + 1), cc = q / (Ld + 1);
-                    tup.push_back((unsigned short)(n | (v << 4) | (d << 8) | (cc << 11)));
-                }
-                r.tupXZ_off = (int)tup.size();
-                for (int e = 0; e < r.xz; ++e) {
-                    const int m = e % r.nM;
-                    int q = e / r.nM;
-                    const int d = q % (Ld + 1); q /= (Ld + 1);
-                    const int cc = q % (Lc + 1); q /= (Lc + 1);
-                    const int b2 = q % (Lb + 1), a2 = q / (Lb + 1);
-                    tup.push_back((unsigned short)(m | (a2 << 4) | (b2 << 7) | (cc << 10) | (d << 13)));
-                }
+                tup.resize(tup.size() + (size_t)r.gsz + (size_t)r.xz);
+                unsigned short *tp = tup.data() + r.tupG_off;
+                for (int cc = 0; cc <= Lc; ++cc)
+                    for (int d = 0; d <= Ld; ++d)
+                        for (int v = 0; v < Lab1; ++v)
+                            for (int n = 0; n < r.nM; ++n) *tp++ = (unsigned short)(n | (v << 4) | (d << 8) | (cc << 11));
+                r.tupXZ_off = r.tupG_off + r.gsz;
+                for (int a2 = 0; a2 <= La; ++a2)
+                    for (int b2 = 0; b2 <= Lb; ++b2)
+                        for (int cc = 0; cc <= Lc; ++cc)
+                            for (int d = 0; d <= Ld; ++d)
+                                for (int m = 0; m < r.nM; ++m) *tp++ = (unsigned short)(m | (a2 << 4) | (b2 << 7) | (cc << 10) | (d << 13));
                 recs[ab * 36 + cd] = r;
             }
         if (ctx->d_lrec) { (void)tf_free(ctx->d_lrec); ctx->d_lrec = nullptr; }
@@ -2025,6 +2024,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical)
         return TF_OK;
     };
     if (!per_class) make_caps();
+    DBG("stage: index-word tables");
     if ((rc = make_lrecs(!per_class))) return rc;
     DBG("stage: team tables");
     // ---- team kernels (tf_eri_team.hip.h): the uncontracted classes of the per-class mode, packed layout.  Per pair class the ket
