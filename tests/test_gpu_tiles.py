@@ -82,20 +82,29 @@ def test_tiles_against_the_reference_einsums_and_the_packed_layout(engine):
 
 
 def test_tiles_at_the_benched_size(engine):
-    """N = 400: the tiles tensor element by element against the packed one on 20 000 samples, J and K against the packed layout's"""
+    """N = 400: the tiles tensor element by element against the packed one on 20 000 samples; J and K against the packed layout's for one
+    density and for the wide passes over four and eight densities (the matrix-core pass of `bench.py --layout tiles --n-dens 8`;
+    scf:55-72, 27-44 for what J and K are -- the packed layout's are pinned to the reference at this size in test_gpu_parity.py)."""
     aos = _synthetic(400)
     N = 400
     rng = np.random.default_rng(5)
-    A = rng.standard_normal((N, N)); P = A + A.T
+    P8 = np.stack([(lambda A: A + A.T)(rng.standard_normal((N, N))) for _ in range(8)])
+    P = P8[0]
     idx = rng.integers(0, N, size=(20000, 4)).astype(np.int32)
     try:
         engine.set_basis(aos).build_eri(True, layout="packed")
         vp = engine.sample_eri(idx)
-        Jp, Kp = engine.fock_jk(P)
+        Jp8, Kp8 = engine.fock_jk(P8)                                        # pairs of densities per pass
+        Jp, Kp = Jp8[0], Kp8[0]
         engine.build_eri(True, layout="tiles")
         assert np.array_equal(engine.sample_eri(idx), vp)
         Jt, Kt = engine.fock_jk(P)
         assert np.abs(Jt - Jp).max() < 1e-11 * np.abs(Jp).max() and np.abs(Kt - Kp).max() < 1e-11 * np.abs(Kp).max()
+        for nd in (4, 8):
+            Jw, Kw = engine.fock_jk(P8[:nd])
+            for d in range(nd):
+                assert np.abs(Jw[d] - Jp8[d]).max() < 1e-11 * np.abs(Jp8[d]).max(), (nd, d)
+                assert np.abs(Kw[d] - Kp8[d]).max() < 1e-11 * np.abs(Kp8[d]).max(), (nd, d)
     finally:
         _reset(engine)
 
