@@ -95,10 +95,13 @@ int tf_cross_overlap(tf_ctx *ctx, int n_ao2, const double *origin2, const int32_
  *      + transform_to_spherical_harmonics (kernel:454-529) -------------------------------- */
 
 /* Build this rank's rows of the (ij|kl) tensor on the device.  spherical = 0 is CARTHARM
- * (kernel:481).  The tensor stays resident in HBM in one of two layouts:
- *   TF_LAYOUT_PACKED (default): the 8-fold unique values, row (i >= j) = all pairs (k >= l) <= (i,j)
- *                               -- ~N^4 bytes (+ cache-line padding) instead of the reference's 8 N^4 (kernel:349);
- *   TF_LAYOUT_ROWS:             rows (i >= j) x full [k][l] -- 4 N^4 bytes. */
+ * (kernel:481).  The tensor stays resident in HBM in one of three layouts:
+ *   TF_LAYOUT_PACKED (default): the 8-fold unique values without the exact zeros of the x/y parity rule, row (i >= j) = the pairs
+ *                               (k >= l) <= (i,j) of its parity class -- ~N^4 / 29 x 8 bytes instead of the reference's 8 N^4 (kernel:349);
+ *   TF_LAYOUT_TILES:            the same values in the operand order of v_mfma_f64_16x16x4, second index innermost: the fastest Fock
+ *                               pass over FOUR OR MORE densities at once (tf_fock_jk with n_dens >= 4, tf_scf_rhf_batch), slower than
+ *                               PACKED for one or two;
+ *   TF_LAYOUT_ROWS:             rows (i >= j) x full [k][l] -- 4 N^4 bytes (N > 1024, and the round-1 baseline). */
 int tf_build_eri(tf_ctx *ctx, int spherical);
 #define TF_LAYOUT_AUTO (-1)
 #define TF_LAYOUT_ROWS 0
@@ -106,7 +109,7 @@ int tf_build_eri(tf_ctx *ctx, int spherical);
 #define TF_LAYOUT_TILES 2
 /* Layout for the next tf_build_eri (TF_LAYOUT_AUTO = packed when the J/K kernel covers N, i.e. N <= 1024). */
 int tf_set_eri_layout(tf_ctx *ctx, int layout);
-/* Layout of the stored tensor (TF_LAYOUT_ROWS / TF_LAYOUT_PACKED), or TF_EINVAL before tf_build_eri. */
+/* Layout of the stored tensor (TF_LAYOUT_ROWS / TF_LAYOUT_PACKED / TF_LAYOUT_TILES), or TF_EINVAL before tf_build_eri. */
 int tf_eri_layout(const tf_ctx *ctx);
 /* Alignment unit of the packed layout, in doubles: pair (k >= l) sits at tri(k) + l of its tensor row, where
  * tri(k) = sum over m = 1..k of (m rounded up to the unit); tensor rows are rounded up to the unit as well. */
